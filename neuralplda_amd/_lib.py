@@ -1,0 +1,75 @@
+"""ctypes binding of libnplda_hip.so (the C ABI of include/nplda_hip.h).
+
+There is deliberately NO fallback here: if the HIP library is missing, or a call returns a
+non-zero status, a RuntimeError is raised.  Nothing in the product path computes on the CPU.
+"""
+import ctypes
+import os
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libnplda_hip.so")
+
+_c_f32p = ctypes.c_void_p
+_c_i64 = ctypes.c_int64
+_c_int = ctypes.c_int
+_c_sz = ctypes.c_size_t
+_c_vp = ctypes.c_void_p
+
+# name -> (restype, argtypes); must list every symbol include/nplda_hip.h declares
+SIGNATURES = {
+    "nplda_abi_version": (_c_int, []),
+    "nplda_max_dim": (_c_int, []),
+    "nplda_strerror": (ctypes.c_char_p, [_c_int]),
+    "nplda_padded_dim": (_c_int, [_c_int, _c_int]),
+    "nplda_packed_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
+    "nplda_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int] * 3 + [_c_vp, _c_sz, _c_vp]),
+    "nplda_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,
+                                       _c_f32p, _c_vp]),
+    "nplda_embed_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
+                                 _c_f32p, _c_vp]),
+}
+
+_lib = None
+
+
+class NpldaHipError(RuntimeError):
+    pass
+
+
+def load():
+    """Load (once) and return the ctypes handle. Import torch first so that the HIP runtime
+    already mapped by torch (same SONAME libamdhip64.so.7) is the one the library binds to."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NpldaHipError(
+            f"{LIB_PATH} is missing: build it with `python -m neuralplda_amd.build` "
+            "(or __graft_entry__.build()). There is no CPU fallback.")
+    try:
+        import torch  # noqa: F401  (maps torch's HIP runtime before ours is resolved)
+    except ImportError:
+        pass
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(code, what):
+    if code != 0:
+        msg = load().nplda_strerror(code)
+        raise NpldaHipError(f"{what} failed with status {code}: {msg.decode() if msg else '?'}")
+
+
+def ptr(t):
+    """Device (or host) address of a torch tensor's first element; None -> NULL."""
+    return None if t is None else t.data_ptr()
+
+
+def current_stream(device=None):
+    import torch
+    return torch.cuda.current_stream(device).cuda_stream

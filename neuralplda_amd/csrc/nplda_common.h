@@ -1,0 +1,69 @@
+// nplda_common.h — shared host/device helpers for libnplda_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+#include "../../include/nplda_hip.h"
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define NPLDA_ABI_VERSION 1
+#define NPLDA_MAX_NB 12            // 12 x 16 = 192 features per layer
+#define NPLDA_MAX_DIM (NPLDA_MAX_NB * 16)
+
+// Number of 16-wide feature blocks the compiled kernel set uses for a layer pair: the kernels
+// are instantiated square (NB1 == NB2 == NB) for NB in {2,4,8,10,11,12}; smaller models are
+// zero-padded up to the next instantiated size.  Returns 0 if unsupported.
+__host__ __device__ inline int nplda_kernel_nb(int D1, int D2) {
+    int nb = ((D1 > D2 ? D1 : D2) + 15) / 16;
+    if (nb <= 2) return 2;
+    if (nb <= 4) return 4;
+    if (nb <= 8) return 8;
+    if (nb <= 10) return 10;
+    if (nb <= 11) return 11;
+    if (nb <= 12) return 12;
+    return 0;
+}
+
+// Packed parameter image (all offsets in floats).  W1 and W2 are stored in the exact order the
+// MFMA A-operand fragments are consumed, so a k16-step of weights is a contiguous run of
+// NB x 64 lanes x float4 that lands in LDS linearly and is read back with conflict-free
+// ds_read_b128 (lane l reads bytes [16 l, 16 l + 16) of its block):
+//   W1p[ks][nb][lane][i] = W1[16 nb + (lane & 15)][16 ks + 4 (lane >> 4) + i]   (0 outside D1 x D0)
+//   W2p[kb][nb][lane][i] = W2[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + i]   (0 outside D2 x D1)
+// followed by zero-padded b1, b2, Q, P = P_sqrt^2 (NB*16 each).
+struct NpldaLayout {
+    int D0, D1, D2;
+    int NB, KS1;  // 16-blocks per layer (square kernel), k16-steps over D0
+    size_t oW1, oW2, ob1, ob2, oQ, oP, total;
+};
+
+__host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
+    NpldaLayout L;
+    L.D0 = D0; L.D1 = D1; L.D2 = D2;
+    L.NB = nplda_kernel_nb(D1, D2);
+    L.KS1 = (D0 + 15) / 16;
+    L.oW1 = 0;
+    L.oW2 = L.oW1 + (size_t)L.KS1 * L.NB * 256;
+    L.ob1 = L.oW2 + (size_t)L.NB * L.NB * 256;
+    L.ob2 = L.ob1 + (size_t)L.NB * 16;
+    L.oQ = L.ob2 + (size_t)L.NB * 16;
+    L.oP = L.oQ + (size_t)L.NB * 16;
+    L.total = L.oP + (size_t)L.NB * 16;
+    return L;
+}
+
+static inline int nplda_dims_ok(int D0, int D1, int D2) {
+    return D0 > 0 && D1 > 0 && D2 > 0 && (D0 % 4) == 0 && nplda_kernel_nb(D1, D2) != 0;
+}
+
+static inline int nplda_launch_status() {
+    hipError_t e = hipGetLastError();
+    return e == hipSuccess ? NPLDA_OK : (int)e;
+}
+
+static inline bool nplda_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
+
+__device__ __forceinline__ float wave_xor_add(float v, int mask) {
+    return v + __shfl_xor(v, mask, 64);
+}

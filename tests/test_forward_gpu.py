@@ -1,0 +1,104 @@
+"""GPU parity: fused HIP forward (C ABI) vs the CPU oracle on identical seeded inputs.
+
+Tolerance: |ds| <= 2e-5 + 1e-5 |s| against the float64 oracle evaluation —
+the reference's own fp32-vs-fp64 gap is 2.5e-6 on this data.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+
+ATOL, RTOL = 2e-5, 1e-5
+
+
+def rand_params(rng, D0, D1, D2, scale=1.0):
+    k1, k2 = 1 / np.sqrt(D0), 1 / np.sqrt(D1)
+    return orc.Params(
+        rng.uniform(-k1, k1, (D1, D0)).astype(np.float32) * scale,
+        rng.uniform(-k1, k1, D1).astype(np.float32),
+        rng.uniform(-k2, k2, (D2, D1)).astype(np.float32),
+        rng.uniform(-k2, k2, D2).astype(np.float32),
+        rng.uniform(0, 1, D2).astype(np.float32),
+        rng.uniform(0, 1, D2).astype(np.float32),
+    )
+
+
+def to_dev(p):
+    return [torch.from_numpy(np.ascontiguousarray(t)).cuda() for t in p.tensors()]
+
+
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (512, 170, 150), (32, 16, 16),
+                                       (64, 40, 24), (512, 128, 128), (256, 192, 180), (512, 100, 60)])
+@pytest.mark.parametrize("B", [1, 15, 64, 1000])
+def test_score_pairs_matches_oracle(hip_lib, D0, D1, D2, B):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(1000 * D1 + B)
+    p = rand_params(rng, D0, D1, D2)
+    x1 = rng.standard_normal((B, D0)).astype(np.float32)
+    x2 = rng.standard_normal((B, D0)).astype(np.float32)
+    packed = ops.pack_params(*to_dev(p))
+    s = ops.score_pairs(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed).cpu().numpy()
+    ref64 = orc.forward(x1, x2, p, np.float64)
+    ref32 = orc.forward(x1, x2, p, np.float32)
+    assert s.shape == (B,)
+    assert np.all(np.abs(s - ref64) <= ATOL + RTOL * np.abs(ref64)), np.abs(s - ref64).max()
+    # and no further from fp64 than ~the fp32 oracle itself is
+    assert np.abs(s - ref64).max() <= 4 * max(np.abs(ref32 - ref64).max(), 1e-6)
+
+
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (32, 16, 16), (64, 40, 24)])
+@pytest.mark.parametrize("N", [1, 31, 33, 777])
+def test_embed_matches_oracle(hip_lib, D0, D1, D2, N):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(7 * D1 + N)
+    p = rand_params(rng, D0, D1, D2)
+    x = rng.standard_normal((N, D0)).astype(np.float32)
+    packed = ops.pack_params(*to_dev(p))
+    z, q = ops.embed(torch.from_numpy(x).cuda(), packed)
+    z, q = z.cpu().numpy(), q.cpu().numpy()
+    zr = orc.extract_plda_embeddings(x, p, np.float64)
+    assert z.shape == (N, packed.ldz)
+    np.testing.assert_allclose(z[:, :D2], zr, atol=2e-6, rtol=1e-5)
+    assert np.all(z[:, D2:] == 0)
+    np.testing.assert_allclose(q, orc.self_term(zr, p, np.float64), atol=2e-6, rtol=1e-5)
+
+
+def test_empty_batch_is_noop(hip_lib):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(0)
+    p = rand_params(rng, 512, 150, 150)
+    packed = ops.pack_params(*to_dev(p))
+    e = torch.empty((0, 512), device="cuda")
+    assert ops.score_pairs(e, e, packed).shape == (0,)
+
+
+def test_zero_row_hits_eps_branch(hip_lib):
+    """A row with W1 x + b1 == 0 exactly: F.normalize divides by eps=1e-12, output stays 0."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(3)
+    p = rand_params(rng, 512, 150, 150)
+    p.b1[:] = 0
+    x1 = rng.standard_normal((40, 512)).astype(np.float32)
+    x2 = rng.standard_normal((40, 512)).astype(np.float32)
+    x1[5] = 0
+    x2[17] = 0
+    packed = ops.pack_params(*to_dev(p))
+    s = ops.score_pairs(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed).cpu().numpy()
+    ref = orc.forward(x1, x2, p, np.float64)
+    assert np.all(np.isfinite(s))
+    np.testing.assert_allclose(s, ref, atol=ATOL, rtol=RTOL)
+
+
+def test_strided_rows(hip_lib):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(5)
+    p = rand_params(rng, 512, 170, 170)
+    big = rng.standard_normal((100, 1024)).astype(np.float32)
+    t = torch.from_numpy(big).cuda()
+    x1, x2 = t[:, :512], t[:, 512:]
+    packed = ops.pack_params(*to_dev(p))
+    s = ops.score_pairs(x1, x2, packed).cpu().numpy()
+    np.testing.assert_allclose(s, orc.forward(big[:, :512], big[:, 512:], p, np.float64), atol=ATOL, rtol=RTOL)
