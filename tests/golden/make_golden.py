@@ -182,12 +182,14 @@ def main():
     msd.alpha = torch.tensor(15.0, dtype=torch.float64)
     msd.lossfn = "SoftCdet"
     scd = msd(torch.from_numpy(xg1).double(), torch.from_numpy(xg2).double())
+    scd.retain_grad()
     Ld = msd.softcdet(scd, torch.from_numpy(tg).double())
     Ld.backward()
     for k, prm in msd.named_parameters():
         if prm.grad is not None:
             out[f"SoftCdet64_grad_{k}"] = prm.grad.numpy().copy()
     out["SoftCdet64_L"] = Ld.detach().numpy()
+    out["SoftCdet64_g"] = scd.grad.numpy().copy()
     save("g3_loss_grad_small.npz", **ps, x1=xg1, x2=xg2, t=tg, theta=np.asarray([-0.5, -0.3]), theta_xent=0.25,
          beta=np.asarray([99.0, 199.0]), alpha=15.0, **out)
 
@@ -388,7 +390,7 @@ def main():
     # it (first rows + column sums) so RNG drift is detected instead of silently changing the inputs.
     from tests import synth
     S_spk, U = 400, 5
-    x9, spk = synth.speaker_structured_xvectors(pk["W1"], pk["b1"], plda["diagonalizing_transform"],
+    x9, spk = synth.speaker_structured_xvectors(pk["W1"], pk["b1"], pk["W2"].astype(np.float64),
                                                 plda["plda_mean"], plda["Psi_across_covar_diag"], S_spk, U, 2.0, 7)
     ia, ib, t9 = synth.trial_list(spk, 20000, 200, U, 7)
     with torch.no_grad():
