@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py — scored trial-pairs/s of the fused NPLDA forward on MI355X (BASELINE.json metric).
+
+A "step" is one pass of the hot path (nplda_score_pairs_f32, the NeuralPlda.forward(x1, x2)
+replacement) over one batch of synthetic trial pairs that is already resident in HBM.  Workload
+at every N: BASELINE.json configs[1] — 1 M trial pairs of 512-d x-vectors through a 512->150->150
+NPLDA, scoring only — PER GPU (weak scaling: the trial list shards across ranks with no data-path
+collective).  `value` = pairs all ranks scored / max-over-ranks wall time.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--dim D]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Extra objects on the JSON line (tier contract): `roofline` (dominant kernel vs the fp32-MFMA peak,
+per-launch duration from HIP events on the launch stream) and `cpu_baseline` (the NumPy oracle of
+the same arithmetic timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_TBPS = 8.0
+
+
+def algorithmic_flops_per_pair(D0, D1, D2):
+    """2*(2*D0*D1 + 2*D1*D2) + 8*D2 (398 400 at 512->150->150)."""
+    return 2 * (2 * D0 * D1 + 2 * D1 * D2) + 8 * D2
+
+
+def make_params(D, device, seed=1234):
+    """512->D->D parameters: the Kaldi-trained model shipped with the reference truncated to D
+    (first D LDA rows, leading DxD PLDA block) when the fixture is present, else
+    seeded random nn.Linear-style init.  Values do not affect timing (fp32 MFMA is data-oblivious
+    apart from DVFS; inputs are random, never zero-filled)."""
+    g1 = os.path.join(ROOT, "tests", "golden", "g1_kaldi_params.npz")
+    if os.path.exists(g1) and D <= 170:
+        d = np.load(g1)
+        arrs = [d["W1"][:D], d["b1"][:D], d["W2"][:D, :D], d["b2"][:D], d["P_sqrt"][:D], d["Q"][:D]]
+        src = "kaldi-init truncated to %d" % D
+    else:
+        r = np.random.default_rng(seed)
+        k1, k2 = 1 / np.sqrt(512), 1 / np.sqrt(D)
+        arrs = [r.uniform(-k1, k1, (D, 512)), r.uniform(-k1, k1, D), r.uniform(-k2, k2, (D, D)),
+                r.uniform(-k2, k2, D), r.uniform(0, 1, D), r.uniform(0, 1, D)]
+        src = "seeded random init"
+    return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device) for a in arrs], src
+
+
+def cpu_baseline(params_np, D0, budget_s=12.0, buf_pairs=102400, chunk=10240):
+    """The oracle (NumPy fp32 restatement of utils/models.py:366-382) on the host cores: same
+    arithmetic, the reference driver's chunking (5*2048 pairs, xvector_NeuralPlda_pytorch.py:172).
+    Bounded sample: sweeps a resident buffer of `buf_pairs` pairs for ~`budget_s` seconds."""
+    from oracle import nplda_oracle as orc
+    p = orc.Params(*params_np)
+    rng = np.random.default_rng(99)
+    x1 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
+    x2 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
+    orc.forward(x1[:chunk], x2[:chunk], p)  # warm-up (BLAS thread pool)
+    done, t0 = 0, time.perf_counter()
+    while True:
+        for lo in range(0, buf_pairs, chunk):
+            orc.forward(x1[lo:lo + chunk], x2[lo:lo + chunk], p)
+        done += buf_pairs
+        el = time.perf_counter() - t0
+        if el >= budget_s:
+            break
+    try:
+        from threadpoolctl import threadpool_info
+        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count() or 1
+    return {"value": done / el, "unit": "pairs/s", "cores": int(threads), "kind": "port",
+            "sample": f"{done} pairs ({el:.1f} s) as sweeps of a {buf_pairs}-pair buffer in chunks of {chunk}; "
+                      f"numpy fp32 oracle, BLAS threads={threads}, {os.cpu_count()} logical cpus visible"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=1 << 20, help="trial pairs per GPU per step")
+    ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    from neuralplda_amd import _lib, ops
+    _lib.load()  # fail loudly if libnplda_hip.so is missing
+
+    D0, D = 512, args.dim
+    params, psrc = make_params(D, dev)
+    packed = ops.pack_params(*params)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # each rank scores its own shard
+    B = args.pairs
+    x1 = torch.randn(B, D0, device=dev, generator=gen)
+    x2 = torch.randn(B, D0, device=dev, generator=gen)
+
+    def step():
+        return ops.score_pairs(x1, x2, packed)
+
+    for _ in range(args.warmup):
+        s = step()
+    torch.cuda.synchronize()
+
+    # Timed region: exactly K steps bracketed by barrier + synchronize on both sides.  The HIP events
+    # bracketing each launch are recorded on the stream the kernel is launched on (torch's current stream).
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if dist is not None:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        s = step()
+        evs[k][1].record()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    checksum = float(s.double().sum().item())
+    if not np.isfinite(checksum):
+        raise SystemExit("non-finite scores")
+
+    if rank == 0:
+        total_pairs = B * world * args.steps
+        flops = algorithmic_flops_per_pair(D0, D, D)
+        achieved = B * flops / (kern_ms * 1e-3) / 1e12
+        traffic = None
+        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the PMC passes
+        if os.path.exists(tfile):
+            try:
+                traffic = json.load(open(tfile)).get(f"score_pairs_D{D}_B{B}")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "scored trial-pairs/sec (512-d xvec)",
+            "value": total_pairs / elapsed,
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"cfg1: {B} trial pairs/GPU/step, 512->{D}->{D} NPLDA, scoring only "
+                                   "(fused NeuralPlda.forward, inputs resident in HBM)",
+                       "pairs_per_gpu_per_step": B, "xvector_dim": D0, "layer1_LDA_dim": D,
+                       "layer2_PLDA_spkfactor_dim": D, "params": psrc, "parallelism": f"trial-list shard x{world}"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                         "kernel": "nplda_fwd_kernel<NB,PAIR>", "kernel_ms": kern_ms,
+                         "flop_per_pair_algorithmic": flops,
+                         "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline([p.cpu().numpy() for p in params], D0, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
