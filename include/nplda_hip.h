@@ -75,6 +75,69 @@ int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, 
  * to the same multiple of 16 (the compiled square kernel size). 0 if unsupported. */
 int nplda_padded_dim(int D1, int D2);
 
+/* ---- training: forward with saved activations, losses, backward ---------------------------- */
+
+/* As nplda_score_pairs_f32, additionally saving what the backward needs: y (2B, ldz) = normalised
+ * layer-1 outputs (rows [0,B) = x1 side, [B,2B) = x2 side), z (2B, ldz) = embeddings in the same
+ * row order, rn (2B) = 1 / max(||u||, 1e-12).  ldz must equal nplda_padded_dim(D1, D2).
+ * Replaces what autograd would save for utils/models.py:366-382. */
+int nplda_forward_train_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
+                            const void* packed, int D0, int D1, int D2, float* s, float* y, float* z,
+                            float* rn, int64_t ldz, nplda_stream_t stream);
+
+/* Number of fp64 batch sums the loss needs: kind 0 = SoftCdet over K thresholds (2 + 4K, K <= 4),
+ * kind 1 = BCE ("crossentropy", 4), kind 2 = hard Cdet at the thresholds (utils/models.py:401-404;
+ * same layout as kind 0, no gradient).  0 if unsupported. */
+int nplda_loss_nsums(int K, int kind);
+
+/* Pass 1 of the loss (utils/models.py:384-393): accumulate, in fp64, every batch-global sum the loss
+ * and its gradient need into sums[nplda_loss_nsums] (zeroed here).  All entries are additive over
+ * shards of a batch: under data parallelism all-reduce(sum) this vector before pass 2.
+ * theta: HOST array of K device pointers (the Th{beta} / threshold_Xent parameters, 1 float each). */
+int nplda_loss_sums_f32(const float* s, const float* t, int64_t B, const float* const* theta, int K,
+                        float alpha, int kind, double* sums, nplda_stream_t stream);
+
+/* Pass 2: loss (1 float), g[i] = dL/ds_i (B floats, may be NULL) and dL/dtheta (K floats, may be
+ * NULL) from the sums.  beta: HOST array of K floats (utils/NpldaConf.py:38). */
+int nplda_loss_finish_f32(const float* s, const float* t, int64_t B, const float* const* theta,
+                          const float* beta, int K, float alpha, int kind, const double* sums,
+                          float* loss, float* g, float* dtheta, nplda_stream_t stream);
+
+/* Floats in the flat gradient [dW1 (D1,D0) | db1 (D1) | dW2 (D2,D1) | db2 (D2) | dP_sqrt (D2) | dQ (D2)]. */
+size_t nplda_grad_floats(int D0, int D1, int D2);
+/* Bytes of caller-provided workspace nplda_backward_f32 needs for a batch of B pairs. */
+size_t nplda_backward_workspace_bytes(int64_t B, int D0, int D1, int D2);
+
+/* Backward of s = NeuralPlda.forward(x1, x2) given g = dL/ds: the autograd of utils/models.py:366-382
+ * hand-derived, three launches, deterministic summation order.
+ * y, z, rn: as saved by nplda_forward_train_f32.  P_sqrt: the raw (D2) parameter (chain rule of
+ * P = P_sqrt^2).  Writes grad_flat (nplda_grad_floats floats). */
+int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
+                       int D0, int D1, int D2, const float* g, const float* y, const float* z,
+                       const float* rn, int64_t ldz, const float* P_sqrt, void* ws, size_t ws_bytes,
+                       float* grad_flat, nplda_stream_t stream);
+
+/* ---- indexed scoring (embed each utterance once, then score index pairs) --------------------- */
+
+/* utils/models.py:372-376 on rows of a pre-embedded table: s[p] = q[i1[p]] + q[i2[p]] +
+ * 2 sum_d P_d z[i1[p], d] z[i2[p], d].  z: (N, ldz) and q: (N) from nplda_embed_f32; i1, i2: int64 (B).
+ * The host gather of utils/sv_trials_loaders.py:418-426 disappears.  Out-of-range indices give NaN. */
+int nplda_score_indexed_f32(const float* z, int64_t ldz, const float* q, int64_t N, const int64_t* i1,
+                            const int64_t* i2, int64_t B, const void* packed, int D0, int D1, int D2,
+                            float* s, nplda_stream_t stream);
+
+/* NeuralPlda.forward_from_plda_embeddings(z1, z2) (utils/models.py:372-376) on two explicit (B, D2)
+ * tensors with arbitrary row strides; P_sqrt, Q are the raw (D2) parameters. */
+int nplda_score_embeddings_f32(const float* z1, int64_t ld1, const float* z2, int64_t ld2, int64_t B,
+                               int D2, const float* P_sqrt, const float* Q, float* s,
+                               nplda_stream_t stream);
+
+/* Device index-select out[r, :] = table[idx[r], :] from a resident (N, D0) x-vector matrix — the
+ * device counterpart of load_xvec_trials_from_numbatch / _from_idbatch
+ * (utils/sv_trials_loaders.py:418-437).  Out-of-range indices give NaN rows. */
+int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int64_t* idx, int64_t B,
+                          int D0, float* out, int64_t ldo, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -27,6 +27,23 @@ SIGNATURES = {
                                        _c_f32p, _c_vp]),
     "nplda_embed_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
                                  _c_f32p, _c_vp]),
+    "nplda_forward_train_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,
+                                         _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i64, _c_vp]),
+    "nplda_loss_nsums": (_c_int, [_c_int, _c_int]),
+    "nplda_loss_sums_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, ctypes.POINTER(ctypes.c_void_p), _c_int,
+                                     ctypes.c_float, _c_int, _c_vp, _c_vp]),
+    "nplda_loss_finish_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, ctypes.POINTER(ctypes.c_void_p),
+                                       ctypes.POINTER(ctypes.c_float), _c_int, ctypes.c_float, _c_int, _c_vp,
+                                       _c_f32p, _c_f32p, _c_f32p, _c_vp]),
+    "nplda_score_indexed_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_int,
+                                         _c_int, _c_int, _c_f32p, _c_vp]),
+    "nplda_score_embeddings_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p,
+                                            _c_f32p, _c_vp]),
+    "nplda_gather_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_f32p, _c_i64, _c_vp]),
+    "nplda_grad_floats": (_c_sz, [_c_int, _c_int, _c_int]),
+    "nplda_backward_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
+    "nplda_backward_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,
+                                    _c_f32p, _c_f32p, _c_f32p, _c_i64, _c_f32p, _c_vp, _c_sz, _c_f32p, _c_vp]),
 }
 
 _lib = None

@@ -1,0 +1,455 @@
+// nplda_backward.hip — hand-derived backward of the Neural-PLDA pair score (gfx950, fp32 MFMA).
+//
+// The reference has no backward code: it is whatever autograd derives for utils/models.py:366-382
+// (138 ATen launches at B = 4096).  Here it is three launches, formulas per
+// SURVEY.md §3.3 (verified against the reference's fp64 autograd in tests/test_oracle_golden.py):
+//
+//  K-A  bwd_data_kernel   per 16-pair tile (same wave/lane layout as the forward):
+//         dz1 = 2 g (Q z1 + P z2),  dz2 = 2 g (Q z2 + P z1)                      -> stored
+//         dy  = dz W2   as a CHAINED MFMA: A = W2^T fragments (packed image, LDS-staged),
+//                       B = dz straight from registers (same k-permutation trick as the forward)
+//         du  = (dy - y (y.dy)) / max(||u||, eps)      (F.normalize backward)     -> stored
+//  K-B  wgrad_kernel      dW2 = [dz1;dz2]^T [y1;y2],  dW1 = [du1;du2]^T [x1;x2]: "A^T B" GEMMs with
+//         K = 2B rows, split-K over waves, 64x64 wave tiles, operands read as float4 straight from
+//         row-major global memory (the 4 components of a float4 address 4 interleaved MFMA blocks, so
+//         no transposition is needed).  The n-tile-0 waves also accumulate the column sums
+//         db2 = sum dz, db1 = sum du, dQ = sum g z^2, dP = sum g z1 z2 as a by-product of their loads.
+//  K-C  reduce_kernel     fixed-order sum of the split-K slabs into one flat gradient buffer
+//         [dW1 | db1 | dW2 | db2 | dP_sqrt (= 4 P_sqrt dP) | dQ]  — deterministic, and the single
+//         buffer a data-parallel all-reduce needs.
+#include "nplda_fwd_kernel.h"
+
+namespace {
+
+using namespace nplda;
+
+// ------------------------------------------------------------------------------------------------
+// K-A
+// ------------------------------------------------------------------------------------------------
+struct BwdArgs {
+    const float* g;       // (n)
+    const float* z;       // (2n, ldz)
+    const float* y;       // (2n, ldz)
+    const float* rn;      // (2n)
+    const float* packed;
+    long long n, ldz;
+    size_t oW2T, oQ, oP, total;
+    float* dz;            // (2n, ldz)
+    float* du;            // (2n, ldz)
+    int ntb;              // tile-blocks = ceil(n / (16 * WAVES))
+};
+
+template <int NB, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a) {
+    constexpr int THREADS = WAVES * 64;
+    constexpr int CH = NB * 64;
+    constexpr int NSLOT = (CH + THREADS - 1) / THREADS;
+    __shared__ f32x4 wbuf[2][CH];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g4 = lane >> 4;
+    const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    const long long avail = (long long)((a.total - a.oW2T) / 4);
+
+    for (int tb = blockIdx.x; tb < a.ntb; tb += gridDim.x) {
+        const long long t0 = ((long long)tb * WAVES + wave) * 16;
+        const bool ok = t0 + j < a.n;
+        const long long rA = ok ? t0 + j : a.n - 1;
+        const long long rB = a.n + rA;
+        f32x4 st[NSLOT];
+        __syncthreads();  // every wave is done reading wbuf from the previous tile
+        chunk_load<CH, THREADS, NSLOT>(W2T, avail, st, tid);
+        const float gi = ok ? a.g[rA] : 0.f;
+        f32x4 dzA[NB], dzB[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
+            const float tg = 2.0f * gi;
+            dzA[nb] = tg * (q * zA + p * zB);
+            dzB[nb] = tg * (q * zB + p * zA);
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dzA[nb];
+                *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dzB[nb];
+            }
+        }
+        chunk_store<CH, THREADS, NSLOT>(wbuf[0], st, tid);
+        __syncthreads();
+
+        f32x4 dyA[NB], dyB[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            dyA[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dyB[nb] = dyA[nb];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int cur = kb & 1;
+            if (kb + 1 < NB) chunk_load<CH, THREADS, NSLOT>(W2T + (size_t)(kb + 1) * CH, avail - (long long)(kb + 1) * CH, st, tid);
+            const f32x4* w = wbuf[cur];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 av = w[nb * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    dyA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], dzA[kb][r], dyA[nb], 0, 0, 0);
+                    dyB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], dzB[kb][r], dyB[nb], 0, 0, 0);
+                }
+            }
+            if (kb + 1 < NB) {
+                chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
+                __syncthreads();
+            }
+        }
+
+        // F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); clamp branch: du = dy / eps
+        const float rnA = a.rn[rA], rnB = a.rn[rB];
+        float dotA = 0.f, dotB = 0.f;
+        // pass 1: dots (y is re-read in pass 2 from L1/L2: cheaper than 80 more live registers)
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 yA = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 yB = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dotA = fmaf(yA[r], dyA[nb][r], dotA);
+                dotB = fmaf(yB[r], dyB[nb][r], dotB);
+            }
+        }
+        dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
+        dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
+        if (rnA >= 1e12f) dotA = 0.f;
+        if (rnB >= 1e12f) dotB = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 yA = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 yB = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA * dotA) * rnA;
+                *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB * dotB) * rnB;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-B : C[m][n] = sum_k A[k][m] * Bm[k][n]   (K = 2n rows; Bm rows come from two segments)
+// ------------------------------------------------------------------------------------------------
+struct WgradProblem {
+    const float* A;       // (2n, lda): dz or du
+    long long lda;
+    const float* B0;      // rows [0, n)
+    const float* B1;      // rows [n, 2n)
+    long long ldb;
+    int M, N;             // valid columns of A / of B (multiples of 4)
+    int MT, NT;           // 64-wide tiles
+    float* slab;          // [ksplit][Mp][Np]
+    int Mp, Np;
+    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}
+};
+
+struct WgradArgs {
+    WgradProblem p[2];
+    long long n;          // pairs; K = 2n
+    int ksplit;
+    long long rows_per_split;  // multiple of 4
+    const float* z;       // (2n, ldz)
+    const float* g;       // (n)
+    long long ldz;
+    float* ext;           // [ksplit][4][Mp] : dQraw, dPraw, db2, db1
+    int Mp;
+    int nw0;              // work items of problem 0 = MT0*NT0*ksplit
+    int nw;               // total work items
+};
+
+constexpr int kPF = 4;  // k4-steps of operand prefetch per wave
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    int w = blockIdx.x * 4 + wave;
+    if (w >= a.nw) return;
+    const int pi = w >= a.nw0 ? 1 : 0;
+    if (pi) w -= a.nw0;
+    const WgradProblem& P = a.p[pi];
+    const int ks = w % a.ksplit;
+    const int tile = w / a.ksplit;
+    const int nt = tile % P.NT, mt = tile / P.NT;
+    const int m0 = mt * 64, n0 = nt * 64;
+    const long long K = 2 * a.n;
+    const long long k0 = (long long)ks * a.rows_per_split;
+    long long k1 = k0 + a.rows_per_split;
+    if (k1 > K) k1 = K;
+    const bool mval = m0 + 4 * i16 < P.M;
+    const bool nval = n0 + 4 * i16 < P.N;
+    const int ext = (nt == 0) ? P.extras : 0;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0;  // column-sum accumulators (per lane: 4 m-values)
+
+    auto loadA = [&](long long row) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < k1 && mval) v = *reinterpret_cast<const f32x4*>(P.A + row * P.lda + m0 + 4 * i16);
+        return v;
+    };
+    auto loadB = [&](long long row) -> f32x4 {
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (row < k1 && nval) {
+            const float* base = row < a.n ? P.B0 + row * P.ldb : P.B1 + (row - a.n) * P.ldb;
+            v = *reinterpret_cast<const f32x4*>(base + n0 + 4 * i16);
+        }
+        return v;
+    };
+
+    f32x4 fa[kPF], fb[kPF];
+#pragma unroll
+    for (int s = 0; s < kPF; ++s) {
+        fa[s] = loadA(k0 + 4 * s + g4);
+        fb[s] = loadB(k0 + 4 * s + g4);
+    }
+    for (long long kk = k0; kk < k1; kk += 4 * kPF) {
+#pragma unroll
+        for (int s = 0; s < kPF; ++s) {
+            const f32x4 av = fa[s], bv = fb[s];
+            const long long row = kk + 4 * s + g4;
+            // prefetch the same slot one round ahead
+            fa[s] = loadA(row + 4 * kPF);
+            fb[s] = loadB(row + 4 * kPF);
+            if (ext) {
+                e0 += av;  // db1 (extras 1) or db2 (extras 2)
+                if (ext == 2 && row < k1 && mval) {
+                    const long long pr = row < a.n ? row : row - a.n;
+                    const float gi = a.g[pr];
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + row * a.ldz + m0 + 4 * i16);
+                    e1 += gi * zv * zv;  // dQ
+                    if (row < a.n) {
+                        const f32x4 zo = *reinterpret_cast<const f32x4*>(a.z + (row + a.n) * a.ldz + m0 + 4 * i16);
+                        e2 += gi * zv * zo;  // dP (each pair once)
+                    }
+                }
+            }
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], bv[cb], acc[ca][cb], 0, 0, 0);
+        }
+    }
+
+    // store the 64x64 tile of this split: D[i][j] of block (ca, cb) is C[m0 + 4 i + ca][n0 + 4 j + cb],
+    // lane (j = i16, g4) holds i = 4 g4 + r.
+    float* slab = P.slab + (size_t)ks * P.Mp * P.Np;
+    if (n0 + 4 * i16 < P.Np) {
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * (4 * g4 + r) + ca;
+                if (m < P.Mp) {
+                    const f32x4 v = {acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]};
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * P.Np + n0 + 4 * i16) = v;
+                }
+            }
+        }
+    }
+    if (ext) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            e0[c] = wave_xor_add(e0[c], 16); e0[c] = wave_xor_add(e0[c], 32);
+            e1[c] = wave_xor_add(e1[c], 16); e1[c] = wave_xor_add(e1[c], 32);
+            e2[c] = wave_xor_add(e2[c], 16); e2[c] = wave_xor_add(e2[c], 32);
+        }
+        if (g4 == 0 && m0 + 4 * i16 < a.Mp) {
+            float* eb = a.ext + (size_t)ks * 4 * a.Mp + m0 + 4 * i16;
+            if (ext == 1) {
+                *reinterpret_cast<f32x4*>(eb + 3 * a.Mp) = e0;
+            } else {
+                *reinterpret_cast<f32x4*>(eb + 0 * a.Mp) = e1;
+                *reinterpret_cast<f32x4*>(eb + 1 * a.Mp) = e2;
+                *reinterpret_cast<f32x4*>(eb + 2 * a.Mp) = e0;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K-C : slabs -> flat gradient [dW1 (D1 x D0) | db1 | dW2 (D2 x D1) | db2 | dP_sqrt | dQ]
+// ------------------------------------------------------------------------------------------------
+struct ReduceArgs {
+    const float* slab1;  // [ksplit][Mp][D0p]   dW1
+    const float* slab2;  // [ksplit][Mp][Mp]    dW2
+    const float* ext;    // [ksplit][4][Mp]
+    const float* P_sqrt;
+    int ksplit, Mp, Np1, D0, D1, D2;
+    float* out;
+};
+
+__global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs a) {
+    const size_t nW1 = (size_t)a.D1 * a.D0, nW2 = (size_t)a.D2 * a.D1;
+    const size_t total = nW1 + a.D1 + nW2 + 3 * (size_t)a.D2;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const float* src;
+    size_t stride;
+    float scale = 1.0f;
+    if (idx < nW1) {
+        const size_t m = idx / a.D0, n = idx % a.D0;
+        src = a.slab1 + m * a.Np1 + n;
+        stride = (size_t)a.Mp * a.Np1;
+    } else if (idx < nW1 + a.D1) {
+        src = a.ext + 3 * a.Mp + (idx - nW1);
+        stride = 4 * (size_t)a.Mp;
+    } else if (idx < nW1 + a.D1 + nW2) {
+        const size_t r = idx - nW1 - a.D1;
+        const size_t m = r / a.D1, n = r % a.D1;
+        src = a.slab2 + m * a.Mp + n;
+        stride = (size_t)a.Mp * a.Mp;
+    } else {
+        const size_t r = idx - nW1 - a.D1 - nW2;
+        const int which = (int)(r / a.D2), f = (int)(r % a.D2);
+        // which: 0 = db2 (ext row 2), 1 = dP_sqrt (ext row 1, times 4 P_sqrt), 2 = dQ (ext row 0)
+        const int row = which == 0 ? 2 : (which == 1 ? 1 : 0);
+        src = a.ext + row * a.Mp + f;
+        stride = 4 * (size_t)a.Mp;
+        if (which == 1) scale = 4.0f * a.P_sqrt[f];
+    }
+    float sum = 0.f;
+    for (int k = 0; k < a.ksplit; ++k) sum += src[k * stride];
+    a.out[idx] = sum * scale;
+}
+
+// ------------------------------------------------------------------------------------------------
+constexpr int kBwdWaves = 4;
+
+struct WsLayout {
+    size_t dz, du, slab1, slab2, ext, total;  // float offsets
+    int ksplit;
+    long long rows_per_split;
+    int Mp, Np1;
+};
+
+WsLayout ws_layout(long long B, const NpldaLayout& L) {
+    WsLayout w;
+    w.Mp = 16 * L.NB;
+    w.Np1 = (L.D0 + 3) / 4 * 4;
+    const long long K = 2 * B;
+    long long ks = (K + 255) / 256;
+    if (ks < 1) ks = 1;
+    if (ks > 32) ks = 32;
+    long long rps = (K + ks - 1) / ks;
+    rps = (rps + 15) / 16 * 16;  // multiple of 4 * kPF
+    w.ksplit = (int)((K + rps - 1) / rps);
+    if (w.ksplit < 1) w.ksplit = 1;
+    w.rows_per_split = rps;
+    const size_t rows = (size_t)(2 * B) * w.Mp;
+    w.dz = 0;
+    w.du = w.dz + rows;
+    w.slab1 = w.du + rows;
+    w.slab2 = w.slab1 + (size_t)w.ksplit * w.Mp * w.Np1;
+    w.ext = w.slab2 + (size_t)w.ksplit * w.Mp * w.Mp;
+    w.total = w.ext + (size_t)w.ksplit * 4 * w.Mp;
+    return w;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nplda_grad_floats(int D0, int D1, int D2) {
+    if (check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return (size_t)D1 * D0 + D1 + (size_t)D2 * D1 + 3 * (size_t)D2;
+}
+
+size_t nplda_backward_workspace_bytes(int64_t B, int D0, int D1, int D2) {
+    if (B < 0 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return ws_layout(B, nplda_layout(D0, D1, D2)).total * sizeof(float);
+}
+
+int nplda_forward_train_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0,
+                            int D1, int D2, float* s, float* y, float* z, float* rn, int64_t ldz,
+                            nplda_stream_t stream) {
+    if (B < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (B == 0) return NPLDA_OK;
+    if (!packed || !s || !rn || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!rows_ok(y, ldz, 16 * L.NB) || !rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
+    FwdArgs a = {};
+    a.xa = x1; a.xb = x2; a.n = B; a.ldx = ldx; a.packed = (const float*)packed;
+    a.out_s = s; a.out_z = z; a.ldz = ldz; a.out_y = y; a.out_rn = rn;
+    return launch_fwd<MODE_TRAIN>(a, L, (hipStream_t)stream);
+}
+
+int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                       int D2, const float* g, const float* y, const float* z, const float* rn, int64_t ldz,
+                       const float* P_sqrt, void* ws, size_t ws_bytes, float* grad_flat, nplda_stream_t stream) {
+    if (B < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (!grad_flat) return NPLDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    const size_t ngrad = nplda_grad_floats(D0, D1, D2);
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(grad_flat, 0, ngrad * sizeof(float), st);
+        return e == hipSuccess ? NPLDA_OK : (int)e;
+    }
+    if (!packed || !g || !rn || !P_sqrt || !ws || !nplda_aligned16(packed) || !nplda_aligned16(ws)) return NPLDA_EINVAL;
+    if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
+    if (!rows_ok(y, ldz, 16 * L.NB) || !rows_ok(z, ldz, 16 * L.NB) || ldz != 16 * L.NB) return NPLDA_EINVAL;
+    const WsLayout W = ws_layout(B, L);
+    if (ws_bytes < W.total * sizeof(float)) return NPLDA_ENOSPC;
+    float* wsf = (float*)ws;
+
+    // K-A
+    BwdArgs b = {};
+    b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = (const float*)packed; b.n = B; b.ldz = ldz;
+    b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
+    b.dz = wsf + W.dz; b.du = wsf + W.du;
+    const long long ntb = (B + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
+    if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
+    b.ntb = (int)ntb;
+    {
+        dim3 grid((unsigned)(ntb < 2048 ? ntb : 2048)), block(kBwdWaves * 64);
+#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves>), grid, block, 0, st, b)
+        switch (L.NB) {
+            case 2: NPLDA_LAUNCH(2); break;
+            case 4: NPLDA_LAUNCH(4); break;
+            case 8: NPLDA_LAUNCH(8); break;
+            case 10: NPLDA_LAUNCH(10); break;
+            case 11: NPLDA_LAUNCH(11); break;
+            case 12: NPLDA_LAUNCH(12); break;
+            default: return NPLDA_EUNSUPPORTED;
+        }
+#undef NPLDA_LAUNCH
+        if (int rc = nplda_launch_status()) return rc;
+    }
+    // K-B
+    WgradArgs wa = {};
+    wa.n = B; wa.ksplit = W.ksplit; wa.rows_per_split = W.rows_per_split;
+    wa.z = z; wa.g = g; wa.ldz = ldz; wa.ext = wsf + W.ext; wa.Mp = W.Mp;
+    WgradProblem& p1 = wa.p[0];  // dW1 = du^T [x1; x2]
+    p1.A = wsf + W.du; p1.lda = ldz; p1.B0 = x1; p1.B1 = x2; p1.ldb = ldx; p1.M = W.Mp; p1.N = D0;
+    p1.MT = (W.Mp + 63) / 64; p1.NT = (D0 + 63) / 64; p1.slab = wsf + W.slab1; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
+    WgradProblem& p2 = wa.p[1];  // dW2 = dz^T [y1; y2]
+    p2.A = wsf + W.dz; p2.lda = ldz; p2.B0 = y; p2.B1 = y + (size_t)B * ldz; p2.ldb = ldz; p2.M = W.Mp; p2.N = W.Mp;
+    p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp; p2.extras = 2;
+    wa.nw0 = p1.MT * p1.NT * W.ksplit;
+    wa.nw = wa.nw0 + p2.MT * p2.NT * W.ksplit;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((wa.nw + 3) / 4)), dim3(256), 0, st, wa);
+    if (int rc = nplda_launch_status()) return rc;
+    // K-C
+    ReduceArgs ra = {};
+    ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
+    ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = D0; ra.D1 = D1; ra.D2 = D2; ra.out = grad_flat;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ngrad + 255) / 256)), dim3(256), 0, st, ra);
+    return nplda_launch_status();
+}
+
+}  // extern "C"

@@ -31,11 +31,12 @@ __host__ __device__ inline int nplda_kernel_nb(int D1, int D2) {
 // ds_read_b128 (lane l reads bytes [16 l, 16 l + 16) of its block):
 //   W1p[ks][nb][lane][i] = W1[16 nb + (lane & 15)][16 ks + 4 (lane >> 4) + i]   (0 outside D1 x D0)
 //   W2p[kb][nb][lane][i] = W2[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + i]   (0 outside D2 x D1)
+//   W2Tp[kb][nb][lane][i] = W2[16 kb + 4 (lane >> 4) + i][16 nb + (lane & 15)]  (W2^T, backward dy = dz W2)
 // followed by zero-padded b1, b2, Q, P = P_sqrt^2 (NB*16 each).
 struct NpldaLayout {
     int D0, D1, D2;
     int NB, KS1;  // 16-blocks per layer (square kernel), k16-steps over D0
-    size_t oW1, oW2, ob1, ob2, oQ, oP, total;
+    size_t oW1, oW2, oW2T, ob1, ob2, oQ, oP, total;
 };
 
 __host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
@@ -45,7 +46,8 @@ __host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
     L.KS1 = (D0 + 15) / 16;
     L.oW1 = 0;
     L.oW2 = L.oW1 + (size_t)L.KS1 * L.NB * 256;
-    L.ob1 = L.oW2 + (size_t)L.NB * L.NB * 256;
+    L.oW2T = L.oW2 + (size_t)L.NB * L.NB * 256;
+    L.ob1 = L.oW2T + (size_t)L.NB * L.NB * 256;
     L.ob2 = L.ob1 + (size_t)L.NB * 16;
     L.oQ = L.ob2 + (size_t)L.NB * 16;
     L.oP = L.oQ + (size_t)L.NB * 16;

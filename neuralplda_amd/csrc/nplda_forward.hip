@@ -1,288 +1,9 @@
-// nplda_forward.hip — fused Neural-PLDA forward for gfx950 (MI355X), fp32 MFMA.
-//
-// Replaces utils/models.py:366-382 of the reference (two nn.Linear, F.normalize, the diagonal
-// quadratic score: 25 ATen launches with every intermediate round-tripping through memory) by
-// ONE kernel that reads x once from HBM and writes only s (pair mode) or z,q (embed mode).
-//
-// Design (not a translation of anything in the reference, which has no device code):
-//  * everything is computed TRANSPOSED:  u^T = W1 x^T,  z^T = W2 y^T.  The weight matrix is the
-//    MFMA A operand (16 features x 4 k) and the data are the B operand (4 k x 16 batch rows), so
-//    the accumulator of v_mfma_f32_16x16x4_f32 holds, in lane (j = lane&15, g = lane>>4), the
-//    features {16 nb + 4 g + r} of batch row j.  That is exactly the B-operand shape of the NEXT
-//    GEMM with the k-permutation "step (kb, r) covers k = 16 kb + 4 g + r" — matched by how the
-//    weights were packed — so the normalised layer-1 output feeds layer 2 straight from
-//    registers: no LDS round trip, no layout change.
-//  * one wave owns 16 trial pairs: group A = the 16 x1 rows, group B = the 16 x2 rows of the SAME
-//    pairs.  z1 and z2 then sit in identical lanes/registers and the score is an elementwise
-//    epilogue + two cross-lane adds.  (Embed mode: groups A/B are 32 consecutive rows.)
-//  * x is streamed HBM -> VGPR as one float4 per lane per group per k16-step (each x element is
-//    used by exactly one wave, so LDS staging would only add traffic); the weights (0.4-0.5 MB,
-//    L2-resident) are streamed L2 -> LDS in fragment order, one k16-step (NB KiB) per barrier,
-//    double-buffered, and read back as conflict-free linear ds_read_b128.
-//  * fp32-input MFMA is exact fp32 (a k-ordered fmaf chain), so results match the reference's
-//    fp32 GEMMs to rounding: tolerance |ds| <= 2e-5 + 1e-5 |s| (tests/).
-//
-// Roofline: MFMA-bound.  Padded work per pair = 2 * 2 * (16 KS1 + 16 NB) * (16 NB) FLOP
-// (430 080 at 512->150->150 vs 398 400 algorithmic); fp32 MFMA peak 157.3 TFLOP/s.
-#include "nplda_common.h"
+// nplda_forward.hip — C-ABI entry points of the fused Neural-PLDA forward (kernel: nplda_fwd_kernel.h).
+#include "nplda_fwd_kernel.h"
 
 namespace {
 
-constexpr int kWaves = 4;
-constexpr int kThreads = kWaves * 64;
-
-enum { MODE_PAIR = 0, MODE_EMBED = 1 };
-
-template <int NB>
-__device__ __forceinline__ void chunk_load(const f32x4* __restrict__ src, f32x4 (&st)[3], int tid) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int idx = tid + kThreads * i;
-        if (idx < NB * 64) st[i] = src[idx];
-    }
-}
-
-template <int NB>
-__device__ __forceinline__ void chunk_store(f32x4* dst, const f32x4 (&st)[3], int tid) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int idx = tid + kThreads * i;
-        if (idx < NB * 64) dst[idx] = st[i];
-    }
-}
-
-__device__ __forceinline__ f32x4 load_x4(const float* p, bool ok) {
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (ok) v = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
-    return v;
-}
-
-template <int NB, int MODE>
-__global__ __launch_bounds__(kThreads, 2) void nplda_fwd_kernel(
-    const float* __restrict__ xa_base, const float* __restrict__ xb_base, long long n, long long ldx,
-    const float* __restrict__ packed, int D0, int KS1, size_t oW2, size_t ob1, size_t ob2, size_t oQ,
-    size_t oP, float* __restrict__ out_s, float* __restrict__ out_z, long long ldz,
-    float* __restrict__ out_q) {
-    __shared__ f32x4 wbuf[2][NB * 64];
-
-    const int tid = threadIdx.x;
-    const int lane = tid & 63;
-    const int wave = tid >> 6;
-    const int j = lane & 15;
-    const int g = lane >> 4;
-
-    long long t0A, t0B;
-    if (MODE == MODE_PAIR) {
-        t0A = ((long long)blockIdx.x * kWaves + wave) * 16;
-        t0B = t0A;
-    } else {
-        t0A = ((long long)blockIdx.x * kWaves + wave) * 32;
-        t0B = t0A + 16;
-    }
-    long long rowA = t0A + j, rowB = t0B + j;
-    const bool okA = rowA < n, okB = rowB < n;
-    if (!okA) rowA = n - 1;
-    if (!okB) rowB = n - 1;
-    const float* pa = xa_base + rowA * ldx + 4 * g;
-    const float* pb = xb_base + rowB * ldx + 4 * g;
-
-    const f32x4* W1p = reinterpret_cast<const f32x4*>(packed);
-    const f32x4* W2p = reinterpret_cast<const f32x4*>(packed + oW2);
-    const f32x4* b1p = reinterpret_cast<const f32x4*>(packed + ob1);
-    const f32x4* b2p = reinterpret_cast<const f32x4*>(packed + ob2);
-    const f32x4* Qp = reinterpret_cast<const f32x4*>(packed + oQ);
-    const f32x4* Pp = reinterpret_cast<const f32x4*>(packed + oP);
-
-    f32x4 st[3];
-    // prologue: weight chunk 0 -> LDS, first x fragments -> registers
-    chunk_load<NB>(W1p, st, tid);
-    f32x4 xa = load_x4(pa, 4 * g < D0);
-    f32x4 xb = load_x4(pb, 4 * g < D0);
-
-    f32x4 accA[NB], accB[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        accA[nb] = b1p[4 * nb + g];
-        accB[nb] = accA[nb];
-    }
-    chunk_store<NB>(wbuf[0], st, tid);
-    __syncthreads();
-
-    // ---- layer 1: u^T = W1 x^T + b1, K = D0 streamed in k16-steps ------------------------------
-    for (int c = 0; c < KS1; ++c) {
-        const int cur = c & 1;
-        const bool more = (c + 1 < KS1);
-        chunk_load<NB>(more ? W1p + (size_t)(c + 1) * NB * 64 : W2p, st, tid);
-        const int kn = 16 * (c + 1) + 4 * g;
-        f32x4 xan = load_x4(pa + 16 * (c + 1), more && kn < D0);
-        f32x4 xbn = load_x4(pb + 16 * (c + 1), more && kn < D0);
-
-        const f32x4* w = wbuf[cur];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 a = w[nb * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                accA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xa[r], accA[nb], 0, 0, 0);
-                accB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], xb[r], accB[nb], 0, 0, 0);
-            }
-        }
-        xa = xan;
-        xb = xbn;
-        chunk_store<NB>(wbuf[cur ^ 1], st, tid);
-        __syncthreads();
-    }
-
-    // ---- F.normalize (utils/models.py:368): y = u / max(||u||_2, 1e-12) ------------------------
-    {
-        float ssA = 0.f, ssB = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                ssA = fmaf(accA[nb][r], accA[nb][r], ssA);
-                ssB = fmaf(accB[nb][r], accB[nb][r], ssB);
-            }
-        }
-        ssA = wave_xor_add(ssA, 16); ssA = wave_xor_add(ssA, 32);
-        ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
-        const float invA = 1.0f / fmaxf(sqrtf(ssA), 1e-12f);
-        const float invB = 1.0f / fmaxf(sqrtf(ssB), 1e-12f);
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            accA[nb] *= invA;
-            accB[nb] *= invB;
-        }
-    }
-
-    // ---- layer 2: z^T = W2 y^T + b2; y comes straight from the layer-1 accumulators -----------
-    f32x4 zA[NB], zB[NB];
-#pragma unroll
-    for (int nb = 0; nb < NB; ++nb) {
-        zA[nb] = b2p[4 * nb + g];
-        zB[nb] = zA[nb];
-    }
-#pragma unroll
-    for (int kb = 0; kb < NB; ++kb) {
-        const int cur = (KS1 + kb) & 1;
-        if (kb + 1 < NB) chunk_load<NB>(W2p + (size_t)(kb + 1) * NB * 64, st, tid);
-        const f32x4* w = wbuf[cur];
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 a = w[nb * 64 + lane];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                zA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], accA[kb][r], zA[nb], 0, 0, 0);
-                zB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[r], accB[kb][r], zB[nb], 0, 0, 0);
-            }
-        }
-        if (kb + 1 < NB) {
-            chunk_store<NB>(wbuf[cur ^ 1], st, tid);
-            __syncthreads();
-        }
-    }
-
-    // ---- epilogue ------------------------------------------------------------------------------
-    if (MODE == MODE_PAIR) {
-        // utils/models.py:372-376: s = sum Q (z1^2 + z2^2) + 2 sum P z1 z2
-        float part = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 q = Qp[4 * nb + g];
-            const f32x4 p = Pp[4 * nb + g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float z1 = zA[nb][r], z2 = zB[nb][r];
-                part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
-                part = fmaf(2.0f * p[r], z1 * z2, part);
-            }
-        }
-        part = wave_xor_add(part, 16);
-        part = wave_xor_add(part, 32);
-        if (g == 0 && okA) out_s[t0A + j] = part;
-    } else {
-        float qa = 0.f, qb = 0.f;
-#pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 q = Qp[4 * nb + g];
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                qa = fmaf(q[r] * zA[nb][r], zA[nb][r], qa);
-                qb = fmaf(q[r] * zB[nb][r], zB[nb][r], qb);
-            }
-            if (okA) *reinterpret_cast<f32x4*>(out_z + rowA * ldz + 16 * nb + 4 * g) = zA[nb];
-            if (okB) *reinterpret_cast<f32x4*>(out_z + rowB * ldz + 16 * nb + 4 * g) = zB[nb];
-        }
-        if (out_q != nullptr) {
-            qa = wave_xor_add(qa, 16); qa = wave_xor_add(qa, 32);
-            qb = wave_xor_add(qb, 16); qb = wave_xor_add(qb, 32);
-            if (g == 0 && okA) out_q[rowA] = qa;
-            if (g == 0 && okB) out_q[rowB] = qb;
-        }
-    }
-}
-
-// One thread per packed float.
-__global__ void nplda_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
-                                  const float* __restrict__ W2, const float* __restrict__ b2,
-                                  const float* __restrict__ P_sqrt, const float* __restrict__ Q,
-                                  NpldaLayout L, float* __restrict__ out) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= L.total) return;
-    float v = 0.f;
-    if (idx < L.ob1) {
-        const bool second = idx >= L.oW2;
-        const size_t rel = second ? idx - L.oW2 : idx;
-        const int i = (int)(rel & 3);
-        const int lane = (int)((rel >> 2) & 63);
-        const size_t blk = rel >> 8;  // ks * NB + nb
-        const int nb = (int)(blk % L.NB);
-        const int ks = (int)(blk / L.NB);
-        const int f = 16 * nb + (lane & 15);
-        const int k = 16 * ks + 4 * (lane >> 4) + i;
-        if (!second) {
-            if (f < L.D1 && k < L.D0) v = W1[(size_t)f * L.D0 + k];
-        } else {
-            if (f < L.D2 && k < L.D1) v = W2[(size_t)f * L.D1 + k];
-        }
-    } else if (idx < L.ob2) {
-        const int f = (int)(idx - L.ob1);
-        if (f < L.D1) v = b1[f];
-    } else if (idx < L.oQ) {
-        const int f = (int)(idx - L.ob2);
-        if (f < L.D2) v = b2[f];
-    } else if (idx < L.oP) {
-        const int f = (int)(idx - L.oQ);
-        if (f < L.D2) v = Q[f];
-    } else {
-        const int f = (int)(idx - L.oP);
-        if (f < L.D2) v = P_sqrt[f] * P_sqrt[f];  // utils/models.py:373
-    }
-    out[idx] = v;
-}
-
-template <int MODE>
-int launch_fwd(const float* xa, const float* xb, long long n, long long ldx, const float* packed,
-               const NpldaLayout& L, float* s, float* z, long long ldz, float* q, hipStream_t st) {
-    const long long per_block = (MODE == MODE_PAIR ? 16 : 32) * kWaves;
-    const long long blocks = (n + per_block - 1) / per_block;
-    if (blocks > 0x7fffffffLL) return NPLDA_EINVAL;
-    dim3 grid((unsigned)blocks), block(kThreads);
-#define NPLDA_LAUNCH(NBV)                                                                        \
-    hipLaunchKernelGGL((nplda_fwd_kernel<NBV, MODE>), grid, block, 0, st, xa, xb, n, ldx, packed, \
-                       L.D0, L.KS1, L.oW2, L.ob1, L.ob2, L.oQ, L.oP, s, z, ldz, q)
-    switch (L.NB) {
-        case 2: NPLDA_LAUNCH(2); break;
-        case 4: NPLDA_LAUNCH(4); break;
-        case 8: NPLDA_LAUNCH(8); break;
-        case 10: NPLDA_LAUNCH(10); break;
-        case 11: NPLDA_LAUNCH(11); break;
-        case 12: NPLDA_LAUNCH(12); break;
-        default: return NPLDA_EUNSUPPORTED;
-    }
-#undef NPLDA_LAUNCH
-    return nplda_launch_status();
-}
+using namespace nplda;
 
 }  // namespace
 
@@ -303,7 +24,7 @@ const char* nplda_strerror(int code) {
 int nplda_padded_dim(int D1, int D2) { return 16 * nplda_kernel_nb(D1, D2); }
 
 size_t nplda_packed_bytes(int D0, int D1, int D2) {
-    if (!nplda_dims_ok(D0, D1, D2)) return 0;
+    if (check_model(D0, D1, D2) != NPLDA_OK) return 0;
     return nplda_layout(D0, D1, D2).total * sizeof(float);
 }
 
@@ -311,8 +32,7 @@ int nplda_pack_params_f32(const float* W1, const float* b1, const float* W2, con
                           const float* P_sqrt, const float* Q, int D0, int D1, int D2, void* packed,
                           size_t packed_bytes, nplda_stream_t stream) {
     if (!W1 || !b1 || !W2 || !b2 || !P_sqrt || !Q || !packed) return NPLDA_EINVAL;
-    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
-    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    if (int rc = check_model(D0, D1, D2)) return rc;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
     if (packed_bytes < L.total * sizeof(float)) return NPLDA_ENOSPC;
     if (!nplda_aligned16(packed)) return NPLDA_EINVAL;
@@ -325,30 +45,28 @@ int nplda_pack_params_f32(const float* W1, const float* b1, const float* W2, con
 int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
                           int D0, int D1, int D2, float* s, nplda_stream_t stream) {
     if (B < 0) return NPLDA_EINVAL;
-    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
-    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    if (int rc = check_model(D0, D1, D2)) return rc;
     if (B == 0) return NPLDA_OK;
-    if (!x1 || !x2 || !packed || !s) return NPLDA_EINVAL;
-    if (ldx < D0 || (ldx % 4) != 0 || !nplda_aligned16(x1) || !nplda_aligned16(x2) ||
-        !nplda_aligned16(packed))
-        return NPLDA_EINVAL;
+    if (!packed || !s || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
-    return launch_fwd<MODE_PAIR>(x1, x2, B, ldx, (const float*)packed, L, s, nullptr, 0, nullptr,
-                                 (hipStream_t)stream);
+    FwdArgs a = {};
+    a.xa = x1; a.xb = x2; a.n = B; a.ldx = ldx; a.packed = (const float*)packed; a.out_s = s;
+    return launch_fwd<MODE_PAIR>(a, L, (hipStream_t)stream);
 }
 
 int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
                     float* z, int64_t ldz, float* q, nplda_stream_t stream) {
     if (N < 0) return NPLDA_EINVAL;
-    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
-    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    if (int rc = check_model(D0, D1, D2)) return rc;
     if (N == 0) return NPLDA_OK;
-    if (!x || !packed || !z) return NPLDA_EINVAL;
+    if (!packed || !nplda_aligned16(packed) || !rows_ok(x, ldx, D0)) return NPLDA_EINVAL;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
-    if (ldx < D0 || (ldx % 4) != 0 || !nplda_aligned16(x) || !nplda_aligned16(packed)) return NPLDA_EINVAL;
-    if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z)) return NPLDA_EINVAL;
-    return launch_fwd<MODE_EMBED>(x, x, N, ldx, (const float*)packed, L, nullptr, z, ldz, q,
-                                  (hipStream_t)stream);
+    if (!rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
+    FwdArgs a = {};
+    a.xa = x; a.xb = x; a.n = N; a.ldx = ldx; a.packed = (const float*)packed;
+    a.out_z = z; a.ldz = ldz; a.out_q = q;
+    return launch_fwd<MODE_EMBED>(a, L, (hipStream_t)stream);
 }
 
 }  // extern "C"

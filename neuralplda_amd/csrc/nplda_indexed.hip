@@ -1,0 +1,153 @@
+// nplda_indexed.hip — the HBM/L2-bound half of the scoring path (gfx950): gather + diagonal score.
+//
+//  * nplda_gather_rows_f32     replaces the per-pair Python dict look-ups of
+//                              utils/sv_trials_loaders.py:418-426 / :429-437 (1.8e4 pairs/s on the host)
+//                              by a device index-select from a resident (N_utt, D0) x-vector matrix.
+//  * nplda_score_indexed_f32   utils/models.py:372-376 on rows gathered from a pre-embedded table:
+//                              s = q[i1] + q[i2] + 2 sum_d P_d z[i1,d] z[i2,d]   (q from nplda_embed_f32)
+//                              Algorithmic bytes/pair = 2*4*D2 + 2*4 + 2*8 + 4 (1 228 B at D2 = 150).
+//  * nplda_score_embeddings_f32  the same formula on two explicit (B, D2) tensors
+//                              (NeuralPlda.forward_from_plda_embeddings).
+// These are pure streaming kernels: float4 row loads, 8 lanes per pair (128 B contiguous per load),
+// three DPP/shuffle adds per pair, nothing staged through LDS (there is no reuse to exploit).
+#include "nplda_common.h"
+
+namespace {
+
+constexpr int kThreads = 256;
+constexpr int kLPP = 8;  // lanes per pair
+
+__device__ __forceinline__ float group8_sum(float v) {
+    v += __shfl_xor(v, 1, 64);
+    v += __shfl_xor(v, 2, 64);
+    v += __shfl_xor(v, 4, 64);
+    return v;
+}
+
+__global__ __launch_bounds__(kThreads) void score_indexed_kernel(const float* __restrict__ z, long long ldz,
+                                                                 const float* __restrict__ q, long long N,
+                                                                 const long long* __restrict__ i1,
+                                                                 const long long* __restrict__ i2, long long B,
+                                                                 const float* __restrict__ P, int ncol4,
+                                                                 float* __restrict__ s) {
+    const int sub = threadIdx.x & (kLPP - 1);
+    const long long stride = (long long)gridDim.x * (kThreads / kLPP);
+    for (long long p = (long long)blockIdx.x * (kThreads / kLPP) + threadIdx.x / kLPP; p < B; p += stride) {
+        const long long a = i1[p], b = i2[p];
+        const bool ok = a >= 0 && a < N && b >= 0 && b < N;
+        float acc = 0.f;
+        if (ok) {
+            const f32x4* za = reinterpret_cast<const f32x4*>(z + a * ldz);
+            const f32x4* zb = reinterpret_cast<const f32x4*>(z + b * ldz);
+            const f32x4* P4 = reinterpret_cast<const f32x4*>(P);
+            for (int c = sub; c < ncol4; c += kLPP) {
+                const f32x4 va = za[c], vb = zb[c], pp = P4[c];
+                acc = fmaf(pp[0] * va[0], vb[0], acc);
+                acc = fmaf(pp[1] * va[1], vb[1], acc);
+                acc = fmaf(pp[2] * va[2], vb[2], acc);
+                acc = fmaf(pp[3] * va[3], vb[3], acc);
+            }
+        }
+        acc = group8_sum(acc);
+        if (sub == 0) s[p] = ok ? q[a] + q[b] + 2.0f * acc : __builtin_nanf("");
+    }
+}
+
+// 16 lanes per pair, scalar (any-stride, any-alignment) loads.
+__global__ __launch_bounds__(kThreads) void score_embeddings_kernel(const float* __restrict__ z1, long long ld1,
+                                                                    const float* __restrict__ z2, long long ld2,
+                                                                    long long B, int D2,
+                                                                    const float* __restrict__ P_sqrt,
+                                                                    const float* __restrict__ Q,
+                                                                    float* __restrict__ s) {
+    const int sub = threadIdx.x & 15;
+    const long long stride = (long long)gridDim.x * (kThreads / 16);
+    for (long long p = (long long)blockIdx.x * (kThreads / 16) + threadIdx.x / 16; p < B; p += stride) {
+        const float* a = z1 + p * ld1;
+        const float* b = z2 + p * ld2;
+        float acc = 0.f;
+        for (int d = sub; d < D2; d += 16) {
+            const float va = a[d], vb = b[d], ps = P_sqrt[d];
+            acc = fmaf(Q[d], fmaf(va, va, vb * vb), acc);
+            acc = fmaf(2.0f * ps * ps, va * vb, acc);
+        }
+        acc += __shfl_xor(acc, 1, 64);
+        acc += __shfl_xor(acc, 2, 64);
+        acc += __shfl_xor(acc, 4, 64);
+        acc += __shfl_xor(acc, 8, 64);
+        if (sub == 0) s[p] = acc;
+    }
+}
+
+// One wave per gathered row: D0/4 float4 per row, lanes stride the row.
+__global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __restrict__ table, long long ldt,
+                                                               long long N, const long long* __restrict__ idx,
+                                                               long long B, int ncol4, float* __restrict__ out,
+                                                               long long ldo) {
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * (kThreads / 64);
+    for (long long r = (long long)blockIdx.x * (kThreads / 64) + threadIdx.x / 64; r < B; r += stride) {
+        const long long i = idx[r];
+        const bool ok = i >= 0 && i < N;
+        const f32x4* src = reinterpret_cast<const f32x4*>(table + (ok ? i : 0) * ldt);
+        f32x4* dst = reinterpret_cast<f32x4*>(out + r * ldo);
+        for (int c = lane; c < ncol4; c += 64) {
+            f32x4 v = src[c];
+            if (!ok) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            __builtin_nontemporal_store(v, dst + c);
+        }
+    }
+}
+
+unsigned grid_for(long long items, int per_block) {
+    long long b = (items + per_block - 1) / per_block;
+    if (b < 1) b = 1;
+    if (b > 256 * 32) b = 256 * 32;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nplda_score_indexed_f32(const float* z, int64_t ldz, const float* q, int64_t N, const int64_t* i1,
+                            const int64_t* i2, int64_t B, const void* packed, int D0, int D1, int D2, float* s,
+                            nplda_stream_t stream) {
+    if (B < 0 || N < 0) return NPLDA_EINVAL;
+    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
+    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    if (B == 0) return NPLDA_OK;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!z || !q || !i1 || !i2 || !packed || !s) return NPLDA_EINVAL;
+    if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z) || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    const float* P = (const float*)packed + L.oP;
+    hipLaunchKernelGGL(score_indexed_kernel, dim3(grid_for(B, kThreads / kLPP)), dim3(kThreads), 0,
+                       (hipStream_t)stream, z, (long long)ldz, q, (long long)N, (const long long*)i1,
+                       (const long long*)i2, (long long)B, P, (D2 + 3) / 4, s);
+    return nplda_launch_status();
+}
+
+int nplda_score_embeddings_f32(const float* z1, int64_t ld1, const float* z2, int64_t ld2, int64_t B, int D2,
+                               const float* P_sqrt, const float* Q, float* s, nplda_stream_t stream) {
+    if (B < 0 || D2 <= 0) return NPLDA_EINVAL;
+    if (B == 0) return NPLDA_OK;
+    if (!z1 || !z2 || !P_sqrt || !Q || !s || ld1 < D2 || ld2 < D2) return NPLDA_EINVAL;
+    hipLaunchKernelGGL(score_embeddings_kernel, dim3(grid_for(B, kThreads / 16)), dim3(kThreads), 0,
+                       (hipStream_t)stream, z1, (long long)ld1, z2, (long long)ld2, (long long)B, D2, P_sqrt, Q, s);
+    return nplda_launch_status();
+}
+
+int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int64_t* idx, int64_t B, int D0,
+                          float* out, int64_t ldo, nplda_stream_t stream) {
+    if (B < 0 || N < 0 || D0 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
+    if (B == 0) return NPLDA_OK;
+    if (!table || !idx || !out || N == 0) return NPLDA_EINVAL;
+    if (ldt < D0 || ldo < D0 || (ldt % 4) != 0 || (ldo % 4) != 0 || !nplda_aligned16(table) || !nplda_aligned16(out))
+        return NPLDA_EINVAL;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream,
+                       table, (long long)ldt, (long long)N, (const long long*)idx, (long long)B, D0 / 4, out,
+                       (long long)ldo);
+    return nplda_launch_status();
+}
+
+}  // extern "C"

@@ -1,0 +1,259 @@
+// nplda_loss.hip — SoftCdet / BCE losses with their hand-derived backward (gfx950).
+//
+// Replaces utils/models.py:384-399 (softcdet, crossentropy, loss) and the autograd graph behind
+// them (~40 tiny launches forward, ~60 backward) by two launches:
+//   1. nplda_loss_sums_f32   : one pass over (s, t) accumulating every batch-global sum the loss
+//                              and its gradient need, in fp64, into a small device vector
+//      sums = [N_t, N_n, {S_miss_k, S_fa_k, D_t_k, D_n_k} for k < K]          (SoftCdet)
+//      sums = [N_t, N_n, sum of BCE terms, sum (p - t)]                        (BCE)
+//      Every entry is ADDITIVE over shards of the batch, so under data parallelism this vector
+//      (<= 18 doubles) is what gets all-reduced — the counts N_t, N_n are batch-global in the
+//      reference's formula (utils/models.py:386).
+//   2. nplda_loss_finish_f32 : loss, dL/dtheta_k and g_i = dL/ds_i from the (global) sums.
+// sigma'(v) is evaluated as e/(1+e)^2, e = exp(-|v|) (no 1 - sigma cancellation: the reference's
+// fp32 autograd loses ~1e-3 relative accuracy there, see tests/test_oracle_golden.py).
+#include "nplda_common.h"
+
+namespace {
+
+constexpr int kMaxK = 4;
+constexpr int kThreads = 256;
+
+struct ThetaPtrs { const float* p[kMaxK]; };
+
+__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
+
+__device__ __forceinline__ double wave_sum_d(double v) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    return v;
+}
+
+template <int NS>
+__device__ __forceinline__ void block_reduce_add(double (&acc)[NS], double* out) {
+    __shared__ double red[kThreads / 64][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double v = wave_sum_d(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+        atomicAdd(out + threadIdx.x, v);
+    }
+}
+
+// kind 0 = SoftCdet, 1 = BCE, 2 = hard Cdet (utils/models.py:401-404: step functions, strict < / >)
+template <int K, bool HARD>
+__global__ __launch_bounds__(kThreads) void loss_sums_softcdet(const float* __restrict__ s,
+                                                               const float* __restrict__ t, long long B,
+                                                               ThetaPtrs th, float alpha, double* sums) {
+    constexpr int NS = 2 + 4 * K;
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+    float theta[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
+        const float si = s[i], ti = t[i], ni = 1.0f - ti;
+        acc[0] += ti;
+        acc[1] += ni;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            float sm, sf, d;
+            if (HARD) {
+                sm = si < theta[k] ? 1.0f : 0.0f;
+                sf = si > theta[k] ? 1.0f : 0.0f;
+                d = 0.0f;
+            } else {
+                const float v = alpha * (theta[k] - si);
+                const float e = __expf(-fabsf(v));
+                const float inv = 1.0f / (1.0f + e);
+                const float sg_pos = inv;        // sigma(|v|)
+                const float sg_neg = e * inv;    // sigma(-|v|)
+                sm = v >= 0.f ? sg_pos : sg_neg;  // sigma(alpha (theta - s))   (miss)
+                sf = v >= 0.f ? sg_neg : sg_pos;  // sigma(alpha (s - theta))   (false alarm)
+                d = e * inv * inv;                // sigma'(v)
+            }
+            acc[2 + 4 * k + 0] += sm * ti;
+            acc[2 + 4 * k + 1] += sf * ni;
+            acc[2 + 4 * k + 2] += d * ti;
+            acc[2 + 4 * k + 3] += d * ni;
+        }
+    }
+    block_reduce_add<NS>(acc, sums);
+}
+
+__global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restrict__ s, const float* __restrict__ t,
+                                                          long long B, ThetaPtrs th, double* sums) {
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float theta = th.p[0][0];
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
+        const float si = s[i], ti = t[i];
+        // F.binary_cross_entropy(sigmoid(s - theta), t): log terms clamped at -100 (utils/models.py:390-393)
+        const float p = 1.0f / (1.0f + expf(-(si - theta)));
+        const float lp = fmaxf(logf(p), -100.0f);
+        const float lq = fmaxf(logf(1.0f - p), -100.0f);
+        acc[0] += ti;
+        acc[1] += 1.0f - ti;
+        acc[2] += -(ti * lp + (1.0f - ti) * lq);
+        acc[3] += p - ti;
+    }
+    block_reduce_add<4>(acc, sums);
+}
+
+struct BetaVals { float b[kMaxK]; };
+
+template <int K>
+__global__ __launch_bounds__(kThreads) void loss_finish_softcdet(const float* __restrict__ s,
+                                                                 const float* __restrict__ t, long long B,
+                                                                 ThetaPtrs th, BetaVals beta, float alpha,
+                                                                 const double* __restrict__ sums, float* loss,
+                                                                 float* __restrict__ g, float* dtheta) {
+    const double Nt = sums[0], Nn = sums[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        double L = 0.0;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            L += sums[2 + 4 * k] / Nt + (double)beta.b[k] * sums[2 + 4 * k + 1] / Nn;
+            if (dtheta)
+                dtheta[k] = (float)(((double)alpha * sums[2 + 4 * k + 2] / Nt -
+                                     (double)beta.b[k] * alpha * sums[2 + 4 * k + 3] / Nn) / K);
+        }
+        if (loss) loss[0] = (float)(L / K);
+    }
+    if (g == nullptr) return;
+    float theta[K], cn[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        theta[k] = th.p[k][0];
+        cn[k] = (float)((double)beta.b[k] * alpha / (Nn * K));
+    }
+    const float ct = (float)(-(double)alpha / (Nt * K));
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
+        const float si = s[i], ti = t[i], ni = 1.0f - ti;
+        float gi = 0.f;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float v = alpha * (theta[k] - si);
+            const float e = __expf(-fabsf(v));
+            const float inv = 1.0f / (1.0f + e);
+            const float d = e * inv * inv;
+            gi += d * (ct * ti + cn[k] * ni);
+        }
+        g[i] = gi;
+    }
+}
+
+__global__ __launch_bounds__(kThreads) void loss_finish_bce(const float* __restrict__ s, const float* __restrict__ t,
+                                                            long long B, ThetaPtrs th,
+                                                            const double* __restrict__ sums, float* loss,
+                                                            float* __restrict__ g, float* dtheta) {
+    const double N = sums[0] + sums[1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (loss) loss[0] = (float)(sums[2] / N);
+        if (dtheta) dtheta[0] = (float)(-sums[3] / N);
+    }
+    if (g == nullptr) return;
+    const float theta = th.p[0][0];
+    const float invN = (float)(1.0 / N);
+    const long long stride = (long long)gridDim.x * kThreads;
+    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
+        const float p = 1.0f / (1.0f + expf(-(s[i] - theta)));
+        g[i] = (p - t[i]) * invN;
+    }
+}
+
+unsigned grid_for(long long B) {
+    long long b = (B + kThreads - 1) / kThreads;
+    if (b < 1) b = 1;
+    if (b > 1024) b = 1024;
+    return (unsigned)b;
+}
+
+}  // namespace
+
+extern "C" {
+
+int nplda_loss_nsums(int K, int kind) {
+    if (kind == 1) return 4;
+    if ((kind != 0 && kind != 2) || K < 1 || K > kMaxK) return 0;
+    return 2 + 4 * K;
+}
+
+int nplda_loss_sums_f32(const float* s, const float* t, int64_t B, const float* const* theta, int K, float alpha,
+                        int kind, double* sums, nplda_stream_t stream) {
+    const int ns = nplda_loss_nsums(K, kind);
+    if (ns == 0) return (kind >= 0 && kind <= 2) ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
+    if (B < 0 || !sums || !theta) return NPLDA_EINVAL;
+    if (B > 0 && (!s || !t)) return NPLDA_EINVAL;
+    ThetaPtrs th = {};
+    for (int k = 0; k < (kind == 1 ? 1 : K); ++k) {
+        if (!theta[k]) return NPLDA_EINVAL;
+        th.p[k] = theta[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * ns, st);
+    if (e != hipSuccess) return (int)e;
+    if (B == 0) return NPLDA_OK;
+    const dim3 grid(grid_for(B)), block(kThreads);
+    if (kind == 1) {
+        hipLaunchKernelGGL(loss_sums_bce, grid, block, 0, st, s, t, (long long)B, th, sums);
+    } else if (kind == 2) {
+        switch (K) {
+            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            default: hipLaunchKernelGGL((loss_sums_softcdet<4, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+        }
+    } else {
+        switch (K) {
+            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            default: hipLaunchKernelGGL((loss_sums_softcdet<4, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+        }
+    }
+    return nplda_launch_status();
+}
+
+int nplda_loss_finish_f32(const float* s, const float* t, int64_t B, const float* const* theta, const float* beta,
+                          int K, float alpha, int kind, const double* sums, float* loss, float* g, float* dtheta,
+                          nplda_stream_t stream) {
+    const int ns = nplda_loss_nsums(K, kind);
+    if (ns == 0) return (kind >= 0 && kind <= 2) ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
+    if (B < 0 || !sums || !theta) return NPLDA_EINVAL;
+    if (B > 0 && g && (!s || !t)) return NPLDA_EINVAL;
+    if (kind != 1 && !beta) return NPLDA_EINVAL;
+    if (kind == 2 && (g || dtheta)) return NPLDA_EINVAL;  // the hard cost has no gradient
+    ThetaPtrs th = {};
+    BetaVals bv = {};
+    for (int k = 0; k < (kind == 1 ? 1 : K); ++k) {
+        if (!theta[k]) return NPLDA_EINVAL;
+        th.p[k] = theta[k];
+        if (kind != 1) bv.b[k] = beta[k];  // beta is a HOST array (config constants, utils/NpldaConf.py:38)
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(g ? grid_for(B) : 1), block(kThreads);
+    if (kind == 1) {
+        hipLaunchKernelGGL(loss_finish_bce, grid, block, 0, st, s, t, (long long)B, th, sums, loss, g, dtheta);
+    } else {
+        switch (K) {
+            case 1: hipLaunchKernelGGL(loss_finish_softcdet<1>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            case 2: hipLaunchKernelGGL(loss_finish_softcdet<2>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            case 3: hipLaunchKernelGGL(loss_finish_softcdet<3>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            default: hipLaunchKernelGGL(loss_finish_softcdet<4>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+        }
+    }
+    return nplda_launch_status();
+}
+
+}  // extern "C"

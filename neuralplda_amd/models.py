@@ -1,0 +1,333 @@
+"""Host-side mirror of the reference's model classes for the hot path (utils/models.py).
+
+`NeuralPlda` and `GaussianBackend` keep the reference's constructor, method names, state-dict keys
+and instance attributes (utils/models.py:348-461, :571-665) so the training / scoring scripts
+(xvector_NeuralPlda_pytorch.py, xvector_generate_scores.py) run unchanged — but every piece of
+arithmetic on the path is a hand-written HIP kernel reached through the C ABI
+(include/nplda_hip.h).  There is NO CPU implementation in this module: CPU tensors are staged
+through the HIP device (the score file generators of the reference hand CPU tensors to forward(),
+utils/scorefile_generator.py:25-34), and if no HIP device / library is present every compute
+method raises.
+"""
+import pickle
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import _lib, kaldi_format, ops
+
+__all__ = ["NeuralPlda", "GaussianBackend", "arr2val"]
+
+
+def arr2val(x, retidx):
+    """utils/models.py:23-27 (kept for scripts that import it)."""
+    if x.size()[0] > 0:
+        return x[retidx].cpu().item()
+    return 1.
+
+
+def _compute_device(*tensors):
+    """Device the kernels run on: the first HIP tensor's device, else the current HIP device."""
+    for t in tensors:
+        if isinstance(t, torch.Tensor) and t.is_cuda:
+            return t.device
+    if not torch.cuda.is_available():
+        raise _lib.NpldaHipError(
+            "neuralplda_amd needs a HIP device: the NPLDA hot path has no CPU implementation "
+            "(the CPU oracle under oracle/ is test infrastructure only)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _to_dev(t, dev):
+    t = t.detach() if t.requires_grad else t
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t if t.device == dev else t.to(dev, non_blocking=True)
+
+
+def _loss_kind(name):
+    if isinstance(name, str):
+        if name.lower() == "softcdet":  # the shipped configs spell it both 'SoftCdet' and 'softCdet'
+            return ops.LOSS_SOFTCDET
+        if name.lower() in ("crossentropy", "bce"):
+            return ops.LOSS_BCE
+    raise ValueError(f"unknown loss {name!r}: expected 'SoftCdet' or 'crossentropy' (utils/models.py:395-399)")
+
+
+# ---------------------------------------------------------------------------------------------------
+# autograd bridges
+# ---------------------------------------------------------------------------------------------------
+
+class _PairScoreFn(torch.autograd.Function):
+    """s = NeuralPlda.forward(x1, x2) with the hand-derived backward."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W1, b1, W2, b2, P_sqrt, Q):
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
+            raise NotImplementedError("gradients w.r.t. the x-vectors are outside the NPLDA hot path")
+        dev = _compute_device(x1, W1)
+        prm = [_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)]
+        packed = ops.pack_params(*prm)
+        X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
+        need = any(ctx.needs_input_grad[2:])  # Function.forward runs with grad mode off: ask the ctx
+        ctx.need = need
+        if need:
+            s, saved = ops.forward_train(X1, X2, packed)
+            ctx.saved = saved
+            ctx.packed = packed
+            ctx.ps = prm[4]
+            ctx.pdev = [t.device for t in (W1, b1, W2, b2, P_sqrt, Q)]
+        else:
+            s = ops.score_pairs(X1, X2, packed)
+        return s if s.device == x1.device else s.to(x1.device)
+
+    @staticmethod
+    def backward(ctx, gs):
+        if not ctx.need:
+            return (None,) * 8
+        dev = ctx.packed.device
+        flat = ops.backward(ctx.saved, _to_dev(gs, dev), ctx.packed, ctx.ps)
+        grads = ops.split_flat_grad(flat, ctx.packed.D0, ctx.packed.D1, ctx.packed.D2)
+        grads = [g if g.device == d else g.to(d) for g, d in zip(grads, ctx.pdev)]
+        ctx.saved = None
+        return (None, None) + tuple(grads)
+
+
+class _EmbedFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, W1, b1, W2, b2, P_sqrt, Q):
+        dev = _compute_device(x, W1)
+        packed = ops.pack_params(*[_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)])
+        z, _ = ops.embed(_to_dev(x, dev), packed, want_q=False)
+        z = z[:, :packed.D2]
+        return z if z.device == x.device else z.to(x.device)
+
+    @staticmethod
+    def backward(ctx, gz):
+        raise NotImplementedError(
+            "backward through extract_plda_embeddings alone is not part of the hot path; "
+            "train through NeuralPlda.forward(x1, x2)")
+
+
+class _EmbScoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z1, z2, P_sqrt, Q):
+        dev = _compute_device(z1, Q)
+        s = ops.score_embeddings(_to_dev(z1, dev), _to_dev(z2, dev), _to_dev(P_sqrt, dev), _to_dev(Q, dev))
+        return s if s.device == z1.device else s.to(z1.device)
+
+    @staticmethod
+    def backward(ctx, gs):
+        raise NotImplementedError(
+            "backward through forward_from_plda_embeddings alone is not part of the hot path; "
+            "train through NeuralPlda.forward(x1, x2)")
+
+
+class _LossFn(torch.autograd.Function):
+    """SoftCdet / BCE with the fused forward+backward kernels.  `reduce_sums` (optional callable)
+    all-reduces the fp64 batch sums across data-parallel ranks before the gradient is formed."""
+
+    @staticmethod
+    def forward(ctx, output, target, kind, alpha, betas, reduce_sums, *thetas):
+        dev = _compute_device(output, target)
+        s, t = _to_dev(output, dev), _to_dev(target, dev)
+        ths = [_to_dev(th, dev) for th in thetas]
+        sums = ops.loss_sums(s, t, ths, alpha, kind)
+        if reduce_sums is not None:
+            sums = reduce_sums(sums)
+        need = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[6:])
+        loss, g, dth = ops.loss_finish(s, t, ths, betas, alpha, kind, sums, want_grad=need)
+        ctx.need = need
+        ctx.nth = len(thetas)
+        if need:
+            ctx.g, ctx.dth = g, dth
+            ctx.odev = output.device
+            ctx.tdev = [th.device for th in thetas]
+        return loss if loss.device == output.device else loss.to(output.device)
+
+    @staticmethod
+    def backward(ctx, gl):
+        if not ctx.need:
+            return (None,) * (6 + ctx.nth)
+        dev = ctx.g.device
+        gl = gl.to(dev)
+        g = ctx.g * gl
+        dths = []
+        for k, d in enumerate(ctx.tdev):
+            v = (ctx.dth[k:k + 1] * gl)
+            dths.append(v if v.device == d else v.to(d))
+        g = g if g.device == ctx.odev else g.to(ctx.odev)
+        return (g, None, None, None, None, None) + tuple(dths)
+
+
+# ---------------------------------------------------------------------------------------------------
+# NeuralPlda
+# ---------------------------------------------------------------------------------------------------
+
+class NeuralPlda(nn.Module):
+    """Drop-in for utils/models.py:348-461.  `nc` is any object with the NpldaConf fields the reference
+    constructor reads (xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim, beta, alpha, device, loss)."""
+
+    def __init__(self, nc):
+        super(NeuralPlda, self).__init__()
+        self.centering_and_LDA = nn.Linear(nc.xvector_dim, nc.layer1_LDA_dim)  # Centering, wccn
+        self.centering_and_wccn_plda = nn.Linear(nc.layer1_LDA_dim, nc.layer2_PLDA_spkfactor_dim)
+        self.P_sqrt = nn.Parameter(torch.rand(nc.layer2_PLDA_spkfactor_dim, requires_grad=True))
+        self.Q = nn.Parameter(torch.rand(nc.layer2_PLDA_spkfactor_dim, requires_grad=True))
+        self.threshold = {}
+        for beta in nc.beta:
+            self.threshold[beta] = nn.Parameter(0 * torch.rand(1, requires_grad=True))
+            self.register_parameter("Th{}".format(int(beta)), self.threshold[beta])
+        self.threshold_Xent = nn.Parameter(0 * torch.rand(1, requires_grad=True))
+        # the reference keeps alpha as a plain tensor attribute (does not follow .to()); only its value is used here
+        self.alpha = torch.tensor(float(nc.alpha))
+        self.beta = nc.beta
+        self.dropout = nn.Dropout(p=0.5)  # defined and never used by the reference (utils/models.py:362)
+        self.lossfn = nc.loss
+        self._reduce_sums = None  # set by neuralplda_amd.dist.make_data_parallel()
+
+    # -- pickles written by the reference (class path utils.models.NeuralPlda) lack our private attributes
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        self.__dict__.setdefault("_reduce_sums", None)
+
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        state["_reduce_sums"] = None  # process-group closures do not pickle
+        return state
+
+    def _params(self):
+        return (self.centering_and_LDA.weight, self.centering_and_LDA.bias, self.centering_and_wccn_plda.weight,
+                self.centering_and_wccn_plda.bias, self.P_sqrt, self.Q)
+
+    def extract_plda_embeddings(self, x):
+        """utils/models.py:366-370 -> (B, D2)."""
+        x = x.reshape(-1, self.centering_and_LDA.in_features) if x.dim() != 2 else x
+        return _EmbedFn.apply(x, *self._params())
+
+    def forward_from_plda_embeddings(self, x1, x2):
+        """utils/models.py:372-376."""
+        return _EmbScoreFn.apply(x1, x2, self.P_sqrt, self.Q)
+
+    def forward(self, x1, x2):
+        """utils/models.py:378-382: (B, D0), (B, D0) -> (B,).  B == 0 returns an empty tensor (the
+        reference crashes there, utils/scorefile_generator.py:29-33)."""
+        D0 = self.centering_and_LDA.in_features
+        if x1.numel() == 0 and x2.numel() == 0:
+            x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
+        return _PairScoreFn.apply(x1, x2, *self._params())
+
+    # -- losses ----------------------------------------------------------------------------------
+    def _alpha(self):
+        return float(self.alpha.item()) if isinstance(self.alpha, torch.Tensor) else float(self.alpha)
+
+    def softcdet(self, output, target):
+        """utils/models.py:384-388."""
+        thetas = [self.threshold[b] for b in self.beta]
+        return _LossFn.apply(output, target, ops.LOSS_SOFTCDET, self._alpha(), [float(b) for b in self.beta],
+                             self._reduce_sums, *thetas)
+
+    def crossentropy(self, output, target):
+        """utils/models.py:390-393."""
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, self.threshold_Xent)
+
+    def loss(self, output, target):
+        """utils/models.py:395-399; accepts the config spelling 'softCdet' as well (conf/voices_config.cfg:25
+        makes the reference return None and crash)."""
+        if _loss_kind(self.lossfn) == ops.LOSS_SOFTCDET:
+            return self.softcdet(output, target)
+        return self.crossentropy(output, target)
+
+    def cdet(self, output, target):
+        """utils/models.py:401-404: hard detection cost at the model thresholds (strict < / >)."""
+        dev = _compute_device(output, target)
+        s, t = _to_dev(output, dev), _to_dev(target, dev)
+        ths = [_to_dev(self.threshold[b], dev) for b in self.beta]
+        sums = ops.loss_sums(s, t, ths, 0.0, ops.LOSS_HARD_CDET)
+        loss, _, _ = ops.loss_finish(s, t, ths, [float(b) for b in self.beta], 0.0, ops.LOSS_HARD_CDET, sums,
+                                     want_grad=False)
+        return loss if loss.device == output.device else loss.to(output.device)
+
+    def minc(self, output, target, update_thresholds=False, showplots=False, exact=False):
+        """utils/models.py:406-436.  Default: the reference's semantics bit for bit (thresholds at target
+        scores only, `arr2val` count-1 / 1.0-when-empty quirks), evaluated by a device sort + binary
+        searches instead of the O(N_tgt * N) Python loop.  exact=True: true minimum over all thresholds."""
+        from . import metrics
+        minc_avg, minc_threshold = metrics.minc(output, target, self.beta, reference_semantics=not exact)
+        if update_thresholds:
+            for beta in self.beta:
+                self.state_dict()["Th{}".format(int(beta))].data.copy_(minc_threshold[beta])
+        return minc_avg, minc_threshold
+
+    # -- initialisation / persistence ---------------------------------------------------------------
+    def LoadPldaParamsFromKaldi(self, mean_vec_file, transform_mat_file, PldaFile):
+        """utils/models.py:441-457, reading the Kaldi files natively (no Kaldi binaries needed)."""
+        plda = kaldi_format.read_plda(PldaFile)
+        transform_mat = kaldi_format.read_matrix(transform_mat_file)
+        mean_vec = kaldi_format.read_vector(mean_vec_file)
+        mdsd = self.state_dict()
+        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
+        mdsd['centering_and_LDA.bias'].data.copy_(
+            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
+        mdsd['centering_and_wccn_plda.weight'].data.copy_(torch.from_numpy(plda['diagonalizing_transform']).float())
+        mdsd['centering_and_wccn_plda.bias'].data.copy_(
+            torch.from_numpy(-plda['diagonalizing_transform'].dot(plda['plda_mean'])).float())
+        mdsd['P_sqrt'].data.copy_(torch.from_numpy(np.sqrt(plda['diagP'])).float())
+        mdsd['Q'].data.copy_(torch.from_numpy(plda['diagQ']).float())
+
+    def SaveModel(self, filename):
+        """utils/models.py:459-461: pickle of the whole module."""
+        with open(filename, 'wb') as f:
+            pickle.dump(self, f)
+
+
+# ---------------------------------------------------------------------------------------------------
+# GaussianBackend (forward only is usable in the reference)
+# ---------------------------------------------------------------------------------------------------
+
+class GaussianBackend(nn.Module):
+    """Drop-in for utils/models.py:571-665 (constructor, forward, forward_getpaired, Kaldi LDA loading)."""
+
+    def __init__(self, nc):
+        super(GaussianBackend, self).__init__()
+        self.centering_and_LDA = nn.Linear(nc.xvector_dim, nc.layer1_LDA_dim)
+        self.centering_and_LDA.weight.requires_grad = False
+        self.centering_and_LDA.bias.requires_grad = False
+        self.paired_mean_target = torch.rand(2 * nc.layer1_LDA_dim)
+        self.paired_cov_inv_target = torch.rand(2 * nc.layer1_LDA_dim, 2 * nc.layer1_LDA_dim)
+        self.paired_mean_nontarget = torch.rand(2 * nc.layer1_LDA_dim)
+        self.paired_cov_inv_nontarget = torch.rand(2 * nc.layer1_LDA_dim, 2 * nc.layer1_LDA_dim)
+
+    def _stats(self, dev):
+        return [_to_dev(t, dev) for t in (self.paired_mean_target, self.paired_cov_inv_target,
+                                          self.paired_mean_nontarget, self.paired_cov_inv_nontarget)]
+
+    def forward(self, x1, x2):
+        """utils/models.py:584-593."""
+        dev = _compute_device(x1, self.centering_and_LDA.weight)
+        W1, b1 = _to_dev(self.centering_and_LDA.weight, dev), _to_dev(self.centering_and_LDA.bias, dev)
+        with torch.no_grad():
+            s = ops.gb_score_pairs(_to_dev(x1, dev), _to_dev(x2, dev), W1, b1, *self._stats(dev))
+        return s if s.device == x1.device else s.to(x1.device)
+
+    def forward_getpaired(self, x1, x2):
+        """utils/models.py:595-601: [normalize(LDA x1), normalize(LDA x2)] -> (B, 2 D1)."""
+        dev = _compute_device(x1, self.centering_and_LDA.weight)
+        W1, b1 = _to_dev(self.centering_and_LDA.weight, dev), _to_dev(self.centering_and_LDA.bias, dev)
+        with torch.no_grad():
+            x = ops.gb_paired(_to_dev(x1, dev), _to_dev(x2, dev), W1, b1)
+        return x if x.device == x1.device else x.to(x1.device)
+
+    def LoadPldaParamsFromKaldi(self, mean_vec_file, transform_mat_file):
+        """utils/models.py:653-658."""
+        transform_mat = kaldi_format.read_matrix(transform_mat_file)
+        mean_vec = kaldi_format.read_vector(mean_vec_file)
+        mdsd = self.state_dict()
+        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
+        mdsd['centering_and_LDA.bias'].data.copy_(
+            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
+
+    def SaveModel(self, filename):
+        with open(filename, 'wb') as f:
+            pickle.dump(self, f)

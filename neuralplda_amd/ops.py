@@ -106,3 +106,196 @@ def embed(x, packed, want_q=True):
                                    _lib.ptr(z), packed.ldz, _lib.ptr(q), _lib.current_stream())
     _lib.check(code, "nplda_embed_f32")
     return z, q
+
+
+# ---- training ---------------------------------------------------------------------------------
+
+LOSS_SOFTCDET, LOSS_BCE, LOSS_HARD_CDET = 0, 1, 2
+
+
+def forward_train(x1, x2, packed):
+    """nplda_forward_train_f32: scores plus the activations the backward needs.
+    Returns (s, saved) with saved = (x1, x2, ld, y, z, rn) device tensors."""
+    lib = _lib.load()
+    x1, ld1 = _rows(x1, "x1", packed.D0)
+    x2, ld2 = _rows(x2, "x2", packed.D0)
+    if x1.shape[0] != x2.shape[0]:
+        raise ValueError("x1 and x2 must have the same number of rows")
+    if ld1 != ld2:
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ld1 = ld2 = packed.D0
+    B = x1.shape[0]
+    dev = x1.device
+    s = torch.empty(B, dtype=torch.float32, device=dev)
+    y = torch.empty((2 * B, packed.ldz), dtype=torch.float32, device=dev)
+    z = torch.empty((2 * B, packed.ldz), dtype=torch.float32, device=dev)
+    rn = torch.empty(2 * B, dtype=torch.float32, device=dev)
+    if B > 0:
+        with torch.cuda.device(dev):
+            code = lib.nplda_forward_train_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(packed.buf), packed.D0,
+                                               packed.D1, packed.D2, _lib.ptr(s), _lib.ptr(y), _lib.ptr(z),
+                                               _lib.ptr(rn), packed.ldz, _lib.current_stream())
+        _lib.check(code, "nplda_forward_train_f32")
+    return s, (x1, x2, ld1, y, z, rn)
+
+
+def backward(saved, g, packed, P_sqrt):
+    """nplda_backward_f32: flat gradient [dW1 | db1 | dW2 | db2 | dP_sqrt | dQ] for dL/ds = g."""
+    lib = _lib.load()
+    x1, x2, ld, y, z, rn = saved
+    B = x1.shape[0]
+    dev = x1.device
+    _require_dev_f32(g, "g")
+    g = g.contiguous()
+    n = lib.nplda_grad_floats(packed.D0, packed.D1, packed.D2)
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    wsb = lib.nplda_backward_workspace_bytes(B, packed.D0, packed.D1, packed.D2)
+    ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
+    ps = P_sqrt.detach().contiguous()
+    with torch.cuda.device(dev):
+        code = lib.nplda_backward_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld, _lib.ptr(packed.buf), packed.D0, packed.D1,
+                                      packed.D2, _lib.ptr(g), _lib.ptr(y), _lib.ptr(z), _lib.ptr(rn), packed.ldz,
+                                      _lib.ptr(ps), _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.current_stream())
+    _lib.check(code, "nplda_backward_f32")
+    return flat
+
+
+def split_flat_grad(flat, D0, D1, D2):
+    """Views (dW1, db1, dW2, db2, dP_sqrt, dQ) into the flat gradient buffer."""
+    o = 0
+    out = []
+    for shape in ((D1, D0), (D1,), (D2, D1), (D2,), (D2,), (D2,)):
+        n = 1
+        for d in shape:
+            n *= d
+        out.append(flat[o:o + n].view(shape))
+        o += n
+    return tuple(out)
+
+
+def _theta_array(thetas):
+    import ctypes
+    arr = (ctypes.c_void_p * len(thetas))()
+    for i, t in enumerate(thetas):
+        _require_dev_f32(t, "theta")
+        arr[i] = t.data_ptr()
+    return arr
+
+
+def loss_sums(s, t, thetas, alpha, kind):
+    """nplda_loss_sums_f32: fp64 vector of batch-global sums (additive across shards)."""
+    lib = _lib.load()
+    _require_dev_f32(s, "output")
+    _require_dev_f32(t, "target")
+    s, t = s.contiguous(), t.contiguous()
+    if s.shape != t.shape or s.dim() != 1:
+        raise ValueError("output and target must be 1-D tensors of the same length")
+    K = len(thetas)
+    ns = lib.nplda_loss_nsums(K, kind)
+    if ns == 0:
+        raise _lib.NpldaHipError(f"loss with {K} thresholds is not supported by the compiled kernels (max 4)")
+    sums = torch.empty(ns, dtype=torch.float64, device=s.device)
+    with torch.cuda.device(s.device):
+        code = lib.nplda_loss_sums_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), K, float(alpha),
+                                       kind, _lib.ptr(sums), _lib.current_stream())
+    _lib.check(code, "nplda_loss_sums_f32")
+    return sums
+
+
+def loss_finish(s, t, thetas, betas, alpha, kind, sums, want_grad=True):
+    """nplda_loss_finish_f32: (loss 0-d tensor, g or None, dtheta (K,) or None)."""
+    import ctypes
+    lib = _lib.load()
+    s, t = s.contiguous(), t.contiguous()
+    K = len(thetas)
+    dev = s.device
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    g = torch.empty_like(s) if want_grad else None
+    dth = torch.empty(K, dtype=torch.float32, device=dev) if want_grad else None
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(dev):
+        code = lib.nplda_loss_finish_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), barr, K,
+                                         float(alpha), kind, _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(g),
+                                         _lib.ptr(dth), _lib.current_stream())
+    _lib.check(code, "nplda_loss_finish_f32")
+    return loss, g, dth
+
+
+# ---- indexed scoring / gather -------------------------------------------------------------------
+
+def _idx(t, name, dev):
+    if not isinstance(t, torch.Tensor):
+        t = torch.as_tensor(t)
+    if t.dtype != torch.int64:
+        t = t.long()
+    if t.device != dev:
+        t = t.to(dev, non_blocking=True)
+    return t.contiguous()
+
+
+def score_indexed(z, q, i1, i2, packed):
+    """nplda_score_indexed_f32: z (N, ldz), q (N) from embed(); i1, i2 int64 (B) -> (B,) scores."""
+    lib = _lib.load()
+    _require_dev_f32(z, "z")
+    _require_dev_f32(q, "q")
+    if z.dim() != 2 or z.stride(1) != 1 or z.stride(0) != packed.ldz or z.shape[0] != q.shape[0]:
+        raise ValueError("z must be the (N, ldz) table returned by embed() and q its (N,) self terms")
+    dev = z.device
+    i1, i2 = _idx(i1, "i1", dev), _idx(i2, "i2", dev)
+    if i1.shape != i2.shape or i1.dim() != 1:
+        raise ValueError("i1 and i2 must be 1-D index tensors of the same length")
+    B = i1.shape[0]
+    s = torch.empty(B, dtype=torch.float32, device=dev)
+    if B == 0:
+        return s
+    with torch.cuda.device(dev):
+        code = lib.nplda_score_indexed_f32(_lib.ptr(z), packed.ldz, _lib.ptr(q), z.shape[0], _lib.ptr(i1),
+                                           _lib.ptr(i2), B, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
+                                           _lib.ptr(s), _lib.current_stream())
+    _lib.check(code, "nplda_score_indexed_f32")
+    return s
+
+
+def score_embeddings(z1, z2, P_sqrt, Q):
+    """nplda_score_embeddings_f32: forward_from_plda_embeddings on explicit (B, D2) tensors."""
+    lib = _lib.load()
+    for n, t in (("z1", z1), ("z2", z2), ("P_sqrt", P_sqrt), ("Q", Q)):
+        _require_dev_f32(t, n)
+    D2 = Q.numel()
+    if z1.dim() != 2 or z1.shape != z2.shape or z1.shape[1] != D2:
+        raise ValueError(f"z1, z2 must both be (B, {D2})")
+    if z1.stride(1) != 1:
+        z1 = z1.contiguous()
+    if z2.stride(1) != 1:
+        z2 = z2.contiguous()
+    B = z1.shape[0]
+    s = torch.empty(B, dtype=torch.float32, device=z1.device)
+    if B == 0:
+        return s
+    ld1 = z1.stride(0) if B > 1 else D2
+    ld2 = z2.stride(0) if B > 1 else D2
+    with torch.cuda.device(z1.device):
+        code = lib.nplda_score_embeddings_f32(_lib.ptr(z1), ld1, _lib.ptr(z2), ld2, B, D2,
+                                              _lib.ptr(P_sqrt.contiguous()), _lib.ptr(Q.contiguous()), _lib.ptr(s),
+                                              _lib.current_stream())
+    _lib.check(code, "nplda_score_embeddings_f32")
+    return s
+
+
+def gather_rows(table, idx):
+    """nplda_gather_rows_f32: out[r] = table[idx[r]] for a resident (N, D0) float32 matrix."""
+    lib = _lib.load()
+    _require_dev_f32(table, "table")
+    if table.dim() != 2 or table.stride(1) != 1 or table.stride(0) % 4 != 0 or table.shape[1] % 4 != 0:
+        raise ValueError("table must be (N, D0) float32 with unit inner stride and D0 % 4 == 0")
+    dev = table.device
+    idx = _idx(idx, "idx", dev)
+    B, D0 = idx.shape[0], table.shape[1]
+    out = torch.empty((B, D0), dtype=torch.float32, device=dev)
+    if B == 0:
+        return out
+    with torch.cuda.device(dev):
+        code = lib.nplda_gather_rows_f32(_lib.ptr(table), table.stride(0), table.shape[0], _lib.ptr(idx), B, D0,
+                                         _lib.ptr(out), D0, _lib.current_stream())
+    _lib.check(code, "nplda_gather_rows_f32")
+    return out

@@ -1,0 +1,293 @@
+"""GPU parity of the training path (loss kernels, hand-derived backward, module autograd) against the
+CPU oracle (fp64) and the reference-generated golden vectors.  Everything goes through the C ABI.
+
+Tolerances: loss rtol 1e-5; g / grads: 1e-4 of the per-tensor max-abs against the fp64
+oracle (the reference's own fp32 autograd is ~1e-2 noisy there, see test_oracle_golden.py).
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class NC:
+    def __init__(self, D0=512, D1=170, D2=170, beta=(99.0, 199.0), alpha=15.0, loss="SoftCdet"):
+        self.xvector_dim, self.layer1_LDA_dim, self.layer2_PLDA_spkfactor_dim = D0, D1, D2
+        self.beta, self.alpha, self.device, self.loss = list(beta), alpha, "cuda", loss
+
+
+def rand_params(rng, D0, D1, D2):
+    k1, k2 = 1 / np.sqrt(D0), 1 / np.sqrt(D1)
+    return orc.Params(rng.uniform(-k1, k1, (D1, D0)).astype(np.float32), rng.uniform(-k1, k1, D1).astype(np.float32),
+                      rng.uniform(-k2, k2, (D2, D1)).astype(np.float32), rng.uniform(-k2, k2, D2).astype(np.float32),
+                      rng.uniform(0, 1, D2).astype(np.float32), rng.uniform(0, 1, D2).astype(np.float32))
+
+
+def model_from(p, nc, thetas=None, theta_xent=None):
+    from neuralplda_amd import models
+    m = models.NeuralPlda(nc)
+    sd = m.state_dict()
+    sd["centering_and_LDA.weight"].copy_(torch.from_numpy(p.W1))
+    sd["centering_and_LDA.bias"].copy_(torch.from_numpy(p.b1))
+    sd["centering_and_wccn_plda.weight"].copy_(torch.from_numpy(p.W2))
+    sd["centering_and_wccn_plda.bias"].copy_(torch.from_numpy(p.b2))
+    sd["P_sqrt"].copy_(torch.from_numpy(p.P_sqrt))
+    sd["Q"].copy_(torch.from_numpy(p.Q))
+    if thetas is not None:
+        for b, th in zip(nc.beta, thetas):
+            sd["Th{}".format(int(b))].fill_(float(th))
+    if theta_xent is not None:
+        sd["threshold_Xent"].fill_(float(theta_xent))
+    return m.cuda()
+
+
+def relmax(a, b):
+    return np.abs(np.asarray(a, np.float64) - b).max() / max(np.abs(b).max(), 1e-30)
+
+
+@pytest.mark.parametrize("K", [1, 2, 3])
+@pytest.mark.parametrize("B", [7, 512, 4096])
+def test_softcdet_kernels(hip_lib, K, B):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(B + K)
+    s = (rng.standard_normal(B) * 0.5 - 1).astype(np.float32)
+    t = (rng.random(B) < 0.15).astype(np.float32)
+    t[0], t[1] = 1, 0
+    theta = [-0.8, -0.6, -1.1][:K]
+    beta = [99.0, 199.0, 9.9][:K]
+    alpha = 15.0
+    S, T = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    ths = [torch.tensor([th], dtype=torch.float32, device="cuda") for th in theta]
+    sums = ops.loss_sums(S, T, ths, alpha, ops.LOSS_SOFTCDET)
+    loss, g, dth = ops.loss_finish(S, T, ths, beta, alpha, ops.LOSS_SOFTCDET, sums)
+    th32 = [float(np.float32(x)) for x in theta]
+    Lref = orc.softcdet(s, t, th32, beta, alpha, np.float64)
+    gref, dthref = orc.softcdet_grad(s, t, th32, beta, alpha)
+    assert abs(loss.item() - Lref) <= 1e-5 * abs(Lref)
+    assert relmax(g.cpu().numpy(), gref) <= 1e-4
+    assert relmax(dth.cpu().numpy(), dthref) <= 1e-4
+    assert abs(sums[0].item() - t.sum()) == 0 and abs(sums[1].item() - (1 - t).sum()) == 0
+    # hard cdet at the same thresholds
+    hs = ops.loss_sums(S, T, ths, 0.0, ops.LOSS_HARD_CDET)
+    hl, _, _ = ops.loss_finish(S, T, ths, beta, 0.0, ops.LOSS_HARD_CDET, hs, want_grad=False)
+    assert abs(hl.item() - orc.cdet(s, t, th32, beta, np.float64)) <= 1e-6 * max(1.0, abs(hl.item()))
+
+
+@pytest.mark.parametrize("B", [5, 1000])
+def test_bce_kernels(hip_lib, B):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(B)
+    s = (rng.standard_normal(B) * 2).astype(np.float32)
+    t = (rng.random(B) < 0.3).astype(np.float32)
+    S, T = torch.from_numpy(s).cuda(), torch.from_numpy(t).cuda()
+    th = [torch.tensor([0.25], dtype=torch.float32, device="cuda")]
+    sums = ops.loss_sums(S, T, th, 0.0, ops.LOSS_BCE)
+    loss, g, dth = ops.loss_finish(S, T, th, [], 0.0, ops.LOSS_BCE, sums)
+    assert abs(loss.item() - orc.crossentropy(s, t, 0.25, np.float64)) <= 1e-5 * abs(loss.item())
+    gref, dref = orc.crossentropy_grad(s, t, 0.25)
+    assert relmax(g.cpu().numpy(), gref) <= 1e-5
+    assert relmax(dth.cpu().numpy(), dref) <= 1e-4
+
+
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (64, 24, 20), (128, 40, 100)])
+@pytest.mark.parametrize("B", [3, 100, 4096])
+def test_backward_matches_oracle(hip_lib, D0, D1, D2, B):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D1 * 7 + B)
+    p = rand_params(rng, D0, D1, D2)
+    x1 = rng.standard_normal((B, D0)).astype(np.float32)
+    x2 = rng.standard_normal((B, D0)).astype(np.float32)
+    g = (rng.standard_normal(B) / B).astype(np.float32)
+    dev = [torch.from_numpy(a).cuda() for a in p.tensors()]
+    packed = ops.pack_params(*dev)
+    s, saved = ops.forward_train(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed)
+    ref_s = orc.forward(x1, x2, p, np.float64)
+    assert np.all(np.abs(s.cpu().numpy() - ref_s) <= 2e-5 + 1e-5 * np.abs(ref_s))
+    # saved activations
+    z1ref, (u1, y1ref, n1) = orc.extract_plda_embeddings(x1, p, np.float64, True)
+    y = saved[3].cpu().numpy()
+    np.testing.assert_allclose(y[:B, :D1], y1ref, atol=2e-6)
+    assert np.all(y[:, D1:] == 0)
+    flat = ops.backward(saved, torch.from_numpy(g).cuda(), packed, dev[4])
+    grads = [t.cpu().numpy() for t in ops.split_flat_grad(flat, D0, D1, D2)]
+    ref = orc.backward(x1, x2, g, p)
+    for name, got in zip(("W1", "b1", "W2", "b2", "P_sqrt", "Q"), grads):
+        assert got.shape == ref[name].shape
+        assert relmax(got, ref[name]) <= 1e-4, (name, relmax(got, ref[name]))
+    # deterministic: same inputs -> bit-identical gradients
+    flat2 = ops.backward(saved, torch.from_numpy(g).cuda(), packed, dev[4])
+    assert torch.equal(flat, flat2)
+
+
+def test_backward_eps_branch(hip_lib):
+    """A row with ||u|| == 0: normalize's clamp branch in the backward (du = dy / eps) must not produce NaN/inf
+    in the other rows' gradients (the reference's autograd gives huge-but-finite values there too)."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(11)
+    p = rand_params(rng, 64, 24, 20)
+    p.b1[:] = 0
+    x1 = rng.standard_normal((50, 64)).astype(np.float32)
+    x2 = rng.standard_normal((50, 64)).astype(np.float32)
+    g = (rng.standard_normal(50) / 50).astype(np.float32)
+    g[9] = 0  # keep the 1/eps row out of the sums so that values stay comparable
+    x1[9] = 0
+    dev = [torch.from_numpy(a).cuda() for a in p.tensors()]
+    packed = ops.pack_params(*dev)
+    s, saved = ops.forward_train(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed)
+    flat = ops.backward(saved, torch.from_numpy(g).cuda(), packed, dev[4])
+    assert torch.isfinite(flat).all()
+    ref = orc.backward(x1, x2, g, p)
+    got = ops.split_flat_grad(flat, 64, 24, 20)
+    assert relmax(got[0].cpu().numpy(), ref["W1"]) <= 1e-4
+
+
+def test_module_golden_g3_small(hip_lib):
+    """NeuralPlda module (autograd bridges) vs the reference's own outputs (fp64 autograd) on G3."""
+    g = np.load(os.path.join(G, "g3_loss_grad_small.npz"))
+    p = orc.Params(g["W1"], g["b1"], g["W2"], g["b2"], g["P_sqrt"], g["Q"])
+    X1, X2, T = (torch.from_numpy(g[k]).cuda() for k in ("x1", "x2", "t"))
+    names = {"centering_and_LDA.weight": "W1", "centering_and_LDA.bias": "b1", "centering_and_wccn_plda.weight": "W2",
+             "centering_and_wccn_plda.bias": "b2", "P_sqrt": "P_sqrt", "Q": "Q"}
+    for lossname, tag in (("SoftCdet", "SoftCdet64"), ("softCdet", "SoftCdet64"), ("crossentropy", "crossentropy")):
+        m = model_from(p, NC(64, 24, 20, loss=lossname), thetas=g["theta"], theta_xent=float(g["theta_xent"]))
+        out = m(X1, X2)
+        L = m.loss(out, T)
+        L.backward()
+        np.testing.assert_allclose(out.detach().cpu().numpy(), g[tag.replace("64", "") + "_s"], atol=2e-5)
+        assert abs(L.item() - float(g[tag + "_L"])) <= 2e-5 * abs(float(g[tag + "_L"]))
+        tol = 1e-4 if tag == "SoftCdet64" else 2e-2  # crossentropy golden is the reference's fp32 autograd
+        for k, prm in m.named_parameters():
+            key = f"{tag}_grad_{k}"
+            if key not in g.files:
+                continue
+            ref = g[key]
+            if prm.grad is None:
+                assert np.all(ref == 0), k
+                continue
+            assert relmax(prm.grad.cpu().numpy(), ref) <= tol, (lossname, k, relmax(prm.grad.cpu().numpy(), ref))
+
+
+def test_module_golden_kaldi170(hip_lib):
+    g1 = np.load(os.path.join(G, "g1_kaldi_params.npz"))
+    f = np.load(os.path.join(G, "g2_forward_kaldi170.npz"))
+    gl = np.load(os.path.join(G, "g3_loss_kaldi170.npz"))
+    p = orc.Params(g1["W1"], g1["b1"], g1["W2"], g1["b2"], g1["P_sqrt"], g1["Q"])
+    m = model_from(p, NC(), thetas=gl["theta"])
+    X1, X2 = torch.from_numpy(f["x1"]).cuda(), torch.from_numpy(f["x2"]).cuda()
+    with torch.no_grad():
+        s = m(X1, X2).cpu().numpy()
+        z1 = m.extract_plda_embeddings(X1).cpu().numpy()
+        sz = m.forward_from_plda_embeddings(torch.from_numpy(f["z1"]).cuda(), torch.from_numpy(f["z2"]).cuda())
+    assert np.all(np.abs(s - f["s"]) <= 2e-5 + 1e-5 * np.abs(f["s"]))
+    assert np.all(np.abs(s - f["s64"]) <= 2e-5 + 1e-5 * np.abs(f["s64"]))
+    np.testing.assert_allclose(z1, f["z1"], atol=2e-6, rtol=1e-5)
+    np.testing.assert_allclose(sz.cpu().numpy(), f["s_from_z"], atol=2e-6, rtol=1e-5)
+    out = m(X1, X2)
+    L = m.loss(out, torch.from_numpy(gl["t"]).cuda())
+    L.backward()
+    assert abs(L.item() - float(gl["L"])) <= 1e-4 * abs(float(gl["L"]))
+    # against the fp64 oracle (the golden here is the reference's noisy fp32 autograd: loose check only)
+    gs, dth = orc.softcdet_grad(f["s64"], gl["t"], gl["theta"].astype(np.float32).astype(np.float64), gl["beta"], 15.0)
+    ref = orc.backward(f["x1"], f["x2"], gs, p)
+    assert relmax(m.centering_and_LDA.weight.grad.cpu().numpy(), ref["W1"]) <= 2e-4
+    assert relmax(m.centering_and_wccn_plda.weight.grad.cpu().numpy(), ref["W2"]) <= 2e-4
+    assert relmax(m.Q.grad.cpu().numpy(), ref["Q"]) <= 2e-4
+    assert relmax(m.P_sqrt.grad.cpu().numpy(), ref["P_sqrt"]) <= 2e-4
+    assert relmax(m.Q.grad.cpu().numpy(), gl["grad_Q"]) <= 2e-2
+    assert relmax([m.Th99.grad.item(), m.Th199.grad.item()], dth) <= 2e-4
+
+
+def test_adam_trajectory_g4(hip_lib):
+    """Three optimiser steps exactly as xvector_NeuralPlda_pytorch.py:35-43 takes them."""
+    from neuralplda_amd import models
+    g = np.load(os.path.join(G, "g4_adam_small.npz"))
+    d = np.load(os.path.join(G, "g3_loss_grad_small.npz"))
+    m = models.NeuralPlda(NC(64, 24, 20))
+    sd = m.state_dict()
+    for k in g["keys"]:
+        sd[str(k)].copy_(torch.from_numpy(g["p0_" + str(k)]))
+    m = m.cuda()
+    opt = torch.optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5)
+    losses = []
+    for step in range(3):
+        opt.zero_grad()
+        lo, hi = step * 128, (step + 1) * 128
+        o = m(torch.from_numpy(d["x1"][lo:hi]).cuda(), torch.from_numpy(d["x2"][lo:hi]).cuda())
+        L = m.loss(o, torch.from_numpy(d["t"][lo:hi]).cuda())
+        losses.append(L.item())
+        L.backward()
+        opt.step()
+    np.testing.assert_allclose(losses, g["losses"], rtol=2e-5)
+    for k in g["keys"]:
+        k = str(k)
+        got = m.state_dict()[k].cpu().numpy()
+        # Adam's first steps move every weight by ~lr regardless of gradient scale: compare the DISPLACEMENT
+        disp_ref = g["p3_" + k] - g["p0_" + k]
+        disp = got - g["p0_" + k]
+        assert np.abs(disp - disp_ref).max() <= 0.05 * max(np.abs(disp_ref).max(), 1e-12) + 1e-7, k
+
+
+@pytest.mark.parametrize("D", [150, 170])
+def test_score_indexed_and_gather(hip_lib, D):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D)
+    p = rand_params(rng, 512, D, D)
+    N, B = 1000, 5000
+    x = rng.standard_normal((N, 512)).astype(np.float32)
+    i1 = rng.integers(0, N, B)
+    i2 = rng.integers(0, N, B)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    X = torch.from_numpy(x).cuda()
+    z, q = ops.embed(X, packed)
+    s = ops.score_indexed(z, q, torch.from_numpy(i1), torch.from_numpy(i2), packed).cpu().numpy()
+    ref = orc.forward(x[i1], x[i2], p, np.float64)
+    assert np.all(np.abs(s - ref) <= 2e-5 + 1e-5 * np.abs(ref))
+    # indexed == dense on the gathered rows (same kernels' arithmetic up to summation order)
+    g1 = ops.gather_rows(X, torch.from_numpy(i1).cuda())
+    assert torch.equal(g1.cpu(), torch.from_numpy(x[i1]))
+    dense = ops.score_pairs(g1, ops.gather_rows(X, torch.from_numpy(i2).cuda()), packed).cpu().numpy()
+    np.testing.assert_allclose(s, dense, atol=1e-5, rtol=1e-5)
+    # out-of-range index -> NaN, not a fault
+    bad = ops.score_indexed(z, q, torch.tensor([0, N]), torch.tensor([1, 2]), packed).cpu().numpy()
+    assert np.isfinite(bad[0]) and np.isnan(bad[1])
+
+
+def test_cpu_tensors_are_staged_through_the_device(hip_lib):
+    """utils/scorefile_generator.py:25-34 moves model and data to CPU before calling forward(): our module
+    must still produce the HIP result (and return it on the CPU), never compute on the host."""
+    rng = np.random.default_rng(2)
+    p = rand_params(rng, 512, 150, 150)
+    m = model_from(p, NC(512, 150, 150)).to(torch.device("cpu"))
+    x1 = rng.standard_normal((33, 512)).astype(np.float32)
+    x2 = rng.standard_normal((33, 512)).astype(np.float32)
+    with torch.no_grad():
+        s = m.forward(torch.from_numpy(x1), torch.from_numpy(x2))
+    assert s.device.type == "cpu"
+    ref = orc.forward(x1, x2, p, np.float64)
+    assert np.all(np.abs(s.numpy() - ref) <= 2e-5 + 1e-5 * np.abs(ref))
+    assert m.forward(torch.tensor([]), torch.tensor([])).shape == (0,)
+
+
+def test_metrics_on_device_match_golden(hip_lib):
+    g = np.load(os.path.join(G, "g5_metrics.npz"))
+    p = rand_params(np.random.default_rng(0), 64, 24, 20)
+    m = model_from(p, NC(64, 24, 20), thetas=g["theta"])
+    S, T = torch.from_numpy(g["s"]).cuda(), torch.from_numpy(g["t"]).cuda()
+    with torch.no_grad():
+        assert abs(m.cdet(S, T).item() - float(g["cdet"])) <= 1e-6 * float(g["cdet"])
+        assert abs(m.softcdet(S, T).item() - float(g["softcdet"])) <= 2e-5 * float(g["softcdet"])
+        assert abs(m.crossentropy(S, T).item() - float(g["xent"])) <= 2e-5 * float(g["xent"])
+        mc, th = m.minc(S, T)
+        assert abs(mc.item() - float(g["minc"])) <= 1e-6
+        assert th[99.0].item() == np.float32(g["minc_th"][0]) and th[199.0].item() == np.float32(g["minc_th"][1])
+        m.minc(S, T, update_thresholds=True)
+        assert m.Th99.item() == np.float32(g["minc_th"][0]) and m.threshold[199.0].item() == np.float32(g["minc_th"][1])
+        mcs, _ = m.minc(torch.from_numpy(g["s_sep"]).cuda(), T)
+        assert abs(mcs.item() - float(g["minc_sep"])) <= 1e-7
+        assert m.minc(torch.from_numpy(g["s_sep"]).cuda(), T, exact=True)[0].item() == 0.0

@@ -1,0 +1,88 @@
+// exp_fwd.hip — within-process interleaved A/B of forward-kernel variants (not product code).
+// build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp_fwd.hip -o tools/exp_fwd
+// run:   tools/exp_fwd [log2_pairs=20] [rounds=3]
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+#include "../neuralplda_amd/csrc/nplda_fwd_kernel.h"
+
+using namespace nplda;
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
+
+__global__ void fill_rand(float* p, size_t n, unsigned seed) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) {
+        unsigned long long h = (i + 1) * 0x9E3779B97F4A7C15ull + seed * 0xD1B54A32D192ED03ull;
+        h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32; h *= 0xD6E8FEB86659FD93ull; h ^= h >> 32;
+        // approx normal: sum of 4 uniforms
+        float u = 0.f;
+        for (int k = 0; k < 4; ++k) u += (float)((h >> (16 * k)) & 0xffff) / 65536.0f;
+        p[i] = (u - 2.0f) * 1.7320508f;
+    }
+}
+
+struct Variant { const char* name; void (*launch)(const FwdArgs&, long long, hipStream_t); };
+
+template <int NB, int WAVES, bool NT, int KPB>
+void launch_v(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
+    hipLaunchKernelGGL((nplda_fwd_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), grid, block, 0, st, a);
+}
+
+int main(int argc, char** argv) {
+    const int lg = argc > 1 ? atoi(argv[1]) : 20;
+    const int rounds = argc > 2 ? atoi(argv[2]) : 3;
+    const int D = argc > 3 ? atoi(argv[3]) : 150;
+    const long long B = 1ll << lg;
+    const int D0 = 512;
+    const NpldaLayout L = nplda_layout(D0, D, D);
+    float *x1, *x2, *s, *packed, *W1, *b1, *W2, *b2, *Ps, *Q;
+    CK(hipMalloc(&x1, B * D0 * 4)); CK(hipMalloc(&x2, B * D0 * 4)); CK(hipMalloc(&s, B * 4));
+    CK(hipMalloc(&packed, L.total * 4));
+    CK(hipMalloc(&W1, D * D0 * 4)); CK(hipMalloc(&b1, D * 4)); CK(hipMalloc(&W2, D * D * 4));
+    CK(hipMalloc(&b2, D * 4)); CK(hipMalloc(&Ps, D * 4)); CK(hipMalloc(&Q, D * 4));
+    fill_rand<<<4096, 256>>>(x1, (size_t)B * D0, 1); fill_rand<<<4096, 256>>>(x2, (size_t)B * D0, 2);
+    fill_rand<<<64, 256>>>(W1, (size_t)D * D0, 3); fill_rand<<<1, 256>>>(b1, D, 4);
+    fill_rand<<<64, 256>>>(W2, (size_t)D * D, 5); fill_rand<<<1, 256>>>(b2, D, 6);
+    fill_rand<<<1, 256>>>(Ps, D, 7); fill_rand<<<1, 256>>>(Q, D, 8);
+    nplda_pack_kernel<<<(unsigned)((L.total + 255) / 256), 256>>>(W1, b1, W2, b2, Ps, Q, L, packed);
+    CK(hipDeviceSynchronize());
+
+    FwdArgs a = {};
+    a.xa = x1; a.xb = x2; a.n = B; a.ldx = D0; a.packed = packed; a.D0 = D0; a.KS1 = L.KS1;
+    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total; a.out_s = s;
+
+    std::vector<Variant> vs;
+    if (L.NB == 10) {
+        vs = { {"w4 plain kpb1", launch_v<10, 4, false, 1>}, {"w4 nt    kpb1", launch_v<10, 4, true, 1>},
+               {"w8 plain kpb1", launch_v<10, 8, false, 1>}, {"w8 nt    kpb1", launch_v<10, 8, true, 1>},
+               {"w4 plain kpb2", launch_v<10, 4, false, 2>}, {"w8 plain kpb2", launch_v<10, 8, false, 2>},
+               {"w8 nt    kpb2", launch_v<10, 8, true, 2>} };
+    } else {
+        vs = { {"w4 plain kpb1", launch_v<11, 4, false, 1>}, {"w8 plain kpb1", launch_v<11, 8, false, 1>},
+               {"w8 plain kpb2", launch_v<11, 8, false, 2>} };
+    }
+    const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    std::vector<float> hs(4096);
+    for (int r = 0; r < rounds; ++r) {
+        for (auto& v : vs) {
+            v.launch(a, B, 0); v.launch(a, B, 0);
+            CK(hipDeviceSynchronize());
+            const int reps = 8;
+            CK(hipEventRecord(e0, 0));
+            for (int i = 0; i < reps; ++i) v.launch(a, B, 0);
+            CK(hipEventRecord(e1, 0));
+            CK(hipEventSynchronize(e1));
+            float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
+            CK(hipMemcpy(hs.data(), s, 4096 * 4, hipMemcpyDeviceToHost));
+            double cs = 0; for (float f : hs) cs += f;
+            printf("round %d  %-14s  %.3f ms  %.3e pairs/s  %.1f TF(alg)  frac %.3f  checksum %.6f\n", r, v.name, ms,
+                   B / (ms * 1e-3), B * flop_alg / (ms * 1e-3) / 1e12, B * flop_alg / (ms * 1e-3) / 1e12 / 157.3, cs);
+        }
+    }
+    return 0;
+}
