@@ -1,0 +1,127 @@
+"""Multi-GPU layer: one process per GPU, torch.distributed over RCCL (backend "nccl" on ROCm) / xGMI.
+
+The reference has no distributed code at all; the partitioning below is this build's
+design:
+
+* scoring        — the trial list is split into `world` contiguous chunks, parameters (0.4 MB) are
+                   replicated, there is NO data-path collective; an optional all-gather assembles the
+                   score vector (4 B per trial).
+* AS-norm        — the R enroll/test rows are sharded (each rank needs the whole cohort row for its
+                   top-N), then ONE all-gather of the per-row (mean, std, mean_top, std_top) — R x 4
+                   doubles, latency-bound.
+* training (DP)  — the minibatch is sharded; SoftCdet normalises by batch-GLOBAL target / non-target
+                   counts (utils/models.py:386), so (1) the fp64 loss sums (<= 18 doubles, all additive)
+                   are all-reduced before g = dL/ds is formed, (2) the flat gradient
+                   [dW1|db1|dW2|db2|dP_sqrt|dQ] (~0.45 MB) is all-reduced with SUM (not mean) in one
+                   call; threshold gradients come from the global sums and are already identical.
+
+All collectives are tiny and latency-bound on a fully connected xGMI node, so they are issued as
+single flat buffers.  Compute is injected as callables, which is also how the gloo/CPU tests drive
+this module with the oracle.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+__all__ = ["init", "world", "shard_bounds", "sharded_apply", "all_gather_rows", "allreduce_sum_",
+           "make_data_parallel", "shard_batch"]
+
+
+def init(backend=None, device=None):
+    """Initialise the default process group from the torchrun environment (RANK, WORLD_SIZE, MASTER_*).
+    backend: "nccl" (= RCCL) when a HIP device is used, "gloo" on CPU."""
+    if dist.is_initialized():
+        return dist.group.WORLD
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29500")
+    kw = {}
+    if backend == "nccl":
+        if device is None:
+            device = torch.device("cuda", int(os.environ.get("LOCAL_RANK", "0")))
+        torch.cuda.set_device(device)
+        kw["device_id"] = device
+    dist.init_process_group(backend, **kw)
+    return dist.group.WORLD
+
+
+def world(group=None):
+    """(rank, world_size); (0, 1) when torch.distributed is not initialised."""
+    if not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def shard_bounds(n, world_size, rank):
+    """Contiguous chunk [lo, hi) of n items for `rank`: chunks of ceil(n / world) (the last may be short
+    or empty), so that an all-gather of fixed-size padded chunks reassembles the list in order."""
+    chunk = (n + world_size - 1) // world_size if world_size > 0 else n
+    lo = min(rank * chunk, n)
+    return lo, min(lo + chunk, n)
+
+
+def sharded_apply(fn, n, group=None, device=None, dtype=torch.float32, gather=True, width=None):
+    """Run fn(lo, hi) -> tensor of shape (hi - lo,) or (hi - lo, width) on this rank's shard of n items.
+    gather=True: every rank receives the full (n,[width]) result (one all-gather of padded chunks)."""
+    rank, ws = world(group)
+    lo, hi = shard_bounds(n, ws, rank)
+    local = fn(lo, hi)
+    if not gather or ws == 1:
+        return local
+    chunk = (n + ws - 1) // ws
+    device = local.device if device is None else device
+    shape = (chunk,) if local.dim() == 1 else (chunk, local.shape[1])
+    pad = torch.zeros(shape, dtype=local.dtype, device=device)
+    pad[: hi - lo] = local
+    out = torch.empty((ws * chunk,) + shape[1:], dtype=local.dtype, device=device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n]
+
+
+def all_gather_rows(local_rows, n_total, group=None):
+    """All-gather row blocks produced under shard_bounds(n_total, ...): (r_local, C) -> (n_total, C)."""
+    rank, ws = world(group)
+    if ws == 1:
+        return local_rows
+    chunk = (n_total + ws - 1) // ws
+    pad = torch.zeros((chunk, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+    pad[: local_rows.shape[0]] = local_rows
+    out = torch.empty((ws * chunk, local_rows.shape[1]), dtype=local_rows.dtype, device=local_rows.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return out[:n_total]
+
+
+def allreduce_sum_(t, group=None):
+    """In-place SUM all-reduce (no-op for a single process). Returns t."""
+    _, ws = world(group)
+    if ws > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t
+
+
+def shard_batch(tensors, group=None):
+    """Slice every tensor of a global minibatch to this rank's contiguous shard."""
+    rank, ws = world(group)
+    n = tensors[0].shape[0]
+    lo, hi = shard_bounds(n, ws, rank)
+    return tuple(t[lo:hi] for t in tensors)
+
+
+def make_data_parallel(model, group=None):
+    """Turn a NeuralPlda into its data-parallel form: each rank feeds its shard of the global minibatch
+    to model(x1, x2) / model.loss(...) / loss.backward() exactly as on one GPU; the loss value and every
+    parameter gradient then equal the single-process result on the whole minibatch.  Parameters must be
+    identical on all ranks at entry (same seed or a broadcast)."""
+    model._reduce_sums = lambda sums: allreduce_sum_(sums, group)
+    model._reduce_flat = lambda flat: allreduce_sum_(flat, group)
+    return model
+
+
+def broadcast_parameters(model, src=0, group=None):
+    _, ws = world(group)
+    if ws > 1:
+        for p in model.parameters():
+            dist.broadcast(p.data, src=src, group=group)
+    return model

@@ -63,15 +63,16 @@ class _PairScoreFn(torch.autograd.Function):
     """s = NeuralPlda.forward(x1, x2) with the hand-derived backward."""
 
     @staticmethod
-    def forward(ctx, x1, x2, W1, b1, W2, b2, P_sqrt, Q):
+    def forward(ctx, x1, x2, reduce_flat, W1, b1, W2, b2, P_sqrt, Q):
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             raise NotImplementedError("gradients w.r.t. the x-vectors are outside the NPLDA hot path")
         dev = _compute_device(x1, W1)
         prm = [_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)]
         packed = ops.pack_params(*prm)
         X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
-        need = any(ctx.needs_input_grad[2:])  # Function.forward runs with grad mode off: ask the ctx
+        need = any(ctx.needs_input_grad[3:])  # Function.forward runs with grad mode off: ask the ctx
         ctx.need = need
+        ctx.reduce_flat = reduce_flat
         if need:
             s, saved = ops.forward_train(X1, X2, packed)
             ctx.saved = saved
@@ -85,13 +86,15 @@ class _PairScoreFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, gs):
         if not ctx.need:
-            return (None,) * 8
+            return (None,) * 9
         dev = ctx.packed.device
         flat = ops.backward(ctx.saved, _to_dev(gs, dev), ctx.packed, ctx.ps)
+        if ctx.reduce_flat is not None:  # data parallel: ONE sum-all-reduce of the flat gradient
+            flat = ctx.reduce_flat(flat)
         grads = ops.split_flat_grad(flat, ctx.packed.D0, ctx.packed.D1, ctx.packed.D2)
         grads = [g if g.device == d else g.to(d) for g, d in zip(grads, ctx.pdev)]
         ctx.saved = None
-        return (None, None) + tuple(grads)
+        return (None, None, None) + tuple(grads)
 
 
 class _EmbedFn(torch.autograd.Function):
@@ -185,16 +188,19 @@ class NeuralPlda(nn.Module):
         self.beta = nc.beta
         self.dropout = nn.Dropout(p=0.5)  # defined and never used by the reference (utils/models.py:362)
         self.lossfn = nc.loss
-        self._reduce_sums = None  # set by neuralplda_amd.dist.make_data_parallel()
+        self._reduce_sums = None  # both set by neuralplda_amd.dist.make_data_parallel()
+        self._reduce_flat = None
 
     # -- pickles written by the reference (class path utils.models.NeuralPlda) lack our private attributes
     def __setstate__(self, state):
-        self.__dict__.update(state)
+        super(NeuralPlda, self).__setstate__(state)
         self.__dict__.setdefault("_reduce_sums", None)
+        self.__dict__.setdefault("_reduce_flat", None)
 
     def __getstate__(self):
         state = self.__dict__.copy()
         state["_reduce_sums"] = None  # process-group closures do not pickle
+        state["_reduce_flat"] = None
         return state
 
     def _params(self):
@@ -216,7 +222,7 @@ class NeuralPlda(nn.Module):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        return _PairScoreFn.apply(x1, x2, *self._params())
+        return _PairScoreFn.apply(x1, x2, self._reduce_flat, *self._params())
 
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):

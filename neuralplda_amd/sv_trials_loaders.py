@@ -1,0 +1,219 @@
+"""Batch interface of the hot path — counterpart of utils/sv_trials_loaders.py:371-437.
+
+Same function names, arguments and outputs as the reference; what changes is where the work happens:
+
+* `combine_trials_and_get_loader` / `get_trials_loaders_dict` consume the torch / numpy RNG streams
+  exactly like the reference (np.random.rand per file, torch DataLoader shuffle), so the kept set and
+  the batch order are identical for identical seeds — but a batch is collated with ONE vectorised
+  index instead of B `TensorDataset.__getitem__` calls.
+* `load_xvec_trials_from_numbatch` / `_from_idbatch` keep the x-vectors in a device-resident
+  (N_utt, 512) matrix built once per `mega_dict` and replace the per-pair Python dict look-ups
+  (utils/sv_trials_loaders.py:420-423, the reference's true bottleneck at 1.8e4 pairs/s) by the HIP
+  gather kernel nplda_gather_rows_f32.  When the caller asks for CPU tensors (`device` is the CPU, as
+  utils/scorefile_generator.py:34 does) the rows are index-selected on the host — that is data
+  movement for a host consumer, not a compute fallback.
+"""
+import os
+
+import numpy as np
+import torch
+from torch.utils.data import DataLoader, Dataset
+
+__all__ = ["combine_trials_and_get_loader", "get_trials_loaders_dict", "load_xvec_trials_from_numbatch",
+           "load_xvec_trials_from_idbatch", "XvectorTable", "xvector_table", "TrialIndexDataset"]
+
+
+# ---------------------------------------------------------------------------------------------------
+# trial lists -> loaders
+# ---------------------------------------------------------------------------------------------------
+
+class TrialIndexDataset(Dataset):
+    """len() == number of kept trials; item i is just i — batches are materialised by the collate_fn."""
+
+    def __init__(self, x1, x2, l):
+        self.x1, self.x2, self.l = x1, x2, l
+        self.dropped = 0
+
+    def __len__(self):
+        return self.x1.shape[0]
+
+    def __getitem__(self, i):
+        return i
+
+    def collate(self, idxs):
+        ii = torch.as_tensor(idxs, dtype=torch.int64)
+        return self.x1[ii], self.x2[ii], self.l[ii]
+
+
+def _read_trials(f, id_to_num_dict, strip_ext_col2):
+    """np.genfromtxt + id mapping as utils/sv_trials_loaders.py:377-383 (:400-406); unknown ids are
+    dropped silently by the reference — here they are counted (returned)."""
+    t = np.genfromtxt(f, dtype='str')
+    if t.ndim == 1:
+        t = t.reshape(1, -1)
+    x1, x2, l = [], [], []
+    dropped = 0
+    for tr in t:
+        try:
+            key2 = os.path.splitext(tr[1])[0] if strip_ext_col2 else tr[1]
+            a, b, c = id_to_num_dict[tr[0]], id_to_num_dict[key2], float(tr[2])
+            x1.append(a); x2.append(b); l.append(c)
+        except Exception:
+            dropped += 1
+    return (torch.tensor(x1, dtype=torch.int64), torch.tensor(x2, dtype=torch.int64),
+            torch.tensor(l, dtype=torch.float32), dropped)
+
+
+def _loader(ds, batch_size):
+    return DataLoader(ds, batch_size=batch_size, shuffle=True, collate_fn=ds.collate)
+
+
+def combine_trials_and_get_loader(trials_key_files_list, id_to_num_dict, subsample_factors=None, batch_size=2048,
+                                  subset=0):
+    """utils/sv_trials_loaders.py:371-392."""
+    if subsample_factors is None:
+        subsample_factors = [1 for w in trials_key_files_list]
+    parts, dropped = [], 0
+    for f, sf in zip(trials_key_files_list, subsample_factors):
+        x1, x2, l, d = _read_trials(f, id_to_num_dict, strip_ext_col2=False)
+        dropped += d
+        inds = torch.from_numpy(np.arange(len(x1))[np.random.rand(len(x1)) < sf])
+        parts.append((x1[inds], x2[inds], l[inds]))
+    x1 = torch.cat([p[0] for p in parts]) if parts else torch.zeros(0, dtype=torch.int64)
+    x2 = torch.cat([p[1] for p in parts]) if parts else torch.zeros(0, dtype=torch.int64)
+    l = torch.cat([p[2] for p in parts]) if parts else torch.zeros(0)
+    if subset > 0:
+        inds = torch.from_numpy(np.arange(len(x1))[np.random.rand(len(x1)) < subset])
+        x1, x2, l = x1[inds], x2[inds], l[inds]
+    ds = TrialIndexDataset(x1, x2, l)
+    ds.dropped = dropped
+    return _loader(ds, batch_size)
+
+
+def get_trials_loaders_dict(trials_key_files_list, id_to_num_dict, subsample_factors=None, batch_size=2048, subset=0):
+    """utils/sv_trials_loaders.py:394-415 (column 2 loses its file extension, key = file basename sans ext)."""
+    trials_loaders_dict = {}
+    if subsample_factors is None:
+        subsample_factors = [1 for w in trials_key_files_list]
+    for f, sf in zip(trials_key_files_list, subsample_factors):
+        x1, x2, l, d = _read_trials(f, id_to_num_dict, strip_ext_col2=True)
+        inds = torch.from_numpy(np.arange(len(x1))[np.random.rand(len(x1)) < sf])
+        x1, x2, l = x1[inds], x2[inds], l[inds]
+        if subset > 0:
+            inds = torch.from_numpy(np.arange(len(x1))[np.random.rand(len(x1)) < subset])
+            x1, x2, l = x1[inds], x2[inds], l[inds]
+        ds = TrialIndexDataset(x1, x2, l)
+        ds.dropped = d
+        trials_loaders_dict[os.path.splitext(os.path.basename(f))[0]] = _loader(ds, batch_size)
+    return trials_loaders_dict
+
+
+# ---------------------------------------------------------------------------------------------------
+# x-vector table (the "mega dict" {utt_id: float32[512]}, dataprep_sre.py:152-167) resident on the device
+# ---------------------------------------------------------------------------------------------------
+
+class XvectorTable:
+    """Row-major (N_utt, D) float32 matrix of a mega dict, with id -> row maps, host and device copies."""
+
+    def __init__(self, mega_dict):
+        self.ids = list(mega_dict.keys())
+        self.row_of = {u: i for i, u in enumerate(self.ids)}
+        self.host = np.ascontiguousarray(np.stack([np.asarray(mega_dict[u], dtype=np.float32) for u in self.ids])
+                                         if self.ids else np.zeros((0, 0), np.float32))
+        self._dev = {}
+        self._num_maps = {}
+
+    @property
+    def dim(self):
+        return self.host.shape[1]
+
+    def on(self, device):
+        device = torch.device(device)
+        key = (device.type, device.index if device.index is not None else (torch.cuda.current_device()
+                                                                           if device.type == "cuda" else -1))
+        if key not in self._dev:
+            self._dev[key] = torch.from_numpy(self.host).to(device)
+        return self._dev[key]
+
+    def rows_from_nums(self, num_to_id_dict):
+        """int64 numpy map num -> table row for a {num: utt_id} dict (cached per dict object)."""
+        k = id(num_to_id_dict)
+        hit = self._num_maps.get(k)
+        if hit is None or hit[0] != len(num_to_id_dict):
+            n = (max(num_to_id_dict.keys()) + 1) if len(num_to_id_dict) else 0
+            m = np.full(n, -1, dtype=np.int64)
+            for num, u in num_to_id_dict.items():
+                r = self.row_of.get(u)
+                if r is not None:
+                    m[int(num)] = r
+            hit = (len(num_to_id_dict), m, {})
+            self._num_maps[k] = hit
+        return hit
+
+    def gather(self, rows, device):
+        """rows: int64 numpy array or torch tensor of table rows -> (B, D) float32 on `device`."""
+        device = torch.device(device)
+        if device.type == "cuda":
+            from . import ops
+            table = self.on(device)
+            if not isinstance(rows, torch.Tensor):
+                rows = torch.from_numpy(np.ascontiguousarray(rows))
+            return ops.gather_rows(table, rows.to(device, non_blocking=True))
+        rows = rows.cpu().numpy() if isinstance(rows, torch.Tensor) else np.asarray(rows)
+        if rows.size and (rows.min() < 0 or rows.max() >= self.host.shape[0]):
+            raise KeyError("trial refers to an utterance that is not in the x-vector table")
+        return torch.from_numpy(self.host[rows]).float().to(device)
+
+
+_TABLES = {}
+
+
+def xvector_table(mega_dict):
+    """The (cached) XvectorTable of a mega dict; rebuilt if the dict object or its size changed."""
+    k = id(mega_dict)
+    hit = _TABLES.get(k)
+    if hit is None or hit[0] != len(mega_dict):
+        if len(_TABLES) > 8:
+            _TABLES.clear()
+        hit = (len(mega_dict), XvectorTable(mega_dict))
+        _TABLES[k] = hit
+    return hit[1]
+
+
+def load_xvec_trials_from_numbatch(mega_dict, num_to_id_dict, data1, data2, device):
+    """utils/sv_trials_loaders.py:418-426: int index batches -> 2 x (B, 512) float32 on `device`."""
+    tab = xvector_table(mega_dict)
+    _, m, devmaps = tab.rows_from_nums(num_to_id_dict)
+    device = torch.device(device)
+    if device.type == "cuda" and isinstance(data1, torch.Tensor) and data1.is_cuda:
+        key = (data1.device.type, data1.device.index)
+        if key not in devmaps:
+            devmaps[key] = torch.from_numpy(m).to(data1.device)
+        mm = devmaps[key]
+        return tab.gather(mm[data1.reshape(-1).long()], device), tab.gather(mm[data2.reshape(-1).long()], device)
+    d1 = data1.cpu().numpy() if isinstance(data1, torch.Tensor) else np.asarray(data1)
+    d2 = data2.cpu().numpy() if isinstance(data2, torch.Tensor) else np.asarray(data2)
+    r1, r2 = m[d1.reshape(-1).astype(np.int64)], m[d2.reshape(-1).astype(np.int64)]
+    if (r1.size and r1.min() < 0) or (r2.size and r2.min() < 0):
+        raise KeyError("trial index refers to an utterance that is not in mega_dict")
+    return tab.gather(r1, device), tab.gather(r2, device)
+
+
+def _ids_to_rows(tab, ids):
+    try:
+        return np.fromiter((tab.row_of[os.path.splitext(os.path.basename(d))[0]] for d in ids), dtype=np.int64,
+                           count=len(ids))
+    except KeyError as e:
+        raise KeyError(f"utterance {e.args[0]!r} is not in mega_dict") from None
+
+
+def load_xvec_trials_from_idbatch(mega_dict, trials, device):
+    """utils/sv_trials_loaders.py:429-437: (B, >=2) array of id strings (directory and extension are
+    stripped from both columns) -> 2 x (B, 512) float32 on `device`.  An empty batch gives (0, 512)."""
+    tab = xvector_table(mega_dict)
+    trials = np.asarray(trials)
+    if trials.size == 0:
+        e = torch.zeros((0, tab.dim), dtype=torch.float32, device=device)
+        return e, e.clone()
+    trials = trials.reshape(-1, trials.shape[-1])
+    return (tab.gather(_ids_to_rows(tab, trials[:, 0]), device), tab.gather(_ids_to_rows(tab, trials[:, 1]), device))

@@ -1,0 +1,246 @@
+"""CPU-only tests: the C-ABI library loads and exports every declared symbol, the host-side mirror of
+the reference interface (module layout, pickling, loaders, config, Kaldi readers, metrics) behaves like
+the reference (golden vectors G1/G5/G8), and the product path refuses to compute without a HIP device."""
+import io
+import os
+import pickle
+import re
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+G = os.path.join(ROOT, "tests", "golden")
+
+
+class NC:
+    def __init__(self, D0=512, D1=170, D2=170, beta=(99.0, 199.0), alpha=15.0, loss="SoftCdet"):
+        self.xvector_dim, self.layer1_LDA_dim, self.layer2_PLDA_spkfactor_dim = D0, D1, D2
+        self.beta, self.alpha, self.device, self.loss = list(beta), alpha, "cpu", loss
+
+
+def test_library_exports_every_declared_symbol(hip_lib):
+    hdr = open(os.path.join(ROOT, "include", "nplda_hip.h")).read()
+    declared = set(re.findall(r"\b(nplda_[a-z0-9_]+)\s*\(", hdr))
+    assert len(declared) >= 15
+    from neuralplda_amd import _lib
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(hip_lib, name), name
+    # argument-free entry points work without a GPU
+    assert hip_lib.nplda_abi_version() == 1
+    assert hip_lib.nplda_max_dim() == 192
+    assert hip_lib.nplda_padded_dim(150, 150) == 160 and hip_lib.nplda_padded_dim(170, 170) == 176
+    assert hip_lib.nplda_packed_bytes(512, 150, 150) > 0 and hip_lib.nplda_packed_bytes(512, 500, 500) == 0
+    assert hip_lib.nplda_loss_nsums(2, 0) == 10 and hip_lib.nplda_loss_nsums(1, 1) == 4 and hip_lib.nplda_loss_nsums(9, 0) == 0
+    assert hip_lib.nplda_grad_floats(512, 170, 170) == 170 * 512 + 170 + 170 * 170 + 3 * 170
+    assert b"invalid argument" in hip_lib.nplda_strerror(-22)
+
+
+def test_module_layout_matches_reference():
+    from neuralplda_amd import models
+    g1 = np.load(os.path.join(G, "g1_kaldi_params.npz"))
+    torch.manual_seed(0)
+    m = models.NeuralPlda(NC())
+    assert list(m.state_dict().keys()) == [str(k) for k in g1["state_dict_keys"]]
+    assert m.threshold[99.0] is m.Th99 and m.threshold[199.0] is m.Th199      # dict aliases registered params
+    assert m.centering_and_LDA.weight.shape == (170, 512) and m.P_sqrt.shape == (170,)
+    assert float(m.alpha) == 15.0 and m.beta == [99.0, 199.0] and m.lossfn == "SoftCdet"
+    assert len(list(m.parameters())) == 9                                         # what optim.Adam receives
+    m2 = m.to(torch.device("cpu"))
+    assert m2.threshold[99.0] is m2.Th99
+    # sdsvc-style beta 9.9 registers as Th9 (utils/models.py:355-358)
+    assert "Th9" in models.NeuralPlda(NC(beta=(9.9,))).state_dict()
+
+
+def test_pickle_roundtrip_and_reference_class_path(tmp_path):
+    from neuralplda_amd import compat, models
+    m = models.NeuralPlda(NC(64, 24, 20))
+    with torch.no_grad():
+        m.Th99.fill_(-0.7)
+    f = tmp_path / "NPLDA_1_0.pt"
+    m.SaveModel(str(f))
+    m2 = pickle.load(open(f, "rb"))
+    assert isinstance(m2, models.NeuralPlda) and m2.threshold[99.0] is m2.Th99 and m2.Th99.item() == pytest.approx(-0.7)
+    assert all(torch.equal(a, b) for a, b in zip(m.state_dict().values(), m2.state_dict().values()))
+    # a pickle that names the reference's class path (utils.models.NeuralPlda) binds to this implementation
+    compat.install()
+    try:
+        old = models.NeuralPlda.__module__
+        models.NeuralPlda.__module__ = "utils.models"
+        try:
+            blob = pickle.dumps(m)
+        finally:
+            models.NeuralPlda.__module__ = old
+        assert b"utils.models" in blob
+        m3 = pickle.loads(blob)
+        assert type(m3) is models.NeuralPlda and m3._reduce_sums is None
+        import utils.models as um
+        assert um.NeuralPlda is models.NeuralPlda and um.GaussianBackend is models.GaussianBackend
+        from utils.sv_trials_loaders import load_xvec_trials_from_numbatch  # noqa: F401
+        from utils.NpldaConf import NpldaConf  # noqa: F401
+    finally:
+        compat.uninstall()
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="only meaningful on a box without a HIP device")
+def test_no_cpu_fallback():
+    from neuralplda_amd import _lib, models
+    m = models.NeuralPlda(NC(64, 24, 20))
+    x = torch.randn(4, 64)
+    with pytest.raises(_lib.NpldaHipError):
+        m(x, x)
+    with pytest.raises(_lib.NpldaHipError):
+        m.softcdet(torch.randn(4), torch.ones(4))
+    with pytest.raises(_lib.NpldaHipError):
+        m.extract_plda_embeddings(x)
+    with pytest.raises(_lib.NpldaHipError):
+        models.GaussianBackend(NC(32, 16, 16))(torch.randn(2, 32), torch.randn(2, 32))
+
+
+def test_kaldi_readers_and_init(tmp_path):
+    from neuralplda_amd import kaldi_format as kf, models
+    rng = np.random.default_rng(5)
+    T = rng.standard_normal((24, 65))
+    mean = rng.standard_normal(64)
+    pm, Dt, psi = rng.standard_normal(24), rng.standard_normal((24, 24)), rng.uniform(0.5, 30, 24)
+    kf.write_matrix_binary(tmp_path / "transform.mat", T, double=False)
+    open(tmp_path / "mean.vec", "w").write(" [ " + " ".join(repr(float(v)) for v in mean) + " ]\n")
+    kf.write_plda_binary(tmp_path / "plda", pm, Dt, psi)
+    np.testing.assert_allclose(kf.read_matrix(tmp_path / "transform.mat"), T.astype(np.float32))
+    np.testing.assert_allclose(kf.read_vector(tmp_path / "mean.vec"), mean)
+    pl = kf.read_plda(tmp_path / "plda")
+    np.testing.assert_array_equal(pl["diagonalizing_transform"], Dt)
+    # text forms of the same objects
+    txt = " [\n" + " \n".join("  " + " ".join(repr(float(v)) for v in r) for r in T) + " ]\n"
+    np.testing.assert_allclose(kf.read_matrix(txt.encode()), T)
+    ptxt = ("<Plda>  [ " + " ".join(map(repr, pm.tolist())) + " ]\n" + " [\n" +
+            " \n".join("  " + " ".join(map(repr, r)) for r in Dt.tolist()) + " ]\n [ " + " ".join(map(repr, psi.tolist())) +
+            " ]\n</Plda> \n")
+    np.testing.assert_allclose(kf.read_plda(ptxt.encode())["Psi_across_covar_diag"], psi)
+    # vector archive (binary)
+    ark = io.BytesIO()
+    for k in ("utt1", "utt2"):
+        ark.write(k.encode() + b" \0B" + b"FV \x04" + np.int32(4).tobytes() + np.arange(4, dtype="<f4").tobytes())
+    got = list(kf.read_vector_ark(ark.getvalue()))
+    assert [k for k, _ in got] == ["utt1", "utt2"] and got[1][1].tolist() == [0, 1, 2, 3]
+    with pytest.raises(kf.KaldiFormatError):
+        kf.read_matrix(b"\0BCM \x04")
+    # LoadPldaParamsFromKaldi == the reference formulas (oracle restates utils/models.py:450-457)
+    m = models.NeuralPlda(NC(64, 24, 24))
+    m.LoadPldaParamsFromKaldi(str(tmp_path / "mean.vec"), str(tmp_path / "transform.mat"), str(tmp_path / "plda"))
+    ref = orc.kaldi_init_params(T.astype(np.float32).astype(np.float64), mean, pm, Dt, psi)
+    sd = m.state_dict()
+    for key, arr in (("centering_and_LDA.weight", ref.W1), ("centering_and_LDA.bias", ref.b1),
+                     ("centering_and_wccn_plda.weight", ref.W2), ("centering_and_wccn_plda.bias", ref.b2),
+                     ("P_sqrt", ref.P_sqrt), ("Q", ref.Q)):
+        np.testing.assert_allclose(sd[key].numpy(), arr, rtol=1e-6, atol=1e-7, err_msg=key)
+    gb = models.GaussianBackend(NC(64, 24, 24))
+    gb.LoadPldaParamsFromKaldi(str(tmp_path / "mean.vec"), str(tmp_path / "transform.mat"))
+    np.testing.assert_allclose(gb.centering_and_LDA.bias.numpy(), ref.b1, rtol=1e-6, atol=1e-7)
+    assert not gb.centering_and_LDA.weight.requires_grad and gb.paired_cov_inv_target.shape == (48, 48)
+
+
+def test_loaders_match_reference_golden(tmp_path):
+    """G8: same kept set, same first batch (identical RNG consumption), same gathered x-vectors."""
+    from neuralplda_amd import sv_trials_loaders as L
+    g = np.load(os.path.join(G, "g8_loaders.npz"))
+    utt = [str(u) for u in g["utt_ids"]]
+    id_to_num = {u: i for i, u in enumerate(utt)}
+    num_to_id = {i: u for i, u in enumerate(utt)}
+    mega = {u: g["xvec"][i] for i, u in enumerate(utt)}
+    trf, vaf = tmp_path / "train_trials.tsv", tmp_path / "val_trials.tsv"
+    trf.write_text(str(g["train_trials_text"]))
+    vaf.write_text(str(g["val_trials_text"]))
+    np.random.seed(1)
+    torch.manual_seed(1)
+    loader = L.combine_trials_and_get_loader([str(trf)], id_to_num, subsample_factors=[0.5], batch_size=32)
+    assert len(loader.dataset) == int(g["n_train_dataset"]) and loader.dataset.dropped == 1
+    d1, d2, t = next(iter(loader))
+    assert d1.dtype == torch.int64 and t.dtype == torch.float32
+    np.testing.assert_array_equal(d1.numpy(), g["batch_d1"])
+    np.testing.assert_array_equal(d2.numpy(), g["batch_d2"])
+    np.testing.assert_array_equal(t.numpy(), g["batch_t"])
+    np.random.seed(2)
+    torch.manual_seed(2)
+    vd = L.get_trials_loaders_dict([str(vaf)], id_to_num, subsample_factors=[1.01], batch_size=50)
+    assert list(vd.keys()) == [str(k) for k in g["val_key"]]
+    v1, v2, vt = next(iter(vd[str(g["val_key"][0])]))
+    assert len(vd[str(g["val_key"][0])].dataset) == int(g["n_val_dataset"])
+    np.testing.assert_array_equal(v1.numpy(), g["val_d1"])
+    np.testing.assert_array_equal(v2.numpy(), g["val_d2"])
+    np.testing.assert_array_equal(vt.numpy(), g["val_t"])
+    # gathers (CPU destination = host index-select, exactly the reference's values)
+    X1, X2 = L.load_xvec_trials_from_numbatch(mega, num_to_id, d1, d2, torch.device("cpu"))
+    np.testing.assert_array_equal(X1.numpy(), g["X1"])
+    np.testing.assert_array_equal(X2.numpy(), g["X2"])
+    I1, I2 = L.load_xvec_trials_from_idbatch(mega, g["idtrials"], torch.device("cpu"))
+    np.testing.assert_array_equal(I1.numpy(), g["I1"])
+    np.testing.assert_array_equal(I2.numpy(), g["I2"])
+    e1, e2 = L.load_xvec_trials_from_idbatch(mega, g["idtrials"][:0], torch.device("cpu"))
+    assert e1.shape == (0, 512) and e2.shape == (0, 512)
+    with pytest.raises(KeyError):
+        L.load_xvec_trials_from_idbatch(mega, np.asarray([["nope.wav", utt[0]]]), torch.device("cpu"))
+
+
+def test_npldaconf(tmp_path):
+    from neuralplda_amd.NpldaConf import NpldaConf
+    from neuralplda_amd import scorefile_generator as sg
+    cfg = tmp_path / "c.cfg"
+    cfg.write_text("""[Paths]
+training_data_trials_list = a.tsv,b.tsv
+validation_trials_list = v.tsv
+test_trials_list = t.tsv
+mega_xvector_scp = x.scp
+mega_xvector_pkl = x.pkl
+meanvec = mean.vec
+transformmat = transform.mat
+kaldiplda = plda
+[NPLDA]
+xvector_dim = 512
+layer1_LDA_dim = 170
+layer2_PLDA_spkfactor_dim = 170
+initialization = kaldi
+device = cuda
+seed = 1
+alpha = 15
+[Training]
+train_subsample_factors=1.01,0.5
+valid_subsample_factors=None
+loss = softCdet
+cmiss = 10
+cfa = 1
+target_probs = 0.01,0.005
+batch_size = 2048
+n_epochs = 20
+lr = 0.0001
+heldout_set_for_th_init = v
+heldout_set_for_lr_decay = v
+[Scoring]
+scorefile_format = sre
+[Logging]
+log_interval = 1000
+""")
+    nc = NpldaConf(str(cfg))
+    assert nc.beta == pytest.approx([9.9, 19.9]) and nc.training_data_trials_list == ["a.tsv", "b.tsv"]
+    assert nc.train_subsample_factors == [1.01, 0.5] and nc.valid_subsample_factors is None
+    assert nc.generate_scorefile is sg.generate_sre_scores and nc.loss == "softCdet" and nc.batch_size == 2048
+    with pytest.raises(IOError):
+        NpldaConf(str(tmp_path / "missing.cfg"))
+
+
+def test_metrics_reference_semantics_on_cpu():
+    from neuralplda_amd import metrics
+    g = np.load(os.path.join(G, "g5_metrics.npz"))
+    S, T = torch.from_numpy(g["s"]), torch.from_numpy(g["t"])
+    mc, th = metrics.minc(S, T, [99.0, 199.0])
+    assert abs(mc.item() - float(g["minc"])) <= 1e-7
+    assert th[99.0].item() == np.float32(g["minc_th"][0]) and th[199.0].item() == np.float32(g["minc_th"][1])
+    mcs, _ = metrics.minc(torch.from_numpy(g["s_sep"]), T, [99.0, 199.0])
+    assert abs(mcs.item() - float(g["minc_sep"])) <= 1e-7 and mcs.item() > 0
+    assert metrics.minc(torch.from_numpy(g["s_sep"]), T, [99.0, 199.0], reference_semantics=False)[0].item() == 0.0
+    assert abs(metrics.eer(S, T) - orc.eer(g["s"], g["t"])) < 1e-9
+    assert abs(metrics.minc_exact(S, T, [99.0])[0].item() - orc.minc_exact(g["s"], g["t"], [99.0])[0]) < 1e-6
