@@ -138,6 +138,32 @@ int nplda_score_embeddings_f32(const float* z1, int64_t ld1, const float* z2, in
 int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int64_t* idx, int64_t B,
                           int D0, float* out, int64_t ldo, nplda_stream_t stream);
 
+/* ---- adaptive score normalisation (utils/adaptive_score_normalization.py:27-73) ------------------ */
+
+/* Bytes of workspace for the spilled cohort score matrix (whole matrix up to 4 GiB, else row chunks). */
+size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M);
+
+/* Cohort score matrix + per-row statistics.  z_rows (R, ldz) / q_rows (R) and z_coh (M, ldz) / q_coh (M)
+ * come from nplda_embed_f32.  For every row r: stats[4r..4r+3] = (mean, std, mean_top, std_top) of the M
+ * cohort scores S[r, m] = NeuralPlda score of (row r, cohort m); std is the population std (ddof = 0);
+ * "top" = the topn SMALLEST scores when select_lowest != 0 (the reference's behaviour:
+ * adaptive_score_normalization.py:32-36 sorts ascending and keeps [:N]) or the topn largest otherwise.
+ * The reference does not compute cohort scores at all (it reads a TSV, :27): this is new functionality. */
+int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                           const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1,
+                           int D2, int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                           nplda_stream_t stream);
+
+/* The row-statistics half alone, on a caller-provided (R, lds) fp32 score matrix (e.g. cohort scores
+ * parsed from the TSV the reference consumes, adaptive_score_normalization.py:27-36). */
+int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int topn, int select_lowest,
+                        double* stats, nplda_stream_t stream);
+
+/* Per trial i: out[4i..4i+3] = (znorm, tnorm, snorm, asnorm1) of raw[i] given the statistics rows ie[i]
+ * (enroll) and it[i] (test) (adaptive_score_normalization.py:65-73).  fp64 like the reference script. */
+int nplda_asnorm_apply_f64(const double* raw, const int64_t* ie, const int64_t* it, int64_t T,
+                           const double* stats, int64_t R, double* out, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

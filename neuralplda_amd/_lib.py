@@ -40,6 +40,11 @@ SIGNATURES = {
     "nplda_score_embeddings_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p,
                                             _c_f32p, _c_vp]),
     "nplda_gather_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_f32p, _c_i64, _c_vp]),
+    "nplda_cohort_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
+    "nplda_cohort_stats_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int,
+                                        _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "nplda_row_stats_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
+    "nplda_asnorm_apply_f64": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp]),
     "nplda_grad_floats": (_c_sz, [_c_int, _c_int, _c_int]),
     "nplda_backward_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
     "nplda_backward_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,

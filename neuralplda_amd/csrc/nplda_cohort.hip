@@ -1,0 +1,346 @@
+// nplda_cohort.hip — adaptive score normalisation on the device (gfx950).
+//
+// The reference's utils/adaptive_score_normalization.py:27-36 READS cohort scores from a TSV that Kaldi
+// wrote, sorts every row on the host and loops over trials in Python (:65-73).  Here the cohort scores
+// are COMPUTED (new functionality; oracle = NeuralPlda.forward on the expanded pair list) and reduced:
+//
+//  K8a cohort_gemm_kernel   S[r, m] = q_r + q_m + 2 sum_d P_d z_r,d z_m,d as an fp32-MFMA tile GEMM
+//                           (K = padded D2 <= 192, so it is MFMA/write-bound, AI ~ 80 FLOP/B): wave
+//                           tile 64 x 64, operands read as float4 straight from the row-major
+//                           embedding tables with the k-permutation trick of the forward kernel, the
+//                           2 P_d factor folded into the A operand, q_r + q_m added in the epilogue.
+//                           S is spilled (R_chunk x M fp32; 0.88 GB for the whole 22 k x 10 k of
+//                           BASELINE cfg3, far below 288 GB) because the per-row top-N needs whole rows.
+//  K8b row_stats_kernel     one workgroup per row: the row is loaded once into LDS (<= 160 KB) as
+//                           order-preserving integer keys; sum and sum of squares in fp64; the N-th
+//                           smallest (reference semantics: ascending sort then [:N],
+//                           adaptive_score_normalization.py:32-36) or N-th largest key is found by a 4 x 8-bit
+//                           MSB radix select on LDS histograms; a last pass accumulates the selected
+//                           values (ties resolved by count, so the result equals sort-then-slice exactly).
+//                           Output (mean, std, mean_top, std_top), population std (ddof = 0), fp64.
+//  K9  asnorm_apply_kernel  per trial: z-norm, t-norm, s-norm, as-norm1 from the two rows' statistics
+//                           (adaptive_score_normalization.py:65-73), fp64, ~100 B/trial: HBM-bound.
+#include "nplda_common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------------------
+// K8a
+// ------------------------------------------------------------------------------------------------
+struct CohortGemmArgs {
+    const float* zr;   // (R, ldz)
+    const float* qr;   // (R)
+    const float* zc;   // (M, ldz)
+    const float* qc;   // (M)
+    const float* P;    // padded (>= 16 * NBK) floats, zero beyond D2
+    long long R, M, ldz, lds;  // lds = row stride of S (>= M)
+    int ksteps;        // k16-steps = padded D2 / 16
+    float* S;
+};
+
+__global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int i16 = lane & 15, g4 = lane >> 4;
+    // block tile 128 x 128 = 2 x 2 waves of 64 x 64
+    const long long r0 = (long long)blockIdx.y * 128 + (wave >> 1) * 64;
+    const long long m0 = (long long)blockIdx.x * 128 + (wave & 1) * 64;
+    if (r0 >= a.R || m0 >= a.M) return;
+
+    const float* pa[4];
+    const float* pb[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        long long r = r0 + 16 * c + i16;
+        long long m = m0 + 16 * c + i16;
+        if (r >= a.R) r = a.R - 1;
+        if (m >= a.M) m = a.M - 1;
+        pa[c] = a.zr + r * a.ldz + 4 * g4;
+        pb[c] = a.zc + m * a.ldz + 4 * g4;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    for (int ks = 0; ks < a.ksteps; ++ks) {
+        const f32x4 p2 = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 16 * ks + 4 * g4);
+        f32x4 fa[4], fb[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            fa[c] = *reinterpret_cast<const f32x4*>(pa[c] + 16 * ks) * p2;
+            fb[c] = *reinterpret_cast<const f32x4*>(pb[c] + 16 * ks);
+        }
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ca][kk], fb[cb][kk], acc[ca][cb], 0, 0, 0);
+    }
+    // epilogue: lane (j = i16, g4) of block (ca, cb) holds rows r0 + 16 ca + 4 g4 + r, column m0 + 16 cb + j
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb) {
+        const long long m = m0 + 16 * cb + i16;
+        if (m >= a.M) continue;
+        const float qm = a.qc[m];
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const long long row = r0 + 16 * ca + 4 * g4 + r;
+                if (row < a.R) a.S[row * a.lds + m] = acc[ca][cb][r] + (a.qr[row] + qm);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// K8b
+// ------------------------------------------------------------------------------------------------
+constexpr int kRowThreads = 512;
+constexpr int kMaxRowLds = 40000;  // floats of one row kept in LDS (160 000 B < 160 KiB)
+
+__device__ __forceinline__ unsigned f2key(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order == ascending unsigned order
+}
+__device__ __forceinline__ float key2f(unsigned k) {
+    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
+    return __uint_as_float(u);
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) red[wave] = v;
+    __syncthreads();
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < kRowThreads / 64; ++w) s += red[w];
+    return s;
+}
+
+// keys live in LDS when the row fits (use_lds), else they are re-read from global every pass
+__global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __restrict__ S, long long lds_stride,
+                                                                long long M, int topn, int lowest, int use_lds,
+                                                                double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);                  // [M] when use_lds
+    unsigned* hist = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                 // [256]
+    double* red = reinterpret_cast<double*>(hist + 256);                       // [8]
+    unsigned* sel = reinterpret_cast<unsigned*>(red + kRowThreads / 64);       // [2]: prefix key, remaining rank
+
+    const long long row = blockIdx.x;
+    const float* src = S + row * lds_stride;
+    const int tid = threadIdx.x;
+
+    // pass 0: load, full-row sums
+    double s1 = 0.0, s2 = 0.0;
+    for (long long i = tid; i < M; i += kRowThreads) {
+        const float v = src[i];
+        unsigned k = f2key(v);
+        if (!lowest) k = ~k;  // N largest == N smallest of the reversed order
+        if (use_lds) keys[i] = k;
+        s1 += (double)v;
+        s2 += (double)v * (double)v;
+    }
+    s1 = block_sum_d(s1, red);
+    s2 = block_sum_d(s2, red);
+    const double n = (double)M;
+    const double mean = s1 / n;
+    double var = s2 / n - mean * mean;
+    if (var < 0.0) var = 0.0;
+
+    long long N = topn;
+    if (N > M) N = M;
+    if (N < 1) N = 1;
+
+    // radix select of the N-th smallest key: 4 passes x 8 bits from the MSB
+    unsigned prefix = 0, prefix_mask = 0;
+    unsigned want = (unsigned)N;  // rank (1-based) still to locate inside the current prefix bucket
+    unsigned less_total = 0;      // keys strictly below the final key
+    for (int pass = 0; pass < 4; ++pass) {
+        const int shift = 24 - 8 * pass;
+        for (int b = tid; b < 256; b += kRowThreads) hist[b] = 0;
+        __syncthreads();
+        for (long long i = tid; i < M; i += kRowThreads) {
+            unsigned k;
+            if (use_lds) k = keys[i];
+            else { k = f2key(src[i]); if (!lowest) k = ~k; }
+            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned cum = 0, b = 0;
+            for (; b < 256; ++b) {
+                if (cum + hist[b] >= want) break;
+                cum += hist[b];
+            }
+            sel[0] = b;
+            sel[1] = cum;
+        }
+        __syncthreads();
+        const unsigned b = sel[0], cum = sel[1];
+        prefix |= b << shift;
+        prefix_mask |= 255u << shift;
+        want -= cum;
+        less_total += cum;
+        __syncthreads();
+    }
+    const unsigned tkey = prefix;           // key of the N-th smallest element
+    const unsigned ties_taken = want;       // how many copies of tkey belong to the first N
+    float tval = key2f(lowest ? tkey : ~tkey);
+
+    // selected sums: everything strictly below tkey, plus ties_taken copies of the threshold value
+    double t1 = 0.0, t2 = 0.0;
+    for (long long i = tid; i < M; i += kRowThreads) {
+        unsigned k;
+        if (use_lds) k = keys[i];
+        else { k = f2key(src[i]); if (!lowest) k = ~k; }
+        if (k < tkey) {
+            const double v = (double)key2f(lowest ? k : ~k);
+            t1 += v;
+            t2 += v * v;
+        }
+    }
+    t1 = block_sum_d(t1, red);
+    t2 = block_sum_d(t2, red);
+    if (tid == 0) {
+        t1 += (double)ties_taken * (double)tval;
+        t2 += (double)ties_taken * (double)tval * (double)tval;
+        const double nn = (double)N;
+        const double mt = t1 / nn;
+        double vt = t2 / nn - mt * mt;
+        if (vt < 0.0) vt = 0.0;
+        double* o = stats + row * 4;
+        o[0] = mean;
+        o[1] = sqrt(var);
+        o[2] = mt;
+        o[3] = sqrt(vt);
+    }
+    (void)less_total;
+}
+
+// ------------------------------------------------------------------------------------------------
+// K9
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void asnorm_apply_kernel(const double* __restrict__ raw,
+                                                           const long long* __restrict__ ie,
+                                                           const long long* __restrict__ it, long long T,
+                                                           const double* __restrict__ stats, long long R,
+                                                           double* __restrict__ out) {
+    const long long stride = (long long)gridDim.x * 256;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < T; i += stride) {
+        const long long e = ie[i], t = it[i];
+        double4 o;
+        if (e < 0 || e >= R || t < 0 || t >= R) {
+            const double nan = __builtin_nan("");
+            o = make_double4(nan, nan, nan, nan);
+        } else {
+            const double r = raw[i];
+            const double4 se = *reinterpret_cast<const double4*>(stats + 4 * e);
+            const double4 st = *reinterpret_cast<const double4*>(stats + 4 * t);
+            const double zn = (r - se.x) / se.y;
+            const double tn = (r - st.x) / st.y;
+            o = make_double4(zn, tn, (zn + tn) / 2, ((r - se.z) / se.w + (r - st.z) / st.w) / 2);
+        }
+        *reinterpret_cast<double4*>(out + 4 * i) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
+    if (R <= 0 || M <= 0) return 0;
+    // whole matrix if it is below 4 GiB, else row chunks of at least 128 rows
+    const unsigned long long row = ((unsigned long long)M + 3) / 4 * 4 * sizeof(float);
+    unsigned long long rows = (unsigned long long)R;
+    const unsigned long long cap = 4ull << 30;
+    if (rows * row > cap) {
+        rows = cap / row;
+        if (rows < 128) rows = 128;
+        rows = rows / 128 * 128;
+    }
+    return (size_t)(rows * row);
+}
+
+int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                           const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1, int D2,
+                           int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                           nplda_stream_t stream) {
+    if (R < 0 || M < 0 || topn < 1) return NPLDA_EINVAL;
+    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
+    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    if (R == 0) return NPLDA_OK;
+    if (M == 0) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!z_rows || !q_rows || !z_coh || !q_coh || !packed || !stats || !ws) return NPLDA_EINVAL;
+    if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z_rows) || !nplda_aligned16(z_coh) ||
+        !nplda_aligned16(packed) || !nplda_aligned16(ws))
+        return NPLDA_EINVAL;
+    const long long lds = (M + 3) / 4 * 4;
+    const size_t row_bytes = (size_t)lds * sizeof(float);
+    long long rows_per = (long long)(ws_bytes / row_bytes);
+    if (rows_per < 1) return NPLDA_ENOSPC;
+    if (rows_per > R) rows_per = R;
+    hipStream_t st = (hipStream_t)stream;
+    const int use_lds = M <= kMaxRowLds ? 1 : 0;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 256 * 4 + (kRowThreads / 64) * 8 + 16;
+    if (use_lds && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shmem);
+        if (e != hipSuccess) return (int)e;
+    }
+    for (long long r0 = 0; r0 < R; r0 += rows_per) {
+        const long long rc = (R - r0 < rows_per) ? R - r0 : rows_per;
+        CohortGemmArgs a;
+        a.zr = z_rows + r0 * ldz; a.qr = q_rows + r0; a.zc = z_coh; a.qc = q_coh;
+        a.P = (const float*)packed + L.oP; a.R = rc; a.M = M; a.ldz = ldz; a.lds = lds; a.ksteps = L.NB; a.S = (float*)ws;
+        dim3 grid((unsigned)((M + 127) / 128), (unsigned)((rc + 127) / 128));
+        hipLaunchKernelGGL(cohort_gemm_kernel, grid, dim3(256), 0, st, a);
+        if (int rc2 = nplda_launch_status()) return rc2;
+        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)rc), dim3(kRowThreads), shmem, st, (const float*)ws,
+                           (long long)lds, (long long)M, topn, select_lowest ? 1 : 0, use_lds, stats + 4 * r0);
+        if (int rc2 = nplda_launch_status()) return rc2;
+    }
+    return NPLDA_OK;
+}
+
+int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int topn, int select_lowest, double* stats,
+                        nplda_stream_t stream) {
+    if (R < 0 || M < 0 || topn < 1) return NPLDA_EINVAL;
+    if (R == 0) return NPLDA_OK;
+    if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
+    const int use_lds = M <= kMaxRowLds ? 1 : 0;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 256 * 4 + (kRowThreads / 64) * 8 + 16;
+    if (use_lds && shmem > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           (int)shmem);
+        if (e != hipSuccess) return (int)e;
+    }
+    if (R > 0x7fffffffLL) return NPLDA_EINVAL;
+    hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)R), dim3(kRowThreads), shmem, (hipStream_t)stream, S,
+                       (long long)lds, (long long)M, topn, select_lowest ? 1 : 0, use_lds, stats);
+    return nplda_launch_status();
+}
+
+int nplda_asnorm_apply_f64(const double* raw, const int64_t* ie, const int64_t* it, int64_t T, const double* stats,
+                           int64_t R, double* out, nplda_stream_t stream) {
+    if (T < 0 || R < 0) return NPLDA_EINVAL;
+    if (T == 0) return NPLDA_OK;
+    if (!raw || !ie || !it || !stats || !out) return NPLDA_EINVAL;
+    if ((((uintptr_t)stats) & 31u) || (((uintptr_t)out) & 31u)) return NPLDA_EINVAL;
+    long long blocks = (T + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(asnorm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, raw,
+                       (const long long*)ie, (const long long*)it, (long long)T, stats, (long long)R, out);
+    return nplda_launch_status();
+}
+
+}  // extern "C"

@@ -299,3 +299,70 @@ def gather_rows(table, idx):
                                          _lib.ptr(out), D0, _lib.current_stream())
     _lib.check(code, "nplda_gather_rows_f32")
     return out
+
+
+# ---- adaptive score normalisation -----------------------------------------------------------------
+
+def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None):
+    """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top)."""
+    lib = _lib.load()
+    for n, t in (("z_rows", z_rows), ("q_rows", q_rows), ("z_coh", z_coh), ("q_coh", q_coh)):
+        _require_dev_f32(t, n)
+    if z_rows.stride(0) != packed.ldz or z_coh.stride(0) != packed.ldz:
+        raise ValueError("z tables must come from embed() (row stride = packed.ldz)")
+    if select not in ("lowest", "highest"):
+        raise ValueError("select must be 'lowest' (reference semantics) or 'highest'")
+    R, M = z_rows.shape[0], z_coh.shape[0]
+    dev = z_rows.device
+    stats = torch.empty((R, 4), dtype=torch.float64, device=dev)
+    if R == 0:
+        return stats
+    wsb = lib.nplda_cohort_workspace_bytes(R, M)
+    if max_ws_bytes is not None:
+        wsb = max(min(wsb, int(max_ws_bytes)), ((M + 3) // 4 * 4) * 4)
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    with torch.cuda.device(dev):
+        code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),
+                                          _lib.ptr(q_coh.contiguous()), M, packed.ldz, _lib.ptr(packed.buf), packed.D0,
+                                          packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0,
+                                          _lib.ptr(stats), _lib.ptr(ws), wsb, _lib.current_stream())
+    _lib.check(code, "nplda_cohort_stats_f32")
+    return stats
+
+
+def row_stats(S, topn=500, select="lowest"):
+    """nplda_row_stats_f32 on an explicit (R, M) float32 score matrix."""
+    lib = _lib.load()
+    _require_dev_f32(S, "S")
+    if S.dim() != 2:
+        raise ValueError("S must be (R, M)")
+    if S.stride(1) != 1:
+        S = S.contiguous()
+    R, M = S.shape
+    stats = torch.empty((R, 4), dtype=torch.float64, device=S.device)
+    if R == 0:
+        return stats
+    with torch.cuda.device(S.device):
+        code = lib.nplda_row_stats_f32(_lib.ptr(S), S.stride(0) if R > 1 else M, R, M, int(topn),
+                                       1 if select == "lowest" else 0, _lib.ptr(stats), _lib.current_stream())
+    _lib.check(code, "nplda_row_stats_f32")
+    return stats
+
+
+def asnorm_apply(raw, ie, it, stats):
+    """nplda_asnorm_apply_f64: raw (T,) -> (T, 4) float64 columns znorm, tnorm, snorm, asnorm1."""
+    lib = _lib.load()
+    dev = stats.device
+    if not stats.is_cuda or stats.dtype != torch.float64 or stats.dim() != 2 or stats.shape[1] != 4:
+        raise ValueError("stats must be the (R, 4) float64 device tensor returned by cohort_stats/row_stats")
+    raw = torch.as_tensor(raw).to(dev).double().contiguous()
+    ie, it = _idx(ie, "ie", dev), _idx(it, "it", dev)
+    T = raw.shape[0]
+    out = torch.empty((T, 4), dtype=torch.float64, device=dev)
+    if T == 0:
+        return out
+    with torch.cuda.device(dev):
+        code = lib.nplda_asnorm_apply_f64(_lib.ptr(raw), _lib.ptr(ie), _lib.ptr(it), T, _lib.ptr(stats.contiguous()),
+                                          stats.shape[0], _lib.ptr(out), _lib.current_stream())
+    _lib.check(code, "nplda_asnorm_apply_f64")
+    return out

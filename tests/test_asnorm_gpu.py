@@ -1,0 +1,133 @@
+"""GPU parity of the AS-norm kernels (cohort MFMA GEMM, per-row radix-select statistics, per-trial
+normalisation) vs the oracle and the golden output of the reference script (G6)."""
+import io
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def rand_params(rng, D0, D1, D2):
+    k1, k2 = 1 / np.sqrt(D0), 1 / np.sqrt(D1)
+    return orc.Params(rng.uniform(-k1, k1, (D1, D0)).astype(np.float32), rng.uniform(-k1, k1, D1).astype(np.float32),
+                      rng.uniform(-k2, k2, (D2, D1)).astype(np.float32), rng.uniform(-k2, k2, D2).astype(np.float32),
+                      rng.uniform(0, 1, D2).astype(np.float32), rng.uniform(0, 1, D2).astype(np.float32))
+
+
+@pytest.mark.parametrize("R,M,topn", [(5, 600, 500), (33, 10000, 500), (3, 7, 500), (4, 50000, 500), (9, 1000, 1),
+                                      (2, 40000, 39999)])
+@pytest.mark.parametrize("select", ["lowest", "highest"])
+def test_row_stats_matches_sort_then_slice(hip_lib, R, M, topn, select):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(R * 1000 + M)
+    S = (rng.standard_normal((R, M)) * (1 + np.arange(R))[:, None] - 0.7).astype(np.float32)
+    S[0, : M // 2] = np.round(S[0, : M // 2], 1)  # heavy ties, also across the selection boundary
+    if R > 1:
+        S[1] = 0.25                                  # a constant row: std exactly 0
+    got = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
+    ref = orc.cohort_stats(S, topn, select)
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=1e-12, atol=1e-12)
+    # std via E[x^2] - mean^2 in fp64: absolute accuracy ~1e-8 of the scale
+    scale = np.abs(S).max(axis=1) + 1
+    assert np.all(np.abs(got[:, 1] - ref[:, 1]) <= 1e-7 * scale)
+    assert np.all(np.abs(got[:, 3] - ref[:, 3]) <= 1e-7 * scale)
+    if R > 1:
+        assert got[1, 1] < 1e-7 and got[1, 3] < 1e-7
+
+
+@pytest.mark.parametrize("D", [150, 170])
+@pytest.mark.parametrize("R,M", [(200, 1000), (130, 257)])
+def test_cohort_stats_full_pipeline(hip_lib, D, R, M):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D + R)
+    p = rand_params(rng, 512, D, D)
+    xr = rng.standard_normal((R, 512)).astype(np.float32)
+    xc = rng.standard_normal((M, 512)).astype(np.float32)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    zr, qr = ops.embed(torch.from_numpy(xr).cuda(), packed)
+    zc, qc = ops.embed(torch.from_numpy(xc).cuda(), packed)
+    topn = 100
+    got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn).cpu().numpy()
+    # oracle: NeuralPlda.forward on the expanded pair list (fp64), then sort-then-slice statistics
+    z_r = orc.extract_plda_embeddings(xr, p, np.float64)
+    z_c = orc.extract_plda_embeddings(xc, p, np.float64)
+    C = orc.cohort_scores(z_r, z_c, p, np.float64)
+    np.testing.assert_allclose(C[:3, :5], [[orc.forward(xr[i:i + 1], xc[j:j + 1], p, np.float64)[0] for j in range(5)]
+                                           for i in range(3)], rtol=1e-9)
+    ref = orc.cohort_stats(C, topn)
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-5)
+    # chunked workspace (forces several GEMM + select rounds) gives the same bits
+    got2 = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, max_ws_bytes=40 * ((M + 3) // 4 * 4) * 4).cpu().numpy()
+    np.testing.assert_array_equal(got, got2)
+    hi = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select="highest").cpu().numpy()
+    np.testing.assert_allclose(hi, orc.cohort_stats(C, topn, "highest"), atol=2e-5, rtol=2e-5)
+
+
+def test_asnorm_apply_and_scorefile_golden(hip_lib, tmp_path):
+    from neuralplda_amd import adaptive_score_normalization as asn, ops
+    g = np.load(os.path.join(G, "g6_asnorm.npz"))
+    ids = [str(i) for i in g["ids"]]
+    # kernel-level: statistics of the golden cohort matrix + per-trial normalisation vs the oracle (fp64)
+    C = g["cohort"]
+    stats = ops.row_stats(torch.from_numpy(C.astype(np.float32)).cuda(), topn=int(g["topn"]))
+    row = {k: i for i, k in enumerate(ids)}
+    ie = np.asarray([row[str(e)] for e in g["enroll"]])
+    it = np.asarray([row[str(t).replace(".sph", "")] for t in g["test"]])
+    out = ops.asnorm_apply(torch.from_numpy(g["raw"]), ie, it, stats).cpu().numpy()
+    ref = orc.asnorm_apply(g["raw"], ie, it, orc.cohort_stats(C.astype(np.float32), int(g["topn"])))
+    np.testing.assert_allclose(out, ref, rtol=1e-9, atol=1e-9)
+    bad = ops.asnorm_apply(torch.tensor([0.5]), [len(ids)], [0], stats).cpu().numpy()
+    assert np.all(np.isnan(bad))
+    # file-level: same TSVs in, the reference script's four files out
+    rawf, cohf = tmp_path / "raw.tsv", tmp_path / "cohort.tsv"
+    with open(rawf, "w") as f:
+        f.write("modelid\tsegmentid\tside\tLLR\n")
+        for e, t, sd, v in zip(g["enroll"], g["test"], g["side"], g["raw"]):
+            f.write(f"{e}\t{t}\t{sd}\t{float(v)!r}\n")
+    with open(cohf, "w") as f:
+        f.write("id\tcohort\tLLR\n")
+        for i, a in enumerate(ids):
+            for j in range(C.shape[1]):
+                f.write(f"{a}\tcoh{j:04d}\t{float(C[i, j])!r}\n")
+    res = asn.normalize_scorefile(str(rawf), str(cohf))
+    for k in ("znorm", "tnorm", "snorm", "asnorm1"):
+        # cohort scores go through fp32 on the device: 1e-6 relative on the normalised score
+        np.testing.assert_allclose(res[k], g[k], rtol=2e-6, atol=2e-6, err_msg=k)
+        txt = open(str(rawf) + f"_{k}.tsv").read()
+        ref_txt = str(g[k + "_text"])
+        assert txt.splitlines()[0] == ref_txt.splitlines()[0]           # "# modelid\tsegmentid\tside\tLLR"
+        tab = np.genfromtxt(io.StringIO(txt), dtype=str, skip_header=1)
+        rtab = np.genfromtxt(io.StringIO(ref_txt), dtype=str, skip_header=1)
+        np.testing.assert_array_equal(tab[:, :-1], rtab[:, :-1])
+        np.testing.assert_allclose(tab[:, -1].astype(float), rtab[:, -1].astype(float), rtol=2e-6, atol=2e-6)
+
+
+def test_asnorm_scores_pipeline(hip_lib):
+    from neuralplda_amd import adaptive_score_normalization as asn, models
+    rng = np.random.default_rng(4)
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+        beta, alpha, device, loss = [99.0], 15.0, "cuda", "SoftCdet"
+
+    torch.manual_seed(4)
+    m = models.NeuralPlda(NC()).cuda()
+    sd = {k: v.detach().cpu().numpy() for k, v in m.state_dict().items()}
+    p = orc.Params(sd["centering_and_LDA.weight"], sd["centering_and_LDA.bias"], sd["centering_and_wccn_plda.weight"],
+                   sd["centering_and_wccn_plda.bias"], sd["P_sqrt"], sd["Q"])
+    R, M, T = 60, 700, 500
+    xr = rng.standard_normal((R, 512)).astype(np.float32)
+    xc = rng.standard_normal((M, 512)).astype(np.float32)
+    ie, it = rng.integers(0, 20, T), rng.integers(20, R, T)
+    raw = orc.forward(xr[ie], xr[it], p, np.float64)
+    out = asn.asnorm_scores(m, torch.from_numpy(xr).cuda(), torch.from_numpy(xc).cuda(), raw, ie, it, topN=200)
+    zr, zc = orc.extract_plda_embeddings(xr, p, np.float64), orc.extract_plda_embeddings(xc, p, np.float64)
+    ref = orc.asnorm_apply(raw, ie, it, orc.cohort_stats(orc.cohort_scores(zr, zc, p, np.float64), 200))
+    np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=5e-4, atol=5e-4)
