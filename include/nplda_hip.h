@@ -164,6 +164,24 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
 int nplda_asnorm_apply_f64(const double* raw, const int64_t* ie, const int64_t* it, int64_t T,
                            const double* stats, int64_t R, double* out, nplda_stream_t stream);
 
+/* ---- GaussianBackend (utils/models.py:571-601) ------------------------------------------------------ */
+
+/* Bytes of the packed GaussianBackend image for a D0 -> D1 LDA (pair dimension 2 D1). 0 if unsupported. */
+size_t gb_packed_bytes(int D0, int D1);
+
+/* Pack centering_and_LDA.weight (D1, D0) / .bias (D1) and the paired statistics paired_mean_target (2 D1),
+ * paired_cov_inv_target (2 D1, 2 D1), paired_mean_nontarget, paired_cov_inv_nontarget
+ * (utils/models.py:574-580) into the fragment-ordered image; folds M = L_n - L_t, v, c (fp64). */
+int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, const float* Lam_t,
+                       const float* mu_n, const float* Lam_n, int D0, int D1, void* packed,
+                       size_t packed_bytes, nplda_stream_t stream);
+
+/* GaussianBackend.forward(x1, x2) -> s (B) (utils/models.py:584-593) and/or
+ * GaussianBackend.forward_getpaired(x1, x2) -> paired (B, 2 D1) contiguous (utils/models.py:595-601).
+ * Either output pointer may be NULL (not both). */
+int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
+                       int D0, int D1, float* s, float* paired, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

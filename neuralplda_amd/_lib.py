@@ -45,6 +45,10 @@ SIGNATURES = {
                                         _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "nplda_row_stats_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     "nplda_asnorm_apply_f64": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp]),
+    "gb_packed_bytes": (_c_sz, [_c_int, _c_int]),
+    "gb_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "gb_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
+                                    _c_vp]),
     "nplda_grad_floats": (_c_sz, [_c_int, _c_int, _c_int]),
     "nplda_backward_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
     "nplda_backward_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,

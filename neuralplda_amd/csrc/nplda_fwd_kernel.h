@@ -30,7 +30,7 @@
 
 namespace nplda {
 
-enum { MODE_PAIR = 0, MODE_EMBED = 1, MODE_TRAIN = 2 };
+enum { MODE_PAIR = 0, MODE_EMBED = 1, MODE_TRAIN = 2, MODE_GB = 3 };
 
 template <int CH, int THREADS, int NSLOT>
 __device__ __forceinline__ void chunk_load(const f32x4* __restrict__ src, long long avail,
@@ -209,6 +209,79 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
             a.out_rn[rowA] = invA;
             a.out_rn[a.n + rowB] = invB;
         }
+    }
+
+    if (MODE == MODE_GB) {
+        // ---- GaussianBackend.forward (utils/models.py:584-593) on x = [y1; y2] --------------------
+        // S = -(x-mu_t)^T L_t (x-mu_t) + (x-mu_n)^T L_n (x-mu_n) = x^T M x + x^T v + c with
+        // M = L_n - L_t (folded when the image was packed).  t = M x + v is four chained MFMA GEMMs
+        // (M11 y1 + M12 y2, M21 y1 + M22 y2) fed straight from the layer-1 accumulators, then
+        // S = y1.t1 + y2.t2 + c.  Packed image: a.oW2 -> G[h_out][h_in][kb][nb] fragments,
+        // a.ob2 -> v (two padded halves), a.oQ -> c.
+        static_assert(MODE != MODE_GB || KPB == 1, "GB mode streams one k16-step per barrier");
+        if (a.out_z != nullptr) {  // forward_getpaired: (n, 2 D1) rows [y1 | y2]
+            const int D1 = (int)a.ldz / 2;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * nb + 4 * g + r;
+                    if (okA && f < D1) {
+                        a.out_z[rowA * a.ldz + f] = accA[nb][r];
+                        a.out_z[rowA * a.ldz + D1 + f] = accB[nb][r];
+                    }
+                }
+            }
+        }
+        if (a.out_s == nullptr) return;
+        const f32x4* vp = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
+        float part = 0.f;
+#pragma unroll
+        for (int ho = 0; ho < 2; ++ho) {
+            f32x4 t[NB];
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) t[nb] = vp[(ho * NB + nb) * 4 + g];
+#pragma unroll
+            for (int hk = 0; hk < 2 * NB; ++hk) {
+                const int q = ho * 2 * NB + hk;
+                const int hi = hk / NB, kb = hk % NB;
+                const int cur = (NC1 + q) & 1;
+                if (q + 1 < 4 * NB) {
+                    const long long nbase = w2base4 + (long long)(q + 1) * CH;
+                    chunk_load<CH, THREADS, NSLOT>(Wall + nbase, total4 - nbase, st, tid);
+                }
+                const f32x4* w = wbuf[cur];
+                // groups of 4 output blocks: 4 independent accumulator chains per fragment quartet
+#pragma unroll
+                for (int nb0 = 0; nb0 < NB; nb0 += 4) {
+                    f32x4 av[4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (nb0 + u < NB) av[u] = w[(nb0 + u) * 64 + lane];
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float bv = hi == 0 ? accA[kb][r] : accB[kb][r];
+#pragma unroll
+                        for (int u = 0; u < 4; ++u)
+                            if (nb0 + u < NB)
+                                t[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], bv, t[nb0 + u], 0, 0, 0);
+                    }
+                }
+                if (q + 1 < 4 * NB) {
+                    chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
+                    __syncthreads();
+                }
+            }
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) part = fmaf(ho == 0 ? accA[nb][r] : accB[nb][r], t[nb][r], part);
+            }
+        }
+        part = wave_xor_add(part, 16);
+        part = wave_xor_add(part, 32);
+        if (g == 0 && okA) a.out_s[t0A + j] = part + a.packed[a.oQ];
+        return;
     }
 
     // ---- layer 2: z^T = W2 y^T + b2; y comes straight from the layer-1 accumulators -----------

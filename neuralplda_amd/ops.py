@@ -366,3 +366,61 @@ def asnorm_apply(raw, ie, it, stats):
                                           stats.shape[0], _lib.ptr(out), _lib.current_stream())
     _lib.check(code, "nplda_asnorm_apply_f64")
     return out
+
+
+# ---- GaussianBackend ---------------------------------------------------------------------------------
+
+def gb_pack(W1, b1, mu_t, Lam_t, mu_n, Lam_n):
+    """gb_pack_params_f32 -> (buffer, D0, D1)."""
+    lib = _lib.load()
+    ts = []
+    for n, t in (("W1", W1), ("b1", b1), ("mu_t", mu_t), ("Lam_t", Lam_t), ("mu_n", mu_n), ("Lam_n", Lam_n)):
+        _require_dev_f32(t, n)
+        ts.append(t.detach().contiguous())
+    D1, D0 = W1.shape
+    if mu_t.numel() != 2 * D1 or Lam_t.shape != (2 * D1, 2 * D1) or mu_n.numel() != 2 * D1 or Lam_n.shape != (2 * D1, 2 * D1):
+        raise ValueError("paired statistics must have dimension 2 * layer1_LDA_dim")
+    if D0 % 4 != 0:
+        raise ValueError(f"xvector_dim must be a multiple of 4 (got {D0})")
+    nbytes = lib.gb_packed_bytes(D0, D1)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"GaussianBackend {D0}->{D1} is outside the compiled kernel set")
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
+    with torch.cuda.device(W1.device):
+        code = lib.gb_pack_params_f32(*[_lib.ptr(t) for t in ts], D0, D1, _lib.ptr(buf), nbytes, _lib.current_stream())
+    _lib.check(code, "gb_pack_params_f32")
+    return buf, D0, D1
+
+
+def _gb_call(x1, x2, packed, want_s, want_paired):
+    lib = _lib.load()
+    buf, D0, D1 = packed
+    x1, ld1 = _rows(x1, "x1", D0)
+    x2, ld2 = _rows(x2, "x2", D0)
+    if x1.shape[0] != x2.shape[0]:
+        raise ValueError("x1 and x2 must have the same number of rows")
+    if ld1 != ld2:
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ld1 = ld2 = D0
+    B = x1.shape[0]
+    s = torch.empty(B, dtype=torch.float32, device=x1.device) if want_s else None
+    paired = torch.empty((B, 2 * D1), dtype=torch.float32, device=x1.device) if want_paired else None
+    if B > 0:
+        with torch.cuda.device(x1.device):
+            code = lib.gb_score_pairs_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
+                                          _lib.ptr(paired), _lib.current_stream())
+        _lib.check(code, "gb_score_pairs_f32")
+    return s, paired
+
+
+def gb_score_pairs(x1, x2, W1, b1, mu_t, Lam_t, mu_n, Lam_n):
+    """GaussianBackend.forward: (B, D0) x 2 -> (B,)."""
+    return _gb_call(x1, x2, gb_pack(W1, b1, mu_t, Lam_t, mu_n, Lam_n), True, False)[0]
+
+
+def gb_paired(x1, x2, W1, b1):
+    """GaussianBackend.forward_getpaired: (B, D0) x 2 -> (B, 2 D1) = [normalize(LDA x1), normalize(LDA x2)]."""
+    D1 = W1.shape[0]
+    z = torch.zeros(2 * D1, dtype=torch.float32, device=W1.device)
+    Z = torch.zeros((2 * D1, 2 * D1), dtype=torch.float32, device=W1.device)
+    return _gb_call(x1, x2, gb_pack(W1, b1, z, Z, z, Z), False, True)[1]

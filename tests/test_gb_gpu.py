@@ -1,0 +1,79 @@
+"""GPU parity of the fused GaussianBackend.forward kernel vs the reference's outputs (G7) and the oracle."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class NC:
+    def __init__(self, D0, D1):
+        self.xvector_dim, self.layer1_LDA_dim, self.layer2_PLDA_spkfactor_dim = D0, D1, D1
+        self.beta, self.alpha, self.device, self.loss = [99.0], 15.0, "cuda", "SoftCdet"
+
+
+def make_gb(D0, D1, W1, b1, mu_t, Lam_t, mu_n, Lam_n):
+    from neuralplda_amd import models
+    gb = models.GaussianBackend(NC(D0, D1))
+    with torch.no_grad():
+        gb.centering_and_LDA.weight.copy_(torch.from_numpy(W1))
+        gb.centering_and_LDA.bias.copy_(torch.from_numpy(b1))
+    gb.paired_mean_target, gb.paired_cov_inv_target = torch.from_numpy(mu_t), torch.from_numpy(Lam_t)
+    gb.paired_mean_nontarget, gb.paired_cov_inv_nontarget = torch.from_numpy(mu_n), torch.from_numpy(Lam_n)
+    return gb.cuda()
+
+
+def test_gb_golden_small(hip_lib):
+    g = np.load(os.path.join(G, "g7_gb.npz"))
+    gb = make_gb(32, 16, g["W1"], g["b1"], g["mu_t"], g["Lam_t"], g["mu_n"], g["Lam_n"])
+    s = gb(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda()).cpu().numpy()
+    mag = np.abs(g["s"]).max()
+    np.testing.assert_allclose(s, g["s"], atol=2e-5 * max(mag, 1.0), rtol=2e-5)
+    xp = gb.forward_getpaired(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(xp, g["paired"], atol=1e-6, rtol=1e-5)
+
+
+def test_gb_kaldi170_golden(hip_lib):
+    g1 = np.load(os.path.join(G, "g1_kaldi_params.npz"))
+    f = np.load(os.path.join(G, "g2_forward_kaldi170.npz"))
+    g = np.load(os.path.join(G, "g7_gb_kaldi170.npz"))
+    rg = np.random.default_rng(int(g["seed"]))
+    A = rg.standard_normal((340, 340)).astype(np.float32)
+    Lt = (A @ A.T / 340 + np.eye(340, dtype=np.float32)).astype(np.float32)
+    A = rg.standard_normal((340, 340)).astype(np.float32)
+    Ln = (A @ A.T / 340 + 0.5 * np.eye(340, dtype=np.float32)).astype(np.float32)
+    mt = (0.05 * rg.standard_normal(340)).astype(np.float32)
+    mn = (0.05 * rg.standard_normal(340)).astype(np.float32)
+    gb = make_gb(512, 170, g1["W1"], g1["b1"], mt, Lt, mn, Ln)
+    s = gb(torch.from_numpy(f["x1"]).cuda(), torch.from_numpy(f["x2"]).cuda()).cpu().numpy()
+    ref64 = orc.gb_forward(f["x1"], f["x2"], g1["W1"], g1["b1"], mt, Lt, mn, Ln, np.float64)
+    # the score is a difference of two O(1) quadratic forms: tolerance relative to their magnitude
+    np.testing.assert_allclose(s, ref64, atol=2e-5, rtol=2e-5)
+    if np.abs(ref64 - g["s"]).max() < 1e-3:  # golden (reference fp32) agrees with the oracle when BLAS Lt/Ln match
+        np.testing.assert_allclose(s, g["s"], atol=5e-5, rtol=5e-5)
+
+
+@pytest.mark.parametrize("D0,D1,B", [(512, 150, 1000), (64, 40, 33), (512, 170, 20000)])
+def test_gb_matches_oracle(hip_lib, D0, D1, B):
+    rng = np.random.default_rng(D1 + B)
+    k = 1 / np.sqrt(D0)
+    W1 = rng.uniform(-k, k, (D1, D0)).astype(np.float32)
+    b1 = rng.uniform(-k, k, D1).astype(np.float32)
+    n2 = 2 * D1
+    Lt = rng.standard_normal((n2, n2)).astype(np.float32)       # deliberately NOT symmetric
+    Ln = rng.standard_normal((n2, n2)).astype(np.float32)
+    mt = (0.1 * rng.standard_normal(n2)).astype(np.float32)
+    mn = (0.1 * rng.standard_normal(n2)).astype(np.float32)
+    x1 = rng.standard_normal((B, D0)).astype(np.float32)
+    x2 = rng.standard_normal((B, D0)).astype(np.float32)
+    gb = make_gb(D0, D1, W1, b1, mt, Lt, mn, Ln)
+    s = gb(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()).cpu().numpy()
+    ref = orc.gb_forward(x1, x2, W1, b1, mt, Lt, mn, Ln, np.float64)
+    scale = max(1.0, np.abs(ref).max())
+    assert np.abs(s - ref).max() <= 3e-5 * scale, np.abs(s - ref).max()
+    assert gb(torch.empty(0, D0).cuda(), torch.empty(0, D0).cuda()).shape == (0,)

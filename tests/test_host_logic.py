@@ -24,7 +24,7 @@ class NC:
 
 def test_library_exports_every_declared_symbol(hip_lib):
     hdr = open(os.path.join(ROOT, "include", "nplda_hip.h")).read()
-    declared = set(re.findall(r"\b(nplda_[a-z0-9_]+)\s*\(", hdr))
+    declared = set(re.findall(r"\b((?:nplda|gb)_[a-z0-9_]+)\s*\(", hdr))
     assert len(declared) >= 15
     from neuralplda_amd import _lib
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
