@@ -17,7 +17,7 @@
 //  K-C  reduce_kernel     fixed-order sum of the split-K slabs into one flat gradient buffer
 //         [dW1 | db1 | dW2 | db2 | dP_sqrt (= 4 P_sqrt dP) | dQ]  — deterministic, and the single
 //         buffer a data-parallel all-reduce needs.
-#include "nplda_fwd_kernel.h"
+#include "nplda_fwd_dispatch.h"
 
 namespace {
 

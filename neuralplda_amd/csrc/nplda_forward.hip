@@ -1,5 +1,5 @@
 // nplda_forward.hip — C-ABI entry points of the fused Neural-PLDA forward (kernel: nplda_fwd_kernel.h).
-#include "nplda_fwd_kernel.h"
+#include "nplda_fwd_dispatch.h"
 
 namespace {
 

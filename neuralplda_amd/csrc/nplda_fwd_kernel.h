@@ -78,7 +78,9 @@ struct FwdArgs {
 };
 
 // WAVES waves per block, each owning 16 pairs (or 32 rows); KPB k16-steps of weights per barrier.
-template <int NB, int MODE, int WAVES, bool NT, int KPB>
+// ABL (ablation bit mask, tools/exp_fwd.hip only; results are WRONG when non-zero): 1 = no weight
+// streaming and no barriers, 2 = no LDS fragment reads, 4 = no x loads after the prologue.
+template <int NB, int MODE, int WAVES, bool NT, int KPB, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_kernel(const FwdArgs a) {
     constexpr int THREADS = WAVES * 64;
     constexpr int STEP4 = NB * 64;          // float4 per k16-step of weights
@@ -143,12 +145,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
         const bool more = (c + 1 < NC1);
         // next chunk: layer-1 chunk c+1, or the first layer-2 chunk
         const long long nbase = more ? (long long)(c + 1) * CH : w2base4;
-        chunk_load<CH, THREADS, NSLOT>(Wall + nbase, total4 - nbase, st, tid);
+        if (!(ABL & 1)) chunk_load<CH, THREADS, NSLOT>(Wall + nbase, total4 - nbase, st, tid);
         f32x4 xan[KPB], xbn[KPB];
 #pragma unroll
         for (int s = 0; s < KPB; ++s) {
             const int ks = KPB * (c + 1) + s;
             const bool ok = more && (16 * ks + 4 * g < D0);
+            if (ABL & 4) { xan[s] = xa[s]; xbn[s] = xb[s]; continue; }
             xan[s] = load_x4<NT>(pa + 16 * ks, ok);
             xbn[s] = load_x4<NT>(pb + 16 * ks, ok);
         }
@@ -158,7 +161,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
             if (KPB * c + s < KS1) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 av = w[s * STEP4 + nb * 64 + lane];
+                    f32x4 av;
+                    if (ABL & 2) { av = st[0]; asm volatile("" : "+v"(av)); } else av = w[s * STEP4 + nb * 64 + lane];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         accA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xa[s][r], accA[nb], 0, 0, 0);
@@ -172,8 +176,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
             xa[s] = xan[s];
             xb[s] = xbn[s];
         }
-        chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
-        __syncthreads();
+        if (!(ABL & 1)) {
+            chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
+            __syncthreads();
+        }
     }
 
     // ---- F.normalize (utils/models.py:368): y = u / max(||u||_2, 1e-12) ------------------------
@@ -295,7 +301,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 #pragma unroll
     for (int c2 = 0; c2 < NC2; ++c2) {
         const int cur = (NC1 + c2) & 1;
-        if (c2 + 1 < NC2) {
+        if (c2 + 1 < NC2 && !(ABL & 1)) {
             const long long nbase = w2base4 + (long long)(c2 + 1) * CH;
             chunk_load<CH, THREADS, NSLOT>(Wall + nbase, total4 - nbase, st, tid);
         }
@@ -307,7 +313,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
             if (kb < NB) {
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 av = w[s * STEP4 + nb * 64 + lane];
+                    f32x4 av;
+                    if (ABL & 2) { av = st[0]; asm volatile("" : "+v"(av)); } else av = w[s * STEP4 + nb * 64 + lane];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         zA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], accA[kb < NB ? kb : 0][r], zA[nb], 0, 0, 0);
@@ -316,7 +323,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
                 }
             }
         }
-        if (c2 + 1 < NC2) {
+        if (c2 + 1 < NC2 && !(ABL & 1)) {
             chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
             __syncthreads();
         }
@@ -405,54 +412,6 @@ static __global__ void nplda_pack_kernel(const float* __restrict__ W1, const flo
         if (f < L.D2) v = P_sqrt[f] * P_sqrt[f];  // utils/models.py:373
     }
     out[idx] = v;
-}
-
-// ---- host-side dispatch (shared by nplda_forward.hip and nplda_backward.hip) --------------------
-// Product configuration, chosen by interleaved A/B runs of tools/exp_fwd.hip on MI355X
-// (profiles/r01b_*): 8 waves/block beats 4 (+7 %), non-temporal x loads +5 % on top, two k16-steps
-// per barrier +2 % at NB = 10 (at NB = 11 the bigger chunk costs registers and loses 1 %).
-// Small batches (fewer than ~2 blocks per CU of 8-wave blocks) use 4-wave blocks instead so that a
-// 4096-pair training minibatch spreads over 64 CUs x 1 wave/SIMD rather than 32 CUs x 2 waves/SIMD.
-constexpr int kpb_for(int nb) { return nb == 10 ? 2 : 1; }
-
-template <int MODE, int WAVES, bool NT>
-static inline int launch_fwd_w(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
-    const long long per_block = (MODE == MODE_EMBED ? 32 : 16) * WAVES;
-    const long long blocks = (a.n + per_block - 1) / per_block;
-    if (blocks > 0x7fffffffLL) return NPLDA_EINVAL;
-    a.D0 = L.D0; a.KS1 = L.KS1;
-    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
-    dim3 grid((unsigned)blocks), block(WAVES * 64);
-#define NPLDA_LAUNCH(NBV, KPB) \
-    hipLaunchKernelGGL((nplda_fwd_kernel<NBV, MODE, WAVES, NT, KPB>), grid, block, 0, st, a)
-    switch (L.NB) {
-        case 2: NPLDA_LAUNCH(2, 1); break;
-        case 4: NPLDA_LAUNCH(4, 1); break;
-        case 8: NPLDA_LAUNCH(8, 1); break;
-        case 10: NPLDA_LAUNCH(10, (WAVES == 8 ? 2 : 1)); break;
-        case 11: NPLDA_LAUNCH(11, 1); break;
-        case 12: NPLDA_LAUNCH(12, 1); break;
-        default: return NPLDA_EUNSUPPORTED;
-    }
-#undef NPLDA_LAUNCH
-    return nplda_launch_status();
-}
-
-template <int MODE>
-static inline int launch_fwd(const FwdArgs& a, const NpldaLayout& L, hipStream_t st) {
-    const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);  // 16-pair-equivalents x 16
-    if (units <= 256 * 64) return launch_fwd_w<MODE, 4, false>(a, L, st);
-    return launch_fwd_w<MODE, 8, true>(a, L, st);
-}
-
-static inline int check_model(int D0, int D1, int D2) {
-    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
-    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
-    return NPLDA_OK;
-}
-
-static inline bool rows_ok(const float* x, int64_t ld, int D) {
-    return x && ld >= D && (ld % 4) == 0 && nplda_aligned16(x);
 }
 
 }  // namespace nplda

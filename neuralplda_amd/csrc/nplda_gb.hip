@@ -6,7 +6,7 @@
 // (B x 2 D1)(2 D1 x 2 D1) GEMMs of the reference collapse to one — S = x^T (L_n - L_t) x + x^T v + c —
 // evaluated as four chained fp32-MFMA block GEMMs straight from the layer-1 accumulators (kernel:
 // MODE_GB in nplda_fwd_kernel.h).  v and c are computed in fp64 when the image is packed.
-#include "nplda_fwd_kernel.h"
+#include "nplda_fwd_dispatch.h"
 
 namespace {
 

@@ -102,3 +102,27 @@ def test_strided_rows(hip_lib):
     packed = ops.pack_params(*to_dev(p))
     s = ops.score_pairs(x1, x2, packed).cpu().numpy()
     np.testing.assert_allclose(s, orc.forward(big[:, :512], big[:, 512:], p, np.float64), atol=ATOL, rtol=RTOL)
+
+
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (512, 192, 192), (64, 40, 24), (72, 150, 150)])
+def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
+    """Batches above 16 384 pairs take the v2 schedule (4 k16-steps per barrier, chunk-ahead x prefetch):
+    pair, embed and train modes must agree with the oracle there too (ragged tail included)."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D1 + D0)
+    p = rand_params(rng, D0, D1, D2)
+    B = 20000 + 37
+    x1 = rng.standard_normal((B, D0)).astype(np.float32)
+    x2 = rng.standard_normal((B, D0)).astype(np.float32)
+    packed = ops.pack_params(*to_dev(p))
+    X1, X2 = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
+    s = ops.score_pairs(X1, X2, packed).cpu().numpy()
+    ref = orc.forward(x1, x2, p, np.float64)
+    assert np.all(np.abs(s - ref) <= ATOL + RTOL * np.abs(ref)), np.abs(s - ref).max()
+    st, saved = ops.forward_train(X1, X2, packed)
+    assert torch.equal(st.cpu(), torch.from_numpy(s))
+    z, q = ops.embed(torch.cat([X1, X2]), packed)
+    zr = orc.extract_plda_embeddings(np.concatenate([x1, x2]), p, np.float64)
+    np.testing.assert_allclose(z.cpu().numpy()[:, :D2], zr, atol=2e-6, rtol=1e-5)
+    assert torch.equal(saved[4][:, :D2].cpu(), z[:, :D2].cpu())          # train-mode z == embed-mode z, bit for bit
+    np.testing.assert_allclose(q.cpu().numpy(), orc.self_term(zr, p, np.float64), atol=2e-6, rtol=1e-5)

@@ -4,7 +4,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../neuralplda_amd/csrc/nplda_fwd_kernel.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_persist.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
 
 using namespace nplda;
 
@@ -32,6 +33,29 @@ void launch_v(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((nplda_fwd_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), grid, block, 0, st, a);
 }
 
+template <int NB, int WAVES, bool NT, int KPB, int ABL>
+void launch_a(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
+    hipLaunchKernelGGL((nplda_fwd_kernel<NB, MODE_PAIR, WAVES, NT, KPB, ABL>), grid, block, 0, st, a);
+}
+
+template <int NB, int WAVES, bool NT, int KPB>
+void launch_2(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
+    hipLaunchKernelGGL((nplda_fwd_v2_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), grid, block, 0, st, a);
+}
+
+template <int NB, int WAVES, bool NT, int KPB>
+void launch_p(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    const int ntiles = (int)((B + per_block - 1) / per_block);
+    int grid = 256 * (WAVES == 8 ? 1 : 2);
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((nplda_fwd_persist_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
+}
+
 int main(int argc, char** argv) {
     const int lg = argc > 1 ? atoi(argv[1]) : 20;
     const int rounds = argc > 2 ? atoi(argv[2]) : 3;
@@ -57,13 +81,13 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"w4 plain kpb1", launch_v<10, 4, false, 1>}, {"w4 nt    kpb1", launch_v<10, 4, true, 1>},
-               {"w8 plain kpb1", launch_v<10, 8, false, 1>}, {"w8 nt    kpb1", launch_v<10, 8, true, 1>},
-               {"w4 plain kpb2", launch_v<10, 4, false, 2>}, {"w8 plain kpb2", launch_v<10, 8, false, 2>},
-               {"w8 nt    kpb2", launch_v<10, 8, true, 2>} };
+        vs = { {"w8 nt    kpb2", launch_v<10, 8, true, 2>},
+               {"v2 w8 nt kpb4", launch_2<10, 8, true, 4>}, {"v2 w8 nt kpb2", launch_2<10, 8, true, 2>},
+               {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v2 w8 pl kpb3", launch_2<10, 8, false, 3>},
+               {"v2 w8 pl kpb5", launch_2<10, 8, false, 5>} };
     } else {
-        vs = { {"w4 plain kpb1", launch_v<11, 4, false, 1>}, {"w8 plain kpb1", launch_v<11, 8, false, 1>},
-               {"w8 plain kpb2", launch_v<11, 8, false, 2>} };
+        vs = { {"w8 nt    kpb1", launch_v<11, 8, true, 1>}, {"v2 w8 nt kpb4", launch_2<11, 8, true, 4>},
+               {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v2 w8 pl kpb3", launch_2<11, 8, false, 3>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
