@@ -24,6 +24,28 @@ __global__ void fill_rand(float* p, size_t n, unsigned seed) {
     }
 }
 
+// FETCH_SIZE calibration: exactly the x access pattern of the forward kernels (one float4 per lane per side per
+// k16-step: 16 rows x 64 B per wave instruction), nothing else.  Known traffic = 2 * B * D0 * 4 bytes.
+template <bool NT>
+__global__ __launch_bounds__(512) void xload_only(const float* xa, const float* xb, long long n, int D0, float* out) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, j = lane & 15, g = lane >> 4;
+    const long long row = ((long long)blockIdx.x * 8 + wave) * 16 + j;
+    if (row >= n) return;
+    const float* pa = xa + row * D0 + 4 * g;
+    const float* pb = xb + row * D0 + 4 * g;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    for (int ks = 0; ks < D0 / 16; ++ks) {
+        acc += load_x4<NT>(pa + 16 * ks, true);
+        acc += load_x4<NT>(pb + 16 * ks, true);
+    }
+    const float v = acc[0] + acc[1] + acc[2] + acc[3];
+    if (v == 123.456f) out[row] = v;  // keep the loads alive without writing
+}
+template <bool NT>
+void launch_x(const FwdArgs& a, long long B, hipStream_t st) {
+    hipLaunchKernelGGL((xload_only<NT>), dim3((unsigned)((B + 127) / 128)), dim3(512), 0, st, a.xa, a.xb, B, a.D0, a.out_s);
+}
+
 struct Variant { const char* name; void (*launch)(const FwdArgs&, long long, hipStream_t); };
 
 template <int NB, int WAVES, bool NT, int KPB>
@@ -81,10 +103,8 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"w8 nt    kpb2", launch_v<10, 8, true, 2>},
-               {"v2 w8 nt kpb4", launch_2<10, 8, true, 4>}, {"v2 w8 nt kpb2", launch_2<10, 8, true, 2>},
-               {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v2 w8 pl kpb3", launch_2<10, 8, false, 3>},
-               {"v2 w8 pl kpb5", launch_2<10, 8, false, 5>} };
+        vs = { {"w8 nt    kpb2", launch_v<10, 8, true, 2>}, {"v2 w8 nt kpb4", launch_2<10, 8, true, 4>},
+               {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"xload plain", launch_x<false>}, {"xload nt", launch_x<true>} };
     } else {
         vs = { {"w8 nt    kpb1", launch_v<11, 8, true, 1>}, {"v2 w8 nt kpb4", launch_2<11, 8, true, 4>},
                {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v2 w8 pl kpb3", launch_2<11, 8, false, 3>} };
