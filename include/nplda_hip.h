@@ -182,6 +182,16 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
 int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
                        int D0, int D1, float* s, float* paired, nplda_stream_t stream);
 
+/* ---- optimiser ----------------------------------------------------------------------------------------- */
+
+/* torch.optim.Adam's update (xvector_NeuralPlda_pytorch.py:139: lr, weight_decay = 1e-5 as L2 term, no amsgrad)
+ * applied to nseg <= 12 (param, grad, exp_avg, exp_avg_sq) segments in one launch.  The four pointer arrays and
+ * numel are HOST arrays of nseg entries (device pointers / element counts).  step: DEVICE float holding the number
+ * of steps taken so far; it is incremented first, then used for the bias correction (graph-replay safe). */
+int nplda_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,
+                        float* const* exp_avg_sq, const int64_t* numel, int nseg, float* step, float lr,
+                        float beta1, float beta2, float eps, float weight_decay, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,10 +43,10 @@ template <int NB, int WAVES>
 __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a) {
     constexpr int THREADS = WAVES * 64;
     constexpr int CH = NB * 64;
-    constexpr int NSLOT = (CH + THREADS - 1) / THREADS;
-    __shared__ f32x4 wbuf[2][CH];
+    constexpr int NSLOT = WAVES > 1 ? (CH + THREADS - 1) / THREADS : 1;
+    __shared__ f32x4 wbuf[2][WAVES > 1 ? CH : 1];
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, j = lane & 15, g4 = lane >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g4 = lane >> 4;
     const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
     const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
@@ -58,8 +58,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
         const long long rA = ok ? t0 + j : a.n - 1;
         const long long rB = a.n + rA;
         f32x4 st[NSLOT];
-        __syncthreads();  // every wave is done reading wbuf from the previous tile
-        chunk_load<CH, THREADS, NSLOT>(W2T, avail, st, tid);
+        if (WAVES > 1) {
+            __syncthreads();  // every wave is done reading wbuf from the previous tile
+            chunk_load<CH, THREADS, NSLOT>(W2T, avail, st, tid);
+        }
         const float gi = ok ? a.g[rA] : 0.f;
         f32x4 dzA[NB], dzB[NB];
 #pragma unroll
@@ -75,8 +77,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
                 *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dzB[nb];
             }
         }
-        chunk_store<CH, THREADS, NSLOT>(wbuf[0], st, tid);
-        __syncthreads();
+        if (WAVES > 1) {
+            chunk_store<CH, THREADS, NSLOT>(wbuf[0], st, tid);
+            __syncthreads();
+        }
 
         f32x4 dyA[NB], dyB[NB];
 #pragma unroll
@@ -87,18 +91,20 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {
             const int cur = kb & 1;
-            if (kb + 1 < NB) chunk_load<CH, THREADS, NSLOT>(W2T + (size_t)(kb + 1) * CH, avail - (long long)(kb + 1) * CH, st, tid);
+            if (WAVES > 1 && kb + 1 < NB)
+                chunk_load<CH, THREADS, NSLOT>(W2T + (size_t)(kb + 1) * CH, avail - (long long)(kb + 1) * CH, st, tid);
             const f32x4* w = wbuf[cur];
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
-                const f32x4 av = w[nb * 64 + lane];
+                // one wave per block (small batches): fragments straight from the L2-resident image, no LDS/barrier
+                const f32x4 av = WAVES > 1 ? w[nb * 64 + lane] : W2T[((size_t)kb * NB + nb) * 64 + lane];
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     dyA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], dzA[kb][r], dyA[nb], 0, 0, 0);
                     dyB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], dzB[kb][r], dyB[nb], 0, 0, 0);
                 }
             }
-            if (kb + 1 < NB) {
+            if (WAVES > 1 && kb + 1 < NB) {
                 chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
                 __syncthreads();
             }
@@ -164,13 +170,16 @@ struct WgradArgs {
     int nw;               // total work items
 };
 
-constexpr int kPF = 4;  // k4-steps of operand prefetch per wave
+constexpr int kPF = 8;  // k4-steps of operand prefetch per wave (HBM/L2 latency ~ 8 x 16 MFMAs)
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+// One block = one (problem, 64x64 tile, k-group) work item; its 4 waves take the 4 quarters of the k-group's
+// rows, then reduce their accumulators through LDS in a fixed order (deterministic) so that only ONE slab per
+// k-group is written.
+template <int EXT>
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, f32x4 (*red)[16 * 64], f32x4 (*rede)[3][16]) {
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
-    int w = blockIdx.x * 4 + wave;
-    if (w >= a.nw) return;
+    int w = blockIdx.x;
     const int pi = w >= a.nw0 ? 1 : 0;
     if (pi) w -= a.nw0;
     const WgradProblem& P = a.p[pi];
@@ -179,12 +188,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int nt = tile % P.NT, mt = tile / P.NT;
     const int m0 = mt * 64, n0 = nt * 64;
     const long long K = 2 * a.n;
-    const long long k0 = (long long)ks * a.rows_per_split;
-    long long k1 = k0 + a.rows_per_split;
+    const long long quarter = a.rows_per_split / 4;
+    const long long k0 = (long long)ks * a.rows_per_split + wave * quarter;
+    long long k1 = k0 + quarter;
     if (k1 > K) k1 = K;
     const bool mval = m0 + 4 * i16 < P.M;
     const bool nval = n0 + 4 * i16 < P.N;
-    const int ext = (nt == 0) ? P.extras : 0;
+    constexpr int ext = EXT;
 
     f32x4 acc[4][4];
 #pragma unroll
@@ -193,18 +203,23 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0;  // column-sum accumulators (per lane: 4 m-values)
 
+    // branch-free operand loads (clamped address + select): a predicated load would force s_waitcnt vmcnt(0)
+    // at every use and defeat the kPF-deep prefetch ring
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const int mcol = mval ? m0 + 4 * i16 : 0;
+    const int ncol = nval ? n0 + 4 * i16 : 0;
     auto loadA = [&](long long row) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < k1 && mval) v = *reinterpret_cast<const f32x4*>(P.A + row * P.lda + m0 + 4 * i16);
-        return v;
+        const bool ok = row < k1 && mval;
+        const long long rc = row < K ? row : K - 1;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(P.A + rc * P.lda + mcol);
+        return ok ? v : zero4;
     };
     auto loadB = [&](long long row) -> f32x4 {
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (row < k1 && nval) {
-            const float* base = row < a.n ? P.B0 + row * P.ldb : P.B1 + (row - a.n) * P.ldb;
-            v = *reinterpret_cast<const f32x4*>(base + n0 + 4 * i16);
-        }
-        return v;
+        const bool ok = row < k1 && nval;
+        const long long rc = row < K ? row : K - 1;
+        const float* base = rc < a.n ? P.B0 + rc * P.ldb : P.B1 + (rc - a.n) * P.ldb;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(base + ncol);
+        return ok ? v : zero4;
     };
 
     f32x4 fa[kPF], fb[kPF];
@@ -223,15 +238,15 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             fb[s] = loadB(row + 4 * kPF);
             if (ext) {
                 e0 += av;  // db1 (extras 1) or db2 (extras 2)
-                if (ext == 2 && row < k1 && mval) {
-                    const long long pr = row < a.n ? row : row - a.n;
-                    const float gi = a.g[pr];
-                    const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + row * a.ldz + m0 + 4 * i16);
+                if (ext == 2) {  // all loads unconditional (clamped), contributions masked by select
+                    const bool ok = row < k1 && mval;
+                    const long long rc = row < K ? row : K - 1;
+                    const long long pr = rc < a.n ? rc : rc - a.n;
+                    const float gi = ok ? a.g[pr] : 0.f;
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + rc * a.ldz + mcol);
+                    const f32x4 zo = *reinterpret_cast<const f32x4*>(a.z + (pr + a.n) * a.ldz + mcol);
                     e1 += gi * zv * zv;  // dQ
-                    if (row < a.n) {
-                        const f32x4 zo = *reinterpret_cast<const f32x4*>(a.z + (row + a.n) * a.ldz + m0 + 4 * i16);
-                        e2 += gi * zv * zo;  // dP (each pair once)
-                    }
+                    e2 += (rc < a.n ? gi : 0.f) * zv * zo;  // dP (each pair once)
                 }
             }
 #pragma unroll
@@ -242,22 +257,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
     }
 
-    // store the 64x64 tile of this split: D[i][j] of block (ca, cb) is C[m0 + 4 i + ca][n0 + 4 j + cb],
-    // lane (j = i16, g4) holds i = 4 g4 + r.
-    float* slab = P.slab + (size_t)ks * P.Mp * P.Np;
-    if (n0 + 4 * i16 < P.Np) {
+    // ---- in-block reduction over the 4 k-quarters (fixed order 0,1,2,3) --------------------------------
 #pragma unroll
-        for (int ca = 0; ca < 4; ++ca) {
+    for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const int m = m0 + 4 * (4 * g4 + r) + ca;
-                if (m < P.Mp) {
-                    const f32x4 v = {acc[ca][0][r], acc[ca][1][r], acc[ca][2][r], acc[ca][3][r]};
-                    *reinterpret_cast<f32x4*>(slab + (size_t)m * P.Np + n0 + 4 * i16) = v;
-                }
-            }
-        }
-    }
+        for (int cb = 0; cb < 4; ++cb) red[wave][(ca * 4 + cb) * 64 + lane] = acc[ca][cb];
     if (ext) {
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
@@ -265,17 +269,63 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             e1[c] = wave_xor_add(e1[c], 16); e1[c] = wave_xor_add(e1[c], 32);
             e2[c] = wave_xor_add(e2[c], 16); e2[c] = wave_xor_add(e2[c], 32);
         }
-        if (g4 == 0 && m0 + 4 * i16 < a.Mp) {
-            float* eb = a.ext + (size_t)ks * 4 * a.Mp + m0 + 4 * i16;
-            if (ext == 1) {
-                *reinterpret_cast<f32x4*>(eb + 3 * a.Mp) = e0;
-            } else {
-                *reinterpret_cast<f32x4*>(eb + 0 * a.Mp) = e1;
-                *reinterpret_cast<f32x4*>(eb + 1 * a.Mp) = e2;
-                *reinterpret_cast<f32x4*>(eb + 2 * a.Mp) = e0;
+        if (g4 == 0) {
+            rede[wave][0][i16] = e0;
+            rede[wave][1][i16] = e1;
+            rede[wave][2][i16] = e2;
+        }
+    }
+    __syncthreads();
+    // wave `ca` finishes block-row ca: D[i][j] of block (ca, cb) is C[m0 + 4 i + ca][n0 + 4 j + cb],
+    // lane (j = i16, g4) holds i = 4 g4 + r.
+    {
+        const int ca = wave;
+        f32x4 sum[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int idx = (ca * 4 + cb) * 64 + lane;
+            sum[cb] = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+        }
+        float* slab = P.slab + (size_t)ks * P.Mp * P.Np;
+        if (n0 + 4 * i16 < P.Np) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const int m = m0 + 4 * (4 * g4 + r) + ca;
+                if (m < P.Mp) {
+                    const f32x4 v = {sum[0][r], sum[1][r], sum[2][r], sum[3][r]};
+                    *reinterpret_cast<f32x4*>(slab + (size_t)m * P.Np + n0 + 4 * i16) = v;
+                }
             }
         }
     }
+    if (ext && wave == 0 && g4 == 0 && m0 + 4 * i16 < a.Mp) {
+        f32x4 t0 = ((rede[0][0][i16] + rede[1][0][i16]) + rede[2][0][i16]) + rede[3][0][i16];
+        f32x4 t1 = ((rede[0][1][i16] + rede[1][1][i16]) + rede[2][1][i16]) + rede[3][1][i16];
+        f32x4 t2 = ((rede[0][2][i16] + rede[1][2][i16]) + rede[2][2][i16]) + rede[3][2][i16];
+        float* eb = a.ext + (size_t)ks * 4 * a.Mp + m0 + 4 * i16;
+        if (ext == 1) {
+            *reinterpret_cast<f32x4*>(eb + 3 * a.Mp) = t0;
+        } else {
+            *reinterpret_cast<f32x4*>(eb + 0 * a.Mp) = t1;
+            *reinterpret_cast<f32x4*>(eb + 1 * a.Mp) = t2;
+            *reinterpret_cast<f32x4*>(eb + 2 * a.Mp) = t0;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+    __shared__ f32x4 red[4][16 * 64];   // [wave][(ca*4+cb)*64 + lane]  (64 KB)
+    __shared__ f32x4 rede[4][3][16];    // column-sum partials
+    int w = blockIdx.x;
+    if (w >= a.nw) return;
+    const int pi = w >= a.nw0 ? 1 : 0;
+    if (pi) w -= a.nw0;
+    const WgradProblem& P = a.p[pi];
+    const int nt = (w / a.ksplit) % P.NT;
+    const int ext = (nt == 0) ? P.extras : 0;  // block-uniform: one specialised body per block
+    if (ext == 0) wgrad_body<0>(a, red, rede);
+    else if (ext == 1) wgrad_body<1>(a, red, rede);
+    else wgrad_body<2>(a, red, rede);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -339,11 +389,12 @@ WsLayout ws_layout(long long B, const NpldaLayout& L) {
     w.Mp = 16 * L.NB;
     w.Np1 = (L.D0 + 3) / 4 * 4;
     const long long K = 2 * B;
-    long long ks = (K + 255) / 256;
+    // k-groups (slabs): each group = 4 waves x >= 128 rows; aim for ~2 blocks per CU over both GEMMs
+    long long ks = (K + 511) / 512;
     if (ks < 1) ks = 1;
-    if (ks > 32) ks = 32;
+    if (ks > 16) ks = 16;
     long long rps = (K + ks - 1) / ks;
-    rps = (rps + 15) / 16 * 16;  // multiple of 4 * kPF
+    rps = (rps + 127) / 128 * 128;  // 4 quarters, each a multiple of 4 * kPF rows
     w.ksplit = (int)((K + rps - 1) / rps);
     if (w.ksplit < 1) w.ksplit = 1;
     w.rows_per_split = rps;
@@ -412,12 +463,16 @@ int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
     b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = (const float*)packed; b.n = B; b.ldz = ldz;
     b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
     b.dz = wsf + W.dz; b.du = wsf + W.du;
-    const long long ntb = (B + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
+    // small batches: one wave per block so that a 4096-pair minibatch (256 tiles) occupies 256 CUs, not 64
+    const int bw = (B <= 16 * 1024 && L.NB != 12) ? 1 : kBwdWaves;  // (NB = 12 spills in the 1-wave form)
+    const long long ntb = (B + 16 * bw - 1) / (16 * bw);
     if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
     b.ntb = (int)ntb;
     {
-        dim3 grid((unsigned)(ntb < 2048 ? ntb : 2048)), block(kBwdWaves * 64);
-#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves>), grid, block, 0, st, b)
+        dim3 grid((unsigned)(ntb < 2048 ? ntb : 2048)), block(bw * 64);
+#define NPLDA_LAUNCH(NBV)                                                                    \
+    if (bw == 1) hipLaunchKernelGGL((bwd_data_kernel<NBV, 1>), grid, block, 0, st, b);       \
+    else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves>), grid, block, 0, st, b)
         switch (L.NB) {
             case 2: NPLDA_LAUNCH(2); break;
             case 4: NPLDA_LAUNCH(4); break;
@@ -442,7 +497,7 @@ int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
     p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp; p2.extras = 2;
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw = wa.nw0 + p2.MT * p2.NT * W.ksplit;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)((wa.nw + 3) / 4)), dim3(256), 0, st, wa);
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
     // K-C
     ReduceArgs ra = {};

@@ -51,7 +51,9 @@ __host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
     L.ob2 = L.ob1 + (size_t)L.NB * 16;
     L.oQ = L.ob2 + (size_t)L.NB * 16;
     L.oP = L.oQ + (size_t)L.NB * 16;
-    L.total = L.oP + (size_t)L.NB * 16;
+    // slack: the kernels fetch whole weight chunks (up to 4 k16-steps) without bounds checks, so that every load
+    // is unconditional and the compiler can count s_waitcnt vmcnt(N) exactly (a predicated load forces vmcnt(0))
+    L.total = L.oP + (size_t)L.NB * 16 + (size_t)4 * L.NB * 256;
     return L;
 }
 

@@ -1,6 +1,7 @@
 // nplda_fwd_dispatch.h — host-side selection of the forward kernel variant (shared by the .hip files).
 #pragma once
 #include "nplda_fwd_kernel.h"
+#include "nplda_fwd_small.h"
 #include "nplda_fwd_v2.h"
 
 namespace nplda {
@@ -10,8 +11,8 @@ namespace nplda {
 //  * large batches: the v2 schedule (nplda_fwd_v2.h) — 8 waves/block, 4 k16-steps of weights per barrier,
 //    x prefetched a whole chunk ahead, plain (cached) x loads: 0.77 of the fp32 MFMA peak at D = 150, 0.81 at
 //    D = 170 (v1 with 2 steps/barrier and non-temporal loads: 0.72 / 0.75).
-//  * batches of <= 16 384 pairs: v1 with 4-wave blocks, so that a 4096-pair training minibatch spreads over
-//    64 CUs x 1 wave/SIMD instead of 32 CUs x 2 waves/SIMD.
+//  * batches of <= 16 384 pairs: the feature-split small-batch schedule (nplda_fwd_small.h): 4 waves share one
+//    16-pair tile, so a 4096-pair training minibatch runs on all 1024 SIMDs (forward 105 us -> see DESIGN.md).
 template <int MODE, int WAVES, bool NT>
 static inline int launch_fwd_v1(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long per_block = (MODE == MODE_EMBED ? 32 : 16) * WAVES;
@@ -54,11 +55,30 @@ static inline int launch_fwd_v2(FwdArgs a, const NpldaLayout& L, hipStream_t st)
 }
 
 template <int MODE>
+static inline int launch_fwd_small(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    const long long per_block = (MODE == MODE_EMBED ? 32 : 16);
+    const long long blocks = (a.n + per_block - 1) / per_block;
+    dim3 grid((unsigned)blocks), block(256);
+#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE>), grid, block, 0, st, a)
+    switch (L.NB) {
+        case 2: NPLDA_LAUNCH(2); break;
+        case 4: NPLDA_LAUNCH(4); break;
+        case 8: NPLDA_LAUNCH(8); break;
+        case 10: NPLDA_LAUNCH(10); break;
+        case 11: NPLDA_LAUNCH(11); break;
+        case 12: NPLDA_LAUNCH(12); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+#undef NPLDA_LAUNCH
+    return nplda_launch_status();
+}
+
+template <int MODE>
 static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
     const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);
-    if (units <= 256 * 64) return launch_fwd_v1<MODE, 4, false>(a, L, st);
+    if (units <= 256 * 64) return launch_fwd_small<MODE>(a, L, st);  // 4 waves share a 16-pair tile
     if (L.NB == 12) return launch_fwd_v1<MODE, 8, true>(a, L, st);  // v2 spills a few registers at NB = 12
     return launch_fwd_v2<MODE>(a, L, st);
 }

@@ -32,13 +32,16 @@ namespace nplda {
 
 enum { MODE_PAIR = 0, MODE_EMBED = 1, MODE_TRAIN = 2, MODE_GB = 3 };
 
+// Loads are UNCONDITIONAL (out-of-range slots re-read the chunk's last float4; the packed image carries a chunk
+// of slack): a load under a runtime predicate becomes a branch, and hipcc then falls back to s_waitcnt vmcnt(0)
+// at the next consumer, which serialises the weight stream behind the in-flight x prefetches.
 template <int CH, int THREADS, int NSLOT>
-__device__ __forceinline__ void chunk_load(const f32x4* __restrict__ src, long long avail,
+__device__ __forceinline__ void chunk_load(const f32x4* __restrict__ src, long long /*avail*/,
                                            f32x4 (&st)[NSLOT], int tid) {
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
         const int idx = tid + THREADS * i;
-        if (idx < CH && idx < avail) st[i] = src[idx];
+        st[i] = src[idx < CH ? idx : CH - 1];
     }
 }
 
@@ -59,6 +62,17 @@ __device__ __forceinline__ f32x4 load_x4(const float* p, bool ok) {
         else v = *reinterpret_cast<const f32x4*>(p);
     }
     return v;
+}
+
+// Branch-free form: always loads (from `psafe`, any valid 16-byte-aligned address, when !ok) and selects zero.
+template <bool NT>
+__device__ __forceinline__ f32x4 load_x4s(const float* p, const float* psafe, bool ok) {
+    const f32x4* q = reinterpret_cast<const f32x4*>(ok ? p : psafe);
+    f32x4 v;
+    if (NT) v = __builtin_nontemporal_load(q);
+    else v = *q;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    return ok ? v : zero;
 }
 
 struct FwdArgs {
@@ -90,7 +104,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;
     const int g = lane >> 4;
 
@@ -106,8 +120,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
     const bool okA = rowA < a.n, okB = rowB < a.n;
     if (!okA) rowA = a.n - 1;
     if (!okB) rowB = a.n - 1;
-    const float* pa = a.xa + rowA * a.ldx + 4 * g;
-    const float* pb = a.xb + rowB * a.ldx + 4 * g;
+    const float* sa = a.xa + rowA * a.ldx;  // row starts: always-valid addresses for the branch-free loads
+    const float* sb = a.xb + rowB * a.ldx;
+    const float* pa = sa + 4 * g;
+    const float* pb = sb + 4 * g;
 
     const f32x4* Wall = reinterpret_cast<const f32x4*>(a.packed);  // W1 steps then W2 steps, contiguous
     const long long total4 = (long long)(a.total / 4);
@@ -126,8 +142,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
         const int kk = 16 * s + 4 * g;
-        xa[s] = load_x4<NT>(pa + 16 * s, kk < D0);
-        xb[s] = load_x4<NT>(pb + 16 * s, kk < D0);
+        xa[s] = load_x4s<NT>(pa + 16 * s, sa, kk < D0);
+        xb[s] = load_x4s<NT>(pb + 16 * s, sb, kk < D0);
     }
 
     f32x4 accA[NB], accB[NB];
@@ -152,8 +168,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
             const int ks = KPB * (c + 1) + s;
             const bool ok = more && (16 * ks + 4 * g < D0);
             if (ABL & 4) { xan[s] = xa[s]; xbn[s] = xb[s]; continue; }
-            xan[s] = load_x4<NT>(pa + 16 * ks, ok);
-            xbn[s] = load_x4<NT>(pb + 16 * ks, ok);
+            xan[s] = load_x4s<NT>(pa + 16 * ks, sa, ok);
+            xbn[s] = load_x4s<NT>(pb + 16 * ks, sb, ok);
         }
         const f32x4* w = wbuf[cur];
 #pragma unroll

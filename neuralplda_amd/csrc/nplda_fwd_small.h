@@ -1,0 +1,239 @@
+// nplda_fwd_small.h — small-batch schedule of the fused forward (training minibatches, B <= 16 384 pairs).
+//
+// The streaming kernels give one wave a whole 16-pair tile: 3 360 serial MFMAs = 45 us, and a 4096-pair
+// minibatch (BASELINE cfg2) is only 256 tiles — a quarter of the chip's 1024 SIMDs, 100 us per forward.
+// Here a tile is shared by the 4 waves of a block, split over OUTPUT FEATURES: wave w owns the 16-wide
+// feature blocks {w, w+4, w+8, ...} of both layers.
+//  * layer 1: every wave reads the tile's x fragments (4x redundant, L2-served) and only ITS weight fragments,
+//    straight from the packed image in L2 into registers with a 4-step register ring — no LDS, no barrier in
+//    the K loop;
+//  * the row norm needs all features: per-wave partial sums of squares meet in LDS (one barrier);
+//  * the normalised y blocks are published to LDS in accumulator layout, which is exactly the B-operand layout
+//    layer 2 consumes (see nplda_fwd_kernel.h), one f32x4 per lane per block: conflict-free;
+//  * layer 2: wave w computes ITS z blocks from all of y (LDS) and its W2 fragments (registers, ring);
+//  * the score is a sum over features: per-wave partials meet in LDS, wave 0 writes s.
+// Same arithmetic per element as the streaming kernels except the order of the cross-feature sums.
+#pragma once
+#include "nplda_fwd_kernel.h"
+
+namespace nplda {
+
+template <int NB, int MODE>
+__global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a) {
+    static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN, "small kernel modes");
+    constexpr int NW = 4;
+    constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
+    constexpr int PF = 4;                    // register-ring depth (k16-steps)
+    __shared__ f32x4 ylds[2][NB][64];        // normalised layer-1 output, accumulator layout
+    __shared__ float red[NW][2][16];         // cross-wave partials (norms, then scores)
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches only
+    const int j = lane & 15;
+    const int g = lane >> 4;
+
+    long long t0A, t0B;
+    if (MODE == MODE_EMBED) {
+        t0A = (long long)blockIdx.x * 32;
+        t0B = t0A + 16;
+    } else {
+        t0A = (long long)blockIdx.x * 16;
+        t0B = t0A;
+    }
+    long long rowA = t0A + j, rowB = t0B + j;
+    const bool okA = rowA < a.n, okB = rowB < a.n;
+    if (!okA) rowA = a.n - 1;
+    if (!okB) rowB = a.n - 1;
+    const float* sa = a.xa + rowA * a.ldx;
+    const float* sb = a.xb + rowB * a.ldx;
+    const float* pa = sa + 4 * g;
+    const float* pb = sb + 4 * g;
+
+    const f32x4* W1p = reinterpret_cast<const f32x4*>(a.packed);
+    const f32x4* W2p = reinterpret_cast<const f32x4*>(a.packed + a.oW2);
+    const f32x4* b1p = reinterpret_cast<const f32x4*>(a.packed + a.ob1);
+    const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    const int KS1 = a.KS1;
+    const int D0 = a.D0;
+
+    // ---- layer 1 --------------------------------------------------------------------------------------------
+    f32x4 accA[NBW], accB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        accB[i] = accA[i];
+    }
+    f32x4 wf[PF][NBW], xa[PF], xb[PF];
+    // every load is unconditional (indices clamped): predicated loads would make hipcc wait vmcnt(0) per step
+    auto fetch1 = [&](int slot, int ks) {
+        const bool in = ks < KS1;
+        const int ksc = in ? ks : KS1 - 1;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        }
+        const bool ok = in && (16 * ks + 4 * g < D0);
+        xa[slot] = load_x4s<false>(pa + 16 * ks, sa, ok);
+        xb[slot] = load_x4s<false>(pb + 16 * ks, sb, ok);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch1(s, s);
+    for (int ks0 = 0; ks0 < KS1; ks0 += PF) {
+#pragma unroll
+        for (int s = 0; s < PF; ++s) {
+            const int ks = ks0 + s;
+            if (ks < KS1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i) {
+                        // no guard: a wave whose i-th block does not exist (nb >= NB) multiplies the clamped
+                        // fragment into an accumulator that is never read — cheaper than a branch per MFMA
+                        accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], xa[s][r], accA[i], 0, 0, 0);
+                        accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], xb[s][r], accB[i], 0, 0, 0);
+                    }
+                }
+            }
+            fetch1(s, ks + PF);
+        }
+    }
+
+    // ---- F.normalize: partial sums of squares over this wave's features -> LDS -> all waves -----------------
+    {
+        float ssA = 0.f, ssB = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (wave + NW * i < NB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ssA = fmaf(accA[i][r], accA[i][r], ssA);
+                    ssB = fmaf(accB[i][r], accB[i][r], ssB);
+                }
+            }
+        }
+        ssA = wave_xor_add(ssA, 16); ssA = wave_xor_add(ssA, 32);
+        ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
+        if (g == 0) {
+            red[wave][0][j] = ssA;
+            red[wave][1][j] = ssB;
+        }
+    }
+    __syncthreads();
+    const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
+    const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB) {
+            accA[i] *= invA;
+            accB[i] *= invB;
+            ylds[0][nb][lane] = accA[i];
+            ylds[1][nb][lane] = accB[i];
+            if (MODE == MODE_TRAIN) {
+                if (okA) *reinterpret_cast<f32x4*>(a.out_y + rowA * a.ldz + 16 * nb + 4 * g) = accA[i];
+                if (okB) *reinterpret_cast<f32x4*>(a.out_y + (a.n + rowB) * a.ldz + 16 * nb + 4 * g) = accB[i];
+            }
+        }
+    }
+    if (MODE == MODE_TRAIN && wave == 0 && g == 0 && okA) {
+        a.out_rn[rowA] = invA;
+        a.out_rn[a.n + rowB] = invB;
+    }
+
+    // ---- layer 2 ------------------------------------------------------------------------------------------------
+    f32x4 zA[NBW], zB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        zA[i] = nb < NB ? b2p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        zB[i] = zA[i];
+    }
+    auto fetch2 = [&](int slot, int kb) {
+        const int kbc = kb < NB ? kb : NB - 1;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            wf[slot][i] = W2p[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch2(s, s);
+    __syncthreads();  // ylds complete (also orders the `red` reuse below after every wave's norm reads)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 yA = ylds[0][kb][lane], yB = ylds[1][kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                zA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yA[r], zA[i], 0, 0, 0);
+                zB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yB[r], zB[i], 0, 0, 0);
+            }
+        }
+        fetch2(s, kb + PF);
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------------------------
+    if (MODE == MODE_PAIR || MODE == MODE_TRAIN) {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            if (nb < NB) {
+                const f32x4 q = Qp[4 * nb + g];
+                const f32x4 p = Pp[4 * nb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = zA[i][r], z2 = zB[i][r];
+                    part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
+                    part = fmaf(2.0f * p[r], z1 * z2, part);
+                }
+                if (MODE == MODE_TRAIN) {
+                    if (okA) *reinterpret_cast<f32x4*>(a.out_z + rowA * a.ldz + 16 * nb + 4 * g) = zA[i];
+                    if (okB) *reinterpret_cast<f32x4*>(a.out_z + (a.n + rowB) * a.ldz + 16 * nb + 4 * g) = zB[i];
+                }
+            }
+        }
+        part = wave_xor_add(part, 16);
+        part = wave_xor_add(part, 32);
+        if (g == 0) red[wave][0][j] = part;
+        __syncthreads();
+        if (wave == 0 && g == 0 && okA)
+            a.out_s[t0A + j] = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+    } else {
+        float qa = 0.f, qb = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            if (nb < NB) {
+                const f32x4 q = Qp[4 * nb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    qa = fmaf(q[r] * zA[i][r], zA[i][r], qa);
+                    qb = fmaf(q[r] * zB[i][r], zB[i][r], qb);
+                }
+                if (okA) *reinterpret_cast<f32x4*>(a.out_z + rowA * a.ldz + 16 * nb + 4 * g) = zA[i];
+                if (okB) *reinterpret_cast<f32x4*>(a.out_z + rowB * a.ldz + 16 * nb + 4 * g) = zB[i];
+            }
+        }
+        qa = wave_xor_add(qa, 16); qa = wave_xor_add(qa, 32);
+        qb = wave_xor_add(qb, 16); qb = wave_xor_add(qb, 32);
+        if (g == 0) {
+            red[wave][0][j] = qa;
+            red[wave][1][j] = qb;
+        }
+        __syncthreads();
+        if (a.out_q != nullptr && wave == 0 && g == 0) {
+            if (okA) a.out_q[rowA] = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+            if (okB) a.out_q[rowB] = ((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j];
+        }
+    }
+}
+
+}  // namespace nplda

@@ -30,7 +30,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
-    const int wave = tid >> 6;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;
     const int g = lane >> 4;
 
@@ -46,11 +46,12 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
     const bool okA = rowA < a.n, okB = rowB < a.n;
     if (!okA) rowA = a.n - 1;
     if (!okB) rowB = a.n - 1;
-    const float* pa = a.xa + rowA * a.ldx + 4 * g;
-    const float* pb = a.xb + rowB * a.ldx + 4 * g;
+    const float* sa = a.xa + rowA * a.ldx;  // row starts: always-valid addresses for the branch-free loads
+    const float* sb = a.xb + rowB * a.ldx;
+    const float* pa = sa + 4 * g;
+    const float* pb = sb + 4 * g;
 
     const f32x4* Wall = reinterpret_cast<const f32x4*>(a.packed);
-    const long long total4 = (long long)(a.total / 4);
     const f32x4* b1p = reinterpret_cast<const f32x4*>(a.packed + a.ob1);
     const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
     const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
@@ -61,12 +62,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
     const long long w2base4 = (long long)(a.oW2 / 4);
 
     f32x4 st[NS];
+    // all staging loads are unconditional (the image carries a chunk of slack): see chunk_load in nplda_fwd_kernel.h
     auto load1 = [&](long long base) {  // first half of the chunk at float4 offset `base`
 #pragma unroll
-        for (int i = 0; i < NS1; ++i) {
-            const int idx = tid + THREADS * i;
-            if (base + idx < total4) st[i] = Wall[base + idx];
-        }
+        for (int i = 0; i < NS1; ++i) st[i] = Wall[base + tid + THREADS * i];
     };
     auto store1 = [&](f32x4* dst) {
 #pragma unroll
@@ -76,7 +75,7 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
 #pragma unroll
         for (int i = 0; i < NS2; ++i) {
             const int idx = HALF + tid + THREADS * i;
-            if (idx < CH && base + idx < total4) st[i] = Wall[base + idx];
+            st[i] = Wall[base + (idx < CH ? idx : CH - 1)];
         }
     };
     auto store2 = [&](f32x4* dst) {
@@ -92,8 +91,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
     f32x4 xa[KPB], xb[KPB];
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
-        xa[s] = load_x4<NT>(pa + 16 * s, 16 * s + 4 * g < D0);
-        xb[s] = load_x4<NT>(pb + 16 * s, 16 * s + 4 * g < D0);
+        xa[s] = load_x4s<NT>(pa + 16 * s, sa, 16 * s + 4 * g < D0);
+        xb[s] = load_x4s<NT>(pb + 16 * s, sb, 16 * s + 4 * g < D0);
     }
     f32x4 accA[NB], accB[NB];
 #pragma unroll
@@ -129,8 +128,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
             {   // slot s is free: fetch k16-step s of the next chunk (a whole chunk ahead of its use)
                 const int ks = KPB * (c + 1) + s;
                 const bool ok = more && (16 * ks + 4 * g < D0);
-                xa[s] = load_x4<NT>(pa + 16 * ks, ok);
-                xb[s] = load_x4<NT>(pb + 16 * ks, ok);
+                xa[s] = load_x4s<NT>(pa + 16 * ks, sa, ok);
+                xb[s] = load_x4s<NT>(pb + 16 * ks, sb, ok);
             }
             if (s == SMID - 1) {
                 store1(wbuf[cur ^ 1]);

@@ -1,0 +1,329 @@
+"""Training / validation driver — counterpart of xvector_NeuralPlda_pytorch.py:30-181.
+
+Same flow as the reference script (`train()` :30-52, `validate()` :56-83, `main_kaldiplda()` :88-181:
+Adam(lr, weight_decay=1e-5), threshold initialisation from a held-out set, per-epoch validation, whole-module
+pickle, score files, LR halving when the held-out minC rises three times in a row with the optimiser
+re-created), with the batch gather, forward, loss, backward all on the device.  Two additions:
+
+* `GraphedTrainStep` captures one whole optimisation step (zero_grad, forward, loss, backward, Adam) into a
+  HIP graph (torch.cuda.graph): the step is ~10 kernel launches on ~1.8 GFLOP of math, i.e. host-launch-bound
+  in eager mode, and a graph replay removes the Python / launch overhead.
+* the configuration path is an argument instead of a literal (:97).
+"""
+import logging
+import os
+import pickle
+import random
+from datetime import datetime
+
+import numpy as np
+import torch
+import torch.optim as optim
+
+from .models import NeuralPlda
+from .NpldaConf import NpldaConf
+from .sv_trials_loaders import (combine_trials_and_get_loader, get_trials_loaders_dict,
+                                load_xvec_trials_from_numbatch)
+
+__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "main_kaldiplda"]
+
+
+def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, valid_loaders=None,
+          step_fn=None):
+    """xvector_NeuralPlda_pytorch.py:30-52.  `step_fn(x1, x2, target) -> loss tensor` may replace the eager
+    step (e.g. a GraphedTrainStep); the loss is read back once per logging interval, not every step."""
+    model.train()
+    losses = []
+    for batch_idx, (data1, data2, target) in enumerate(train_loader):
+        data1, data2, target = data1.to(device), data2.to(device), target.to(device)
+        data1_xvec, data2_xvec = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
+        if step_fn is not None and (isinstance(step_fn, FusedTrainStep)
+                                    or data1_xvec.shape[0] == getattr(step_fn, "batch_size", -1)):
+            loss = step_fn(data1_xvec, data2_xvec, target)
+        else:
+            optimizer.zero_grad()
+            output = model(data1_xvec, data2_xvec)
+            loss = model.loss(output, target)
+            loss.backward()
+            optimizer.step()
+        losses.append(loss.detach())
+        if batch_idx % nc.log_interval == 0:
+            mean_loss = float(torch.stack([l.reshape(()).float() for l in losses]).mean().item())
+            msg = 'Train Epoch: {} [{}/{} ({:.0f}%)]\t {}: {:.6f}'.format(
+                epoch, batch_idx * len(data1), len(train_loader.dataset), 100. * batch_idx / len(train_loader),
+                nc.loss, mean_loss)
+            print(msg)
+            logging.info(msg)
+            losses = []
+
+
+def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, update_thresholds=False):
+    """xvector_NeuralPlda_pytorch.py:56-83 (scores are collected in a list, not by repeated torch.cat)."""
+    model.eval()
+    with torch.no_grad():
+        targets, scores = [], []
+        for data1, data2, target in data_loader:
+            data1, data2, target = data1.to(device), data2.to(device), target.to(device)
+            x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
+            targets.append(target)
+            scores.append(model.forward(x1, x2))
+        targets, scores = torch.cat(targets), torch.cat(scores)
+        soft_cdet_loss = model.softcdet(scores, targets)
+        cdet_mdl = model.cdet(scores, targets)
+        minc, minc_threshold = model.minc(scores, targets, update_thresholds)
+    lines = ['\n\nTest set: C_det (mdl): {:.4f}\n'.format(float(cdet_mdl)),
+             'Test set: soft C_det (mdl): {:.4f}\n'.format(float(soft_cdet_loss)),
+             'Test set: C_min: {:.4f}\n'.format(float(minc))]
+    lines += ['Test set: argmin threshold [{}]: {:.4f}\n'.format(beta, float(minc_threshold[beta])) for beta in nc.beta]
+    for ln in lines:
+        logging.info(ln)
+        print(ln)
+    return minc, minc_threshold
+
+
+class GraphedTrainStep:
+    """One optimisation step (zero_grad -> forward -> loss -> backward -> optimizer.step) captured in a HIP graph.
+
+    x1, x2: (B, D0) float32, target: (B,) float32 on the model's device, fixed B.  The optimiser must be
+    capture-safe (torch.optim.Adam(..., capturable=True); `make_optimizer` builds one).  Returns the loss of the
+    step as a 0-d device tensor (valid until the next call)."""
+
+    def __init__(self, model, optimizer, batch_size, xvector_dim=None, warmup=3):
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise ValueError("GraphedTrainStep needs the model on a HIP device")
+        self.model, self.optimizer, self.batch_size = model, optimizer, int(batch_size)
+        D0 = xvector_dim or model.centering_and_LDA.in_features
+        dev = p.device
+        self.x1 = torch.zeros(self.batch_size, D0, device=dev)
+        self.x2 = torch.zeros(self.batch_size, D0, device=dev)
+        self.t = torch.zeros(self.batch_size, device=dev)
+        self.t[::2] = 1  # a valid label mix for the warm-up steps (both classes present)
+        self._graph = None
+        self._loss = None
+        self._warmup = warmup
+
+    def _step(self):
+        self.optimizer.zero_grad(set_to_none=False)
+        out = self.model(self.x1, self.x2)
+        loss = self.model.loss(out, self.t)
+        loss.backward()
+        self.optimizer.step()
+        return loss.detach()
+
+    def _capture(self):
+        # warm-up on a side stream (allocator pools, lazy optimiser state), restoring the parameters afterwards
+        state = [p.detach().clone() for p in self.model.parameters()]
+        had_state = len(self.optimizer.state) > 0
+        saved_opt = ({id(k): {n: (v.clone() if torch.is_tensor(v) else v) for n, v in st.items()}
+                      for k, st in self.optimizer.state.items()} if had_state else None)
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            for _ in range(self._warmup):
+                self._step()
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for p, v in zip(self.model.parameters(), state):
+                p.copy_(v)
+        for k, st in self.optimizer.state.items():  # undo the warm-up's effect on the moments / step count
+            for n, v in st.items():
+                if torch.is_tensor(v):
+                    if saved_opt is not None and id(k) in saved_opt:
+                        v.copy_(saved_opt[id(k)][n])
+                    else:
+                        v.zero_()
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss = self._step()
+
+    def __call__(self, x1, x2, target):
+        if self._graph is None:
+            self._capture()
+        self.x1.copy_(x1, non_blocking=True)
+        self.x2.copy_(x2, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self._graph.replay()
+        return self._loss
+
+
+class FusedTrainStep:
+    """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser:
+    pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat gradient) -> one-launch Adam
+    (nplda_adam_step_f32, same update rule as torch.optim.Adam(lr, weight_decay) of the reference,
+    xvector_NeuralPlda_pytorch.py:139) — nine launches, optionally replayed from a HIP graph.
+    With `reduce_sums` / `reduce_flat` callables (neuralplda_amd.dist) it is the data-parallel step (eager only)."""
+
+    def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
+        from . import _lib, ops
+        from .models import _loss_kind
+        self._lib, self._ops = _lib, ops
+        p = next(model.parameters())
+        if not p.is_cuda:
+            raise ValueError("FusedTrainStep needs the model on a HIP device")
+        self.model, self.dev = model, p.device
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.kind = _loss_kind(model.lossfn)
+        self.thetas = ([model.threshold[b] for b in model.beta] if self.kind == ops.LOSS_SOFTCDET
+                       else [model.threshold_Xent])
+        self.betas_loss = [float(b) for b in model.beta] if self.kind == ops.LOSS_SOFTCDET else []
+        self.alpha = model._alpha() if self.kind == ops.LOSS_SOFTCDET else 0.0
+        self.params = list(model._params())
+        D1, D0 = self.params[0].shape
+        D2 = self.params[2].shape[0]
+        self.dims = (D0, D1, D2)
+        n = _lib.load().nplda_grad_floats(D0, D1, D2)
+        K = len(self.thetas)
+        self.m = torch.zeros(n + K, device=self.dev)
+        self.v = torch.zeros(n + K, device=self.dev)
+        self.step_count = torch.zeros(1, device=self.dev)
+        self.batch_size = batch_size
+        self.use_graph = bool(graph) and batch_size is not None
+        self._graph = None
+        self._loss = None
+        self.reduce_sums = getattr(model, "_reduce_sums", None)
+        self.reduce_flat = getattr(model, "_reduce_flat", None)
+        if self.use_graph and (self.reduce_sums is not None or self.reduce_flat is not None):
+            raise ValueError("graph replay and data-parallel reductions cannot be combined; pass graph=False")
+        if self.use_graph:
+            self.x1 = torch.zeros(batch_size, D0, device=self.dev)
+            self.x2 = torch.zeros(batch_size, D0, device=self.dev)
+            self.t = torch.zeros(batch_size, device=self.dev)
+            self.t[::2] = 1
+
+    def _eager(self, x1, x2, t):
+        import ctypes
+        ops, lib = self._ops, self._lib.load()
+        D0, D1, D2 = self.dims
+        with torch.no_grad():
+            prm = [q.detach() for q in self.params]
+            packed = ops.pack_params(*prm)
+            s, saved = ops.forward_train(x1, x2, packed)
+            ths = [th.detach() for th in self.thetas]
+            sums = ops.loss_sums(s, t, ths, self.alpha, self.kind)
+            if self.reduce_sums is not None:
+                sums = self.reduce_sums(sums)
+            loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
+            flat = ops.backward(saved, g, packed, prm[4])
+            if self.reduce_flat is not None:
+                flat = self.reduce_flat(flat)
+            # segments: the six tensors of the flat gradient, then one scalar per threshold
+            grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
+            tensors = prm + ths
+            nseg = len(tensors)
+            arr = lambda ptrs: (ctypes.c_void_p * nseg)(*ptrs)  # noqa: E731
+            offs, o = [], 0
+            for q in tensors:
+                offs.append(o)
+                o += q.numel()
+            code = lib.nplda_adam_step_f32(
+                arr([q.data_ptr() for q in tensors]), arr([gq.data_ptr() for gq in grads]),
+                arr([self.m.data_ptr() + 4 * of for of in offs]), arr([self.v.data_ptr() + 4 * of for of in offs]),
+                (ctypes.c_int64 * nseg)(*[q.numel() for q in tensors]), nseg, self.step_count.data_ptr(), self.lr,
+                self.betas[0], self.betas[1], self.eps, self.wd, self._lib.current_stream())
+            self._lib.check(code, "nplda_adam_step_f32")
+        return loss
+
+    def _capture(self):
+        state = [q.detach().clone() for q in self.params + self.thetas]
+        m0, v0, s0 = self.m.clone(), self.v.clone(), self.step_count.clone()
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._eager(self.x1, self.x2, self.t)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        with torch.no_grad():
+            for q, val in zip(self.params + self.thetas, state):
+                q.copy_(val)
+            self.m.copy_(m0)
+            self.v.copy_(v0)
+            self.step_count.copy_(s0)
+        self._graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._graph):
+            self._loss = self._eager(self.x1, self.x2, self.t)
+
+    def __call__(self, x1, x2, target):
+        if not self.use_graph or x1.shape[0] != self.batch_size:
+            return self._eager(x1, x2, target)
+        if self._graph is None:
+            self._capture()
+        self.x1.copy_(x1, non_blocking=True)
+        self.x2.copy_(x2, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self._graph.replay()
+        return self._loss
+
+
+def make_optimizer(model, lr, weight_decay=1e-5, capturable=False):
+    """Adam as the reference configures it (xvector_NeuralPlda_pytorch.py:139)."""
+    return optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=capturable)
+
+
+def main_kaldiplda(configfile='conf/voices_config.cfg', use_graph=True):
+    """xvector_NeuralPlda_pytorch.py:88-181."""
+    timestamp = int(datetime.timestamp(datetime.now()))
+    print(timestamp)
+    os.makedirs('logs', exist_ok=True)
+    os.makedirs('models', exist_ok=True)
+    os.makedirs('scores', exist_ok=True)
+    logging.basicConfig(filename='logs/kaldiplda_{}.log'.format(timestamp), filemode='a',
+                        format='%(levelname)s: %(message)s', datefmt='%H:%M:%S', level=logging.DEBUG)
+    nc = NpldaConf(configfile)
+    torch.manual_seed(nc.seed)
+    np.random.seed(nc.seed)
+    random.seed(nc.seed)
+    logging.info("Started at {}\n\n {} \n\n".format(datetime.now(), open(configfile).read()))
+    use_cuda = torch.cuda.is_available()
+    if not use_cuda:
+        raise RuntimeError("neuralplda_amd needs a HIP device")
+    device = torch.device(nc.device if str(nc.device).startswith("cuda") else "cuda")
+
+    mega_xvec_dict = pickle.load(open(nc.mega_xvector_pkl, 'rb'))
+    num_to_id_dict = {i: j for i, j in enumerate(list(mega_xvec_dict))}
+    id_to_num_dict = {v: k for k, v in num_to_id_dict.items()}
+    train_loader = combine_trials_and_get_loader(nc.training_data_trials_list, id_to_num_dict,
+                                                 subsample_factors=nc.train_subsample_factors,
+                                                 batch_size=nc.batch_size)
+    valid_loaders = get_trials_loaders_dict(nc.validation_trials_list, id_to_num_dict,
+                                            subsample_factors=nc.valid_subsample_factors,
+                                            batch_size=5 * nc.batch_size)
+    model = NeuralPlda(nc).to(device)
+    if nc.initialization == 'kaldi':
+        model.LoadPldaParamsFromKaldi(nc.meanvec, nc.transformmat, nc.kaldiplda)
+    lr = nc.lr
+    optimizer = make_optimizer(model, lr)
+    step_fn = FusedTrainStep(model, lr, weight_decay=1e-5, batch_size=nc.batch_size, graph=use_graph)
+
+    print("Initializing the thresholds... Training and validation loss printed now is not meaningful.")
+    validate(nc, model, device, mega_xvec_dict, num_to_id_dict, valid_loaders[nc.heldout_set_for_th_init],
+             update_thresholds=True)
+    all_losses = []
+    for epoch in range(1, nc.n_epochs + 1):
+        train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, valid_loaders,
+              step_fn=step_fn)
+        val_losses = {}
+        for val_set, loader in valid_loaders.items():
+            print("Validating on {}".format(val_set))
+            val_losses[val_set], _ = validate(nc, model, device, mega_xvec_dict, num_to_id_dict, loader)
+        all_losses.append(float(val_losses[nc.heldout_set_for_lr_decay]))
+        model.SaveModel("models/NPLDA_{}_{}.pt".format(epoch, timestamp))
+        for trial_file in nc.test_trials_list:
+            nc.generate_scorefile("scores/scores_kaldipldanet_CUDA_Random{}_{}.txt".format(
+                epoch, os.path.splitext(os.path.basename(trial_file))[0]), trial_file, mega_xvec_dict, model,
+                device, 5 * nc.batch_size)
+        # LR halving: three strictly increasing held-out minC values, optimiser re-created (:174-179)
+        if len(all_losses) >= 3 and all_losses[-1] > all_losses[-2] > all_losses[-3]:
+            lr = lr / 2
+            print("REDUCING LEARNING RATE to {} since loss trend looks like {}".format(lr, all_losses[-3:]))
+            logging.info("REDUCING LEARNING RATE to {} since loss trend looks like {}".format(lr, all_losses[-3:]))
+            optimizer = make_optimizer(model, lr)  # moments reset, as the reference re-creates Adam (:177)
+            step_fn = FusedTrainStep(model, lr, weight_decay=1e-5, batch_size=nc.batch_size, graph=use_graph)
+    return model
+
+
+if __name__ == '__main__':
+    import sys
+    main_kaldiplda(*(sys.argv[1:2]))

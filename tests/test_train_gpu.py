@@ -291,3 +291,67 @@ def test_metrics_on_device_match_golden(hip_lib):
         mcs, _ = m.minc(torch.from_numpy(g["s_sep"]).cuda(), T)
         assert abs(mcs.item() - float(g["minc_sep"])) <= 1e-7
         assert m.minc(torch.from_numpy(g["s_sep"]).cuda(), T, exact=True)[0].item() == 0.0
+
+
+def test_graphed_step_matches_eager(hip_lib):
+    """A HIP-graph replay of the whole optimisation step gives the same trajectory as the eager step."""
+    from neuralplda_amd import models, train
+    rng = np.random.default_rng(21)
+    p = rand_params(rng, 512, 150, 150)
+    B = 512
+    xs = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(4)]
+
+    def run(graphed):
+        m = model_from(p, NC(512, 150, 150), thetas=[-0.5, -0.3])
+        opt = train.make_optimizer(m, 1e-3, capturable=graphed)
+        losses = []
+        if graphed:
+            step = train.GraphedTrainStep(m, opt, B)
+            for x1, x2, t in xs:
+                losses.append(step(x1, x2, t).item())
+        else:
+            for x1, x2, t in xs:
+                opt.zero_grad()
+                L = m.loss(m(x1, x2), t)
+                L.backward()
+                opt.step()
+                losses.append(L.item())
+        return losses, {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}
+
+    le, pe = run(False)
+    lg, pg = run(True)
+    np.testing.assert_allclose(lg, le, rtol=1e-5)
+    for k in pe:
+        np.testing.assert_allclose(pg[k], pe[k], rtol=1e-4, atol=1e-6, err_msg=k)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("lossname", ["SoftCdet", "crossentropy"])
+def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
+    """FusedTrainStep (direct C-ABI launches + one-launch Adam) follows the autograd + torch.optim.Adam
+    trajectory of the reference's training loop (xvector_NeuralPlda_pytorch.py:35-43, :139)."""
+    from neuralplda_amd import train
+    rng = np.random.default_rng(31)
+    p = rand_params(rng, 512, 170, 170)
+    B = 256
+    xs = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(5)]
+    m_ref = model_from(p, NC(loss=lossname), thetas=[-0.5, -0.3], theta_xent=0.1)
+    opt = train.make_optimizer(m_ref, 1e-3)
+    ref_losses = []
+    for x1, x2, t in xs:
+        opt.zero_grad()
+        L = m_ref.loss(m_ref(x1, x2), t)
+        L.backward()
+        opt.step()
+        ref_losses.append(L.item())
+    m = model_from(p, NC(loss=lossname), thetas=[-0.5, -0.3], theta_xent=0.1)
+    step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+    losses = [step(x1, x2, t).item() for x1, x2, t in xs]
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    assert step.step_count.item() == 5
