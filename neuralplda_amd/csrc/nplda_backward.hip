@@ -140,6 +140,121 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
     }
 }
 
+// Small-batch form of K-A (B <= 16 384 pairs): the 4 waves of a block share one 16-pair tile, split over feature
+// blocks exactly like nplda_fwd_small.h — each wave forms dz for ITS blocks and publishes them to LDS in
+// accumulator layout (= the B operand of the chained MFMA), computes ITS dy blocks from all of dz with W2^T
+// fragments read straight from the L2-resident image through a register ring, and the y.dy dot product of the
+// normalize backward is reduced across the waves through LDS.
+template <int NB>
+__global__ __launch_bounds__(256, 1) void bwd_data_small_kernel(const BwdArgs a) {
+    constexpr int NW = 4;
+    constexpr int NBW = (NB + NW - 1) / NW;
+    constexpr int PF = 4;
+    __shared__ f32x4 dzlds[2][NB][64];
+    __shared__ float red[NW][2][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g4 = lane >> 4;
+    const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+
+    const long long t0 = (long long)blockIdx.x * 16;
+    const bool ok = t0 + j < a.n;
+    const long long rA = ok ? t0 + j : a.n - 1;
+    const long long rB = a.n + rA;
+
+    f32x4 wf[PF][NBW];
+    auto fetch = [&](int slot, int kb) {
+        const int kbc = kb < NB ? kb : NB - 1;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            wf[slot][i] = W2T[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch(s, s);
+
+    const float tg = ok ? 2.0f * a.g[rA] : 0.f;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB) {
+            const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
+            const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
+            const f32x4 dA = tg * (q * zA + p * zB);
+            const f32x4 dB = tg * (q * zB + p * zA);
+            dzlds[0][nb][lane] = dA;
+            dzlds[1][nb][lane] = dB;
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dA;
+                *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dB;
+            }
+        }
+    }
+    __syncthreads();
+
+    f32x4 dyA[NBW], dyB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        dyA[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dyB[i] = dyA[i];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 dA = dzlds[0][kb][lane], dB = dzlds[1][kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                dyA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], dA[r], dyA[i], 0, 0, 0);
+                dyB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], dB[r], dyB[i], 0, 0, 0);
+            }
+        }
+        fetch(s, kb + PF);
+    }
+
+    // F.normalize backward on this wave's blocks; the dot product y.dy runs over ALL features -> LDS reduction
+    f32x4 yA[NBW], yB[NBW];
+    float dotA = 0.f, dotB = 0.f;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        const int nbc = nb < NB ? nb : NB - 1;
+        yA[i] = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nbc + 4 * g4);
+        yB[i] = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nbc + 4 * g4);
+        if (nb < NB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dotA = fmaf(yA[i][r], dyA[i][r], dotA);
+                dotB = fmaf(yB[i][r], dyB[i][r], dotB);
+            }
+        }
+    }
+    dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
+    dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
+    if (g4 == 0) {
+        red[wave][0][j] = dotA;
+        red[wave][1][j] = dotB;
+    }
+    __syncthreads();
+    dotA = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+    dotB = ((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j];
+    const float rnA = a.rn[rA], rnB = a.rn[rB];
+    if (rnA >= 1e12f) dotA = 0.f;
+    if (rnB >= 1e12f) dotB = 0.f;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB && ok) {
+            *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[i] - yA[i] * dotA) * rnA;
+            *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[i] - yB[i] * dotB) * rnB;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------
 // K-B : C[m][n] = sum_k A[k][m] * Bm[k][n]   (K = 2n rows; Bm rows come from two segments)
 // ------------------------------------------------------------------------------------------------
@@ -389,10 +504,14 @@ WsLayout ws_layout(long long B, const NpldaLayout& L) {
     w.Mp = 16 * L.NB;
     w.Np1 = (L.D0 + 3) / 4 * 4;
     const long long K = 2 * B;
-    // k-groups (slabs): each group = 4 waves x >= 128 rows; aim for ~2 blocks per CU over both GEMMs
+    // k-groups (slabs): each group = one block of 4 waves x >= 128 rows.  A block holds 68 KB of LDS, so 2 are
+    // resident per CU: keep (64x64 tiles) x (k-groups) <= 512 blocks so that the grid is a single resident wave
+    // (528 blocks ran as 512 + a 16-block tail at twice the time).
+    const long long tiles = (long long)((w.Mp + 63) / 64) * ((L.D0 + 63) / 64) + (long long)((w.Mp + 63) / 64) * ((w.Mp + 63) / 64);
     long long ks = (K + 511) / 512;
-    if (ks < 1) ks = 1;
     if (ks > 16) ks = 16;
+    if (ks * tiles > 512) ks = 512 / tiles;
+    if (ks < 1) ks = 1;
     long long rps = (K + ks - 1) / ks;
     rps = (rps + 127) / 128 * 128;  // 4 quarters, each a multiple of 4 * kPF rows
     w.ksplit = (int)((K + rps - 1) / rps);
@@ -463,15 +582,15 @@ int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
     b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = (const float*)packed; b.n = B; b.ldz = ldz;
     b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
     b.dz = wsf + W.dz; b.du = wsf + W.du;
-    // small batches: one wave per block so that a 4096-pair minibatch (256 tiles) occupies 256 CUs, not 64
-    const int bw = (B <= 16 * 1024 && L.NB != 12) ? 1 : kBwdWaves;  // (NB = 12 spills in the 1-wave form)
-    const long long ntb = (B + 16 * bw - 1) / (16 * bw);
+    const long long ntb = (B + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
     if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
     b.ntb = (int)ntb;
     {
-        dim3 grid((unsigned)(ntb < 2048 ? ntb : 2048)), block(bw * 64);
-#define NPLDA_LAUNCH(NBV)                                                                    \
-    if (bw == 1) hipLaunchKernelGGL((bwd_data_kernel<NBV, 1>), grid, block, 0, st, b);       \
+        // small batches: 4 waves share a 16-pair tile (feature split), so a 4096-pair minibatch fills 256 CUs
+        const bool small = B <= 16 * 1024;
+        dim3 grid(small ? (unsigned)((B + 15) / 16) : (unsigned)(ntb < 2048 ? ntb : 2048)), block(256);
+#define NPLDA_LAUNCH(NBV)                                                                 \
+    if (small) hipLaunchKernelGGL((bwd_data_small_kernel<NBV>), grid, block, 0, st, b);    \
     else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves>), grid, block, 0, st, b)
         switch (L.NB) {
             case 2: NPLDA_LAUNCH(2); break;

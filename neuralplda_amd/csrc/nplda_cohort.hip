@@ -14,9 +14,10 @@
 //  K8b row_stats_kernel     one workgroup per row: the row is loaded once into LDS (<= 160 KB) as
 //                           order-preserving integer keys; sum and sum of squares in fp64; the N-th
 //                           smallest (reference semantics: ascending sort then [:N],
-//                           adaptive_score_normalization.py:32-36) or N-th largest key is found by a 4 x 8-bit
-//                           MSB radix select on LDS histograms; a last pass accumulates the selected
-//                           values (ties resolved by count, so the result equals sort-then-slice exactly).
+//                           adaptive_score_normalization.py:32-36) or N-th largest
+//                           key is found by a 4-ary search on the integer key space (three pivot counts per
+//                           pass in registers, shuffle + LDS reduction, no atomics); a last pass accumulates the
+//                           selected values (ties resolved by count, so the result equals sort-then-slice exactly).
 //                           Output (mean, std, mean_top, std_top), population std (ddof = 0), fp64.
 //  K9  asnorm_apply_kernel  per trial: z-norm, t-norm, s-norm, as-norm1 from the two rows' statistics
 //                           (adaptive_score_normalization.py:65-73), fp64, ~100 B/trial: HBM-bound.
@@ -130,26 +131,44 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                                                                 double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);                  // [M] when use_lds
-    unsigned* hist = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                 // [256]
-    double* red = reinterpret_cast<double*>(hist + 256);                       // [8]
-    unsigned* sel = reinterpret_cast<unsigned*>(red + kRowThreads / 64);       // [2]: prefix key, remaining rank
+    unsigned* cnt = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                  // [2][8][4] count partials
+    double* red = reinterpret_cast<double*>(cnt + 64);                         // [8]
+    constexpr int NWV = kRowThreads / 64;
 
     const long long row = blockIdx.x;
     const float* src = S + row * lds_stride;
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // pass 0: load, full-row sums
+    // pass 0: load, full-row sums, key range
     double s1 = 0.0, s2 = 0.0;
+    unsigned kmin = 0xffffffffu, kmax = 0u;
     for (long long i = tid; i < M; i += kRowThreads) {
         const float v = src[i];
         unsigned k = f2key(v);
         if (!lowest) k = ~k;  // N largest == N smallest of the reversed order
         if (use_lds) keys[i] = k;
+        kmin = k < kmin ? k : kmin;
+        kmax = k > kmax ? k : kmax;
         s1 += (double)v;
         s2 += (double)v * (double)v;
     }
     s1 = block_sum_d(s1, red);
     s2 = block_sum_d(s2, red);
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        const unsigned a = __shfl_xor(kmin, m, 64), b = __shfl_xor(kmax, m, 64);
+        kmin = a < kmin ? a : kmin;
+        kmax = b > kmax ? b : kmax;
+    }
+    if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
+    __syncthreads();
+    unsigned lo = 0xffffffffu, hi = 0u;
+#pragma unroll
+    for (int w = 0; w < NWV; ++w) {
+        lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
+        hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
+    }
+    __syncthreads();
     const double n = (double)M;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
@@ -158,45 +177,45 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     long long N = topn;
     if (N > M) N = M;
     if (N < 1) N = 1;
+    const unsigned want = (unsigned)N;
 
-    // radix select of the N-th smallest key: 4 passes x 8 bits from the MSB
-    unsigned prefix = 0, prefix_mask = 0;
-    unsigned want = (unsigned)N;  // rank (1-based) still to locate inside the current prefix bucket
-    unsigned less_total = 0;      // keys strictly below the final key
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int b = tid; b < 256; b += kRowThreads) hist[b] = 0;
-        __syncthreads();
+    // N-th smallest key T by 4-ary search on the integer key space: every iteration counts, for three pivots,
+    // the keys <= pivot (register counters + shuffle/LDS reduction — no atomics: cohort scores of one row share
+    // their leading bits, which serialises an LDS-histogram radix select) and keeps the quarter that holds rank N.
+    for (int it = 0; lo < hi; ++it) {
+        const unsigned long long span = (unsigned long long)hi - lo;
+        const unsigned p1 = lo + (unsigned)(span / 4), p2 = lo + (unsigned)(span / 2), p3 = lo + (unsigned)(span / 4 * 3);
+        unsigned c1 = 0, c2 = 0, c3 = 0;
         for (long long i = tid; i < M; i += kRowThreads) {
             unsigned k;
             if (use_lds) k = keys[i];
             else { k = f2key(src[i]); if (!lowest) k = ~k; }
-            if ((k & prefix_mask) == prefix) atomicAdd(&hist[(k >> shift) & 255u], 1u);
+            c1 += k <= p1;
+            c2 += k <= p2;
+            c3 += k <= p3;
         }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0, b = 0;
-            for (; b < 256; ++b) {
-                if (cum + hist[b] >= want) break;
-                cum += hist[b];
-            }
-            sel[0] = b;
-            sel[1] = cum;
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            c1 += __shfl_xor(c1, m, 64);
+            c2 += __shfl_xor(c2, m, 64);
+            c3 += __shfl_xor(c3, m, 64);
         }
+        unsigned* cb = cnt + (it & 1) * 32;
+        if (lane == 0) { cb[wave * 4] = c1; cb[wave * 4 + 1] = c2; cb[wave * 4 + 2] = c3; }
         __syncthreads();
-        const unsigned b = sel[0], cum = sel[1];
-        prefix |= b << shift;
-        prefix_mask |= 255u << shift;
-        want -= cum;
-        less_total += cum;
-        __syncthreads();
+        c1 = c2 = c3 = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { c1 += cb[w * 4]; c2 += cb[w * 4 + 1]; c3 += cb[w * 4 + 2]; }
+        if (c1 >= want) hi = p1;
+        else if (c2 >= want) { lo = p1 + 1; hi = p2; }
+        else if (c3 >= want) { lo = p2 + 1; hi = p3; }
+        else lo = p3 + 1;
     }
-    const unsigned tkey = prefix;           // key of the N-th smallest element
-    const unsigned ties_taken = want;       // how many copies of tkey belong to the first N
+    const unsigned tkey = lo;  // key of the N-th smallest element
     float tval = key2f(lowest ? tkey : ~tkey);
 
-    // selected sums: everything strictly below tkey, plus ties_taken copies of the threshold value
-    double t1 = 0.0, t2 = 0.0;
+    // selected sums: everything strictly below tkey, plus (N - #less) copies of the threshold value (ties)
+    double t1 = 0.0, t2 = 0.0, nless = 0.0;
     for (long long i = tid; i < M; i += kRowThreads) {
         unsigned k;
         if (use_lds) k = keys[i];
@@ -205,13 +224,16 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             const double v = (double)key2f(lowest ? k : ~k);
             t1 += v;
             t2 += v * v;
+            nless += 1.0;
         }
     }
     t1 = block_sum_d(t1, red);
     t2 = block_sum_d(t2, red);
+    nless = block_sum_d(nless, red);
     if (tid == 0) {
-        t1 += (double)ties_taken * (double)tval;
-        t2 += (double)ties_taken * (double)tval * (double)tval;
+        const double ties_taken = (double)N - nless;
+        t1 += ties_taken * (double)tval;
+        t2 += ties_taken * (double)tval * (double)tval;
         const double nn = (double)N;
         const double mt = t1 / nn;
         double vt = t2 / nn - mt * mt;
@@ -222,7 +244,6 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         o[2] = mt;
         o[3] = sqrt(vt);
     }
-    (void)less_total;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -291,7 +312,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 256 * 4 + (kRowThreads / 64) * 8 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -318,7 +339,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 256 * 4 + (kRowThreads / 64) * 8 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
