@@ -291,13 +291,19 @@ constexpr int kPF = 8;  // k4-steps of operand prefetch per wave (HBM/L2 latency
 // rows, then reduce their accumulators through LDS in a fixed order (deterministic) so that only ONE slab per
 // k-group is written.
 template <int EXT>
-__device__ __forceinline__ void wgrad_body(const WgradArgs& a, f32x4 (*red)[16 * 64], f32x4 (*rede)[3][16]) {
+__device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProblem P, int w, f32x4 (*red)[16 * 64],
+                                           f32x4 (*rede)[3][16]) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
-    int w = blockIdx.x;
-    const int pi = w >= a.nw0 ? 1 : 0;
-    if (pi) w -= a.nw0;
-    const WgradProblem& P = a.p[pi];
+    // P is a by-value copy of the problem descriptor (pointers in registers): indexing a.p[pi] inside the loop made
+    // hipcc re-load the operand base pointers from the kernarg segment every k-step, a dependent load in front
+    // of every operand load
+    const float* __restrict__ PA = P.A;
+    const float* __restrict__ PB0 = P.B0;
+    const float* __restrict__ PB1 = P.B1;
+    const long long lda = P.lda, ldb = P.ldb, npairs = a.n, ldz = a.ldz;
+    const float* __restrict__ zptr = a.z;
+    const float* __restrict__ gptr = a.g;
     const int ks = w % a.ksplit;
     const int tile = w / a.ksplit;
     const int nt = tile % P.NT, mt = tile / P.NT;
@@ -326,13 +332,13 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, f32x4 (*red)[16 *
     auto loadA = [&](long long row) -> f32x4 {
         const bool ok = row < k1 && mval;
         const long long rc = row < K ? row : K - 1;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(P.A + rc * P.lda + mcol);
+        const f32x4 v = *reinterpret_cast<const f32x4*>(PA + rc * lda + mcol);
         return ok ? v : zero4;
     };
     auto loadB = [&](long long row) -> f32x4 {
         const bool ok = row < k1 && nval;
         const long long rc = row < K ? row : K - 1;
-        const float* base = rc < a.n ? P.B0 + rc * P.ldb : P.B1 + (rc - a.n) * P.ldb;
+        const float* base = rc < npairs ? PB0 + rc * ldb : PB1 + (rc - npairs) * ldb;
         const f32x4 v = *reinterpret_cast<const f32x4*>(base + ncol);
         return ok ? v : zero4;
     };
@@ -356,12 +362,12 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, f32x4 (*red)[16 *
                 if (ext == 2) {  // all loads unconditional (clamped), contributions masked by select
                     const bool ok = row < k1 && mval;
                     const long long rc = row < K ? row : K - 1;
-                    const long long pr = rc < a.n ? rc : rc - a.n;
-                    const float gi = ok ? a.g[pr] : 0.f;
-                    const f32x4 zv = *reinterpret_cast<const f32x4*>(a.z + rc * a.ldz + mcol);
-                    const f32x4 zo = *reinterpret_cast<const f32x4*>(a.z + (pr + a.n) * a.ldz + mcol);
+                    const long long pr = rc < npairs ? rc : rc - npairs;
+                    const float gi = ok ? gptr[pr] : 0.f;
+                    const f32x4 zv = *reinterpret_cast<const f32x4*>(zptr + rc * ldz + mcol);
+                    const f32x4 zo = *reinterpret_cast<const f32x4*>(zptr + (pr + npairs) * ldz + mcol);
                     e1 += gi * zv * zv;  // dQ
-                    e2 += (rc < a.n ? gi : 0.f) * zv * zo;  // dP (each pair once)
+                    e2 += (rc < npairs ? gi : 0.f) * zv * zo;  // dP (each pair once)
                 }
             }
 #pragma unroll
@@ -435,12 +441,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     if (w >= a.nw) return;
     const int pi = w >= a.nw0 ? 1 : 0;
     if (pi) w -= a.nw0;
-    const WgradProblem& P = a.p[pi];
+    const WgradProblem P = pi ? a.p[1] : a.p[0];
     const int nt = (w / a.ksplit) % P.NT;
     const int ext = (nt == 0) ? P.extras : 0;  // block-uniform: one specialised body per block
-    if (ext == 0) wgrad_body<0>(a, red, rede);
-    else if (ext == 1) wgrad_body<1>(a, red, rede);
-    else wgrad_body<2>(a, red, rede);
+    if (ext == 0) wgrad_body<0>(a, P, w, red, rede);
+    else if (ext == 1) wgrad_body<1>(a, P, w, red, rede);
+    else wgrad_body<2>(a, P, w, red, rede);
 }
 
 // ------------------------------------------------------------------------------------------------
