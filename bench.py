@@ -56,31 +56,50 @@ def make_params(D, device, seed=1234):
 
 
 def cpu_baseline(params_np, D0, budget_s=12.0, buf_pairs=102400, chunk=10240):
-    """The oracle (NumPy fp32 restatement of utils/models.py:366-382) on the host cores: same
-    arithmetic, the reference driver's chunking (5*2048 pairs, xvector_NeuralPlda_pytorch.py:172).
-    Bounded sample: sweeps a resident buffer of `buf_pairs` pairs for ~`budget_s` seconds."""
+    """The oracle (NumPy fp32 restatement of utils/models.py:366-382) on the host cores: same arithmetic, the
+    reference driver's chunking (5*2048 pairs, xvector_NeuralPlda_pytorch.py:172).  The BLAS thread count is
+    calibrated first (more threads than ~32 hurts these 10240x512x150 GEMMs); then a bounded sample sweeps a
+    resident buffer of `buf_pairs` pairs for ~`budget_s` seconds."""
     from oracle import nplda_oracle as orc
     p = orc.Params(*params_np)
     rng = np.random.default_rng(99)
     x1 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
     x2 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
-    orc.forward(x1[:chunk], x2[:chunk], p)  # warm-up (BLAS thread pool)
+
+    def sweep(n_pairs):
+        for lo in range(0, n_pairs, chunk):
+            orc.forward(x1[lo:lo + chunk], x2[lo:lo + chunk], p)
+
+    ncpu = os.cpu_count() or 1
+    threads, limiter = ncpu, None
+    try:
+        from threadpoolctl import threadpool_limits
+        best = (0.0, ncpu)
+        for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
+            with threadpool_limits(limits=nt, user_api="blas"):
+                sweep(2 * chunk)  # warm-up at this width
+                t0 = time.perf_counter()
+                sweep(4 * chunk)
+                rate = 4 * chunk / (time.perf_counter() - t0)
+            if rate > best[0]:
+                best = (rate, nt)
+        threads = best[1]
+        limiter = threadpool_limits(limits=threads, user_api="blas")
+    except Exception:
+        sweep(chunk)
     done, t0 = 0, time.perf_counter()
     while True:
-        for lo in range(0, buf_pairs, chunk):
-            orc.forward(x1[lo:lo + chunk], x2[lo:lo + chunk], p)
+        sweep(buf_pairs)
         done += buf_pairs
         el = time.perf_counter() - t0
         if el >= budget_s:
             break
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([i.get("num_threads", 1) for i in threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count() or 1
+    if limiter is not None:
+        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
     return {"value": done / el, "unit": "pairs/s", "cores": int(threads), "kind": "port",
             "sample": f"{done} pairs ({el:.1f} s) as sweeps of a {buf_pairs}-pair buffer in chunks of {chunk}; "
-                      f"numpy fp32 oracle, BLAS threads={threads}, {os.cpu_count()} logical cpus visible"}
+                      f"numpy fp32 oracle, BLAS threads={threads} (best of a calibration sweep), "
+                      f"{ncpu} logical cpus visible"}
 
 
 def main():
@@ -179,7 +198,7 @@ def main():
                        "layer2_PLDA_spkfactor_dim": D, "params": psrc, "parallelism": f"trial-list shard x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "nplda_fwd_kernel<NB,PAIR>", "kernel_ms": kern_ms,
+                         "kernel": "nplda_fwd_v2_kernel<NB, PAIR, 8 waves, 4 k16-steps/barrier>", "kernel_ms": kern_ms,
                          "flop_per_pair_algorithmic": flops,
                          "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
         }

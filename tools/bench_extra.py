@@ -71,7 +71,14 @@ def main():
             opt.step()
 
         ms_t = timeit(step, reps=20)
-        out[f"D{D}"].update({"train_step_ms_B4096": ms_t, "train_pairs_per_s": Bt / ms_t * 1e3})
+        out[f"D{D}"].update({"train_step_eager_autograd_torchAdam_ms_B4096": ms_t,
+                             "train_eager_pairs_per_s": Bt / ms_t * 1e3})
+        from neuralplda_amd import train as ntrain
+        torch.manual_seed(D)
+        mf = models.NeuralPlda(NC(D)).to(dev)
+        fs = ntrain.FusedTrainStep(mf, 1e-4, batch_size=Bt, graph=False)
+        ms_f = timeit(lambda: fs(x1, x2, t), reps=50)
+        out[f"D{D}"].update({"train_step_fused_ms_B4096": ms_f, "train_fused_pairs_per_s": Bt / ms_f * 1e3})
         fwd_only = timeit(lambda: ops.forward_train(x1, x2, packed), reps=20)
         out[f"D{D}"]["forward_train_ms_B4096"] = fwd_only
         s, saved = ops.forward_train(x1, x2, packed)

@@ -103,11 +103,12 @@ int main(int argc, char** argv) {
 
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"w8 nt    kpb2", launch_v<10, 8, true, 2>}, {"v2 w8 nt kpb4", launch_2<10, 8, true, 4>},
-               {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"xload plain", launch_x<false>}, {"xload nt", launch_x<true>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v2 w4 pl kpb4", launch_2<10, 4, false, 4>},
+               {"v2 w4 pl kpb3", launch_2<10, 4, false, 3>}, {"v2 w4 pl kpb2", launch_2<10, 4, false, 2>},
+               {"v2 w4 nt kpb4", launch_2<10, 4, true, 4>} };
     } else {
-        vs = { {"w8 nt    kpb1", launch_v<11, 8, true, 1>}, {"v2 w8 nt kpb4", launch_2<11, 8, true, 4>},
-               {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v2 w8 pl kpb3", launch_2<11, 8, false, 3>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v2 w4 pl kpb3", launch_2<11, 4, false, 3>},
+               {"v2 w4 pl kpb2", launch_2<11, 4, false, 2>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
