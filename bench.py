@@ -110,6 +110,9 @@ def main():
     ap.add_argument("--pairs", type=int, default=1 << 20, help="trial pairs per GPU per step")
     ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -131,7 +134,7 @@ def main():
 
     D0, D = 512, args.dim
     params, psrc = make_params(D, dev)
-    packed = ops.pack_params(*params)
+    packed = ops.pack_params(*params, precision=args.precision)
     gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # each rank scores its own shard
     B = args.pairs
     x1 = torch.randn(B, D0, device=dev, generator=gen)
@@ -168,6 +171,25 @@ def main():
     if not np.isfinite(checksum):
         raise SystemExit("non-finite scores")
 
+    alt = None
+    if rank == 0 and args.precision == "fp32" and not args.no_alt:
+        # the opt-in split-bf16 scoring kernel on the same inputs (reported beside, never as `value`)
+        pk3 = ops.pack_params(*params, precision="bf16x3")
+        s3 = ops.score_pairs(x1, x2, pk3)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(10):
+            s3 = ops.score_pairs(x1, x2, pk3)
+        e1.record()
+        torch.cuda.synchronize()
+        ms3 = e0.elapsed_time(e1) / 10
+        nb = (D + 15) // 16
+        issued = 6 * 2 * 2 * (32 * ((D0 + 31) // 32) + 32 * ((nb + 1) // 2)) * 16 * nb  # bf16 MFMA FLOPs per pair
+        alt = {"precision": "bf16x3 (3-way bf16 split, 6 MFMA passes, fp32-class accuracy)", "kernel_ms": ms3,
+               "pairs_per_s_1gpu": B / (ms3 * 1e-3), "max_abs_diff_vs_fp32_scores": float((s3 - s).abs().max().item()),
+               "bf16_mfma_TFLOPs_issued": B * issued / (ms3 * 1e-3) / 1e12, "bf16_dense_peak_TFLOPs": 2500.0}
+
     if rank == 0:
         total_pairs = B * world * args.steps
         flops = algorithmic_flops_per_pair(D0, D, D)
@@ -202,6 +224,11 @@ def main():
                          "flop_per_pair_algorithmic": flops,
                          "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
         }
+        if args.precision == "bf16x3":
+            out["dtype"] = "bf16x3"
+            out["roofline"]["kernel"] = "nplda_fwd_bf16x3_kernel (6 bf16 MFMA passes per fp32 product)"
+        if alt is not None:
+            out["alt_bf16x3"] = alt
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline([p.cpu().numpy() for p in params], D0, args.cpu_seconds)
         print(json.dumps(out), flush=True)

@@ -192,6 +192,21 @@ int nplda_adam_step_f32(float* const* params, const float* const* grads, float* 
                         float* const* exp_avg_sq, const int64_t* numel, int nseg, float* step, float lr,
                         float beta1, float beta2, float eps, float weight_decay, nplda_stream_t stream);
 
+/* ---- split-bf16 scoring (opt-in) --------------------------------------------------------------------------- */
+
+/* Same functions as nplda_pack_params_f32 / nplda_score_pairs_f32 / nplda_embed_f32 computed on the bf16 matrix
+ * pipe with every fp32 operand split into three bf16 pieces and six MFMA passes per product (csrc/nplda_fwd_bf16x3.h):
+ * fp32-class accuracy (the dropped cross terms are <= 2^-23 relative; scores within the same 2e-5 + 1e-5 |s| tolerance
+ * of the fp64 oracle), ~1.5x the throughput of the exact-fp32 kernels.  Uses its own packed image. */
+size_t nplda_bf16x3_packed_bytes(int D0, int D1, int D2);
+int nplda_pack_params_bf16x3(const float* W1, const float* b1, const float* W2, const float* b2,
+                             const float* P_sqrt, const float* Q, int D0, int D1, int D2, void* packed,
+                             size_t packed_bytes, nplda_stream_t stream);
+int nplda_score_pairs_bf16x3(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
+                             int D0, int D1, int D2, float* s, nplda_stream_t stream);
+int nplda_embed_bf16x3(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
+                       float* z, int64_t ldz, float* q, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

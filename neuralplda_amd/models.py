@@ -63,14 +63,16 @@ class _PairScoreFn(torch.autograd.Function):
     """s = NeuralPlda.forward(x1, x2) with the hand-derived backward."""
 
     @staticmethod
-    def forward(ctx, x1, x2, reduce_flat, W1, b1, W2, b2, P_sqrt, Q):
+    def forward(ctx, x1, x2, opts, W1, b1, W2, b2, P_sqrt, Q):
+        reduce_flat, precision = opts
         if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
             raise NotImplementedError("gradients w.r.t. the x-vectors are outside the NPLDA hot path")
         dev = _compute_device(x1, W1)
         prm = [_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)]
-        packed = ops.pack_params(*prm)
-        X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
         need = any(ctx.needs_input_grad[3:])  # Function.forward runs with grad mode off: ask the ctx
+        # training always runs the exact-fp32 kernels; `precision` only selects the inference kernel
+        packed = ops.pack_params(*prm, precision="fp32" if need else precision)
+        X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
         ctx.need = need
         ctx.reduce_flat = reduce_flat
         if need:
@@ -190,12 +192,15 @@ class NeuralPlda(nn.Module):
         self.lossfn = nc.loss
         self._reduce_sums = None  # both set by neuralplda_amd.dist.make_data_parallel()
         self._reduce_flat = None
+        # inference kernel: "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, fp32-class accuracy, ~1.5x faster)
+        self.scoring_precision = "fp32"
 
     # -- pickles written by the reference (class path utils.models.NeuralPlda) lack our private attributes
     def __setstate__(self, state):
         super(NeuralPlda, self).__setstate__(state)
         self.__dict__.setdefault("_reduce_sums", None)
         self.__dict__.setdefault("_reduce_flat", None)
+        self.__dict__.setdefault("scoring_precision", "fp32")
 
     def __getstate__(self):
         state = self.__dict__.copy()
@@ -222,7 +227,8 @@ class NeuralPlda(nn.Module):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        return _PairScoreFn.apply(x1, x2, self._reduce_flat, *self._params())
+        return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32")),
+                                  *self._params())
 
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):

@@ -10,12 +10,13 @@ from . import _lib
 
 
 class PackedParams:
-    """MFMA-fragment-ordered image of one parameter set (see csrc/nplda_common.h)."""
+    """MFMA-fragment-ordered image of one parameter set (see csrc/nplda_common.h).  precision: "fp32" (exact
+    fp32 MFMA, default) or "bf16x3" (split-bf16 image for the opt-in scoring kernels, csrc/nplda_fwd_bf16x3.h)."""
 
-    __slots__ = ("buf", "D0", "D1", "D2", "ldz")
+    __slots__ = ("buf", "D0", "D1", "D2", "ldz", "precision")
 
-    def __init__(self, buf, D0, D1, D2, ldz):
-        self.buf, self.D0, self.D1, self.D2, self.ldz = buf, D0, D1, D2, ldz
+    def __init__(self, buf, D0, D1, D2, ldz, precision="fp32"):
+        self.buf, self.D0, self.D1, self.D2, self.ldz, self.precision = buf, D0, D1, D2, ldz, precision
 
     @property
     def device(self):
@@ -47,9 +48,11 @@ def _rows(t, name, D0):
     return t, ld
 
 
-def pack_params(W1, b1, W2, b2, P_sqrt, Q):
-    """nplda_pack_params_f32: nn.Linear-layout parameters -> PackedParams on the same device."""
+def pack_params(W1, b1, W2, b2, P_sqrt, Q, precision="fp32"):
+    """nplda_pack_params_f32 (or nplda_pack_params_bf16x3): nn.Linear-layout parameters -> PackedParams."""
     lib = _lib.load()
+    if precision not in ("fp32", "bf16x3"):
+        raise ValueError("precision must be 'fp32' or 'bf16x3'")
     for n, t in (("W1", W1), ("b1", b1), ("W2", W2), ("b2", b2), ("P_sqrt", P_sqrt), ("Q", Q)):
         _require_dev_f32(t, n)
     D1, D0 = W1.shape
@@ -58,17 +61,18 @@ def pack_params(W1, b1, W2, b2, P_sqrt, Q):
         raise ValueError("inconsistent parameter shapes")
     if D0 % 4 != 0:
         raise ValueError(f"xvector_dim must be a multiple of 4 (got {D0}); pad the x-vectors")
-    nbytes = lib.nplda_packed_bytes(D0, D1, D2)
+    b3 = precision == "bf16x3"
+    nbytes = (lib.nplda_bf16x3_packed_bytes if b3 else lib.nplda_packed_bytes)(D0, D1, D2)
     if nbytes == 0:
         raise _lib.NpldaHipError(
             f"model {D0}->{D1}->{D2} is outside the compiled kernel set (max dim {lib.nplda_max_dim()})")
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
     ts = [t.detach().contiguous() for t in (W1, b1, W2, b2, P_sqrt, Q)]
+    fn = lib.nplda_pack_params_bf16x3 if b3 else lib.nplda_pack_params_f32
     with torch.cuda.device(W1.device):
-        code = lib.nplda_pack_params_f32(*[_lib.ptr(t) for t in ts], D0, D1, D2, _lib.ptr(buf), nbytes,
-                                         _lib.current_stream())
-    _lib.check(code, "nplda_pack_params_f32")
-    return PackedParams(buf, D0, D1, D2, lib.nplda_padded_dim(D1, D2))
+        code = fn(*[_lib.ptr(t) for t in ts], D0, D1, D2, _lib.ptr(buf), nbytes, _lib.current_stream())
+    _lib.check(code, "nplda_pack_params_bf16x3" if b3 else "nplda_pack_params_f32")
+    return PackedParams(buf, D0, D1, D2, lib.nplda_padded_dim(D1, D2), precision)
 
 
 def score_pairs(x1, x2, packed):
@@ -85,10 +89,11 @@ def score_pairs(x1, x2, packed):
     s = torch.empty(B, dtype=torch.float32, device=x1.device)
     if B == 0:
         return s
+    fn = lib.nplda_score_pairs_bf16x3 if packed.precision == "bf16x3" else lib.nplda_score_pairs_f32
     with torch.cuda.device(x1.device):
-        code = lib.nplda_score_pairs_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(packed.buf), packed.D0,
-                                         packed.D1, packed.D2, _lib.ptr(s), _lib.current_stream())
-    _lib.check(code, "nplda_score_pairs_f32")
+        code = fn(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
+                  _lib.ptr(s), _lib.current_stream())
+    _lib.check(code, "nplda_score_pairs_" + ("bf16x3" if packed.precision == "bf16x3" else "f32"))
     return s
 
 
@@ -101,10 +106,11 @@ def embed(x, packed, want_q=True):
     q = torch.empty(N, dtype=torch.float32, device=x.device) if want_q else None
     if N == 0:
         return z, q
+    fn = lib.nplda_embed_bf16x3 if packed.precision == "bf16x3" else lib.nplda_embed_f32
     with torch.cuda.device(x.device):
-        code = lib.nplda_embed_f32(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
-                                   _lib.ptr(z), packed.ldz, _lib.ptr(q), _lib.current_stream())
-    _lib.check(code, "nplda_embed_f32")
+        code = fn(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2, _lib.ptr(z), packed.ldz,
+                  _lib.ptr(q), _lib.current_stream())
+    _lib.check(code, "nplda_embed_" + ("bf16x3" if packed.precision == "bf16x3" else "f32"))
     return z, q
 
 
@@ -113,10 +119,16 @@ def embed(x, packed, want_q=True):
 LOSS_SOFTCDET, LOSS_BCE, LOSS_HARD_CDET = 0, 1, 2
 
 
+def _need_fp32(packed, what):
+    if packed.precision != "fp32":
+        raise ValueError(f"{what} needs the fp32 parameter image (pack_params(..., precision='fp32'))")
+
+
 def forward_train(x1, x2, packed):
     """nplda_forward_train_f32: scores plus the activations the backward needs.
     Returns (s, saved) with saved = (x1, x2, ld, y, z, rn) device tensors."""
     lib = _lib.load()
+    _need_fp32(packed, "forward_train")
     x1, ld1 = _rows(x1, "x1", packed.D0)
     x2, ld2 = _rows(x2, "x2", packed.D0)
     if x1.shape[0] != x2.shape[0]:
@@ -236,6 +248,7 @@ def _idx(t, name, dev):
 def score_indexed(z, q, i1, i2, packed):
     """nplda_score_indexed_f32: z (N, ldz), q (N) from embed(); i1, i2 int64 (B) -> (B,) scores."""
     lib = _lib.load()
+    _need_fp32(packed, "score_indexed")
     _require_dev_f32(z, "z")
     _require_dev_f32(q, "q")
     if z.dim() != 2 or z.stride(1) != 1 or z.stride(0) != packed.ldz or z.shape[0] != q.shape[0]:
@@ -306,6 +319,7 @@ def gather_rows(table, idx):
 def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None):
     """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top)."""
     lib = _lib.load()
+    _need_fp32(packed, "cohort_stats")
     for n, t in (("z_rows", z_rows), ("q_rows", q_rows), ("z_coh", z_coh), ("q_coh", q_coh)):
         _require_dev_f32(t, n)
     if z_rows.stride(0) != packed.ldz or z_coh.stride(0) != packed.ldz:

@@ -4,8 +4,10 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#include <cmath>
 #include "../neuralplda_amd/csrc/nplda_fwd_persist.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_bf16x3.h"
 
 using namespace nplda;
 
@@ -44,6 +46,16 @@ __global__ __launch_bounds__(512) void xload_only(const float* xa, const float* 
 template <bool NT>
 void launch_x(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((xload_only<NT>), dim3((unsigned)((B + 127) / 128)), dim3(512), 0, st, a.xa, a.xb, B, a.D0, a.out_s);
+}
+
+static Bf3Args g_b3;
+template <int NB, int WAVES, int KPB>
+void launch_b3(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
+    Bf3Args b = g_b3;
+    b.out_s = a.out_s;
+    hipLaunchKernelGGL((nplda_fwd_bf16x3_kernel<NB, MODE_PAIR, WAVES, KPB>), grid, block, 0, st, b);
 }
 
 struct Variant { const char* name; void (*launch)(const FwdArgs&, long long, hipStream_t); };
@@ -101,14 +113,25 @@ int main(int argc, char** argv) {
     a.xa = x1; a.xb = x2; a.n = B; a.ldx = D0; a.packed = packed; a.D0 = D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total; a.out_s = s;
 
+    // bf16x3 image
+    const Bf3Layout L3 = bf3_layout(D0, D, D);
+    float* img3; CK(hipMalloc(&img3, L3.total * 4));
+    {
+        const size_t nthreads = L3.ob1 / 4 + (L3.total - L3.ob1);
+        nplda_pack_bf16x3_kernel<<<(unsigned)((nthreads + 255) / 256), 256>>>(W1, b1, W2, b2, Ps, Q, L3, img3);
+        CK(hipDeviceSynchronize());
+    }
+    g_b3 = Bf3Args{};
+    g_b3.xa = x1; g_b3.xb = x2; g_b3.n = B; g_b3.ldx = D0; g_b3.img = img3; g_b3.D0 = D0; g_b3.KC1 = L3.KC1;
+    g_b3.oW2 = L3.oW2; g_b3.ob1 = L3.ob1; g_b3.ob2 = L3.ob2; g_b3.oQ = L3.oQ; g_b3.oP = L3.oP;
+    std::vector<float> sref(1 << 16);
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v2 w4 pl kpb4", launch_2<10, 4, false, 4>},
-               {"v2 w4 pl kpb3", launch_2<10, 4, false, 3>}, {"v2 w4 pl kpb2", launch_2<10, 4, false, 2>},
-               {"v2 w4 nt kpb4", launch_2<10, 4, true, 4>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<10, 8, 2>},
+               {"b3 w8 kpb1", launch_b3<10, 8, 1>}, {"b3 w4 kpb1", launch_b3<10, 4, 1>} };
     } else {
-        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v2 w4 pl kpb3", launch_2<11, 4, false, 3>},
-               {"v2 w4 pl kpb2", launch_2<11, 4, false, 2>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<11, 8, 2>},
+               {"b3 w8 kpb1", launch_b3<11, 8, 1>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
@@ -125,8 +148,10 @@ int main(int argc, char** argv) {
             float ms; CK(hipEventElapsedTime(&ms, e0, e1)); ms /= reps;
             CK(hipMemcpy(hs.data(), s, 4096 * 4, hipMemcpyDeviceToHost));
             double cs = 0; for (float f : hs) cs += f;
-            printf("round %d  %-14s  %.3f ms  %.3e pairs/s  %.1f TF(alg)  frac %.3f  checksum %.6f\n", r, v.name, ms,
-                   B / (ms * 1e-3), B * flop_alg / (ms * 1e-3) / 1e12, B * flop_alg / (ms * 1e-3) / 1e12 / 157.3, cs);
+            if (&v == &vs[0]) sref.assign(hs.begin(), hs.end());
+            double md = 0; for (int i = 0; i < 4096; ++i) md = fmax(md, fabs((double)hs[i] - sref[i]));
+            printf("round %d  %-14s  %.3f ms  %.3e pairs/s  %.1f TF(alg)  frac %.3f  checksum %.6f  max|d vs first| %.2e\n", r, v.name, ms,
+                   B / (ms * 1e-3), B * flop_alg / (ms * 1e-3) / 1e12, B * flop_alg / (ms * 1e-3) / 1e12 / 157.3, cs, md);
         }
     }
     return 0;
