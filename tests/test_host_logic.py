@@ -244,3 +244,49 @@ def test_metrics_reference_semantics_on_cpu():
     assert metrics.minc(torch.from_numpy(g["s_sep"]), T, [99.0, 199.0], reference_semantics=False)[0].item() == 0.0
     assert abs(metrics.eer(S, T) - orc.eer(g["s"], g["t"])) < 1e-9
     assert abs(metrics.minc_exact(S, T, [99.0])[0].item() - orc.minc_exact(g["s"], g["t"], [99.0])[0]) < 1e-6
+
+
+def test_abi_argument_validation_needs_no_gpu(hip_lib):
+    """Every entry point validates its arguments before touching the device: bad arguments give NPLDA_E* codes and
+    empty batches are successful no-ops — checked here without a GPU (nothing is launched)."""
+    import ctypes
+    EINVAL, EUNSUP = -22, -95
+    dummy = ctypes.create_string_buffer(4096)
+    p = ctypes.addressof(dummy)
+    p16 = (p + 15) // 16 * 16
+    L = hip_lib
+    # empty batches: OK without any pointer
+    assert L.nplda_score_pairs_f32(None, None, 0, 512, None, 512, 150, 150, None, None) == 0
+    assert L.nplda_embed_f32(None, 0, 512, None, 512, 150, 150, None, 160, None, None) == 0
+    assert L.nplda_score_indexed_f32(None, 160, None, 0, None, None, 0, None, 512, 150, 150, None, None) == 0
+    assert L.nplda_gather_rows_f32(None, 512, 10, None, 0, 512, None, 512, None) == 0
+    assert L.nplda_forward_train_f32(None, None, 0, 512, None, 512, 150, 150, None, None, None, None, 160, None) == 0
+    assert L.gb_score_pairs_f32(None, None, 0, 512, None, 512, 170, None, None, None) == 0
+    assert L.nplda_asnorm_apply_f64(None, None, None, 0, None, 5, None, None) == 0
+    assert L.nplda_score_pairs_bf16x3(None, None, 0, 512, None, 512, 150, 150, None, None) == 0
+    # negative sizes, null pointers, misaligned rows, unsupported dimensions
+    assert L.nplda_score_pairs_f32(p16, p16, -1, 512, p16, 512, 150, 150, p16, None) == EINVAL
+    assert L.nplda_score_pairs_f32(None, p16, 4, 512, p16, 512, 150, 150, p16, None) == EINVAL
+    assert L.nplda_score_pairs_f32(p16 + 4, p16, 4, 512, p16, 512, 150, 150, p16, None) == EINVAL   # 16-byte alignment
+    assert L.nplda_score_pairs_f32(p16, p16, 4, 510, p16, 512, 150, 150, p16, None) == EINVAL       # ldx < D0
+    assert L.nplda_score_pairs_f32(p16, p16, 4, 512, p16, 510, 150, 150, p16, None) == EINVAL       # D0 % 4
+    assert L.nplda_score_pairs_f32(p16, p16, 4, 512, p16, 512, 500, 150, p16, None) == EUNSUP
+    assert L.nplda_embed_f32(p16, 4, 512, p16, 512, 150, 150, p16, 150, None, None) == EINVAL       # ldz < padded dim
+    assert L.nplda_pack_params_f32(p16, p16, p16, p16, p16, p16, 512, 150, 150, p16, 16, None) == -28  # ENOSPC
+    assert L.nplda_pack_params_f32(p16, p16, None, p16, p16, p16, 512, 150, 150, p16, 1 << 30, None) == EINVAL
+    assert L.nplda_backward_f32(p16, p16, 4, 512, p16, 512, 150, 150, p16, p16, p16, p16, 160, p16, p16, 16, p16,
+                                None) == -28
+    assert L.nplda_loss_sums_f32(p16, p16, 4, None, 2, 15.0, 0, p16, None) == EINVAL
+    th = (ctypes.c_void_p * 2)(p16, p16)
+    assert L.nplda_loss_sums_f32(p16, p16, 4, th, 9, 15.0, 0, p16, None) == EUNSUP                  # K > 4
+    assert L.nplda_loss_sums_f32(p16, p16, 4, th, 2, 15.0, 7, p16, None) == EINVAL                  # unknown loss kind
+    assert L.nplda_cohort_stats_f32(p16, p16, 4, p16, p16, 0, 160, p16, 512, 150, 150, 500, 1, p16, p16, 4096, None) == EINVAL
+    assert L.nplda_row_stats_f32(p16, 4, 2, 8, 500, 1, p16, None) == EINVAL                          # lds < M
+    assert L.nplda_gather_rows_f32(p16, 512, 10, p16, 4, 510, p16, 512, None) == EINVAL
+    assert L.gb_pack_params_f32(p16, p16, p16, p16, p16, p16, 512, 500, p16, 1 << 30, None) == EUNSUP
+    assert L.nplda_adam_step_f32(None, None, None, None, None, 3, p16, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == EINVAL
+    # sizes
+    assert L.nplda_backward_workspace_bytes(4096, 512, 150, 150) > 2 * 8192 * 160 * 4
+    assert L.nplda_cohort_workspace_bytes(22000, 10000) == 22000 * 10000 * 4
+    assert L.nplda_cohort_workspace_bytes(10 ** 7, 10 ** 4) <= (4 << 30)
+    assert L.gb_packed_bytes(512, 170) > 4 * 176 * 176 * 4 and L.nplda_bf16x3_packed_bytes(512, 150, 150) > 0

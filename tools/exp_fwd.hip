@@ -49,13 +49,13 @@ void launch_x(const FwdArgs& a, long long B, hipStream_t st) {
 }
 
 static Bf3Args g_b3;
-template <int NB, int WAVES, int KPB>
+template <int NB, int WAVES, int KPB, bool EARLY = false>
 void launch_b3(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
     dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
     Bf3Args b = g_b3;
     b.out_s = a.out_s;
-    hipLaunchKernelGGL((nplda_fwd_bf16x3_kernel<NB, MODE_PAIR, WAVES, KPB>), grid, block, 0, st, b);
+    hipLaunchKernelGGL((nplda_fwd_bf16x3_kernel<NB, MODE_PAIR, WAVES, KPB, EARLY>), grid, block, 0, st, b);
 }
 
 struct Variant { const char* name; void (*launch)(const FwdArgs&, long long, hipStream_t); };
@@ -128,7 +128,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     if (L.NB == 10) {
         vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<10, 8, 2>},
-               {"b3 w8 kpb1", launch_b3<10, 8, 1>}, {"b3 w4 kpb1", launch_b3<10, 4, 1>} };
+               {"b3 w8 kpb2 early", launch_b3<10, 8, 2, true>}, {"b3 w4 kpb1 early", launch_b3<10, 4, 1, true>},
+               {"b3 w8 kpb1 early", launch_b3<10, 8, 1, true>} };
     } else {
         vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<11, 8, 2>},
                {"b3 w8 kpb1", launch_b3<11, 8, 1>} };
