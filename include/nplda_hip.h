@@ -176,11 +176,24 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
                        const float* mu_n, const float* Lam_n, int D0, int D1, void* packed,
                        size_t packed_bytes, nplda_stream_t stream);
 
+/* Same image for an explicit quadratic form on x = [y1; y2]: S = x^T M x + x^T v + c with M (2 D1, 2 D1) row-major,
+ * v (2 D1) or NULL, c a host scalar.  DPlda.forward (utils/models.py:484-495) is this form: its 2 D^2 + D outer-product
+ * features times a single linear unit collapse to M = [[Ww, Wb], [Wb, Ww]], v = [ws; ws], c = bias — the 57 970
+ * features per pair the reference materialises are never formed. */
+int gb_pack_quadform_f32(const float* W1, const float* b1, const float* M, const float* v, float c, int D0, int D1,
+                         void* packed, size_t packed_bytes, nplda_stream_t stream);
+
 /* GaussianBackend.forward(x1, x2) -> s (B) (utils/models.py:584-593) and/or
  * GaussianBackend.forward_getpaired(x1, x2) -> paired (B, 2 D1) contiguous (utils/models.py:595-601).
  * Either output pointer may be NULL (not both). */
 int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
                        int D0, int D1, float* s, float* paired, nplda_stream_t stream);
+
+/* The same score WITHOUT the normalisation step: rows of y1/y2 are used as layer-1 inputs as they are, i.e.
+ * s = x^T M x + x^T v + c with x = [W1 y1 + b1; W1 y2 + b1].  With W1 = I (D0 = padded D1), b1 = 0 this is
+ * DPlda.forward_from_plda_embeddings (utils/models.py:484-490) on already-extracted embeddings. */
+int gb_score_rows_f32(const float* y1, const float* y2, int64_t B, int64_t ldy, const void* packed, int D0, int D1,
+                      float* s, nplda_stream_t stream);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------- */
 

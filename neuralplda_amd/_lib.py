@@ -47,6 +47,9 @@ SIGNATURES = {
     "nplda_asnorm_apply_f64": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp]),
     "gb_packed_bytes": (_c_sz, [_c_int, _c_int]),
     "gb_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "gb_pack_quadform_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_vp, _c_sz,
+                                      _c_vp]),
+    "gb_score_rows_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_vp]),
     "gb_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
                                     _c_vp]),
     "nplda_adam_step_f32": (_c_int, [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(ctypes.c_int64), _c_int, _c_vp,

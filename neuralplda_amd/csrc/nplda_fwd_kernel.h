@@ -89,6 +89,7 @@ struct FwdArgs {
     float* out_q;         // (rows) self terms                 [embed, optional]
     float* out_y;         // train: (2n, ldz) normalised layer-1 outputs, x1 rows then x2 rows
     float* out_rn;        // train: (2n) 1/max(||u||, eps)
+    int no_norm;          // MODE_GB only: skip F.normalize (rows are already the paired embeddings)
 };
 
 // WAVES waves per block, each owning 16 pairs (or 32 rows); KPB k16-steps of weights per barrier.
@@ -214,6 +215,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
         ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
         invA = 1.0f / fmaxf(sqrtf(ssA), 1e-12f);
         invB = 1.0f / fmaxf(sqrtf(ssB), 1e-12f);
+        if (MODE == MODE_GB && a.no_norm) invA = invB = 1.0f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
             accA[nb] *= invA;

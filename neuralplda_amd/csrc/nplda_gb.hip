@@ -27,7 +27,7 @@ GbLayout gb_layout(int D0, int D1) {
     L.ob1 = L.oG + 4 * (size_t)L.NB * L.NB * 256;
     L.ov = L.ob1 + (size_t)L.NB * 16;
     L.oc = L.ov + 2 * (size_t)L.NB * 16;
-    L.total = L.oc + 4;
+    L.total = L.oc + 4 + (size_t)L.NB * 256;  // + one k16-step of slack (unconditional chunk loads)
     return L;
 }
 
@@ -57,7 +57,7 @@ __global__ void gb_pack_kernel(const float* __restrict__ W1, const float* __rest
             const int k = 16 * kb + 4 * (lane >> 4) + i;
             if (f < D1 && k < D1) {
                 const size_t r = (size_t)(ho * D1 + f), c = (size_t)(hi * D1 + k);
-                v = Ln[r * n2 + c] - Lt[r * n2 + c];
+                v = Lt ? Ln[r * n2 + c] - Lt[r * n2 + c] : Ln[r * n2 + c];  // Lt == NULL: M is given directly
             }
         }
     } else {
@@ -100,6 +100,19 @@ __global__ __launch_bounds__(512) void gb_vc_kernel(const float* __restrict__ mu
         double c = 0.0;
         for (int w = 0; w < 8; ++w) c += red[w];
         out[L.oc] = (float)c;
+        out[L.oc + 1] = out[L.oc + 2] = out[L.oc + 3] = 0.f;
+    }
+}
+
+// explicit quadratic form S = x^T M x + x^T v + c: v (2 D1) and c are given
+__global__ __launch_bounds__(512) void gb_vc_direct_kernel(const float* __restrict__ vin, float c, GbLayout L,
+                                                           float* __restrict__ out) {
+    for (int i = threadIdx.x; i < 2 * L.NB * 16; i += 512) {
+        const int h = i / (L.NB * 16), f = i % (L.NB * 16);
+        out[L.ov + i] = (f < L.D1 && vin) ? vin[h * L.D1 + f] : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        out[L.oc] = c;
         out[L.oc + 1] = out[L.oc + 2] = out[L.oc + 3] = 0.f;
     }
 }
@@ -154,8 +167,36 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
     return nplda_launch_status();
 }
 
+int gb_pack_quadform_f32(const float* W1, const float* b1, const float* M, const float* v, float c, int D0, int D1,
+                          void* packed, size_t packed_bytes, nplda_stream_t stream) {
+    if (!W1 || !b1 || !M || !packed) return NPLDA_EINVAL;
+    if (int rc = gb_check(D0, D1)) return rc;
+    const GbLayout L = gb_layout(D0, D1);
+    if (packed_bytes < L.total * sizeof(float)) return NPLDA_ENOSPC;
+    if (!nplda_aligned16(packed)) return NPLDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((L.ov + 255) / 256)), dim3(256), 0, st, W1, b1,
+                       (const float*)nullptr, M, L, (float*)packed);
+    if (int rc = nplda_launch_status()) return rc;
+    hipLaunchKernelGGL(gb_vc_direct_kernel, dim3(1), dim3(512), 0, st, v, c, L, (float*)packed);
+    return nplda_launch_status();
+}
+
+static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                         float* s, float* paired, int no_norm, nplda_stream_t stream);
+
 int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
                        float* s, float* paired, nplda_stream_t stream) {
+    return gb_score_impl(x1, x2, B, ldx, packed, D0, D1, s, paired, 0, stream);
+}
+
+int gb_score_rows_f32(const float* y1, const float* y2, int64_t B, int64_t ldy, const void* packed, int D0, int D1,
+                      float* s, nplda_stream_t stream) {
+    return gb_score_impl(y1, y2, B, ldy, packed, D0, D1, s, nullptr, 1, stream);
+}
+
+static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                         float* s, float* paired, int no_norm, nplda_stream_t stream) {
     if (B < 0) return NPLDA_EINVAL;
     if (int rc = gb_check(D0, D1)) return rc;
     if (B == 0) return NPLDA_OK;
@@ -167,6 +208,7 @@ int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
     a.D0 = D0; a.KS1 = L.KS1;
     a.oW2 = L.oG; a.ob1 = L.ob1; a.ob2 = L.ov; a.oQ = L.oc; a.oP = L.oc; a.total = L.total;
     a.out_s = s; a.out_z = paired; a.ldz = 2 * (long long)D1;
+    a.no_norm = no_norm;
     if (B <= 256 * 64) return launch_gb<4, false>(a, L, (hipStream_t)stream);
     return launch_gb<8, true>(a, L, (hipStream_t)stream);
 }

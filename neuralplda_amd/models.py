@@ -295,6 +295,94 @@ class NeuralPlda(nn.Module):
 
 
 # ---------------------------------------------------------------------------------------------------
+# DPlda (forward / scoring only here; the reference never trains it in any shipped recipe)
+# ---------------------------------------------------------------------------------------------------
+
+class DPlda(NeuralPlda):
+    """Drop-in for utils/models.py:463-569: same constructor fields, parameter names (centering_and_LDA,
+    logistic_regres, Th<beta>) and methods.  forward never forms the 2 D^2 + D outer-product features per pair:
+    the linear unit over them is the quadratic form x^T M x + x^T v + c on x = [y1; y2], evaluated by the fused
+    LDA + normalise + quadratic-form kernel (MODE_GB).  Losses / cdet / minc are shared with NeuralPlda (the
+    reference's DPlda.crossentropy has no threshold: threshold_Xent is fixed at 0 here).  Scores carry no
+    autograd graph — training DPlda is out of scope."""
+
+    def __init__(self, nc):
+        nn.Module.__init__(self)
+        self.centering_and_LDA = nn.Linear(nc.xvector_dim, nc.layer1_LDA_dim)  # Centering, wccn
+        self.logistic_regres = nn.Linear(nc.layer1_LDA_dim * nc.layer1_LDA_dim * 2 + nc.layer1_LDA_dim, 1)
+        self.threshold = {}
+        for beta in nc.beta:
+            self.threshold[beta] = nn.Parameter(0 * torch.rand(1, requires_grad=True))
+            self.register_parameter("Th{}".format(int(beta)), self.threshold[beta])
+        self.alpha = torch.tensor(float(nc.alpha))
+        self.beta = nc.beta
+        self.dropout = nn.Dropout(p=0.5)
+        self.lossfn = nc.loss
+        self._reduce_sums = None
+        self._reduce_flat = None
+        self.scoring_precision = "fp32"
+
+    def _lda(self, dev):
+        return _to_dev(self.centering_and_LDA.weight, dev), _to_dev(self.centering_and_LDA.bias, dev)
+
+    def _quadform(self, dev):
+        D1 = self.centering_and_LDA.out_features
+        return ops.dplda_quadform(_to_dev(self.logistic_regres.weight, dev), self.logistic_regres.bias, D1)
+
+    def extract_plda_embeddings(self, x):
+        """utils/models.py:479-482: normalize(LDA x) -> (B, D1)."""
+        D0, D1 = self.centering_and_LDA.in_features, self.centering_and_LDA.out_features
+        x = x.reshape(-1, D0) if x.dim() != 2 else x
+        dev = _compute_device(x, self.centering_and_LDA.weight)
+        with torch.no_grad():
+            xd = _to_dev(x, dev)
+            y = ops.gb_paired(xd, xd, *self._lda(dev))[:, :D1]
+        return y if y.device == x.device else y.to(x.device)
+
+    def forward_from_plda_embeddings(self, x1, x2):
+        """utils/models.py:484-490 on (B, D1) embeddings (used as they are, not re-normalised)."""
+        D1 = self.centering_and_LDA.out_features
+        dev = _compute_device(x1, self.logistic_regres.weight)
+        with torch.no_grad():
+            M, v, c = self._quadform(dev)
+            Dp = (D1 + 3) // 4 * 4  # rows must be float4-addressable: identity layer 1 over zero-padded columns
+            eye = torch.eye(D1, Dp, dtype=torch.float32, device=dev)
+            packed = ops.quadform_pack(eye, torch.zeros(D1, dtype=torch.float32, device=dev), M, v, c)
+            pad = (lambda t: torch.nn.functional.pad(_to_dev(t, dev).float(), (0, Dp - D1)))
+            s = ops.quadform_score_rows(pad(x1), pad(x2), packed)
+        return s if s.device == x1.device else s.to(x1.device)
+
+    def forward(self, x1, x2):
+        """utils/models.py:492-495: (B, D0) x 2 -> (B,)."""
+        D0 = self.centering_and_LDA.in_features
+        if x1.numel() == 0 and x2.numel() == 0:
+            x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
+        dev = _compute_device(x1, self.centering_and_LDA.weight)
+        with torch.no_grad():
+            M, v, c = self._quadform(dev)
+            packed = ops.quadform_pack(*self._lda(dev), M, v, c)
+            s = ops.quadform_score_pairs(_to_dev(x1, dev), _to_dev(x2, dev), packed)
+        return s if s.device == x1.device else s.to(x1.device)
+
+    def crossentropy(self, output, target):
+        """utils/models.py:503-506: BCE(sigmoid(output), target) — no threshold."""
+        zero = torch.zeros(1, dtype=torch.float32, device=output.device)
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, zero)
+
+    def LoadParamsFromKaldi(self, mean_vec_file, transform_mat_file):
+        """utils/models.py:551-564."""
+        transform_mat = kaldi_format.read_matrix(transform_mat_file)
+        mean_vec = kaldi_format.read_vector(mean_vec_file)
+        mdsd = self.state_dict()
+        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
+        mdsd['centering_and_LDA.bias'].data.copy_(
+            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
+
+    def LoadPldaParamsFromKaldi(self, *a, **k):
+        raise AttributeError("DPlda has no PLDA layer; use LoadParamsFromKaldi(mean_vec_file, transform_mat_file)")
+
+
+# ---------------------------------------------------------------------------------------------------
 # GaussianBackend (forward only is usable in the reference, SURVEY.md §2.1)
 # ---------------------------------------------------------------------------------------------------
 

@@ -438,3 +438,64 @@ def gb_paired(x1, x2, W1, b1):
     z = torch.zeros(2 * D1, dtype=torch.float32, device=W1.device)
     Z = torch.zeros((2 * D1, 2 * D1), dtype=torch.float32, device=W1.device)
     return _gb_call(x1, x2, gb_pack(W1, b1, z, Z, z, Z), False, True)[1]
+
+
+def quadform_pack(W1, b1, M, v, c):
+    """gb_pack_quadform_f32: image for S = x^T M x + x^T v + c on x = [normalize(LDA x1); normalize(LDA x2)]."""
+    lib = _lib.load()
+    for n, t in (("W1", W1), ("b1", b1), ("M", M)):
+        _require_dev_f32(t, n)
+    D1, D0 = W1.shape
+    if M.shape != (2 * D1, 2 * D1) or (v is not None and v.numel() != 2 * D1):
+        raise ValueError("M must be (2 D1, 2 D1) and v (2 D1)")
+    if D0 % 4 != 0:
+        raise ValueError(f"xvector_dim must be a multiple of 4 (got {D0})")
+    nbytes = lib.gb_packed_bytes(D0, D1)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"model {D0}->{D1} is outside the compiled kernel set")
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
+    ts = [W1.detach().contiguous(), b1.detach().contiguous(), M.detach().contiguous(),
+          None if v is None else v.detach().contiguous()]
+    with torch.cuda.device(W1.device):
+        code = lib.gb_pack_quadform_f32(_lib.ptr(ts[0]), _lib.ptr(ts[1]), _lib.ptr(ts[2]), _lib.ptr(ts[3]), float(c), D0,
+                                        D1, _lib.ptr(buf), nbytes, _lib.current_stream())
+    _lib.check(code, "gb_pack_quadform_f32")
+    return buf, D0, D1
+
+
+def quadform_score_pairs(x1, x2, packed):
+    """(B, D0) x 2 -> (B,) scores of the packed quadratic form (kernel: MODE_GB of the fused forward)."""
+    return _gb_call(x1, x2, packed, True, False)[0]
+
+
+def quadform_score_rows(y1, y2, packed):
+    """gb_score_rows_f32: like quadform_score_pairs with the normalisation step skipped."""
+    lib = _lib.load()
+    buf, D0, D1 = packed
+    y1, ld1 = _rows(y1, "y1", D0)
+    y2, ld2 = _rows(y2, "y2", D0)
+    if y1.shape[0] != y2.shape[0]:
+        raise ValueError("y1 and y2 must have the same number of rows")
+    if ld1 != ld2:
+        y1, y2 = y1.contiguous(), y2.contiguous()
+        ld1 = ld2 = D0
+    B = y1.shape[0]
+    s = torch.empty(B, dtype=torch.float32, device=y1.device)
+    if B > 0:
+        with torch.cuda.device(y1.device):
+            code = lib.gb_score_rows_f32(_lib.ptr(y1), _lib.ptr(y2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
+                                         _lib.current_stream())
+        _lib.check(code, "gb_score_rows_f32")
+    return s
+
+
+def dplda_quadform(wlr, blr, D1):
+    """DPlda's single linear unit over [y1 y2^T + y2 y1^T, y1 y1^T + y2 y2^T, y1 + y2] (utils/models.py:484-490)
+    as (M, v, c) of x^T M x + x^T v + c, x = [y1; y2]:  M = [[Ww, Wb], [Wb, Ww]], v = [ws; ws], c = bias."""
+    w = wlr.detach().reshape(-1)
+    n = D1 * D1
+    if w.numel() != 2 * n + D1:
+        raise ValueError("logistic_regres.weight must have 2 D1^2 + D1 inputs")
+    Wb, Ww, ws = w[:n].reshape(D1, D1), w[n:2 * n].reshape(D1, D1), w[2 * n:]
+    M = torch.cat([torch.cat([Ww, Wb], 1), torch.cat([Wb, Ww], 1)], 0).contiguous()
+    return M, torch.cat([ws, ws]).contiguous(), float(blr.detach().reshape(-1)[0])

@@ -314,6 +314,28 @@ def gb_forward(x1, x2, W1, b1, mu_t, Lam_t, mu_n, Lam_n, dtype=np.float32):
 
 
 # ---------------------------------------------------------------------------------------------
+# DPlda.forward (utils/models.py:479-495)
+# ---------------------------------------------------------------------------------------------
+
+def dplda_forward(x1, x2, W1, b1, wlr, blr, dtype=np.float32):
+    """LDA + normalize, explicit outer-product features [y1 y2^T + y2 y1^T, y1 y1^T + y2 y2^T, y1 + y2] and a
+    single linear unit (utils/models.py:484-495).  wlr: (1, 2 D^2 + D), blr: (1,)."""
+    W1, b1 = _as(W1, dtype), _as(b1, dtype)
+    y1, _ = normalize(_as(x1, dtype) @ W1.T + b1, dtype)
+    y2, _ = normalize(_as(x2, dtype) @ W1.T + b1, dtype)
+    return dplda_from_embeddings(y1, y2, wlr, blr, dtype)
+
+
+def dplda_from_embeddings(y1, y2, wlr, blr, dtype=np.float32):
+    y1, y2 = _as(y1, dtype), _as(y2, dtype)
+    B = y1.shape[0]
+    between = (y1[:, :, None] * y2[:, None, :] + y2[:, :, None] * y1[:, None, :]).reshape(B, -1)
+    within = (y1[:, :, None] * y1[:, None, :] + y2[:, :, None] * y2[:, None, :]).reshape(B, -1)
+    feats = np.concatenate([between, within, y1 + y2], axis=1)
+    return feats @ _as(wlr, dtype).reshape(-1) + dtype(np.asarray(blr).reshape(-1)[0])
+
+
+# ---------------------------------------------------------------------------------------------
 # Kaldi PLDA -> (P, Q) (utils/Kaldi2NumpyUtils/kaldiPlda2numpydict.py:34-38, utils/models.py:450-457)
 # ---------------------------------------------------------------------------------------------
 

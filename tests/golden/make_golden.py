@@ -334,6 +334,33 @@ def main():
         sg2 = gb2.forward(torch.from_numpy(x1), torch.from_numpy(x2))
     save("g7_gb_kaldi170.npz", seed=77, s=sg2.numpy())
 
+    # ---- G10: DPlda.forward (utils/models.py:463-495), forward only -------------------------------------------
+    ncd = NC(D0=64, D1=24, D2=24)
+    torch.manual_seed(10)
+    dp = refm.DPlda(ncd)
+    rng10 = np.random.default_rng(10)  # own stream: the fixtures generated after this block must not move
+    xd1 = rng10.standard_normal((50, 64)).astype(np.float32)
+    xd2 = rng10.standard_normal((50, 64)).astype(np.float32)
+    with torch.no_grad():
+        sd_ = dp.forward(torch.from_numpy(xd1), torch.from_numpy(xd2))
+        yd = dp.extract_plda_embeddings(torch.from_numpy(xd1))
+        sfe = dp.forward_from_plda_embeddings(yd, dp.extract_plda_embeddings(torch.from_numpy(xd2)))
+    save("g10_dplda_small.npz", W1=dp.centering_and_LDA.weight.detach().numpy(), b1=dp.centering_and_LDA.bias.detach().numpy(),
+         wlr=dp.logistic_regres.weight.detach().numpy(), blr=dp.logistic_regres.bias.detach().numpy(), x1=xd1, x2=xd2,
+         s=sd_.numpy(), y1=yd.numpy(), s_from_emb=sfe.numpy(),
+         state_dict_keys=np.asarray(list(dp.state_dict().keys())))
+    ncd2 = NC(D0=512, D1=170, D2=170)
+    dp2 = refm.DPlda(ncd2)
+    rgd = np.random.default_rng(1010)
+    wlr2 = (rgd.standard_normal((1, 2 * 170 * 170 + 170)) * 0.05).astype(np.float32)
+    with torch.no_grad():
+        dp2.centering_and_LDA.weight.copy_(torch.from_numpy(pk["W1"]))
+        dp2.centering_and_LDA.bias.copy_(torch.from_numpy(pk["b1"]))
+        dp2.logistic_regres.weight.copy_(torch.from_numpy(wlr2))
+        dp2.logistic_regres.bias.fill_(0.125)
+        sd2 = dp2.forward(torch.from_numpy(x1), torch.from_numpy(x2))
+    save("g10_dplda_kaldi170.npz", seed=1010, s=sd2.numpy())
+
     # ---- G8: loaders and score-file writers ----------------------------------------------------------
     nutt = 150
     utt_ids = [f"spk{u // 5:03d}-utt{u:04d}" for u in range(nutt)]

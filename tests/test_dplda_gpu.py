@@ -1,0 +1,101 @@
+"""GPU parity of DPlda.forward (utils/models.py:463-495) evaluated as a quadratic form by the fused MODE_GB kernel,
+against reference outputs (G10) and the oracle.  Tolerance: |ds| <= 2e-5 + 2e-5 |s| (fp32 MFMA vs fp32/fp64 BLAS)."""
+import os
+import pickle
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+class NC:
+    def __init__(self, D0, D1, beta=(99.0, 199.0)):
+        self.xvector_dim, self.layer1_LDA_dim, self.layer2_PLDA_spkfactor_dim = D0, D1, D1
+        self.beta, self.alpha, self.device, self.loss = list(beta), 15.0, "cuda", "SoftCdet"
+
+
+def make(D0, D1, W1, b1, wlr, blr):
+    from neuralplda_amd import models
+    m = models.DPlda(NC(D0, D1))
+    with torch.no_grad():
+        m.centering_and_LDA.weight.copy_(torch.from_numpy(np.asarray(W1)))
+        m.centering_and_LDA.bias.copy_(torch.from_numpy(np.asarray(b1)))
+        m.logistic_regres.weight.copy_(torch.from_numpy(np.asarray(wlr)))
+        m.logistic_regres.bias.copy_(torch.from_numpy(np.asarray(blr, dtype=np.float32).reshape(1)))
+    return m.cuda()
+
+
+def test_dplda_golden_small(hip_lib):
+    g = np.load(os.path.join(G, "g10_dplda_small.npz"), allow_pickle=True)
+    m = make(64, 24, g["W1"], g["b1"], g["wlr"], g["blr"])
+    assert set(m.state_dict().keys()) == set(str(k) for k in g["state_dict_keys"])
+    x1, x2 = torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda()
+    s = m(x1, x2).cpu().numpy()
+    np.testing.assert_allclose(s, g["s"], atol=2e-5, rtol=2e-5)
+    y1 = m.extract_plda_embeddings(x1)
+    np.testing.assert_allclose(y1.cpu().numpy(), g["y1"], atol=1e-6, rtol=1e-5)
+    sfe = m.forward_from_plda_embeddings(y1, m.extract_plda_embeddings(x2)).cpu().numpy()
+    np.testing.assert_allclose(sfe, g["s_from_emb"], atol=2e-5, rtol=2e-5)
+    # embeddings are used as given (no re-normalisation): scale them and compare with the oracle
+    y2 = m.extract_plda_embeddings(x2)
+    ref = orc.dplda_from_embeddings(1.5 * y1.cpu().numpy(), 0.5 * y2.cpu().numpy(), g["wlr"], g["blr"], np.float64)
+    got = m.forward_from_plda_embeddings(1.5 * y1, 0.5 * y2).cpu().numpy()
+    np.testing.assert_allclose(got, ref, atol=2e-5, rtol=2e-5)
+
+
+def test_dplda_kaldi170_golden(hip_lib):
+    g1 = np.load(os.path.join(G, "g1_kaldi_params.npz"))
+    f = np.load(os.path.join(G, "g2_forward_kaldi170.npz"))
+    k = np.load(os.path.join(G, "g10_dplda_kaldi170.npz"))
+    rg = np.random.default_rng(int(k["seed"]))
+    wlr = (rg.standard_normal((1, 2 * 170 * 170 + 170)) * 0.05).astype(np.float32)
+    m = make(512, 170, g1["W1"], g1["b1"], wlr, [0.125])
+    s = m(torch.from_numpy(f["x1"]).cuda(), torch.from_numpy(f["x2"]).cuda()).cpu().numpy()
+    np.testing.assert_allclose(s, k["s"], atol=2e-5, rtol=2e-5)
+    y = m.extract_plda_embeddings(torch.from_numpy(f["x1"]).cuda())
+    s2 = m.forward_from_plda_embeddings(y, m.extract_plda_embeddings(torch.from_numpy(f["x2"]).cuda())).cpu().numpy()
+    np.testing.assert_allclose(s2, k["s"], atol=2e-5, rtol=2e-5)  # D1 = 170 exercises the zero-padded identity layer
+
+
+@pytest.mark.parametrize("B", [0, 1, 17, 16385, 70001])
+def test_dplda_vs_oracle_sizes(hip_lib, B):
+    rg = np.random.default_rng(B + 5)
+    D0, D1 = 128, 40
+    W1 = (rg.standard_normal((D1, D0)) / np.sqrt(D0)).astype(np.float32)
+    b1 = (0.1 * rg.standard_normal(D1)).astype(np.float32)
+    wlr = (0.2 * rg.standard_normal((1, 2 * D1 * D1 + D1))).astype(np.float32)
+    m = make(D0, D1, W1, b1, wlr, [-0.3])
+    x1 = rg.standard_normal((B, D0)).astype(np.float32)
+    x2 = rg.standard_normal((B, D0)).astype(np.float32)
+    s = m(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()).cpu().numpy()
+    assert s.shape == (B,)
+    n = min(B, 3000)
+    if n:
+        idx = rg.choice(B, n, replace=False)
+        ref = orc.dplda_forward(x1[idx], x2[idx], W1, b1, wlr, [-0.3], np.float64)
+        np.testing.assert_allclose(s[idx], ref, atol=2e-5, rtol=2e-5)
+
+
+def test_dplda_losses_metrics_and_pickle(hip_lib, tmp_path):
+    g = np.load(os.path.join(G, "g10_dplda_small.npz"), allow_pickle=True)
+    m = make(64, 24, g["W1"], g["b1"], g["wlr"], g["blr"])
+    s = m(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())
+    t = (torch.arange(50, device="cuda") % 3 == 0).float()
+    sn, tn = s.cpu().numpy(), t.cpu().numpy()
+    assert abs(float(m.softcdet(s, t)) - float(orc.softcdet(sn, tn, [0.0, 0.0], [99.0, 199.0], 15.0, np.float64))) < 1e-5
+    assert abs(float(m.crossentropy(s, t)) - float(orc.crossentropy(sn, tn, 0.0, np.float64))) < 1e-6
+    assert abs(float(m.cdet(s, t)) - float(orc.cdet(sn, tn, [0.0, 0.0], [99.0, 199.0]))) < 1e-6
+    mc, th = m.minc(s, t, update_thresholds=True)
+    ref_mc, ref_th = orc.minc_reference(sn, tn, [99.0, 199.0])
+    assert abs(float(mc) - float(ref_mc)) < 1e-6
+    assert abs(float(m.state_dict()["Th99"]) - float(ref_th[99.0])) < 1e-6
+    p = tmp_path / "dplda.pt"
+    m.SaveModel(str(p))
+    m2 = pickle.load(open(p, "rb"))
+    s2 = m2(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())
+    assert torch.equal(s, s2)

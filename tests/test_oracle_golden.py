@@ -180,3 +180,23 @@ def test_g9_e2e_scores_and_metrics(g1):
     np.testing.assert_allclose([th[99.0], th[199.0]], g["minc_ref_th"], rtol=1e-6)
     e = orc.eer(g["s"], g["t"])
     assert 0.002 < e < 0.08
+
+
+def test_g10_dplda_forward(g1):
+    """DPlda.forward / forward_from_plda_embeddings (utils/models.py:479-495) against reference outputs."""
+    g = np.load(os.path.join(G, "g10_dplda_small.npz"), allow_pickle=True)
+    s32 = orc.dplda_forward(g["x1"], g["x2"], g["W1"], g["b1"], g["wlr"], g["blr"], np.float32)
+    s64 = orc.dplda_forward(g["x1"], g["x2"], g["W1"], g["b1"], g["wlr"], g["blr"], np.float64)
+    np.testing.assert_allclose(s32, g["s"], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(s64, g["s"], atol=2e-6, rtol=2e-5)
+    np.testing.assert_allclose(g["s_from_emb"], g["s"], atol=1e-6)
+    assert list(g["state_dict_keys"]) == ["Th99", "centering_and_LDA.weight", "centering_and_LDA.bias",
+                                          "logistic_regres.weight", "logistic_regres.bias"] or \
+        set(g["state_dict_keys"]) >= {"centering_and_LDA.weight", "logistic_regres.weight"}
+    # Kaldi-initialised LDA at the production width with a seeded linear unit
+    f = np.load(os.path.join(G, "g2_forward_kaldi170.npz"))
+    k = np.load(os.path.join(G, "g10_dplda_kaldi170.npz"))
+    rg = np.random.default_rng(int(k["seed"]))
+    wlr = (rg.standard_normal((1, 2 * 170 * 170 + 170)) * 0.05).astype(np.float32)
+    s = orc.dplda_forward(f["x1"], f["x2"], g1["W1"], g1["b1"], wlr, np.asarray([0.125]), np.float64)
+    np.testing.assert_allclose(s, k["s"], atol=2e-5, rtol=2e-5)
