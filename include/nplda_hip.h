@@ -195,6 +195,21 @@ int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
 int gb_score_rows_f32(const float* y1, const float* y2, int64_t B, int64_t ldy, const void* packed, int D0, int D1,
                       float* s, nplda_stream_t stream);
 
+/* ---- weighted moments of paired rows (Gaussian-backend statistics, DPlda weight gradient) ---------------------- */
+
+/* For c in {0, 1} (w1 may be NULL -> only c = 0):
+ *     cnt[c] = sum_k w_c[k],  sum[c][i] = sum_k w_c[k] x[k][i],  sq[c][i][j] = sum_k w_c[k] x[k][i] x[k][j]
+ * over the B rows of x (B, ldx), n valid columns.  Replaces the per-batch `x[mask].sum(0)` / `x[mask].t() @ x[mask]`
+ * accumulation of xvector_GaussianBackend_pytorch.py:40-52 (w_0 = [t > 0.5], w_1 = [t < 0.5]; accumulate = 1 adds
+ * into the outputs so batches can be streamed) and, with w_0 = dL/ds, yields the gradient of DPlda's linear unit
+ * (utils/models.py:484-490) without the 2 D^2 + D features.  Products in exact fp32 on MFMA, reduction over the
+ * row groups in fp64; outputs are DEVICE doubles: cnt (2), sum (2, n), sq (2, n, n) [first half only if w1 == NULL].
+ * Requires n % 4 == 0, n <= 2 * nplda_max_dim(), ldx % 4 == 0, x 16-byte aligned. */
+size_t nplda_moments_workspace_bytes(int64_t B, int n);
+int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, const float* w0, const float* w1,
+                               double* cnt, double* sum, double* sq, int accumulate, void* workspace,
+                               size_t workspace_bytes, nplda_stream_t stream);
+
 /* ---- optimiser ----------------------------------------------------------------------------------------- */
 
 /* torch.optim.Adam's update (xvector_NeuralPlda_pytorch.py:139: lr, weight_decay = 1e-5 as L2 term, no amsgrad)

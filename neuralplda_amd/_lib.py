@@ -52,6 +52,9 @@ SIGNATURES = {
     "gb_score_rows_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_vp]),
     "gb_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
                                     _c_vp]),
+    "nplda_moments_workspace_bytes": (_c_sz, [_c_i64, _c_int]),
+    "nplda_weighted_moments_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p, _c_vp, _c_vp, _c_vp,
+                                            _c_int, _c_vp, _c_sz, _c_vp]),
     "nplda_adam_step_f32": (_c_int, [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(ctypes.c_int64), _c_int, _c_vp,
                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                      _c_vp]),

@@ -1,0 +1,283 @@
+// Weighted first / second moments of paired-embedding rows on gfx950:
+//     cnt[c] = sum_k w_c[k],   sum[c][i] = sum_k w_c[k] x[k][i],   sq[c][i][j] = sum_k w_c[k] x[k][i] x[k][j]
+// for up to two weight vectors (c = 0, 1) in ONE pass over x.  Two callers:
+//   * the Gaussian-backend "training" pass, xvector_GaussianBackend_pytorch.py:30-56 of the reference: per-class
+//     sum x and sum x x^T of x = forward_getpaired(x1, x2) with w_0 = [t > 0.5], w_1 = [t < 0.5];
+//   * the gradient of DPlda's linear unit (utils/models.py:484-490): with w_0 = dL/ds the feature-weight gradient
+//     sum_k g_k [y1 y2^T + y2 y1^T, y1 y1^T + y2 y2^T, y1 + y2] is a fold of sq / sum (see ops.dplda_fold_grad).
+// Split-K exact-fp32 MFMA "A^T B" GEMM (A = w .* x, B = x), upper-triangular 64x64 tiles only (the result is
+// symmetric), float4-strided operand loads, in-block LDS reduction over the 4 k-quarters in a fixed order, then an
+// fp64 reduction over the k-groups -> bitwise deterministic.  Bound: MFMA at large B (2 n^2 flop per row and
+// class, halved by symmetry), launch latency at training-batch sizes.
+#include <hip/hip_runtime.h>
+
+#include "nplda_common.h"
+
+namespace {
+
+constexpr int kMaxN = 2 * NPLDA_MAX_DIM;  // paired rows: [y1; y2]
+constexpr int kPFm = 6;                   // k4-steps of operand prefetch per wave
+
+struct MomArgs {
+    const float* x;
+    long long ldx, B;
+    int n;                 // valid columns (multiple of 4)
+    const float* w0;
+    const float* w1;       // unused when NC == 1
+    int T;                 // 64-wide tiles per side
+    int ntile;             // T (T + 1) / 2 upper-triangular tiles
+    int kgroups;
+    long long rows_per_group;  // multiple of 16
+    int Np;                // 64 T
+    float* slab;           // [class][kgroup][Np][Np]   (upper tiles written)
+    float* ext;            // [class][kgroup][Np + 4]   column sums, then the weight sum
+};
+
+__device__ __forceinline__ void tile_of(int t, int T, int& mt, int& nt) {
+    // row-major enumeration of the upper triangle: (0,0) (0,1) ... (0,T-1) (1,1) ...
+    mt = 0;
+    int rowlen = T;
+    while (t >= rowlen) { t -= rowlen; --rowlen; ++mt; }
+    nt = mt + t;
+}
+
+template <int NC>
+__global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
+    __shared__ f32x4 red[4][16 * 64];  // [wave][(ca*4+cb)*64 + lane]  (64 KB), reused per class
+    __shared__ f32x4 rede[4][NC][16];
+    __shared__ float redc[4][NC];
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int i16 = lane & 15, g4 = lane >> 4;
+    const int kg = blockIdx.x / a.ntile;
+    int mt, nt;
+    tile_of(blockIdx.x % a.ntile, a.T, mt, nt);
+    const int m0 = mt * 64, n0 = nt * 64;
+    const bool diag = mt == nt;
+    const float* __restrict__ X = a.x;
+    const float* __restrict__ W0 = a.w0;
+    const float* __restrict__ W1 = a.w1;
+    const long long ldx = a.ldx, B = a.B;
+    const long long quarter = a.rows_per_group / 4;
+    const long long k0 = (long long)kg * a.rows_per_group + wave * quarter;
+    long long k1 = k0 + quarter;
+    if (k1 > B) k1 = B;
+    const bool mval = m0 + 4 * i16 < a.n;
+    const bool nval = n0 + 4 * i16 < a.n;
+    const int mcol = mval ? m0 + 4 * i16 : 0;
+    const int ncol = nval ? n0 + 4 * i16 : 0;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    f32x4 acc[NC][4][4];
+#pragma unroll
+    for (int c = 0; c < NC; ++c)
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) acc[c][ca][cb] = zero4;
+    f32x4 es[NC];
+    float ec[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) { es[c] = zero4; ec[c] = 0.f; }
+
+    // branch-free loads: clamped row / column + select (a predicated load costs an s_waitcnt vmcnt(0) per use)
+    struct Frag { f32x4 xa, xb; float w[NC]; };
+    auto load = [&](long long row) -> Frag {
+        Frag f;
+        const bool ok = row < k1;
+        const long long rc = row < B ? row : B - 1;
+        const f32x4 va = *reinterpret_cast<const f32x4*>(X + rc * ldx + mcol);
+        const f32x4 vb = *reinterpret_cast<const f32x4*>(X + rc * ldx + ncol);
+        f.xa = mval ? va : zero4;
+        f.xb = nval ? vb : zero4;
+        const float w0 = W0[rc];
+        f.w[0] = ok ? w0 : 0.f;
+        if (NC == 2) {
+            const float w1 = W1[rc];
+            f.w[NC - 1] = ok ? w1 : 0.f;
+        }
+        return f;
+    };
+
+    Frag ring[kPFm];
+#pragma unroll
+    for (int s = 0; s < kPFm; ++s) ring[s] = load(k0 + 4 * s + g4);
+    for (long long kk = k0; kk < k1; kk += 4 * kPFm) {
+#pragma unroll
+        for (int s = 0; s < kPFm; ++s) {
+            const Frag f = ring[s];
+            ring[s] = load(kk + 4 * s + g4 + 4 * kPFm);
+#pragma unroll
+            for (int c = 0; c < NC; ++c) {
+                const f32x4 av = f.w[c] * f.xa;
+                if (diag) {  // block-uniform
+                    es[c] += av;
+                    ec[c] += f.w[c];
+                }
+#pragma unroll
+                for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[c][ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[ca], f.xb[cb], acc[c][ca][cb], 0, 0, 0);
+            }
+        }
+    }
+
+    if (diag) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                es[c][j] = wave_xor_add(es[c][j], 16);
+                es[c][j] = wave_xor_add(es[c][j], 32);
+            }
+            ec[c] = wave_xor_add(ec[c], 16);
+            ec[c] = wave_xor_add(ec[c], 32);
+            if (g4 == 0) rede[wave][c][i16] = es[c];
+            if (lane == 0) redc[wave][c] = ec[c];
+        }
+    }
+    // ---- in-block reduction over the 4 k-quarters (fixed order), one class at a time through the same LDS ----
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+        if (c) __syncthreads();
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb) red[wave][(ca * 4 + cb) * 64 + lane] = acc[c][ca][cb];
+        __syncthreads();
+        // wave `ca` finishes block-row ca: D[i][j] of block (ca, cb) is C[m0 + 4 i + ca][n0 + 4 j + cb];
+        // lane (j = i16, g4) holds i = 4 g4 + r
+        const int ca = wave;
+        f32x4 sum[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+            const int idx = (ca * 4 + cb) * 64 + lane;
+            sum[cb] = ((red[0][idx] + red[1][idx]) + red[2][idx]) + red[3][idx];
+        }
+        float* slab = a.slab + ((size_t)c * a.kgroups + kg) * a.Np * a.Np;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + 4 * (4 * g4 + r) + ca;
+            const f32x4 v = {sum[0][r], sum[1][r], sum[2][r], sum[3][r]};
+            *reinterpret_cast<f32x4*>(slab + (size_t)m * a.Np + n0 + 4 * i16) = v;
+        }
+    }
+    if (diag && wave == 0) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+            float* eb = a.ext + ((size_t)c * a.kgroups + kg) * (a.Np + 4);
+            if (g4 == 0)
+                *reinterpret_cast<f32x4*>(eb + m0 + 4 * i16) =
+                    ((rede[0][c][i16] + rede[1][c][i16]) + rede[2][c][i16]) + rede[3][c][i16];
+            if (lane == 0 && mt == 0) eb[a.Np] = ((redc[0][c] + redc[1][c]) + redc[2][c]) + redc[3][c];
+        }
+    }
+}
+
+struct MomReduceArgs {
+    const float* slab;
+    const float* ext;
+    int nc, n, Np, kgroups, accumulate;
+    double* cnt;   // [nc]
+    double* sum;   // [nc][n]
+    double* sq;    // [nc][n][n]
+};
+
+__global__ __launch_bounds__(256) void moments_reduce_kernel(const MomReduceArgs a) {
+    const size_t per = (size_t)a.n * a.n + a.n + 1;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= per * a.nc) return;
+    const int c = (int)(idx / per);
+    const size_t e = idx % per;
+    double s = 0.0;
+    double* dst;
+    if (e < (size_t)a.n * a.n) {
+        int i = (int)(e / a.n), j = (int)(e % a.n);
+        dst = a.sq + (size_t)c * a.n * a.n + e;
+        if (i > j) { const int t = i; i = j; j = t; }  // upper triangle only (lower tiles are not computed; inside
+                                                      // diagonal tiles (w x_i) x_j and (w x_j) x_i round differently)
+        const float* p = a.slab + (size_t)c * a.kgroups * a.Np * a.Np + (size_t)i * a.Np + j;
+        for (int k = 0; k < a.kgroups; ++k) s += (double)p[(size_t)k * a.Np * a.Np];
+    } else {
+        const int col = (int)(e - (size_t)a.n * a.n);  // n columns, then the weight sum
+        dst = col < a.n ? a.sum + (size_t)c * a.n + col : a.cnt + c;
+        const float* p = a.ext + (size_t)c * a.kgroups * (a.Np + 4) + (col < a.n ? col : a.Np);
+        for (int k = 0; k < a.kgroups; ++k) s += (double)p[(size_t)k * (a.Np + 4)];
+    }
+    *dst = a.accumulate ? *dst + s : s;
+}
+
+struct MomPlan {
+    int T, ntile, kgroups, Np;
+    long long rows_per_group;
+    size_t slab_floats, ext_floats;
+};
+
+MomPlan mom_plan(long long B, int n) {
+    MomPlan p;
+    p.T = (n + 63) / 64;
+    p.Np = 64 * p.T;
+    p.ntile = p.T * (p.T + 1) / 2;
+    long long kg = 512 / p.ntile;  // ~2 blocks per CU in one wave of blocks
+    if (kg < 1) kg = 1;
+    const long long maxkg = (B + 15) / 16;
+    if (kg > maxkg) kg = maxkg < 1 ? 1 : maxkg;
+    long long rpg = (B + kg - 1) / kg;
+    rpg = (rpg + 15) / 16 * 16;
+    if (rpg < 16) rpg = 16;
+    p.rows_per_group = rpg;
+    p.kgroups = (int)((B + rpg - 1) / rpg);
+    if (p.kgroups < 1) p.kgroups = 1;
+    p.slab_floats = (size_t)2 * p.kgroups * p.Np * p.Np;
+    p.ext_floats = (size_t)2 * p.kgroups * (p.Np + 4);
+    return p;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t nplda_moments_workspace_bytes(int64_t B, int n) {
+    if (B < 0 || n <= 0 || n > kMaxN || (n & 3)) return 0;
+    const MomPlan p = mom_plan(B, n);
+    return (p.slab_floats + p.ext_floats) * sizeof(float);
+}
+
+int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, const float* w0, const float* w1,
+                               double* cnt, double* sum, double* sq, int accumulate, void* workspace,
+                               size_t workspace_bytes, nplda_stream_t stream) {
+    if (B < 0 || n <= 0) return NPLDA_EINVAL;
+    if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
+    if (!cnt || !sum || !sq) return NPLDA_EINVAL;
+    const int nc = w1 ? 2 : 1;
+    hipStream_t st = (hipStream_t)stream;
+    if (B == 0) {
+        if (!accumulate) {
+            if (hipError_t e = hipMemsetAsync(cnt, 0, sizeof(double) * nc, st)) return (int)e;
+            if (hipError_t e = hipMemsetAsync(sum, 0, sizeof(double) * nc * n, st)) return (int)e;
+            if (hipError_t e = hipMemsetAsync(sq, 0, sizeof(double) * nc * n * n, st)) return (int)e;
+        }
+        return NPLDA_OK;
+    }
+    if (!x || !w0 || !workspace) return NPLDA_EINVAL;
+    if (ldx < n || (ldx & 3) || !nplda_aligned16(x) || !nplda_aligned16(workspace)) return NPLDA_EINVAL;
+    const MomPlan p = mom_plan(B, n);
+    if (workspace_bytes < (p.slab_floats + p.ext_floats) * sizeof(float)) return NPLDA_ENOSPC;
+    MomArgs a;
+    a.x = x; a.ldx = ldx; a.B = B; a.n = n; a.w0 = w0; a.w1 = w1;
+    a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
+    a.slab = (float*)workspace;
+    a.ext = a.slab + p.slab_floats;
+    const dim3 grid((unsigned)(p.ntile * p.kgroups));
+    if (nc == 2) hipLaunchKernelGGL(moments_kernel<2>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(moments_kernel<1>, grid, dim3(256), 0, st, a);
+    if (int rc = nplda_launch_status()) return rc;
+    MomReduceArgs r;
+    r.slab = a.slab; r.ext = a.ext; r.nc = nc; r.n = n; r.Np = p.Np; r.kgroups = p.kgroups; r.accumulate = accumulate;
+    r.cnt = cnt; r.sum = sum; r.sq = sq;
+    const size_t total = ((size_t)n * n + n + 1) * nc;
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    return nplda_launch_status();
+}
+
+}  // extern "C"

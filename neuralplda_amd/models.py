@@ -129,6 +129,40 @@ class _EmbScoreFn(torch.autograd.Function):
             "train through NeuralPlda.forward(x1, x2)")
 
 
+class _DPldaScoreFn(torch.autograd.Function):
+    """DPlda.forward with a gradient for the linear unit only (the recipe freezes the LDA,
+    xvector_DPlda_pytorch.py:140-147): forward = fused LDA + normalise + quadratic form, saving the paired rows
+    [y1, y2]; backward = one weighted-moments pass (sum_k g_k x x^T) folded into d wlr, d bias."""
+
+    @staticmethod
+    def forward(ctx, x1, x2, W1, b1, wlr, blr):
+        dev = _compute_device(x1, W1)
+        D1 = W1.shape[0]
+        W1d, b1d = _to_dev(W1, dev), _to_dev(b1, dev)
+        M, v, c = ops.dplda_quadform(_to_dev(wlr, dev), blr, D1)
+        packed = ops.quadform_pack(W1d, b1d, M, v, c)
+        need = any(ctx.needs_input_grad[2:])
+        ctx.lda_needs = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
+        s, paired = ops._gb_call(_to_dev(x1, dev), _to_dev(x2, dev), packed, True, need)
+        ctx.need, ctx.D1 = need, D1
+        ctx.devs = (wlr.device, blr.device)
+        if need:
+            ctx.save_for_backward(paired)
+        return s if s.device == x1.device else s.to(x1.device)
+
+    @staticmethod
+    def backward(ctx, gs):
+        if not ctx.need:
+            return (None,) * 6
+        if ctx.lda_needs:
+            raise NotImplementedError("DPlda trains with centering_and_LDA frozen (xvector_DPlda_pytorch.py:140-147): "
+                                      "set requires_grad = False on its weight and bias")
+        (paired,) = ctx.saved_tensors
+        g = gs.to(paired.device, torch.float32).contiguous()
+        dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), ctx.D1)
+        return None, None, None, None, dw.to(ctx.devs[0]), db.to(ctx.devs[1])
+
+
 class _LossFn(torch.autograd.Function):
     """SoftCdet / BCE with the fused forward+backward kernels.  `reduce_sums` (optional callable)
     all-reduces the fp64 batch sums across data-parallel ranks before the gradient is formed."""
@@ -304,7 +338,8 @@ class DPlda(NeuralPlda):
     the linear unit over them is the quadratic form x^T M x + x^T v + c on x = [y1; y2], evaluated by the fused
     LDA + normalise + quadratic-form kernel (MODE_GB).  Losses / cdet / minc are shared with NeuralPlda (the
     reference's DPlda.crossentropy has no threshold: threshold_Xent is fixed at 0 here).  Scores carry no
-    autograd graph — training DPlda is out of scope."""
+    autograd graph w.r.t. the LDA: like the reference's recipe (xvector_DPlda_pytorch.py:140-147) only logistic_regres
+    and the thresholds train; their gradient is a weighted-moments pass over the paired rows (ops.weighted_moments)."""
 
     def __init__(self, nc):
         nn.Module.__init__(self)
@@ -357,12 +392,8 @@ class DPlda(NeuralPlda):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        dev = _compute_device(x1, self.centering_and_LDA.weight)
-        with torch.no_grad():
-            M, v, c = self._quadform(dev)
-            packed = ops.quadform_pack(*self._lda(dev), M, v, c)
-            s = ops.quadform_score_pairs(_to_dev(x1, dev), _to_dev(x2, dev), packed)
-        return s if s.device == x1.device else s.to(x1.device)
+        return _DPldaScoreFn.apply(x1, x2, self.centering_and_LDA.weight, self.centering_and_LDA.bias,
+                                   self.logistic_regres.weight, self.logistic_regres.bias)
 
     def crossentropy(self, output, target):
         """utils/models.py:503-506: BCE(sigmoid(output), target) — no threshold."""
@@ -398,6 +429,39 @@ class GaussianBackend(nn.Module):
         self.paired_cov_inv_target = torch.rand(2 * nc.layer1_LDA_dim, 2 * nc.layer1_LDA_dim)
         self.paired_mean_nontarget = torch.rand(2 * nc.layer1_LDA_dim)
         self.paired_cov_inv_nontarget = torch.rand(2 * nc.layer1_LDA_dim, 2 * nc.layer1_LDA_dim)
+        # The reference's GaussianBackend.softcdet/cdet/minc (utils/models.py:603-651) read alpha / beta / threshold /
+        # lossfn that its constructor never sets; here they are taken from nc when it has them, as
+        # plain attributes (state_dict stays {centering_and_LDA.*} like the reference's).
+        self.beta = list(getattr(nc, "beta", []))
+        self.alpha = torch.tensor(float(getattr(nc, "alpha", 1.0)))
+        self.threshold = {b: torch.zeros(1) for b in self.beta}
+        self.lossfn = getattr(nc, "loss", "SoftCdet")
+        self._reduce_sums = None
+
+    def __setstate__(self, state):
+        super(GaussianBackend, self).__setstate__(state)
+        for k, v in (("beta", []), ("alpha", torch.tensor(1.0)), ("threshold", {}), ("lossfn", "SoftCdet"),
+                     ("_reduce_sums", None)):
+            self.__dict__.setdefault(k, v)
+
+    _alpha = NeuralPlda._alpha
+    softcdet = NeuralPlda.softcdet
+    loss = NeuralPlda.loss
+    cdet = NeuralPlda.cdet
+
+    def crossentropy(self, output, target):
+        """utils/models.py:609-612: BCE(sigmoid(output), target)."""
+        zero = torch.zeros(1, dtype=torch.float32, device=output.device)
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, zero)
+
+    def minc(self, output, target, update_thresholds=False, showplots=False, exact=False):
+        """utils/models.py:625-651 (thresholds live in self.threshold, not in the state dict)."""
+        from . import metrics
+        minc_avg, minc_threshold = metrics.minc(output, target, self.beta, reference_semantics=not exact)
+        if update_thresholds:
+            for beta in self.beta:
+                self.threshold[beta] = minc_threshold[beta].detach().reshape(1).clone()
+        return minc_avg, minc_threshold
 
     def _stats(self, dev):
         return [_to_dev(t, dev) for t in (self.paired_mean_target, self.paired_cov_inv_target,
@@ -418,6 +482,30 @@ class GaussianBackend(nn.Module):
         with torch.no_grad():
             x = ops.gb_paired(_to_dev(x1, dev), _to_dev(x2, dev), W1, b1)
         return x if x.device == x1.device else x.to(x1.device)
+
+    # -- closed-form "training" (xvector_GaussianBackend_pytorch.py:30-56) -------------------------------------------
+    def accumulate_statistics(self, x1, x2, target, stats=None):
+        """One batch of the accumulation loop (:40-52): paired rows x = forward_getpaired(x1, x2), then per class
+        count, sum x and sum x x^T in a single weighted-moments pass (class 0 = target > 0.5, class 1 = target < 0.5).
+        Returns the running (cnt (2,), sum (2, 2 D1), sq (2, 2 D1, 2 D1)) fp64 device tensors."""
+        dev = _compute_device(x1, self.centering_and_LDA.weight)
+        W1, b1 = _to_dev(self.centering_and_LDA.weight, dev), _to_dev(self.centering_and_LDA.bias, dev)
+        with torch.no_grad():
+            x = ops.gb_paired(_to_dev(x1, dev), _to_dev(x2, dev), W1, b1)
+            t = _to_dev(target, dev).float()
+            return ops.weighted_moments(x, (t > 0.5).float(), (t < 0.5).float(), out=stats)
+
+    def fit_statistics(self, stats):
+        """:53-56, quirk included: the non-target class divides both moments by (count - 1), the target class by
+        count.  The 2 D1 x 2 D1 inverses are taken in fp64 (the reference: fp32 torch.inverse)."""
+        cnt, sm, sq = stats
+        ct, cn = cnt[0], cnt[1] - 1
+        mu_t, mu_n = sm[0] / ct, sm[1] / cn
+        cov_t = sq[0] / ct - torch.outer(mu_t, mu_t)
+        cov_n = sq[1] / cn - torch.outer(mu_n, mu_n)
+        self.paired_mean_target, self.paired_cov_inv_target = mu_t.float(), torch.linalg.inv(cov_t).float()
+        self.paired_mean_nontarget, self.paired_cov_inv_nontarget = mu_n.float(), torch.linalg.inv(cov_n).float()
+        return self
 
     def LoadPldaParamsFromKaldi(self, mean_vec_file, transform_mat_file):
         """utils/models.py:653-658."""

@@ -499,3 +499,53 @@ def dplda_quadform(wlr, blr, D1):
     Wb, Ww, ws = w[:n].reshape(D1, D1), w[n:2 * n].reshape(D1, D1), w[2 * n:]
     M = torch.cat([torch.cat([Ww, Wb], 1), torch.cat([Wb, Ww], 1)], 0).contiguous()
     return M, torch.cat([ws, ws]).contiguous(), float(blr.detach().reshape(-1)[0])
+
+
+def weighted_moments(x, w0, w1=None, out=None):
+    """nplda_weighted_moments_f32: x (B, n) fp32, w0/w1 (B,) fp32 -> (cnt (nc,), sum (nc, n), sq (nc, n, n)) doubles,
+    nc = 2 if w1 is given else 1.  `out` = a previous result to accumulate into (streamed batches)."""
+    lib = _lib.load()
+    _require_dev_f32(x, "x")
+    _require_dev_f32(w0, "w0")
+    if w1 is not None:
+        _require_dev_f32(w1, "w1")
+    if x.dim() != 2:
+        raise ValueError("x must be 2-D")
+    B, n = x.shape
+    if x.stride(1) != 1 or x.stride(0) % 4 != 0 or x.data_ptr() % 16 != 0:
+        x = x.contiguous()
+    if n % 4 != 0:
+        raise ValueError(f"row length must be a multiple of 4 (got {n})")
+    ws = [w0.contiguous()] + ([w1.contiguous()] if w1 is not None else [])
+    if any(w.numel() != B for w in ws):
+        raise ValueError("weights must have one entry per row")
+    nc = len(ws)
+    if out is None:
+        cnt = torch.empty(nc, dtype=torch.float64, device=x.device)
+        sm = torch.empty((nc, n), dtype=torch.float64, device=x.device)
+        sq = torch.empty((nc, n, n), dtype=torch.float64, device=x.device)
+        acc = 0
+    else:
+        cnt, sm, sq = out
+        if cnt.shape != (nc,) or sm.shape != (nc, n) or sq.shape != (nc, n, n) or sq.dtype != torch.float64:
+            raise ValueError("`out` does not match this call")
+        acc = 1
+    nbytes = lib.nplda_moments_workspace_bytes(B, n)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"row length {n} is outside the compiled kernel set")
+    wsb = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
+    with torch.cuda.device(x.device):
+        code = lib.nplda_weighted_moments_f32(_lib.ptr(x), B, x.stride(0) if B > 0 else n, n, _lib.ptr(ws[0]),
+                                              _lib.ptr(ws[1]) if nc == 2 else None, _lib.ptr(cnt), _lib.ptr(sm),
+                                              _lib.ptr(sq), acc, _lib.ptr(wsb), nbytes, _lib.current_stream())
+    _lib.check(code, "nplda_weighted_moments_f32")
+    return cnt, sm, sq
+
+
+def dplda_fold_grad(cnt, sm, sq, D1):
+    """(cnt, sum, sq) of paired rows weighted by g = dL/ds -> gradient of DPlda's linear unit (utils/models.py:484-490):
+    d wlr = [G12 + G21 | G11 + G22 | s1 + s2] (row-major blocks of G = sum g x x^T), d bias = sum g."""
+    G = sq[0]
+    G11, G12, G21, G22 = G[:D1, :D1], G[:D1, D1:], G[D1:, :D1], G[D1:, D1:]
+    dw = torch.cat([(G12 + G21).reshape(-1), (G11 + G22).reshape(-1), sm[0, :D1] + sm[0, D1:]])
+    return dw.float().reshape(1, -1), cnt[:1].float()

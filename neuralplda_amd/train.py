@@ -25,7 +25,8 @@ from .NpldaConf import NpldaConf
 from .sv_trials_loaders import (combine_trials_and_get_loader, get_trials_loaders_dict,
                                 load_xvec_trials_from_numbatch)
 
-__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "main_kaldiplda"]
+__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "main_kaldiplda", "main_dplda",
+           "train_gaussian_backend"]
 
 
 def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, valid_loaders=None,
@@ -257,6 +258,24 @@ class FusedTrainStep:
         return self._loss
 
 
+def train_gaussian_backend(nc, model, train_loader, mega_xvec_dict, num_to_id_dict, device=None):
+    """xvector_GaussianBackend_pytorch.py:30-56 (`train`): one pass over the loader accumulating per-class counts,
+    sums and second moments of the paired rows, then the closed-form means / inverse covariances.  The x-vectors are
+    gathered on the device (the reference's script feeds the index batches to forward_getpaired, :41 — a bug; the
+    x-vector batches it built one line above are what is meant)."""
+    from .sv_trials_loaders import load_xvec_trials_from_numbatch
+    device = device or next(model.parameters()).device
+    model.eval()
+    stats = None
+    with torch.no_grad():
+        for data1, data2, target in train_loader:
+            x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
+            stats = model.accumulate_statistics(x1, x2, target.to(device), stats)
+    if stats is None:
+        raise ValueError("empty training loader")
+    return model.fit_statistics(stats)
+
+
 def make_optimizer(model, lr, weight_decay=1e-5, capturable=False):
     """Adam as the reference configures it (xvector_NeuralPlda_pytorch.py:139)."""
     return optim.Adam(model.parameters(), lr=lr, weight_decay=weight_decay, capturable=capturable)
@@ -321,6 +340,63 @@ def main_kaldiplda(configfile='conf/voices_config.cfg', use_graph=True):
             logging.info("REDUCING LEARNING RATE to {} since loss trend looks like {}".format(lr, all_losses[-3:]))
             optimizer = make_optimizer(model, lr)  # moments reset, as the reference re-creates Adam (:177)
             step_fn = FusedTrainStep(model, lr, weight_decay=1e-5, batch_size=nc.batch_size, graph=use_graph)
+    return model
+
+
+def main_dplda(configfile='conf/voices_config.cfg'):
+    """xvector_DPlda_pytorch.py:88-189: the same driver around DPlda — Kaldi LDA loaded and frozen (:131-147), Adam
+    over logistic_regres + thresholds, eager steps (forward = fused quadratic form, backward = weighted moments)."""
+    from .models import DPlda
+    timestamp = int(datetime.timestamp(datetime.now()))
+    for d in ('logs', 'models', 'scores'):
+        os.makedirs(d, exist_ok=True)
+    logging.basicConfig(filename='logs/dplda_{}.log'.format(timestamp), filemode='a',
+                        format='%(levelname)s: %(message)s', datefmt='%H:%M:%S', level=logging.DEBUG)
+    nc = NpldaConf(configfile)
+    torch.manual_seed(nc.seed)
+    np.random.seed(nc.seed)
+    random.seed(nc.seed)
+    if not torch.cuda.is_available():
+        raise RuntimeError("neuralplda_amd needs a HIP device")
+    device = torch.device(nc.device if str(nc.device).startswith("cuda") else "cuda")
+    mega_xvec_dict = pickle.load(open(nc.mega_xvector_pkl, 'rb'))
+    num_to_id_dict = {i: j for i, j in enumerate(list(mega_xvec_dict))}
+    id_to_num_dict = {v: k for k, v in num_to_id_dict.items()}
+    train_loader = combine_trials_and_get_loader(nc.training_data_trials_list, id_to_num_dict,
+                                                 subsample_factors=nc.train_subsample_factors,
+                                                 batch_size=nc.batch_size)
+    valid_loaders = get_trials_loaders_dict(nc.validation_trials_list, id_to_num_dict,
+                                            subsample_factors=nc.valid_subsample_factors,
+                                            batch_size=5 * nc.batch_size)
+    model = DPlda(nc).to(device)
+    if nc.initialization == 'kaldi':
+        model.LoadParamsFromKaldi(nc.meanvec, nc.transformmat)
+    updatable = []
+    for name, prm in model.named_parameters():
+        if 'centering_and_LDA' in name:
+            prm.requires_grad = False
+        else:
+            updatable.append(prm)
+    lr = nc.lr
+    optimizer = optim.Adam(updatable, lr=lr, weight_decay=1e-5)
+    validate(nc, model, device, mega_xvec_dict, num_to_id_dict, valid_loaders[nc.heldout_set_for_th_init],
+             update_thresholds=True)
+    all_losses = []
+    for epoch in range(1, nc.n_epochs + 1):
+        train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch)
+        val_losses = {}
+        for val_set, loader in valid_loaders.items():
+            val_losses[val_set], _ = validate(nc, model, device, mega_xvec_dict, num_to_id_dict, loader)
+        all_losses.append(float(val_losses[nc.heldout_set_for_lr_decay]))
+        model.SaveModel("models/NPLDA_{}_{}.pt".format(epoch, timestamp))
+        for trial_file in nc.test_trials_list:
+            nc.generate_scorefile("scores/kaldipldanet_epoch{}_{}_{}.txt".format(
+                epoch, os.path.splitext(os.path.basename(trial_file))[0], timestamp), trial_file, mega_xvec_dict, model,
+                device, 5 * nc.batch_size)
+        if len(all_losses) >= 3 and all_losses[-1] > all_losses[-2] > all_losses[-3]:
+            lr = lr / 2
+            logging.info("REDUCING LEARNING RATE to {} since loss trend looks like {}".format(lr, all_losses[-3:]))
+            optimizer = optim.Adam(updatable, lr=lr, weight_decay=1e-5)
     return model
 
 

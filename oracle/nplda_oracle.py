@@ -335,6 +335,38 @@ def dplda_from_embeddings(y1, y2, wlr, blr, dtype=np.float32):
     return feats @ _as(wlr, dtype).reshape(-1) + dtype(np.asarray(blr).reshape(-1)[0])
 
 
+def dplda_backward(y1, y2, g, dtype=np.float64):
+    """Gradient of sum_i g_i s_i w.r.t. DPlda's linear unit (utils/models.py:484-490): the features are
+    [y1 y2^T + y2 y1^T, y1 y1^T + y2 y2^T, y1 + y2], so d wlr = g^T feats and d bias = sum g."""
+    y1, y2, g = _as(y1, dtype), _as(y2, dtype), _as(g, dtype)
+    B = y1.shape[0]
+    between = (y1[:, :, None] * y2[:, None, :] + y2[:, :, None] * y1[:, None, :]).reshape(B, -1)
+    within = (y1[:, :, None] * y1[:, None, :] + y2[:, :, None] * y2[:, None, :]).reshape(B, -1)
+    feats = np.concatenate([between, within, y1 + y2], axis=1)
+    return (g @ feats).reshape(1, -1), np.asarray([g.sum()], dtype=dtype)
+
+
+def weighted_moments(x, w, dtype=np.float64):
+    """cnt = sum w, sum = w^T x, sq = x^T diag(w) x — the accumulators of
+    xvector_GaussianBackend_pytorch.py:31-52 for one class mask w."""
+    x, w = _as(x, dtype), _as(w, dtype)
+    return w.sum(), w @ x, (x * w[:, None]).T @ x
+
+
+def gb_fit(paired, t, dtype=np.float64):
+    """Closed-form Gaussian-backend "training" (xvector_GaussianBackend_pytorch.py:30-56), from the paired rows
+    x = forward_getpaired(x1, x2) and labels t.  Quirk kept: the non-target class divides BOTH its sum and its
+    second moment by (count - 1), the target class by count (:53-56).  Returns mu_t, Lam_t, mu_n, Lam_n."""
+    x, t = _as(paired, dtype), _as(t, dtype)
+    ct, st, qt = weighted_moments(x, (t > 0.5).astype(dtype), dtype)
+    cn, sn, qn = weighted_moments(x, (t < 0.5).astype(dtype), dtype)
+    mu_t = st / ct
+    Lam_t = np.linalg.inv(qt / ct - np.outer(mu_t, mu_t))
+    mu_n = sn / (cn - 1)
+    Lam_n = np.linalg.inv(qn / (cn - 1) - np.outer(mu_n, mu_n))
+    return mu_t, Lam_t, mu_n, Lam_n
+
+
 # ---------------------------------------------------------------------------------------------
 # Kaldi PLDA -> (P, Q) (utils/Kaldi2NumpyUtils/kaldiPlda2numpydict.py:34-38, utils/models.py:450-457)
 # ---------------------------------------------------------------------------------------------

@@ -15,6 +15,7 @@ generate_{sre,voices}_scores, utils/adaptive_score_normalization.py (exec'd with
 hard-coded input paths substituted), torch.optim.Adam as driven by xvector_NeuralPlda_pytorch.py:139.
 """
 import io
+import copy
 import os
 import re
 import subprocess
@@ -360,6 +361,27 @@ def main():
         dp2.logistic_regres.bias.fill_(0.125)
         sd2 = dp2.forward(torch.from_numpy(x1), torch.from_numpy(x2))
     save("g10_dplda_kaldi170.npz", seed=1010, s=sd2.numpy())
+    # gradient of the linear unit (the recipe trains logistic_regres + thresholds with the LDA frozen,
+    # xvector_DPlda_pytorch.py:140-147): reference autograd, fp32 and an fp64 re-evaluation
+    td = (rng10.random(50) < 0.3).astype(np.float32)
+    outg = {}
+    for tag, mdl, cast in (("f32", dp, lambda a: torch.from_numpy(a)), ("f64", copy.deepcopy(dp).double(), lambda a: torch.from_numpy(a).double())):
+        with torch.no_grad():
+            mdl.threshold[99.0].fill_(0.2)
+            mdl.threshold[199.0].fill_(0.35)
+        for lossname in ("SoftCdet", "crossentropy"):
+            mdl.lossfn = lossname
+            mdl.zero_grad()
+            sg_ = mdl(cast(xd1), cast(xd2))
+            Lg_ = mdl.loss(sg_, cast(td))
+            Lg_.backward()
+            outg[f"{lossname}_{tag}_L"] = Lg_.detach().numpy()
+            outg[f"{lossname}_{tag}_dwlr"] = mdl.logistic_regres.weight.grad.numpy().copy()
+            outg[f"{lossname}_{tag}_dblr"] = mdl.logistic_regres.bias.grad.numpy().copy()
+            if lossname == "SoftCdet":
+                outg[f"{lossname}_{tag}_dTh99"] = mdl.threshold[99.0].grad.numpy().copy()
+                outg[f"{lossname}_{tag}_dTh199"] = mdl.threshold[199.0].grad.numpy().copy()
+    save("g10_dplda_grad.npz", t=td, theta=np.asarray([0.2, 0.35]), **outg)
 
     # ---- G8: loaders and score-file writers ----------------------------------------------------------
     nutt = 150

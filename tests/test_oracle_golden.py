@@ -200,3 +200,26 @@ def test_g10_dplda_forward(g1):
     wlr = (rg.standard_normal((1, 2 * 170 * 170 + 170)) * 0.05).astype(np.float32)
     s = orc.dplda_forward(f["x1"], f["x2"], g1["W1"], g1["b1"], wlr, np.asarray([0.125]), np.float64)
     np.testing.assert_allclose(s, k["s"], atol=2e-5, rtol=2e-5)
+
+
+def test_g10_dplda_gradients():
+    """Oracle chain (forward -> loss grad -> dplda_backward) against the reference's autograd (G10 grad)."""
+    g = np.load(os.path.join(G, "g10_dplda_small.npz"), allow_pickle=True)
+    gg = np.load(os.path.join(G, "g10_dplda_grad.npz"))
+    f64 = np.float64
+    y1, _ = orc.normalize(g["x1"].astype(f64) @ g["W1"].astype(f64).T + g["b1"], f64)
+    y2, _ = orc.normalize(g["x2"].astype(f64) @ g["W1"].astype(f64).T + g["b1"], f64)
+    s = orc.dplda_from_embeddings(y1, y2, g["wlr"], g["blr"], f64)
+    theta = [float(v) for v in gg["theta"]]  # the fp64 re-evaluation filled its thresholds in fp64
+    L = orc.softcdet(s, gg["t"], theta, [99.0, 199.0], 15.0, f64)
+    gs, dth = orc.softcdet_grad(s, gg["t"], theta, [99.0, 199.0], 15.0, f64)
+    dw, db = orc.dplda_backward(y1, y2, gs)
+    np.testing.assert_allclose(L, gg["SoftCdet_f64_L"], rtol=1e-9)
+    np.testing.assert_allclose(dw, gg["SoftCdet_f64_dwlr"], atol=1e-9, rtol=1e-8)
+    np.testing.assert_allclose(db, gg["SoftCdet_f64_dblr"], rtol=1e-9)
+    np.testing.assert_allclose(dth, [gg["SoftCdet_f64_dTh99"][0], gg["SoftCdet_f64_dTh199"][0]], rtol=1e-9)
+    np.testing.assert_allclose(dw, gg["SoftCdet_f32_dwlr"], atol=2e-5, rtol=1e-4)
+    gx, _ = orc.crossentropy_grad(s, gg["t"], 0.0, f64)
+    dwx, dbx = orc.dplda_backward(y1, y2, gx)
+    np.testing.assert_allclose(dwx, gg["crossentropy_f64_dwlr"], atol=1e-11, rtol=1e-8)
+    np.testing.assert_allclose(dbx, gg["crossentropy_f64_dblr"], rtol=1e-9)
