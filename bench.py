@@ -121,13 +121,21 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    # NPLDA_BENCH_BACKEND=gloo is a plumbing dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # share devices, timing meaningless); the driver's runs use the default: RCCL, one rank per GPU
+    backend = os.environ.get("NPLDA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from neuralplda_amd import _lib, ops
     _lib.load()  # fail loudly if libnplda_hip.so is missing
@@ -163,7 +171,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
