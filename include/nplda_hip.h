@@ -183,6 +183,12 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
 int gb_pack_quadform_f32(const float* W1, const float* b1, const float* M, const float* v, float c, int D0, int D1,
                          void* packed, size_t packed_bytes, nplda_stream_t stream);
 
+/* The same image straight from DPlda's parameters: wlr = logistic_regres.weight (1, 2 D1^2 + D1) laid out
+ * [Wb | Ww | ws] as utils/models.py:484-490 concatenates the features, blr = logistic_regres.bias (1); both DEVICE
+ * pointers (no host read of the bias, so a training loop stays asynchronous). */
+int gb_pack_dplda_f32(const float* W1, const float* b1, const float* wlr, const float* blr, int D0, int D1,
+                      void* packed, size_t packed_bytes, nplda_stream_t stream);
+
 /* GaussianBackend.forward(x1, x2) -> s (B) (utils/models.py:584-593) and/or
  * GaussianBackend.forward_getpaired(x1, x2) -> paired (B, 2 D1) contiguous (utils/models.py:595-601).
  * Either output pointer may be NULL (not both). */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "gb_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "gb_pack_quadform_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, ctypes.c_float, _c_int, _c_int, _c_vp, _c_sz,
                                       _c_vp]),
+    "gb_pack_dplda_f32": (_c_int, [_c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
     "gb_score_rows_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_vp]),
     "gb_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
                                     _c_vp]),

@@ -31,9 +31,11 @@ GbLayout gb_layout(int D0, int D1) {
     return L;
 }
 
+// Lt != NULL: G = Ln - Lt.  Lt == NULL, dplda == 0: G = Ln (an explicit 2 D1 x 2 D1 form).  dplda == 1: Ln is DPlda's
+// logistic_regres.weight [Wb | Ww | ws] (utils/models.py:466,484-490): diagonal blocks Ww, off-diagonal blocks Wb.
 __global__ void gb_pack_kernel(const float* __restrict__ W1, const float* __restrict__ b1,
                                const float* __restrict__ Lt, const float* __restrict__ Ln, GbLayout L,
-                               float* __restrict__ out) {
+                               float* __restrict__ out, int dplda) {
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L.ov) return;  // v and c are written by gb_vc_kernel
     float v = 0.f;
@@ -57,7 +59,8 @@ __global__ void gb_pack_kernel(const float* __restrict__ W1, const float* __rest
             const int k = 16 * kb + 4 * (lane >> 4) + i;
             if (f < D1 && k < D1) {
                 const size_t r = (size_t)(ho * D1 + f), c = (size_t)(hi * D1 + k);
-                v = Lt ? Ln[r * n2 + c] - Lt[r * n2 + c] : Ln[r * n2 + c];  // Lt == NULL: M is given directly
+                if (dplda) v = Ln[(size_t)(ho == hi ? D1 * D1 : 0) + (size_t)f * D1 + k];
+                else v = Lt ? Ln[r * n2 + c] - Lt[r * n2 + c] : Ln[r * n2 + c];
             }
         }
     } else {
@@ -117,6 +120,20 @@ __global__ __launch_bounds__(512) void gb_vc_direct_kernel(const float* __restri
     }
 }
 
+// DPlda: v = [ws; ws] with ws = the last D1 weights, c = the bias (read on the device: no host sync)
+__global__ __launch_bounds__(512) void gb_vc_dplda_kernel(const float* __restrict__ wlr, const float* __restrict__ blr,
+                                                          GbLayout L, float* __restrict__ out) {
+    const float* ws = wlr + 2 * (size_t)L.D1 * L.D1;
+    for (int i = threadIdx.x; i < 2 * L.NB * 16; i += 512) {
+        const int f = i % (L.NB * 16);
+        out[L.ov + i] = f < L.D1 ? ws[f] : 0.f;
+    }
+    if (threadIdx.x == 0) {
+        out[L.oc] = blr[0];
+        out[L.oc + 1] = out[L.oc + 2] = out[L.oc + 3] = 0.f;
+    }
+}
+
 int gb_check(int D0, int D1) {
     if (D0 <= 0 || D1 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
     if (nplda_kernel_nb(D1, D1) == 0) return NPLDA_EUNSUPPORTED;
@@ -161,7 +178,7 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
     if (!nplda_aligned16(packed)) return NPLDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((L.ov + 255) / 256)), dim3(256), 0, st, W1, b1, Lam_t, Lam_n, L,
-                       (float*)packed);
+                       (float*)packed, 0);
     if (int rc = nplda_launch_status()) return rc;
     hipLaunchKernelGGL(gb_vc_kernel, dim3(1), dim3(512), 0, st, mu_t, Lam_t, mu_n, Lam_n, L, (float*)packed);
     return nplda_launch_status();
@@ -176,9 +193,24 @@ int gb_pack_quadform_f32(const float* W1, const float* b1, const float* M, const
     if (!nplda_aligned16(packed)) return NPLDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((L.ov + 255) / 256)), dim3(256), 0, st, W1, b1,
-                       (const float*)nullptr, M, L, (float*)packed);
+                       (const float*)nullptr, M, L, (float*)packed, 0);
     if (int rc = nplda_launch_status()) return rc;
     hipLaunchKernelGGL(gb_vc_direct_kernel, dim3(1), dim3(512), 0, st, v, c, L, (float*)packed);
+    return nplda_launch_status();
+}
+
+int gb_pack_dplda_f32(const float* W1, const float* b1, const float* wlr, const float* blr, int D0, int D1,
+                      void* packed, size_t packed_bytes, nplda_stream_t stream) {
+    if (!W1 || !b1 || !wlr || !blr || !packed) return NPLDA_EINVAL;
+    if (int rc = gb_check(D0, D1)) return rc;
+    const GbLayout L = gb_layout(D0, D1);
+    if (packed_bytes < L.total * sizeof(float)) return NPLDA_ENOSPC;
+    if (!nplda_aligned16(packed)) return NPLDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((L.ov + 255) / 256)), dim3(256), 0, st, W1, b1,
+                       (const float*)nullptr, wlr, L, (float*)packed, 1);
+    if (int rc = nplda_launch_status()) return rc;
+    hipLaunchKernelGGL(gb_vc_dplda_kernel, dim3(1), dim3(512), 0, st, wlr, blr, L, (float*)packed);
     return nplda_launch_status();
 }
 

@@ -139,8 +139,7 @@ class _DPldaScoreFn(torch.autograd.Function):
         dev = _compute_device(x1, W1)
         D1 = W1.shape[0]
         W1d, b1d = _to_dev(W1, dev), _to_dev(b1, dev)
-        M, v, c = ops.dplda_quadform(_to_dev(wlr, dev), blr, D1)
-        packed = ops.quadform_pack(W1d, b1d, M, v, c)
+        packed = ops.dplda_pack(W1d, b1d, _to_dev(wlr, dev), _to_dev(blr, dev))
         need = any(ctx.needs_input_grad[2:])
         ctx.lda_needs = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
         s, paired = ops._gb_call(_to_dev(x1, dev), _to_dev(x2, dev), packed, True, need)

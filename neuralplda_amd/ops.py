@@ -463,6 +463,27 @@ def quadform_pack(W1, b1, M, v, c):
     return buf, D0, D1
 
 
+def dplda_pack(W1, b1, wlr, blr):
+    """gb_pack_dplda_f32: the quadratic-form image straight from DPlda's parameters (no host sync, no temporaries)."""
+    lib = _lib.load()
+    for n, t in (("W1", W1), ("b1", b1), ("wlr", wlr), ("blr", blr)):
+        _require_dev_f32(t, n)
+    D1, D0 = W1.shape
+    if wlr.numel() != 2 * D1 * D1 + D1 or blr.numel() != 1:
+        raise ValueError("logistic_regres must be Linear(2 D1^2 + D1, 1)")
+    if D0 % 4 != 0:
+        raise ValueError(f"xvector_dim must be a multiple of 4 (got {D0})")
+    nbytes = lib.gb_packed_bytes(D0, D1)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"model {D0}->{D1} is outside the compiled kernel set")
+    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
+    ts = [t.detach().contiguous() for t in (W1, b1, wlr, blr)]
+    with torch.cuda.device(W1.device):
+        code = lib.gb_pack_dplda_f32(*[_lib.ptr(t) for t in ts], D0, D1, _lib.ptr(buf), nbytes, _lib.current_stream())
+    _lib.check(code, "gb_pack_dplda_f32")
+    return buf, D0, D1
+
+
 def quadform_score_pairs(x1, x2, packed):
     """(B, D0) x 2 -> (B,) scores of the packed quadratic form (kernel: MODE_GB of the fused forward)."""
     return _gb_call(x1, x2, packed, True, False)[0]

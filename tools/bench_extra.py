@@ -117,6 +117,32 @@ def main():
     ms_g = timeit(lambda: ops._gb_call(x1, x2, gpk, True, False))
     out["gaussian_backend_D170"] = {"pairs_per_s": Bg / ms_g * 1e3, "ms_512k": ms_g,
                                     "TFLOPs_padded": Bg * (2 * 2 * 512 * 176 + 2 * 4 * 176 * 176) / ms_g / 1e9}
+    # weighted moments of paired rows (n = 340): GB statistics pass (two classes) and DPlda gradient (one weight vector)
+    paired = ops._gb_call(x1, x2, gpk, False, True)[1]
+    t = (torch.rand(Bg, device=dev, generator=gen) < 0.1).float()
+    ms_m2 = timeit(lambda: ops.weighted_moments(paired, t, 1 - t), reps=5, warm=2)
+    small = paired[:2048].contiguous()
+    gsm = torch.randn(2048, device=dev, generator=gen)
+    ms_m1 = timeit(lambda: ops.weighted_moments(small, gsm), reps=20)
+    out["weighted_moments_n340"] = {"two_class_ms_512k_rows": ms_m2, "rows_per_s": Bg / ms_m2 * 1e3,
+                                    "TFLOPs_upper_triangle": 2 * 2.0 * Bg * 340 * 341 / 2 / ms_m2 / 1e9,
+                                    "one_class_ms_2048_rows": ms_m1}
+    # DPlda: scoring at D = 170 and one recipe step (LDA frozen, Adam on the linear unit) at B = 2048
+    dp = models.DPlda(NC(170)).to(dev)
+    for prm in dp.centering_and_LDA.parameters():
+        prm.requires_grad = False
+    with torch.no_grad():
+        ms_d = timeit(lambda: dp(x1, x2))
+    opt = torch.optim.Adam([p for p in dp.parameters() if p.requires_grad], lr=1e-4, weight_decay=1e-5)
+    xa, xb, tt = x1[:2048].contiguous(), x2[:2048].contiguous(), t[:2048].contiguous()
+
+    def dstep():
+        opt.zero_grad()
+        L = dp.loss(dp(xa, xb), tt)
+        L.backward()
+        opt.step()
+    ms_ds = timeit(dstep, reps=20)
+    out["dplda_D170"] = {"score_pairs_per_s": Bg / ms_d * 1e3, "score_ms_512k": ms_d, "train_step_ms_B2048": ms_ds}
     print(json.dumps(out, indent=1))
 
 
