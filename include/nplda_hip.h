@@ -216,6 +216,38 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
                                double* cnt, double* sum, double* sq, int accumulate, void* workspace,
                                size_t workspace_bytes, nplda_stream_t stream);
 
+/* ---- host-side text I/O of the trial-list path (no device work; plain host pointers) ------------------------------ */
+
+/* Rows and columns of a whitespace-separated table held in memory, with np.genfromtxt(dtype=str) semantics (the
+ * reader of utils/scorefile_generator.py:26,45 and utils/sv_trials_loaders.py:377,400): any run of blanks separates
+ * columns, '#' starts a comment, blank lines are skipped.  Returns the number of data rows (>= 0) and their column
+ * count in *ncols, or NPLDA_EINVAL when rows have different column counts (genfromtxt raises there). */
+int64_t nplda_text_scan(const char* text, size_t len, int* ncols);
+
+/* Resolve columns 0 and 1 of every data row after the first skip_rows to numbers through an id table, replacing the
+ * per-trial Python loops of utils/sv_trials_loaders.py:379-383 / :402-406 (dict look-ups, float(label)) and :432-433
+ * (basename / splitext per id).  mode1 / mode2: 0 = id as written, 1 = os.path.splitext(id)[0],
+ * 2 = os.path.splitext(os.path.basename(id))[0].  ids: n_ids ids separated by single '\n' bytes, id i =
+ * ids[id_off[i] .. id_off[i+1] - 1) (id_off has n_ids + 1 entries); a repeated id resolves to its last occurrence
+ * (dict semantics).  id_num (n_ids) maps a table position to the number stored (NULL: the position itself).
+ * label_col >= 0: that column is parsed like Python's float() into label.  Rows with an unknown id, an unparsable
+ * label or too few columns are skipped, as the reference's bare `except: pass` does; *first_bad_row (optional) gets
+ * the first such row (relative to skip_rows) or -1, so that a caller with KeyError semantics (:433) can raise.
+ * Outputs have room for every data row; *n_kept rows are written; row_of (optional) = source row of each. */
+int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1, int mode2, int label_col,
+                      const char* ids, const int64_t* id_off, const int64_t* id_num, int64_t n_ids, int64_t* i1,
+                      int64_t* i2, float* label, int64_t* row_of, int64_t* n_kept, int64_t* first_bad_row);
+
+/* Write a score file: optional header line, then for each of the first n data rows after skip_rows its first
+ * keep_cols columns joined by tabs, a tab, and the score formatted as str(np.float32) — byte for byte what
+ * np.savetxt(np.c_[trials, scores.astype(str)], fmt='%s', delimiter='\t') writes at
+ * utils/scorefile_generator.py:38 (keep_cols = all columns, header = columns + "\tLLR") and :55 (keep_cols = 2). */
+int nplda_scores_write(const char* path, const char* text, size_t len, int64_t skip_rows, int keep_cols,
+                       const char* header, const float* scores, int64_t n);
+
+/* str(np.float32(v)) into out (>= 32 bytes, NUL-terminated); returns the length. */
+int nplda_format_f32(float v, char* out);
+
 /* ---- optimiser ----------------------------------------------------------------------------------------- */
 
 /* torch.optim.Adam's update (xvector_NeuralPlda_pytorch.py:139: lr, weight_decay = 1e-5 as L2 term, no amsgrad)

@@ -24,7 +24,8 @@ def _hipcc():
 
 
 def sources():
-    return sorted(glob.glob(os.path.join(CSRC, "*.hip")))
+    """Device code (*.hip) and the host-only translation units (*.cpp), all built by hipcc into one library."""
+    return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
 def _stale(out, deps):
@@ -44,7 +45,7 @@ def build(force=False, verbose=False):
     objs = []
     procs = []
     for src in srcs:
-        obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
+        obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
         if force or _stale(obj, [src] + hdrs):
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]

@@ -81,29 +81,65 @@ def score_trials(model, mega_dict, ids1, ids2, device=None, batch_size=1 << 22):
     return torch.cat(out).cpu().numpy() if out else np.zeros(0, np.float32)
 
 
-def generate_sre_scores(score_filename, trials_file, mega_dict, model, device, batch_size=102400):
-    """utils/scorefile_generator.py:22-39: header + input columns + LLR."""
-    trials = np.genfromtxt(trials_file, dtype='str')
-    trials = trials.reshape(-1, trials.shape[-1]) if trials.ndim == 2 else trials.reshape(1, -1)
-    header = '\t'.join(trials[0]) + '\tLLR'
-    trials = trials[1:]
+def _score_rows(model, tab, r1, r2, device, batch_size=1 << 22):
+    """Scores of trials given as x-vector table rows (int64 numpy).  NPLDA: each distinct utterance is embedded once,
+    then index pairs are scored; other models: dense batched forward of gathered rows."""
+    if len(r1) == 0:
+        return np.zeros(0, np.float32)
+    dev = _pick_device(model, device)
+    with torch.no_grad():
+        if hasattr(model, "centering_and_wccn_plda"):
+            used = np.zeros(len(tab.ids), dtype=bool)
+            used[r1] = True
+            used[r2] = True
+            rows = np.flatnonzero(used)
+            remap = np.cumsum(used) - 1
+            j1, j2 = remap[r1], remap[r2]
+            packed = _model_packed(model, dev)
+            z, q = ops.embed(tab.gather(rows, dev), packed)
+            out = [ops.score_indexed(z, q, torch.from_numpy(j1[lo:lo + batch_size]),
+                                     torch.from_numpy(j2[lo:lo + batch_size]), packed)
+                   for lo in range(0, len(j1), batch_size)]
+        else:
+            step = min(batch_size, 1 << 18)
+            out = [model.forward(tab.gather(r1[lo:lo + step], dev), tab.gather(r2[lo:lo + step], dev))
+                   for lo in range(0, len(r1), step)]
+        return torch.cat(out).float().cpu().numpy()
+
+
+def _generate(score_filename, trials_file, mega_dict, model, device, skip_rows, keep_cols, with_header):
+    from . import textio
+    with open(trials_file, "rb") as fh:
+        text = fh.read()
+    rows, ncols = textio.scan(text)
+    if rows < skip_rows or (rows > skip_rows and ncols < 2):
+        raise ValueError(f"{trials_file}: not a trials file")
+    tab = xvector_table(mega_dict)
+    r1, r2, _, _, bad = textio.lookup(text, tab.idblob, skip_rows, textio.BASENAME_SPLITEXT,
+                                      textio.BASENAME_SPLITEXT, rows=rows)
+    if bad >= 0:  # the reference raises KeyError at utils/sv_trials_loaders.py:433
+        toks = textio.row_tokens(text, bad + skip_rows)
+        norm = [os.path.splitext(os.path.basename(d))[0] for d in toks[:2]]
+        missing = [u for u in norm if u not in tab.row_of]
+        raise KeyError(f"utterance {missing[0] if missing else norm!r} is not in mega_dict")
     was_training = model.training
     model = model.eval()
-    S = score_trials(model, mega_dict, trials[:, 0], trials[:, 1], device)
-    scores = np.asarray(S).astype(str)
-    np.savetxt(score_filename, np.c_[trials, scores], header=header, fmt='%s', delimiter='\t', comments='')
+    S = _score_rows(model, tab, r1, r2, device)
+    header = None
+    if with_header:
+        header = '\t'.join(textio.row_tokens(text, 0)) + '\tLLR'
+    textio.write_scores(score_filename, text, S, skip_rows=skip_rows, keep_cols=ncols if keep_cols is None else keep_cols,
+                        header=header)
     if was_training:
         model.train()
+
+
+def generate_sre_scores(score_filename, trials_file, mega_dict, model, device, batch_size=102400):
+    """utils/scorefile_generator.py:22-39: header + input columns + LLR.  One native pass reads the trials file and
+    resolves both id columns to table rows (nplda_text_lookup), one writes the TSV (nplda_scores_write)."""
+    _generate(score_filename, trials_file, mega_dict, model, device, skip_rows=1, keep_cols=None, with_header=True)
 
 
 def generate_voices_scores(score_filename, trials_file, mega_dict, model, device, batch_size=102400):
     """utils/scorefile_generator.py:41-56: first two columns + score, no header."""
-    trials = np.genfromtxt(trials_file, dtype='str')
-    trials = (trials.reshape(-1, trials.shape[-1]) if trials.ndim == 2 else trials.reshape(1, -1))[:, :2]
-    was_training = model.training
-    model = model.eval()
-    S = score_trials(model, mega_dict, trials[:, 0], trials[:, 1], device)
-    scores = np.asarray(S).astype(str)
-    np.savetxt(score_filename, np.c_[trials, scores], fmt='%s', delimiter='\t', comments='')
-    if was_training:
-        model.train()
+    _generate(score_filename, trials_file, mega_dict, model, device, skip_rows=0, keep_cols=2, with_header=False)

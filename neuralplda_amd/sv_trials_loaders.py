@@ -45,23 +45,33 @@ class TrialIndexDataset(Dataset):
         return self.x1[ii], self.x2[ii], self.l[ii]
 
 
+_IDBLOBS = {}
+
+
+def _dict_blob(id_to_num_dict):
+    """textio.IdBlob of an {utt_id: num} dict, cached per dict object (rebuilt when its size changes)."""
+    from . import textio
+    k = id(id_to_num_dict)
+    hit = _IDBLOBS.get(k)
+    if hit is None or hit[0] != len(id_to_num_dict):
+        if len(_IDBLOBS) > 8:
+            _IDBLOBS.clear()
+        hit = (len(id_to_num_dict), textio.IdBlob.from_dict(id_to_num_dict))
+        _IDBLOBS[k] = hit
+    return hit[1]
+
+
 def _read_trials(f, id_to_num_dict, strip_ext_col2):
-    """np.genfromtxt + id mapping as utils/sv_trials_loaders.py:377-383 (:400-406); unknown ids are
-    dropped silently by the reference — here they are counted (returned)."""
-    t = np.genfromtxt(f, dtype='str')
-    if t.ndim == 1:
-        t = t.reshape(1, -1)
-    x1, x2, l = [], [], []
-    dropped = 0
-    for tr in t:
-        try:
-            key2 = os.path.splitext(tr[1])[0] if strip_ext_col2 else tr[1]
-            a, b, c = id_to_num_dict[tr[0]], id_to_num_dict[key2], float(tr[2])
-            x1.append(a); x2.append(b); l.append(c)
-        except Exception:
-            dropped += 1
-    return (torch.tensor(x1, dtype=torch.int64), torch.tensor(x2, dtype=torch.int64),
-            torch.tensor(l, dtype=torch.float32), dropped)
+    """np.genfromtxt + the per-trial id mapping loop of utils/sv_trials_loaders.py:377-383 (:400-406) as one native
+    pass over the file (nplda_text_lookup); rows with unknown ids / bad labels are dropped silently by the
+    reference — here they are counted (returned)."""
+    from . import textio
+    with open(f, "rb") as fh:
+        text = fh.read()
+    rows, _ = textio.scan(text)
+    x1, x2, l, _, _ = textio.lookup(text, _dict_blob(id_to_num_dict), 0, textio.RAW,
+                                    textio.SPLITEXT if strip_ext_col2 else textio.RAW, label_col=2, rows=rows)
+    return (torch.from_numpy(x1.copy()), torch.from_numpy(x2.copy()), torch.from_numpy(l.copy()), rows - len(x1))
 
 
 def _loader(ds, batch_size):
@@ -122,6 +132,15 @@ class XvectorTable:
                                          if self.ids else np.zeros((0, 0), np.float32))
         self._dev = {}
         self._num_maps = {}
+        self._idblob = None
+
+    @property
+    def idblob(self):
+        """The id -> row table in the layout the native text routines read (built once)."""
+        if self._idblob is None:
+            from . import textio
+            self._idblob = textio.IdBlob(self.ids)
+        return self._idblob
 
     @property
     def dim(self):
