@@ -227,7 +227,8 @@ int64_t nplda_text_scan(const char* text, size_t len, int* ncols);
 /* Resolve columns 0 and 1 of every data row after the first skip_rows to numbers through an id table, replacing the
  * per-trial Python loops of utils/sv_trials_loaders.py:379-383 / :402-406 (dict look-ups, float(label)) and :432-433
  * (basename / splitext per id).  mode1 / mode2: 0 = id as written, 1 = os.path.splitext(id)[0],
- * 2 = os.path.splitext(os.path.basename(id))[0].  ids: n_ids ids separated by single '\n' bytes, id i =
+ * 2 = os.path.splitext(os.path.basename(id))[0], 3 = id.replace('.sph', '') (utils/adaptive_score_normalization.py:25).
+ * ids: n_ids ids separated by single '\n' bytes, id i =
  * ids[id_off[i] .. id_off[i+1] - 1) (id_off has n_ids + 1 entries); a repeated id resolves to its last occurrence
  * (dict semantics).  id_num (n_ids) maps a table position to the number stored (NULL: the position itself).
  * label_col >= 0: that column is parsed like Python's float() into label.  Rows with an unknown id, an unparsable
@@ -239,14 +240,30 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
                       int64_t* i2, float* label, int64_t* row_of, int64_t* n_kept, int64_t* first_bad_row);
 
 /* Write a score file: optional header line, then for each of the first n data rows after skip_rows its first
- * keep_cols columns joined by tabs, a tab, and the score formatted as str(np.float32) — byte for byte what
+ * keep_cols columns joined by tabs, a tab, and the score formatted as str(np.float32) (scores_f64 = 0, float array)
+ * or str(np.float64) (scores_f64 = 1, double array) — byte for byte what
  * np.savetxt(np.c_[trials, scores.astype(str)], fmt='%s', delimiter='\t') writes at
- * utils/scorefile_generator.py:38 (keep_cols = all columns, header = columns + "\tLLR") and :55 (keep_cols = 2). */
+ * utils/scorefile_generator.py:38 (keep_cols = all columns, header = columns + "\tLLR"), :55 (keep_cols = 2) and
+ * utils/adaptive_score_normalization.py:81-84 (doubles, keep_cols = all but the last, header "# " + columns). */
 int nplda_scores_write(const char* path, const char* text, size_t len, int64_t skip_rows, int keep_cols,
-                       const char* header, const float* scores, int64_t n);
+                       const char* header, const void* scores, int scores_f64, int64_t n);
 
-/* str(np.float32(v)) into out (>= 32 bytes, NUL-terminated); returns the length. */
+/* str(np.float32(v)) / str(np.float64(v)) into out (>= 32 bytes, NUL-terminated); returns the length. */
 int nplda_format_f32(float v, char* out);
+int nplda_format_f64(double v, char* out);
+
+/* One column (col < 0 counts from the end: -1 = last) of the n data rows after skip_rows parsed like Python's
+ * float(): the `.astype(float)` of utils/adaptive_score_normalization.py:24,32.  NPLDA_EINVAL if a token does not
+ * parse or the table has fewer / more rows than n. */
+int nplda_text_column_f64(const char* text, size_t len, int64_t skip_rows, int col, double* out, int64_t n);
+
+/* Number of distinct tokens in a column: len(np.unique(tab[:, col])) of utils/adaptive_score_normalization.py:28. */
+int nplda_text_count_unique(const char* text, size_t len, int64_t skip_rows, int col, int64_t* n_unique);
+
+/* Byte spans (start offset into text, length) of column col in rows skip_rows + k * stride, k = 0..n-1: the row ids
+ * of the reshaped cohort table, utils/adaptive_score_normalization.py:38. */
+int nplda_text_column_spans(const char* text, size_t len, int64_t skip_rows, int col, int64_t stride, int64_t* start,
+                            int64_t* length, int64_t n);
 
 /* ---- optimiser ----------------------------------------------------------------------------------------- */
 

@@ -60,8 +60,12 @@ SIGNATURES = {
     "nplda_text_lookup": (_c_int, [ctypes.c_char_p, _c_sz, _c_i64, _c_int, _c_int, _c_int, ctypes.c_char_p, _c_vp, _c_vp,
                                    _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),
     "nplda_scores_write": (_c_int, [ctypes.c_char_p, ctypes.c_char_p, _c_sz, _c_i64, _c_int, ctypes.c_char_p, _c_vp,
-                                    _c_i64]),
+                                    _c_int, _c_i64]),
     "nplda_format_f32": (_c_int, [ctypes.c_float, ctypes.c_char_p]),
+    "nplda_format_f64": (_c_int, [ctypes.c_double, ctypes.c_char_p]),
+    "nplda_text_column_f64": (_c_int, [ctypes.c_char_p, _c_sz, _c_i64, _c_int, _c_vp, _c_i64]),
+    "nplda_text_count_unique": (_c_int, [ctypes.c_char_p, _c_sz, _c_i64, _c_int, ctypes.POINTER(_c_i64)]),
+    "nplda_text_column_spans": (_c_int, [ctypes.c_char_p, _c_sz, _c_i64, _c_int, _c_i64, _c_vp, _c_vp, _c_i64]),
     "nplda_adam_step_f32": (_c_int, [ctypes.POINTER(ctypes.c_void_p)] * 4 + [ctypes.POINTER(ctypes.c_int64), _c_int, _c_vp,
                                      ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float, ctypes.c_float,
                                      _c_vp]),

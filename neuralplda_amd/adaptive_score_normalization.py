@@ -42,31 +42,42 @@ def normalize_scorefile(raw_score_filename, cohort_score_filename, topN=ASnorm_t
                         write=True):
     """File-level equivalent of running utils/adaptive_score_normalization.py with its two paths set.
     Returns {"znorm","tnorm","snorm","asnorm1"} -> float64 numpy arrays (and writes the four TSVs)."""
+    from . import textio
     dev = _device(device)
-    raw_tab = np.genfromtxt(raw_score_filename, dtype='str')
-    header = raw_tab[0]
-    raw_tab = raw_tab[1:]
-    trials_enroll, trials_test = raw_tab[:, 0], raw_tab[:, 1]
-    raw_scores = raw_tab[:, -1].astype(float)
-    trials_test = np.asarray([w.replace('.sph', '') for w in trials_test])
-    coh = np.genfromtxt(cohort_score_filename, dtype='str', skip_header=1)
-    num_unlabelled = len(np.unique(coh[:, 1]))
-    cohort_matrix = coh[:, -1].astype(float).reshape(-1, num_unlabelled)
-    row_ids = coh[:, 0].reshape(-1, num_unlabelled)[:, 0]
-    row_of = dict(zip(row_ids, range(len(row_ids))))  # later duplicates win, as in the reference's dict(zip())
+    with open(raw_score_filename, "rb") as fh:
+        raw_text = fh.read()
+    with open(cohort_score_filename, "rb") as fh:
+        fh.readline()  # skip_header=1: the first LINE, before any comment / blank-line handling (:27)
+        coh_text = fh.read()
+    raw_rows, raw_cols = textio.scan(raw_text)
+    coh_rows, coh_cols = textio.scan(coh_text)
+    if raw_rows < 1 or raw_cols < 3 or coh_cols < 3:
+        raise ValueError("score files need at least (id, id, score) columns and a header row")
+    header = textio.row_tokens(raw_text, 0)
+    n_trials = raw_rows - 1
+    raw_scores = textio.column_f64(raw_text, -1, n_trials, skip_rows=1)
+    num_unlabelled = textio.count_unique(coh_text, 1)
+    if num_unlabelled == 0 or coh_rows % num_unlabelled:
+        raise ValueError("cohort score file: rows are not a whole number of cohort blocks")  # reshape(-1, M) fails (:32)
+    R = coh_rows // num_unlabelled
+    cohort_matrix = textio.column_f64(coh_text, -1, coh_rows).reshape(R, num_unlabelled)
+    row_ids = textio.column_tokens(coh_text, 0, R, stride=num_unlabelled)
+    blob = textio.IdBlob(row_ids)  # a repeated id resolves to its last block, as the reference's dict(zip()) does
     S = torch.from_numpy(np.ascontiguousarray(cohort_matrix, dtype=np.float32)).to(dev)
     stats = ops.row_stats(S, topn=topN, select=select)
-    try:
-        ie = np.fromiter((row_of[e] for e in trials_enroll), dtype=np.int64, count=len(trials_enroll))
-        it = np.fromiter((row_of[t] for t in trials_test), dtype=np.int64, count=len(trials_test))
-    except KeyError as e:
-        raise KeyError(f"id {e.args[0]!r} of the trial list has no row in the cohort score file") from None
+    ie, it, _, _, bad = textio.lookup(raw_text, blob, 1, textio.RAW, textio.STRIP_SPH, rows=raw_rows)
+    if bad >= 0:
+        toks = textio.row_tokens(raw_text, bad + 1)
+        cand = [toks[0], toks[1].replace('.sph', '')]
+        known = set(row_ids)
+        miss = [c for c in cand if c not in known]
+        raise KeyError(f"id {(miss[0] if miss else cand)!r} of the trial list has no row in the cohort score file")
     out = ops.asnorm_apply(torch.from_numpy(raw_scores), ie, it, stats).cpu().numpy()
-    res = {k: out[:, c] for c, k in enumerate(("znorm", "tnorm", "snorm", "asnorm1"))}
+    res = {k: np.ascontiguousarray(out[:, c]) for c, k in enumerate(("znorm", "tnorm", "snorm", "asnorm1"))}
     if write:
-        for k, col in res.items():
-            np.savetxt(raw_score_filename + f'_{k}.tsv', np.c_[raw_tab[:, :-1], col.astype(str)],
-                       header='\t'.join(header), fmt='%s', delimiter='\t')
+        for k, col in res.items():  # np.savetxt's default comment prefix "# " goes in front of the header (:81-84)
+            textio.write_scores(raw_score_filename + f'_{k}.tsv', raw_text, col, skip_rows=1, keep_cols=raw_cols - 1,
+                                header='# ' + '\t'.join(header))
     return res
 
 

@@ -65,9 +65,23 @@ inline Tok strip_ext(Tok t) {
     return Tok{t.p, dot};
 }
 
-inline Tok normalise(Tok t, int mode) {
+// mode 3: str.replace('.sph', '') — every occurrence removed (utils/adaptive_score_normalization.py:25); needs a
+// scratch buffer when something is removed
+inline Tok normalise(Tok t, int mode, std::string* scratch = nullptr) {
     if (mode == 1) return strip_ext(t);
     if (mode == 2) return strip_ext(basename_of(t));
+    if (mode == 3 && scratch && t.n >= 4) {
+        const char* hit = nullptr;
+        for (size_t i = 0; i + 4 <= t.n; ++i)
+            if (memcmp(t.p + i, ".sph", 4) == 0) { hit = t.p + i; break; }
+        if (!hit) return t;
+        scratch->clear();
+        for (size_t i = 0; i < t.n;) {
+            if (i + 4 <= t.n && memcmp(t.p + i, ".sph", 4) == 0) i += 4;
+            else scratch->push_back(t.p[i++]);
+        }
+        return Tok{scratch->data(), scratch->size()};
+    }
     return t;
 }
 
@@ -134,13 +148,11 @@ inline bool parse_label(Tok t, float* out) {
     return true;
 }
 
-}  // namespace
-
-extern "C" {
-
-int nplda_format_f32(float v, char* out) {
-    // str(np.float32(v)): shortest digits that round-trip in float32; positional for 1e-4 <= |v| < 1e16 (and 0)
-    // with at least one digit after the point, else scientific with a >= 2-digit exponent and no trailing ".0"
+// str(np.float32(v)) / str(np.float64(v)): shortest digits that round-trip in the type; positional for
+// 1e-4 <= |v| < 1e16 (and 0) with at least one digit after the point, else scientific with a >= 2-digit exponent
+// and no trailing ".0"
+template <typename T>
+int format_np(T v, char* out) {
     if (std::isnan(v)) { memcpy(out, "nan", 4); return 3; }
     if (std::isinf(v)) {
         if (v < 0) { memcpy(out, "-inf", 5); return 4; }
@@ -149,10 +161,10 @@ int nplda_format_f32(float v, char* out) {
     }
     char* o = out;
     if (std::signbit(v)) { *o++ = '-'; v = -v; }
-    if (v == 0.0f) { memcpy(o, "0.0", 4); return (int)(o - out) + 3; }
+    if (v == (T)0) { memcpy(o, "0.0", 4); return (int)(o - out) + 3; }
     char sci[48];
     const auto r = std::to_chars(sci, sci + sizeof(sci), v, std::chars_format::scientific);  // d[.ddd]e[+-]XX
-    char digits[16];
+    char digits[24];
     int nd = 0;
     const char* p = sci;
     for (; p < r.ptr && *p != 'e'; ++p)
@@ -193,6 +205,123 @@ int nplda_format_f32(float v, char* out) {
     return (int)(o - out);
 }
 
+// Python float(token): see parse_label; doubles for score columns ("astype(float)")
+inline bool parse_f64(Tok t, double* out) {
+    const char* p = t.p;
+    const char* e = t.p + t.n;
+    if (p == e) return false;
+    bool neg = false;
+    if (*p == '+' || *p == '-') { neg = *p == '-'; ++p; }
+    if (p == e || *p == '+' || *p == '-') return false;
+    double v = 0.0;
+    const auto r = std::from_chars(p, e, v, std::chars_format::general);
+    if (r.ec == std::errc::result_out_of_range) {
+        if (r.ptr != e) return false;
+        // from_chars leaves v untouched: overflow -> inf, underflow -> 0 like strtod
+        const std::string tmp(p, e);
+        v = strtod(tmp.c_str(), nullptr);
+    } else if (r.ec != std::errc() || r.ptr != e) {
+        return false;
+    }
+    *out = neg ? -v : v;
+    return true;
+}
+
+// visit the tokens of every data row after skip_rows; fn(row_index_after_skip, tokens, ntokens) -> false stops
+template <typename F>
+inline void for_rows(const char* text, size_t len, int64_t skip_rows, F&& fn) {
+    const char* p = text;
+    const char* end = text + len;
+    int64_t row = 0;
+    Tok tk[64];
+    while (p < end) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
+        const char* e = nl ? nl : end;
+        const int n = split_line(p, e, tk, 64);
+        p = nl ? nl + 1 : end;
+        if (n == 0) continue;
+        const int64_t r = row++;
+        if (r < skip_rows) continue;
+        if (!fn(r - skip_rows, tk, n < 64 ? n : 64)) return;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int nplda_format_f32(float v, char* out) { return format_np<float>(v, out); }
+int nplda_format_f64(double v, char* out) { return format_np<double>(v, out); }
+
+int nplda_text_column_f64(const char* text, size_t len, int64_t skip_rows, int col, double* out, int64_t n) {
+    if ((!text && len) || (!out && n) || n < 0 || col < -64 || col > 63) return NPLDA_EINVAL;
+    int rc = NPLDA_OK;
+    int64_t got = 0;
+    for_rows(text, len, skip_rows, [&](int64_t r, const Tok* tk, int nt) {
+        if (r >= n) return false;
+        const int c = col < 0 ? nt + col : col;
+        if (c < 0 || c >= nt || !parse_f64(tk[c], &out[r])) { rc = NPLDA_EINVAL; return false; }
+        got = r + 1;
+        return true;
+    });
+    if (rc == NPLDA_OK && got != n) rc = NPLDA_EINVAL;
+    return rc;
+}
+
+int nplda_text_count_unique(const char* text, size_t len, int64_t skip_rows, int col, int64_t* n_unique) {
+    if ((!text && len) || !n_unique || col < -64 || col > 63) return NPLDA_EINVAL;
+    std::vector<Tok> slot(1 << 12, Tok{nullptr, 0});
+    uint64_t mask = slot.size() - 1;
+    int64_t count = 0;
+    int rc = NPLDA_OK;
+    auto insert = [&](std::vector<Tok>& tab, uint64_t m, Tok t) -> bool {  // true if new
+        uint64_t h = hash_bytes(t.p, t.n) & m;
+        while (true) {
+            Tok& s = tab[h];
+            if (!s.p) { s = t; return true; }
+            if (s.n == t.n && memcmp(s.p, t.p, t.n) == 0) return false;
+            h = (h + 1) & m;
+        }
+    };
+    for_rows(text, len, skip_rows, [&](int64_t, const Tok* tk, int nt) {
+        const int c = col < 0 ? nt + col : col;
+        if (c < 0 || c >= nt) { rc = NPLDA_EINVAL; return false; }
+        if (insert(slot, mask, tk[c])) {
+            if ((uint64_t)(++count) * 2 > mask) {  // grow
+                std::vector<Tok> bigger(slot.size() * 2, Tok{nullptr, 0});
+                const uint64_t bm = bigger.size() - 1;
+                for (const Tok& t : slot)
+                    if (t.p) insert(bigger, bm, t);
+                slot.swap(bigger);
+                mask = bm;
+            }
+        }
+        return true;
+    });
+    *n_unique = count;
+    return rc;
+}
+
+int nplda_text_column_spans(const char* text, size_t len, int64_t skip_rows, int col, int64_t stride, int64_t* start,
+                            int64_t* length, int64_t n) {
+    if ((!text && len) || !start || !length || n < 0 || stride < 1 || col < -64 || col > 63) return NPLDA_EINVAL;
+    int rc = NPLDA_OK;
+    int64_t got = 0;
+    for_rows(text, len, skip_rows, [&](int64_t r, const Tok* tk, int nt) {
+        if (r % stride) return true;
+        const int64_t k = r / stride;
+        if (k >= n) return false;
+        const int c = col < 0 ? nt + col : col;
+        if (c < 0 || c >= nt) { rc = NPLDA_EINVAL; return false; }
+        start[k] = tk[c].p - text;
+        length[k] = (int64_t)tk[c].n;
+        got = k + 1;
+        return true;
+    });
+    if (rc == NPLDA_OK && got != n) rc = NPLDA_EINVAL;
+    return rc;
+}
+
 int64_t nplda_text_scan(const char* text, size_t len, int* ncols) {
     if ((!text && len) || !ncols) return NPLDA_EINVAL;
     const char* p = text;
@@ -219,13 +348,14 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
                       const char* ids, const int64_t* id_off, const int64_t* id_num, int64_t n_ids, int64_t* i1,
                       int64_t* i2, float* label, int64_t* row_of, int64_t* n_kept, int64_t* first_bad_row) {
     if ((!text && len) || !ids || !id_off || n_ids < 0 || !i1 || !i2 || !n_kept) return NPLDA_EINVAL;
-    if (mode1 < 0 || mode1 > 2 || mode2 < 0 || mode2 > 2 || label_col > 62) return NPLDA_EINVAL;
+    if (mode1 < 0 || mode1 > 3 || mode2 < 0 || mode2 > 3 || label_col > 62) return NPLDA_EINVAL;
     if (label_col >= 0 && !label) return NPLDA_EINVAL;
     const IdTable tab(ids, id_off, n_ids);
     const char* p = text;
     const char* end = text + len;
     int64_t row = 0, kept = 0, bad = -1;
     Tok tk[64];
+    std::string scratch;
     const int need = label_col >= 0 ? (label_col + 1 > 2 ? label_col + 1 : 2) : 2;
     while (p < end) {
         const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
@@ -239,8 +369,8 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
         int64_t a = -1, b = -1;
         float lab = 0.f;
         if (ok) {
-            a = tab.find(normalise(tk[0], mode1));
-            b = tab.find(normalise(tk[1], mode2));
+            a = tab.find(normalise(tk[0], mode1, &scratch));
+            b = tab.find(normalise(tk[1], mode2, &scratch));
             ok = a >= 0 && b >= 0;
             if (ok && label_col >= 0) ok = parse_label(tk[label_col], &lab);
         }
@@ -260,7 +390,7 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
 }
 
 int nplda_scores_write(const char* path, const char* text, size_t len, int64_t skip_rows, int keep_cols,
-                       const char* header, const float* scores, int64_t n) {
+                       const char* header, const void* scores, int scores_f64, int64_t n) {
     if (!path || (!text && len) || (!scores && n) || n < 0 || keep_cols < 1 || keep_cols > 64) return NPLDA_EINVAL;
     FILE* f = fopen(path, "wb");
     if (!f) return NPLDA_EINVAL;
@@ -293,7 +423,9 @@ int nplda_scores_write(const char* path, const char* text, size_t len, int64_t s
             buf.insert(buf.end(), tk[c].p, tk[c].p + tk[c].n);
             buf.push_back('\t');
         }
-        const int k = nplda_format_f32(scores[out++], num);
+        const int k = scores_f64 ? format_np<double>(((const double*)scores)[out], num)
+                                 : format_np<float>(((const float*)scores)[out], num);
+        ++out;
         buf.insert(buf.end(), num, num + k);
         buf.push_back('\n');
         if (buf.size() > (1u << 22) - 4096 && !flush()) { rc = NPLDA_EINVAL; break; }

@@ -10,9 +10,10 @@ import numpy as np
 
 from . import _lib
 
-__all__ = ["IdBlob", "scan", "lookup", "write_scores", "format_f32", "row_tokens"]
+__all__ = ["IdBlob", "scan", "lookup", "write_scores", "format_f32", "format_f64", "row_tokens", "column_f64",
+           "count_unique", "column_tokens"]
 
-RAW, SPLITEXT, BASENAME_SPLITEXT = 0, 1, 2
+RAW, SPLITEXT, BASENAME_SPLITEXT, STRIP_SPH = 0, 1, 2, 3
 
 
 class IdBlob:
@@ -78,11 +79,14 @@ def lookup(text, idblob, skip_rows=0, mode1=RAW, mode2=RAW, label_col=-1, rows=N
 
 
 def write_scores(path, text, scores, skip_rows=0, keep_cols=2, header=None):
+    """float32 scores are written as str(np.float32), float64 scores as str(np.float64)."""
     text = _text(text)
-    scores = np.ascontiguousarray(scores, dtype=np.float32)
+    scores = np.asarray(scores)
+    f64 = scores.dtype == np.float64
+    scores = np.ascontiguousarray(scores, dtype=np.float64 if f64 else np.float32)
     code = _lib.load().nplda_scores_write(str(path).encode(), text, len(text), skip_rows, keep_cols,
                                           None if header is None else header.encode("utf-8"),
-                                          scores.ctypes.data, len(scores))
+                                          scores.ctypes.data, int(f64), len(scores))
     _lib.check(code, "nplda_scores_write")
 
 
@@ -90,6 +94,41 @@ def format_f32(v):
     buf = ctypes.create_string_buffer(32)
     n = _lib.load().nplda_format_f32(float(np.float32(v)), buf)
     return buf.raw[:n].decode()
+
+
+def format_f64(v):
+    buf = ctypes.create_string_buffer(32)
+    n = _lib.load().nplda_format_f64(float(v), buf)
+    return buf.raw[:n].decode()
+
+
+def column_f64(text, col, n, skip_rows=0):
+    """Column `col` (negative: from the end) of the n data rows after skip_rows as float64; ValueError if a token is
+    not a number (as ndarray.astype(float) raises)."""
+    text = _text(text)
+    out = np.empty(n, dtype=np.float64)
+    code = _lib.load().nplda_text_column_f64(text, len(text), skip_rows, col, out.ctypes.data, n)
+    if code != 0:
+        raise ValueError("could not convert a score column to float (or the table changed size)")
+    return out
+
+
+def count_unique(text, col, skip_rows=0):
+    text = _text(text)
+    k = ctypes.c_int64(0)
+    _lib.check(_lib.load().nplda_text_count_unique(text, len(text), skip_rows, col, ctypes.byref(k)),
+               "nplda_text_count_unique")
+    return int(k.value)
+
+
+def column_tokens(text, col, n, skip_rows=0, stride=1):
+    """Tokens of column `col` in rows skip_rows + k * stride, k < n, as a list of str."""
+    text = _text(text)
+    st = np.empty(n, dtype=np.int64)
+    ln = np.empty(n, dtype=np.int64)
+    _lib.check(_lib.load().nplda_text_column_spans(text, len(text), skip_rows, col, stride, st.ctypes.data,
+                                                   ln.ctypes.data, n), "nplda_text_column_spans")
+    return [text[a:a + b].decode("utf-8") for a, b in zip(st.tolist(), ln.tolist())]
 
 
 def row_tokens(text, row):

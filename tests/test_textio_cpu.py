@@ -160,3 +160,50 @@ def test_loaders_drop_and_count(tmp_path):
     x1, x2, l, dropped = svl._read_trials(str(p), id_to_num, strip_ext_col2=False)
     assert np.array_equal(x1.numpy(), r1) and np.array_equal(x2.numpy(), r2) and np.array_equal(l.numpy(), rl)
     assert dropped == len(rows) - len(r1) == 1
+
+
+def test_f64_columns_unique_spans_and_sph_mode(tmp_path):
+    rng = np.random.default_rng(9)
+    R, M = 7, 13
+    rid = [f"enr{r}" if r % 2 else f"tst{r}.sph" for r in range(R)]
+    vals = rng.standard_normal(R * M) * np.repeat(10.0 ** rng.integers(-8, 8, R), M)
+    lines = ["modelid\tsegment\tside\tLLR"] + [f"{rid[k // M]}\tcoh{k % M:03d}\ta\t{float(vals[k])!r}" for k in range(R * M)]
+    p = tmp_path / "coh.tsv"
+    p.write_text("\n".join(lines) + "\n")
+    ref = np.genfromtxt(p, dtype="str", skip_header=1)
+    text = "\n".join(lines[1:]) + "\n"
+    assert textio.scan(text) == ref.shape
+    got = textio.column_f64(text, -1, R * M)
+    assert np.array_equal(got, ref[:, -1].astype(float)) and np.array_equal(got, vals)
+    assert np.array_equal(textio.column_f64(text, 3, R * M), got)
+    assert textio.count_unique(text, 1) == len(np.unique(ref[:, 1])) == M
+    assert textio.count_unique(text, 0) == R
+    assert textio.column_tokens(text, 0, R, stride=M) == list(ref[:, 0].reshape(-1, M)[:, 0])
+    with pytest.raises(ValueError):
+        textio.column_f64(text, 1, R * M)  # not numbers
+    with pytest.raises(ValueError):
+        textio.column_f64(text, -1, R * M + 1)  # fewer rows than asked
+    # '.sph' removal anywhere in the id (str.replace), both columns
+    blob = textio.IdBlob([w.replace(".sph", "") for w in rid] + ["ab"])
+    trial_text = "\n".join(f"{rid[a]} {rid[b]} x" for a, b in [(0, 1), (2, 3), (6, 0)]) + "\na.sphb a.sph.sphb x\n"
+    i1, i2, _, _, bad = textio.lookup(trial_text, blob, 0, textio.STRIP_SPH, textio.STRIP_SPH)
+    assert bad == -1 and i1.tolist() == [0, 2, 6, R] and i2.tolist() == [1, 3, 0, R]
+
+
+def test_format_f64_and_f64_writer(tmp_path):
+    rng = np.random.default_rng(2)
+    vals = np.concatenate([rng.standard_normal(5000) * s for s in (1, 1e-4, 1e-6, 1e5, 1e15, 1e20, 1e-300, 1e300)]
+                          + [rng.integers(0, 2 ** 63, 20000, dtype=np.uint64).view(np.float64),
+                             np.asarray([0.0, -0.0, 1e-4, 9.9999e-5, 1e16, 9.99e15, 1.0, 1e5, 5e-324, 1.7976931348623157e308,
+                                         np.inf, -np.inf, np.nan, 0.1, 1 / 3])])
+    ref = vals.astype(str)
+    for v, r in zip(vals.tolist(), ref.tolist()):
+        assert textio.format_f64(v) == r
+    rows = np.asarray([[f"e{k}", f"t{k}.sph", "a", "0.5"] for k in range(300)])
+    text = "modelid\tsegmentid\tside\tLLR\n" + "\n".join("\t".join(r) for r in rows) + "\n"
+    sc = vals[:300].copy()
+    ref_p, out_p = tmp_path / "ref.tsv", tmp_path / "out.tsv"
+    np.savetxt(ref_p, np.c_[rows[:, :-1], sc.astype(str)], header="\t".join(["modelid", "segmentid", "side", "LLR"]),
+               fmt="%s", delimiter="\t")
+    textio.write_scores(out_p, text, sc, skip_rows=1, keep_cols=3, header="# " + "\t".join(["modelid", "segmentid", "side", "LLR"]))
+    assert out_p.read_bytes() == ref_p.read_bytes()
