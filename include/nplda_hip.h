@@ -216,6 +216,23 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
                                double* cnt, double* sum, double* sq, int accumulate, void* workspace,
                                size_t workspace_bytes, nplda_stream_t stream);
 
+/* ---- detection-cost sweep (validation metrics) -------------------------------------------------------------------- */
+
+/* NeuralPlda.minc (utils/models.py:406-436) for N scores / labels and K <= 8 betas (HOST array), replacing its
+ * O(N_tgt * N) Python loop by a device sort + prefix scan + one sweep kernel.
+ *   exact = 0: the reference's semantics bit for bit — thresholds swept over the target scores only, counts through
+ *              arr2val (:23-27: count - 1, or 1.0 when the set is empty), float32 arithmetic in the reference's order;
+ *              minc[k] = min_i P_miss_i + beta_k P_fa_i, thr[k] = the target score attaining it (first occurrence),
+ *              minc_avg = sum(minc) / K.
+ *   exact = 1: the true minimum of P_miss(th) + beta P_fa(th) over every distinct score and +inf ("target" iff
+ *              s >= th), in fp64; eer (optional) = the equal error rate by linear interpolation at the crossing.
+ * Labels: target iff t > 0.5, non-target iff t < 0.5 (as :407-408).  minc, thr (K), minc_avg (1), eer (1 or NULL)
+ * are DEVICE floats.  N < 2^31. */
+size_t nplda_detcost_workspace_bytes(int64_t N);
+int nplda_detcost_sweep_f32(const float* scores, const float* target, int64_t N, const float* betas, int K, int exact,
+                            float* minc, float* thr, float* minc_avg, float* eer, void* workspace,
+                            size_t workspace_bytes, nplda_stream_t stream);
+
 /* ---- host-side text I/O of the trial-list path (no device work; plain host pointers) ------------------------------ */
 
 /* Rows and columns of a whitespace-separated table held in memory, with np.genfromtxt(dtype=str) semantics (the

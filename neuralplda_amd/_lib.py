@@ -56,6 +56,9 @@ SIGNATURES = {
     "nplda_moments_workspace_bytes": (_c_sz, [_c_i64, _c_int]),
     "nplda_weighted_moments_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p, _c_vp, _c_vp, _c_vp,
                                             _c_int, _c_vp, _c_sz, _c_vp]),
+    "nplda_detcost_workspace_bytes": (_c_sz, [_c_i64]),
+    "nplda_detcost_sweep_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, ctypes.POINTER(ctypes.c_float), _c_int, _c_int, _c_f32p,
+                                         _c_f32p, _c_f32p, _c_f32p, _c_vp, _c_sz, _c_vp]),
     "nplda_text_scan": (_c_i64, [ctypes.c_char_p, _c_sz, ctypes.POINTER(_c_int)]),
     "nplda_text_lookup": (_c_int, [ctypes.c_char_p, _c_sz, _c_i64, _c_int, _c_int, _c_int, ctypes.c_char_p, _c_vp, _c_vp,
                                    _c_i64, _c_vp, _c_vp, _c_vp, _c_vp, ctypes.POINTER(_c_i64), ctypes.POINTER(_c_i64)]),

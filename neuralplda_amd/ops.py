@@ -570,3 +570,31 @@ def dplda_fold_grad(cnt, sm, sq, D1):
     G11, G12, G21, G22 = G[:D1, :D1], G[:D1, D1:], G[D1:, :D1], G[D1:, D1:]
     dw = torch.cat([(G12 + G21).reshape(-1), (G11 + G22).reshape(-1), sm[0, :D1] + sm[0, D1:]])
     return dw.float().reshape(1, -1), cnt[:1].float()
+
+
+def detcost_sweep(scores, target, betas, exact=False, want_eer=False):
+    """nplda_detcost_sweep_f32 -> (minc (K,), thr (K,), minc_avg (1,), eer (1,) or None), float32 device tensors."""
+    lib = _lib.load()
+    _require_dev_f32(scores, "scores")
+    _require_dev_f32(target, "target")
+    s, t = scores.detach().reshape(-1).contiguous(), target.detach().reshape(-1).contiguous()
+    if s.numel() != t.numel():
+        raise ValueError("scores and targets must have the same length")
+    K = len(betas)
+    if K < 1:
+        raise ValueError("at least one beta")
+    N = s.numel()
+    nbytes = lib.nplda_detcost_workspace_bytes(N)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"{N} scores are outside the supported range")
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=s.device)
+    out = torch.empty(2 * K + 2, dtype=torch.float32, device=s.device)
+    import ctypes
+    barr = (ctypes.c_float * K)(*[float(b) for b in betas])
+    base = out.data_ptr()
+    with torch.cuda.device(s.device):
+        code = lib.nplda_detcost_sweep_f32(_lib.ptr(s), _lib.ptr(t), N, barr, K, 1 if exact else 0, base, base + 4 * K,
+                                           base + 8 * K, (base + 8 * K + 4) if want_eer else None, _lib.ptr(ws), nbytes,
+                                           _lib.current_stream())
+    _lib.check(code, "nplda_detcost_sweep_f32")
+    return out[:K], out[K:2 * K], out[2 * K:2 * K + 1], (out[2 * K + 1:] if want_eer else None)

@@ -143,6 +143,16 @@ def main():
         opt.step()
     ms_ds = timeit(dstep, reps=20)
     out["dplda_D170"] = {"score_pairs_per_s": Bg / ms_d * 1e3, "score_ms_512k": ms_d, "train_step_ms_B2048": ms_ds}
+    # validation metrics: minc (reference semantics) / exact min-DCF + EER over N scores
+    from neuralplda_amd import metrics
+    for N in (1 << 20, 10_000_000):
+        sc = torch.randn(N, device=dev, generator=gen)
+        tg = (torch.rand(N, device=dev, generator=gen) < 0.05).float()
+        sc = sc + 2 * tg
+        ms_r = timeit(lambda: ops.detcost_sweep(sc, tg, [99.0, 199.0]), reps=5, warm=2)
+        ms_e = timeit(lambda: ops.detcost_sweep(sc, tg, [99.0, 199.0], exact=True, want_eer=True), reps=5, warm=2)
+        out[f"detcost_N{N}"] = {"minc_reference_semantics_ms": ms_r, "exact_mindcf_eer_ms": ms_e,
+                                "scores_per_s": N / ms_r * 1e3}
     print(json.dumps(out, indent=1))
 
 
