@@ -130,15 +130,25 @@ struct FinalArgs {
     float* eer;       // [1] or NULL (exact mode only)
 };
 
-__global__ __launch_bounds__(64) void final_kernel(const FinalArgs a) {
-    const int k = threadIdx.x;
+// wave k reduces slot k of the block partials (slot kMaxBeta = the EER crossing); then one lane per slot finishes
+__global__ __launch_bounds__(64 * (kMaxBeta + 1)) void final_kernel(const FinalArgs a) {
+    const int lane = threadIdx.x & 63, slot = threadIdx.x >> 6;
     const long long n = a.n;
     const unsigned long long tot = n ? a.pref[n - 1] + a.lab[n - 1] : 0ull;
     const long long Nt = (long long)(tot >> 32), Nn = (long long)(tot & 0xffffffffull);
     __shared__ double mv[kMaxBeta];
-    if (k < a.K) {
-        Best b = Best{INFINITY, 0x7fffffffffffffffll};
-        for (int j = 0; j < a.nblocks; ++j) b = better(b, a.part[(size_t)j * (kMaxBeta + 1) + k]);
+    __shared__ Best cross;
+    Best b = Best{INFINITY, 0x7fffffffffffffffll};
+    for (int j = lane; j < a.nblocks; j += 64) b = better(b, a.part[(size_t)j * (kMaxBeta + 1) + slot]);
+    for (int off = 32; off > 0; off >>= 1) {
+        Best o;
+        o.v = __shfl_xor(b.v, off);
+        o.i = __shfl_xor(b.i, off);
+        b = better(b, o);
+    }
+    if (slot == kMaxBeta && lane == 0) cross = b;
+    const int k = slot;
+    if (lane == 0 && k < a.K) {
         float th;
         if (!a.exact) {
             // the winner is a rank in the sorted TARGET list: recover its score = the (rank+1)-th target in order
@@ -167,7 +177,7 @@ __global__ __launch_bounds__(64) void final_kernel(const FinalArgs a) {
         a.thr[k] = th;
     }
     __syncthreads();
-    if (k == 0) {
+    if (threadIdx.x == 0) {
         if (!a.exact) {  // sum(mincs) / len(mincs) on float32 tensors
             float s = (float)mv[0];
             for (int j = 1; j < a.K; ++j) s = __fadd_rn(s, (float)mv[j]);
@@ -180,8 +190,7 @@ __global__ __launch_bounds__(64) void final_kernel(const FinalArgs a) {
         if (a.eer) {
             float e = NAN;
             if (a.exact && n > 0 && Nt > 0 && Nn > 0) {
-                Best c = Best{INFINITY, 0x7fffffffffffffffll};
-                for (int j = 0; j < a.nblocks; ++j) c = better(c, a.part[(size_t)j * (kMaxBeta + 1) + kMaxBeta]);
+                Best c = cross;
                 auto rates = [&](long long p, double& pm, double& pf) {
                     const unsigned long long pr = a.pref[p];
                     pm = (double)(long long)(pr >> 32) / (double)Nt;
@@ -284,7 +293,7 @@ int nplda_detcost_sweep_f32(const float* scores, const float* target, int64_t N,
     FinalArgs f;
     f.key = keys; f.lab = lab; f.pref = pref; f.n = N; f.K = K; f.exact = exact ? 1 : 0; f.nblocks = nblocks;
     f.part = part; f.minc = minc; f.thr = thr; f.minc_avg = minc_avg; f.eer = eer;
-    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(64), 0, st, f);
+    hipLaunchKernelGGL(final_kernel, dim3(1), dim3(64 * (kMaxBeta + 1)), 0, st, f);
     return nplda_launch_status();
 }
 

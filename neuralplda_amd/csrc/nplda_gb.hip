@@ -71,40 +71,48 @@ __global__ void gb_pack_kernel(const float* __restrict__ W1, const float* __rest
 }
 
 // v = -(L_n + L_n^T) mu_n + (L_t + L_t^T) mu_t,  c = mu_n^T L_n mu_n - mu_t^T L_t mu_t   (fp64)
-__global__ __launch_bounds__(512) void gb_vc_kernel(const float* __restrict__ mut, const float* __restrict__ Lt,
-                                                    const float* __restrict__ mun, const float* __restrict__ Ln,
-                                                    GbLayout L, float* __restrict__ out) {
-    __shared__ double red[8];
+// One 64-lane block per (padded) entry of v; the per-row parts of c go to a scratch of doubles in the image's slack.
+__global__ __launch_bounds__(64) void gb_v_kernel(const float* __restrict__ mut, const float* __restrict__ Lt,
+                                                  const float* __restrict__ mun, const float* __restrict__ Ln,
+                                                  GbLayout L, float* __restrict__ out) {
     const int D1 = L.D1, n2 = 2 * D1;
-    double cpart = 0.0;
-    for (int i = threadIdx.x; i < 2 * L.NB * 16; i += 512) {
-        const int h = i / (L.NB * 16), f = i % (L.NB * 16);
-        float v = 0.f;
-        if (f < D1) {
-            const int r = h * D1 + f;
-            double acc = 0.0, wn = 0.0, wt = 0.0;
-            for (int c = 0; c < n2; ++c) {
-                const double ln = Ln[(size_t)r * n2 + c], lnT = Ln[(size_t)c * n2 + r];
-                const double lt = Lt[(size_t)r * n2 + c], ltT = Lt[(size_t)c * n2 + r];
-                acc += -(ln + lnT) * (double)mun[c] + (lt + ltT) * (double)mut[c];
-                wn += ln * (double)mun[c];
-                wt += lt * (double)mut[c];
-            }
-            v = (float)acc;
-            cpart += (double)mun[r] * wn - (double)mut[r] * wt;
+    const int i = blockIdx.x;
+    const int h = i / (L.NB * 16), f = i % (L.NB * 16);
+    double* cpart = reinterpret_cast<double*>(out + L.oc + 4);
+    double acc = 0.0, wn = 0.0, wt = 0.0;
+    const int r = h * D1 + f;
+    if (f < D1) {
+        for (int c = threadIdx.x; c < n2; c += 64) {
+            const double ln = Ln[(size_t)r * n2 + c], lnT = Ln[(size_t)c * n2 + r];
+            const double lt = Lt[(size_t)r * n2 + c], ltT = Lt[(size_t)c * n2 + r];
+            acc += -(ln + lnT) * (double)mun[c] + (lt + ltT) * (double)mut[c];
+            wn += ln * (double)mun[c];
+            wt += lt * (double)mut[c];
         }
-        out[L.ov + i] = v;
     }
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) cpart += __shfl_xor(cpart, m, 64);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cpart;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        double c = 0.0;
-        for (int w = 0; w < 8; ++w) c += red[w];
-        out[L.oc] = (float)c;
-        out[L.oc + 1] = out[L.oc + 2] = out[L.oc + 3] = 0.f;
+    for (int m = 32; m >= 1; m >>= 1) {
+        acc += __shfl_xor(acc, m, 64);
+        wn += __shfl_xor(wn, m, 64);
+        wt += __shfl_xor(wt, m, 64);
     }
+    if (threadIdx.x == 0) {
+        out[L.ov + i] = f < D1 ? (float)acc : 0.f;
+        cpart[i] = f < D1 ? (double)mun[r] * wn - (double)mut[r] * wt : 0.0;
+    }
+}
+
+__global__ __launch_bounds__(64) void gb_c_kernel(GbLayout L, float* __restrict__ out) {
+    double* cpart = reinterpret_cast<double*>(out + L.oc + 4);
+    const int n = 2 * L.NB * 16;
+    double c = 0.0;
+    for (int i = threadIdx.x; i < n; i += 64) c += cpart[i];
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) c += __shfl_xor(c, m, 64);
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 64) cpart[i] = 0.0;  // leave the slack as zeros
+    if (threadIdx.x == 0) out[L.oc] = (float)c;
+    if (threadIdx.x < 3) out[L.oc + 1 + threadIdx.x] = 0.f;
 }
 
 // explicit quadratic form S = x^T M x + x^T v + c: v (2 D1) and c are given
@@ -180,7 +188,9 @@ int gb_pack_params_f32(const float* W1, const float* b1, const float* mu_t, cons
     hipLaunchKernelGGL(gb_pack_kernel, dim3((unsigned)((L.ov + 255) / 256)), dim3(256), 0, st, W1, b1, Lam_t, Lam_n, L,
                        (float*)packed, 0);
     if (int rc = nplda_launch_status()) return rc;
-    hipLaunchKernelGGL(gb_vc_kernel, dim3(1), dim3(512), 0, st, mu_t, Lam_t, mu_n, Lam_n, L, (float*)packed);
+    hipLaunchKernelGGL(gb_v_kernel, dim3(2 * L.NB * 16), dim3(64), 0, st, mu_t, Lam_t, mu_n, Lam_n, L, (float*)packed);
+    if (int rc = nplda_launch_status()) return rc;
+    hipLaunchKernelGGL(gb_c_kernel, dim3(1), dim3(64), 0, st, L, (float*)packed);
     return nplda_launch_status();
 }
 
