@@ -15,7 +15,7 @@
 //  * explicit fragment double buffering inside a chunk: the next fragment pair is read from LDS before
 //    the 16 MFMAs of the current pair are issued.
 #pragma once
-#include "nplda_fwd_kernel.h"
+#include "../../neuralplda_amd/csrc/nplda_fwd_kernel.h"
 
 namespace nplda {
 

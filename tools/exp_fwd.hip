@@ -5,8 +5,9 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
-#include "../neuralplda_amd/csrc/nplda_fwd_persist.h"
+#include "exp/nplda_fwd_persist.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
+#include "exp/nplda_fwd_v3.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_bf16x3.h"
 
 using namespace nplda;
@@ -81,6 +82,15 @@ void launch_2(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((nplda_fwd_v2_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), grid, block, 0, st, a);
 }
 
+template <int NB, int WAVES, bool NT, int KPB, int BPC>
+void launch_3(const FwdArgs& a, long long B, hipStream_t st) {
+    const long long per_block = 16 * WAVES;
+    const int ntiles = (int)((B + per_block - 1) / per_block);
+    int grid = 256 * BPC;
+    if (grid > ntiles) grid = ntiles;
+    hipLaunchKernelGGL((nplda_fwd_v3_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
+}
+
 template <int NB, int WAVES, bool NT, int KPB>
 void launch_p(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
@@ -127,12 +137,12 @@ int main(int argc, char** argv) {
     std::vector<float> sref(1 << 16);
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<10, 8, 2>},
-               {"b3 w8 kpb2 early", launch_b3<10, 8, 2, true>}, {"b3 w4 kpb1 early", launch_b3<10, 4, 1, true>},
-               {"b3 w8 kpb1 early", launch_b3<10, 8, 1, true>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v3 w8 kpb4 x1", launch_3<10, 8, false, 4, 1>},
+               {"v3 w4 kpb4 x2", launch_3<10, 4, false, 4, 2>}, {"v3 w4 kpb2 x2", launch_3<10, 4, false, 2, 2>},
+               {"v3 w8 kpb2 x1", launch_3<10, 8, false, 2, 1>} };
     } else {
-        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"b3 w8 kpb2", launch_b3<11, 8, 2>},
-               {"b3 w8 kpb1", launch_b3<11, 8, 1>} };
+        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v3 w8 kpb4 x1", launch_3<11, 8, false, 4, 1>},
+               {"v3 w4 kpb4 x2", launch_3<11, 4, false, 4, 2>}, {"v3 w4 kpb2 x2", launch_3<11, 4, false, 2, 2>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
