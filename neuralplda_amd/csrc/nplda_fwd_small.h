@@ -20,7 +20,7 @@ namespace nplda {
 
 template <int NB, int MODE>
 __global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a) {
-    static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN, "small kernel modes");
+    static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN || MODE == MODE_GB, "small kernel modes");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
     constexpr int PF = 4;                    // register-ring depth (k16-steps)
@@ -124,8 +124,9 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a
         }
     }
     __syncthreads();
-    const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
-    const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
+    float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
+    float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
+    if (MODE == MODE_GB && a.no_norm) invA = invB = 1.0f;
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int nb = wave + NW * i;
@@ -143,6 +144,78 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a
     if (MODE == MODE_TRAIN && wave == 0 && g == 0 && okA) {
         a.out_rn[rowA] = invA;
         a.out_rn[a.n + rowB] = invB;
+    }
+
+    if (MODE == MODE_GB) {
+        // ---- quadratic form on x = [y1; y2] (GaussianBackend.forward / DPlda.forward; image: nplda_gb.hip) --------
+        // t_ho = v_ho + sum_hi G[ho][hi] y_hi for this wave's feature blocks, S = y1.t_0 + y2.t_1 + c.  Every G
+        // fragment is used by exactly one MFMA quartet, so it goes L2 -> register ring like the layer-1 weights.
+        if (a.out_z != nullptr) {  // forward_getpaired: (n, 2 D1) rows [y1 | y2]
+            const int D1 = (int)a.ldz / 2;
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const int nb = wave + NW * i;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int f = 16 * nb + 4 * g + r;
+                    if (nb < NB && okA && f < D1) {
+                        a.out_z[rowA * a.ldz + f] = accA[i][r];
+                        a.out_z[rowA * a.ldz + D1 + f] = accB[i][r];
+                    }
+                }
+            }
+        }
+        if (a.out_s == nullptr) return;
+        const f32x4* Gp = W2p;   // a.oW2 -> G[2 ho + hi][kb][nb] fragments
+        const f32x4* vp = b2p;   // a.ob2 -> v, two padded halves
+        auto fetchg = [&](int slot, int q) {  // q = (2 ho + hi) * NB + kb
+            const int qc = q < 4 * NB ? q : 4 * NB - 1;
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const int nb = wave + NW * i;
+                wf[slot][i] = Gp[((size_t)qc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+            }
+        };
+#pragma unroll
+        for (int s = 0; s < PF; ++s) fetchg(s, s);
+        __syncthreads();  // ylds complete
+        float part = 0.f;
+#pragma unroll
+        for (int ho = 0; ho < 2; ++ho) {
+            f32x4 t[NBW];
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                const int nb = wave + NW * i;
+                t[i] = nb < NB ? vp[(ho * NB + nb) * 4 + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int hk = 0; hk < 2 * NB; ++hk) {
+                const int q = ho * 2 * NB + hk;
+                const int s = q % PF;
+                const f32x4 yv = ylds[hk / NB][hk % NB][lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int i = 0; i < NBW; ++i)
+                        t[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yv[r], t[i], 0, 0, 0);
+                }
+                fetchg(s, q + PF);
+            }
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                if (wave + NW * i < NB) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) part = fmaf(ho == 0 ? accA[i][r] : accB[i][r], t[i][r], part);
+                }
+            }
+        }
+        part = wave_xor_add(part, 16);
+        part = wave_xor_add(part, 32);
+        if (g == 0) red[wave][0][j] = part;
+        __syncthreads();
+        if (wave == 0 && g == 0 && okA)
+            a.out_s[t0A + j] = (((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]) + a.packed[a.oQ];
+        return;
     }
 
     // ---- layer 2 ------------------------------------------------------------------------------------------------

@@ -168,6 +168,24 @@ int launch_gb(FwdArgs a, const GbLayout& L, hipStream_t st) {
     return nplda_launch_status();
 }
 
+// batches of <= 16 384 pairs: the feature-split schedule (4 waves share a 16-pair tile), as for NeuralPlda
+int launch_gb_small(FwdArgs a, const GbLayout& L, hipStream_t st) {
+    const long long blocks = (a.n + 15) / 16;
+    dim3 grid((unsigned)blocks), block(256);
+#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE_GB>), grid, block, 0, st, a)
+    switch (L.NB) {
+        case 2: NPLDA_LAUNCH(2); break;
+        case 4: NPLDA_LAUNCH(4); break;
+        case 8: NPLDA_LAUNCH(8); break;
+        case 10: NPLDA_LAUNCH(10); break;
+        case 11: NPLDA_LAUNCH(11); break;
+        case 12: NPLDA_LAUNCH(12); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+#undef NPLDA_LAUNCH
+    return nplda_launch_status();
+}
+
 }  // namespace
 
 extern "C" {
@@ -251,7 +269,7 @@ static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ld
     a.oW2 = L.oG; a.ob1 = L.ob1; a.ob2 = L.ov; a.oQ = L.oc; a.oP = L.oc; a.total = L.total;
     a.out_s = s; a.out_z = paired; a.ldz = 2 * (long long)D1;
     a.no_norm = no_norm;
-    if (B <= 256 * 64) return launch_gb<4, false>(a, L, (hipStream_t)stream);
+    if (B <= 256 * 64) return launch_gb_small(a, L, (hipStream_t)stream);
     return launch_gb<8, true>(a, L, (hipStream_t)stream);
 }
 

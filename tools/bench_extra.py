@@ -115,7 +115,12 @@ def main():
     x1 = torch.randn(Bg, 512, device=dev, generator=gen)
     x2 = torch.randn(Bg, 512, device=dev, generator=gen)
     ms_g = timeit(lambda: ops._gb_call(x1, x2, gpk, True, False))
-    out["gaussian_backend_D170"] = {"pairs_per_s": Bg / ms_g * 1e3, "ms_512k": ms_g,
+    xs1, xs2 = x1[:2048].contiguous(), x2[:2048].contiguous()
+    ms_gs = timeit(lambda: ops._gb_call(xs1, xs2, gpk, True, True), reps=50)
+    xm1, xm2 = x1[:10240].contiguous(), x2[:10240].contiguous()
+    ms_gm = timeit(lambda: ops._gb_call(xm1, xm2, gpk, True, False), reps=50)
+    out["gaussian_backend_D170"] = {"pairs_per_s": Bg / ms_g * 1e3, "ms_512k": ms_g, "ms_2048_with_paired": ms_gs,
+                                    "ms_10240": ms_gm,
                                     "TFLOPs_padded": Bg * (2 * 2 * 512 * 176 + 2 * 4 * 176 * 176) / ms_g / 1e9}
     # weighted moments of paired rows (n = 340): GB statistics pass (two classes) and DPlda gradient (one weight vector)
     paired = ops._gb_call(x1, x2, gpk, False, True)[1]
