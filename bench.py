@@ -228,7 +228,7 @@ def main():
                        "layer2_PLDA_spkfactor_dim": D, "params": psrc, "parallelism": f"trial-list shard x{world}"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "nplda_fwd_v2_kernel<NB, PAIR, 8 waves, 4 k16-steps/barrier>", "kernel_ms": kern_ms,
+                         "kernel": "nplda_fwd_v3_kernel<NB, PAIR, 8 waves, 2 k16-steps/barrier> (persistent; v2 at D = 170)", "kernel_ms": kern_ms,
                          "flop_per_pair_algorithmic": flops,
                          "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
         }

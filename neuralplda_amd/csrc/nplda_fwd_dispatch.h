@@ -3,14 +3,17 @@
 #include "nplda_fwd_kernel.h"
 #include "nplda_fwd_small.h"
 #include "nplda_fwd_v2.h"
+#include "nplda_fwd_v3.h"
 
 namespace nplda {
 
 // Product configuration, chosen by interleaved A/B runs of tools/exp_fwd.hip on MI355X
-// (profiles/r01b_*, r01d_*):
-//  * large batches: the v2 schedule (nplda_fwd_v2.h) — 8 waves/block, 4 k16-steps of weights per barrier,
-//    x prefetched a whole chunk ahead, plain (cached) x loads: 0.77 of the fp32 MFMA peak at D = 150, 0.81 at
-//    D = 170 (v1 with 2 steps/barrier and non-temporal loads: 0.72 / 0.75).
+// (profiles/r01b_*, r01d_*, r01t_*):
+//  * large batches, pair scoring, NB <= 10: the persistent continuous-stream schedule (nplda_fwd_v3.h),
+//    8 waves/block, one block per CU, 2 k16-steps of weights per barrier: 0.81 of the fp32 MFMA peak at D = 150;
+//  * large batches otherwise (NB = 11, embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
+//    per barrier, x prefetched a whole chunk ahead, plain (cached) x loads: 0.80 at D = 150, 0.83 at D = 170
+//    (v3 spills at NB = 11; v1 with non-temporal loads was 0.72 / 0.75);
 //  * batches of <= 16 384 pairs: the feature-split small-batch schedule (nplda_fwd_small.h): 4 waves share one
 //    16-pair tile, so a 4096-pair training minibatch runs on all 1024 SIMDs (forward 105 us -> see DESIGN.md).
 template <int MODE, int WAVES, bool NT>
@@ -40,7 +43,9 @@ static inline int launch_fwd_v2(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     const long long blocks = (a.n + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return NPLDA_EINVAL;
     dim3 grid((unsigned)blocks), block(WAVES * 64);
-#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_v2_kernel<NBV, MODE, WAVES, false, 4>), grid, block, 0, st, a)
+    // 2 k16-steps per barrier (4 at NB = 2, where a 2-step chunk is smaller than one staging pass of the block)
+#define NPLDA_LAUNCH(NBV) \
+    hipLaunchKernelGGL((nplda_fwd_v2_kernel<NBV, MODE, WAVES, false, (NBV == 2 ? 4 : 2)>), grid, block, 0, st, a)
     switch (L.NB) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
@@ -48,6 +53,32 @@ static inline int launch_fwd_v2(FwdArgs a, const NpldaLayout& L, hipStream_t st)
         case 10: NPLDA_LAUNCH(10); break;
         case 11: NPLDA_LAUNCH(11); break;
         case 12: NPLDA_LAUNCH(12); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+#undef NPLDA_LAUNCH
+    return nplda_launch_status();
+}
+
+// persistent grid: one 8-wave block per CU walks the tiles blockIdx.x, + gridDim.x, ...
+template <int MODE>
+static inline int launch_fwd_v3(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    constexpr int WAVES = 8;
+    const long long per_block = (MODE == MODE_EMBED ? 32 : 16) * WAVES;
+    const long long ntiles = (a.n + per_block - 1) / per_block;
+    if (ntiles > 0x7fffffffLL) return NPLDA_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long blocks = ntiles < cus ? ntiles : cus;
+    dim3 grid((unsigned)blocks), block(WAVES * 64);
+#define NPLDA_LAUNCH(NBV) \
+    hipLaunchKernelGGL((nplda_fwd_v3_kernel<NBV, MODE, WAVES, false, (NBV == 2 ? 4 : 2)>), grid, block, 0, st, a, (int)ntiles)
+    switch (L.NB) {
+        case 2: NPLDA_LAUNCH(2); break;
+        case 4: NPLDA_LAUNCH(4); break;
+        case 8: NPLDA_LAUNCH(8); break;
+        case 10: NPLDA_LAUNCH(10); break;
         default: return NPLDA_EUNSUPPORTED;
     }
 #undef NPLDA_LAUNCH
@@ -80,6 +111,7 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);
     if (units <= 256 * 64) return launch_fwd_small<MODE>(a, L, st);  // 4 waves share a 16-pair tile
     if (L.NB == 12) return launch_fwd_v1<MODE, 8, true>(a, L, st);  // v2 spills a few registers at NB = 12
+    if (MODE == MODE_PAIR && L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);  // embed mode spills in v3
     return launch_fwd_v2<MODE>(a, L, st);
 }
 

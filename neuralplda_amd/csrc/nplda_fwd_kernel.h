@@ -64,15 +64,21 @@ __device__ __forceinline__ f32x4 load_x4(const float* p, bool ok) {
     return v;
 }
 
-// Branch-free form: always loads (from `psafe`, any valid 16-byte-aligned address, when !ok) and selects zero.
+// Branch-free form: always loads — from `psafe` (the start of the SAME row, always valid and 16-byte aligned) when !ok —
+// and returns what it loaded, WITHOUT zeroing the !ok case.  That is sound because every consumer multiplies these
+// values into weight fragments that are zero wherever ok is false for a real reason (k >= D0: the packed image pads W1's
+// k range with zeros), and the stand-in values come from the same input row, so a non-finite value can only reach the
+// score of the row it belongs to.  It matters: a `ok ? v : 0` select after the load is scheduled by hipcc at the end of
+// the chunk that ISSUED the load (the selected value is what the loop carries), behind an `s_waitcnt vmcnt(0)` — i.e.
+// every chunk ended by waiting out the full HBM latency of the x prefetch it had just issued (16 % of the kernel;
+// found in the ISA in front of s_barrier, profiles/r01s_*).
 template <bool NT>
 __device__ __forceinline__ f32x4 load_x4s(const float* p, const float* psafe, bool ok) {
     const f32x4* q = reinterpret_cast<const f32x4*>(ok ? p : psafe);
     f32x4 v;
     if (NT) v = __builtin_nontemporal_load(q);
     else v = *q;
-    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
-    return ok ? v : zero;
+    return v;
 }
 
 struct FwdArgs {

@@ -10,7 +10,7 @@
 // chunk are refilled with the first k16-steps of the next tile's rows (they sit in registers that layer 2 does
 // not need).  No register is added for the cross-tile prefetch; only the first tile of a block pays a prologue.
 #pragma once
-#include "../../neuralplda_amd/csrc/nplda_fwd_kernel.h"
+#include "nplda_fwd_kernel.h"
 
 namespace nplda {
 

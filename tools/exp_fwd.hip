@@ -7,7 +7,7 @@
 #include <cmath>
 #include "exp/nplda_fwd_persist.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
-#include "exp/nplda_fwd_v3.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_v3.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_bf16x3.h"
 
 using namespace nplda;
