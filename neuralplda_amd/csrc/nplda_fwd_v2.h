@@ -3,7 +3,8 @@
 // Ablations on MI355X (tools/exp_fwd.hip, profiles/r01d_ablation.txt) put the v1 kernel at 0.72 of the fp32
 // MFMA peak, the barrier + weight-staging work at 10 % and the x loads at 4 %; LDS fragment reads cost nothing.
 // v2 therefore keeps v1's structure but
-//  * streams KPB = 4 k16-steps of weights per barrier (half the barriers of v1's KPB = 2) through two 40-44 KB
+//  * streams KPB k16-steps of weights per barrier (product: 2; 4 was best before the post-load select was removed,
+//    see load_x4s) through two
 //    LDS buffers, staging each chunk through registers in TWO halves (load first half at chunk start, store it
 //    and load the second half mid-chunk, store that at the end) so the staging registers do not grow;
 //  * gives x its own 4-slot ring: slot s is reloaded with k16-step s of the NEXT chunk right after its last

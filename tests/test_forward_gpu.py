@@ -106,7 +106,7 @@ def test_strided_rows(hip_lib):
 
 @pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (512, 192, 192), (64, 40, 24), (72, 150, 150)])
 def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
-    """Batches above 16 384 pairs take the v2 schedule (4 k16-steps per barrier, chunk-ahead x prefetch):
+    """Batches above 16 384 pairs take the streaming schedules (v3 persistent for pair scoring at NB <= 10, else v2):
     pair, embed and train modes must agree with the oracle there too (ragged tail included)."""
     from neuralplda_amd import ops
     rng = np.random.default_rng(D1 + D0)
@@ -126,3 +126,28 @@ def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
     np.testing.assert_allclose(z.cpu().numpy()[:, :D2], zr, atol=2e-6, rtol=1e-5)
     assert torch.equal(saved[4][:, :D2].cpu(), z[:, :D2].cpu())          # train-mode z == embed-mode z, bit for bit
     np.testing.assert_allclose(q.cpu().numpy(), orc.self_term(zr, p, np.float64), atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("D0,D,B", [(72, 40, 300), (72, 150, 20000 + 37), (512, 150, 70000), (100, 24, 5000)])
+def test_non_finite_rows_stay_in_their_own_scores(hip_lib, D0, D, B):
+    """The kernels load a row's own leading elements as stand-ins where the k range is padded (their weights are zero)
+    instead of zero-filling: a NaN / Inf in one trial's x-vector may therefore only reach that trial's score."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D0 + B)
+    p = rand_params(rng, D0, D, D)
+    x1 = rng.standard_normal((B, D0)).astype(np.float32)
+    x2 = rng.standard_normal((B, D0)).astype(np.float32)
+    packed = ops.pack_params(*to_dev(p))
+    clean = ops.score_pairs(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed).cpu().numpy()
+    bad1, bad2 = [3, B // 2, B - 1], [7, B // 3]
+    x1[bad1, 0] = np.nan
+    x2[bad2, 1] = np.inf
+    s = ops.score_pairs(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), packed).cpu().numpy()
+    hit = np.zeros(B, bool)
+    hit[bad1] = True
+    hit[bad2] = True
+    assert not np.isfinite(s[hit]).any()
+    assert np.array_equal(s[~hit], clean[~hit])
+    z, _ = ops.embed(torch.from_numpy(x1).cuda(), packed)
+    zf = np.isfinite(z.cpu().numpy()[:, :D]).all(axis=1)
+    assert not zf[bad1].any() and zf[np.setdiff1d(np.arange(B), bad1)].all()

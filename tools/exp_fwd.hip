@@ -137,12 +137,12 @@ int main(int argc, char** argv) {
     std::vector<float> sref(1 << 16);
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"v2 w8 pl kpb4", launch_2<10, 8, false, 4>}, {"v3 w8 kpb4 x1", launch_3<10, 8, false, 4, 1>},
-               {"v3 w4 kpb4 x2", launch_3<10, 4, false, 4, 2>}, {"v3 w4 kpb2 x2", launch_3<10, 4, false, 2, 2>},
+        vs = { {"v1 w4 kpb2", launch_a<10, 4, false, 2, 0>}, {"v1 w4 kpb2 -wstream", launch_a<10, 4, false, 2, 1>},
+               {"v1 w4 kpb2 -ldsread", launch_a<10, 4, false, 2, 2>}, {"v1 w4 kpb2 -xload", launch_a<10, 4, false, 2, 4>},
+               {"v1 w4 kpb2 -all", launch_a<10, 4, false, 2, 7>}, {"v1 w4 kpb2 -w-x", launch_a<10, 4, false, 2, 5>},
                {"v3 w8 kpb2 x1", launch_3<10, 8, false, 2, 1>} };
     } else {
-        vs = { {"v2 w8 pl kpb4", launch_2<11, 8, false, 4>}, {"v3 w8 kpb4 x1", launch_3<11, 8, false, 4, 1>},
-               {"v3 w4 kpb4 x2", launch_3<11, 4, false, 4, 2>}, {"v3 w4 kpb2 x2", launch_3<11, 4, false, 2, 2>} };
+        vs = { {"v2 w8 kpb2", launch_2<11, 8, false, 2>}, {"v1 w8 kpb2", launch_v<11, 8, false, 2>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
