@@ -10,9 +10,10 @@ namespace nplda {
 // Product configuration, chosen by interleaved A/B runs of tools/exp_fwd.hip on MI355X
 // (profiles/r01b_*, r01d_*, r01t_*):
 //  * large batches, pair scoring, NB <= 10: the persistent continuous-stream schedule (nplda_fwd_v3.h),
-//    8 waves/block, one block per CU, 2 k16-steps of weights per barrier: 0.81 of the fp32 MFMA peak at D = 150;
+//    8 waves/block, one block per CU, 2 k16-steps of weights per barrier, LDS fragments read 4 feature blocks at a
+//    time: 0.82 of the fp32 MFMA peak at D = 150;
 //  * large batches otherwise (NB = 11, embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
-//    per barrier, x prefetched a whole chunk ahead, plain (cached) x loads: 0.80 at D = 150, 0.83 at D = 170
+//    per barrier, x prefetched a whole chunk ahead, plain (cached) x loads: 0.81 at D = 150, 0.84 at D = 170
 //    (v3 spills at NB = 11; v1 with non-temporal loads was 0.72 / 0.75);
 //  * batches of <= 16 384 pairs: the feature-split small-batch schedule (nplda_fwd_small.h): 4 waves share one
 //    16-pair tile, so a 4096-pair training minibatch runs on all 1024 SIMDs (forward 105 us -> see DESIGN.md).
@@ -111,7 +112,9 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);
     if (units <= 256 * 64) return launch_fwd_small<MODE>(a, L, st);  // 4 waves share a 16-pair tile
     if (L.NB == 12) return launch_fwd_v1<MODE, 8, true>(a, L, st);  // v2 spills a few registers at NB = 12
-    if (MODE == MODE_PAIR && L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);  // embed mode spills in v3
+    if constexpr (MODE == MODE_PAIR) {  // embed / train modes spill in v3
+        if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
+    }
     return launch_fwd_v2<MODE>(a, L, st);
 }
 

@@ -14,7 +14,7 @@
 
 namespace nplda {
 
-template <int NB, int MODE, int WAVES, bool NT, int KPB>
+template <int NB, int MODE, int WAVES, bool NT, int KPB, int G = 4>
 __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdArgs a) {
     static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN, "v2 kernel modes");
     constexpr int THREADS = WAVES * 64;
@@ -116,13 +116,24 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
 #pragma unroll
         for (int s = 0; s < KPB; ++s) {
             if (KPB * c + s < KS1) {
+                // G feature blocks per LDS wait: their fragments are read together and the MFMAs run r-major across
+                // them, so the wave stalls on LDS latency once per 8 G MFMAs (hipcc issues each read right before
+                // its first use) and every accumulator chain has 2 G MFMAs between dependent instructions
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 av = w[s * STEP4 + nb * 64 + lane];
+                for (int nb0 = 0; nb0 < NB; nb0 += G) {
+                    f32x4 av[G];
+#pragma unroll
+                    for (int u = 0; u < G; ++u)
+                        if (nb0 + u < NB) av[u] = w[s * STEP4 + (nb0 + u) * 64 + lane];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        accA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xa[s][r], accA[nb], 0, 0, 0);
-                        accB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], xb[s][r], accB[nb], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < G; ++u) {
+                            if (nb0 + u < NB) {
+                                accA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xa[s][r], accA[nb0 + u], 0, 0, 0);
+                                accB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xb[s][r], accB[nb0 + u], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
@@ -194,12 +205,20 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
             const int kb = KPB * c2 + s;
             if (kb < NB) {
 #pragma unroll
-                for (int nb = 0; nb < NB; ++nb) {
-                    const f32x4 av = w[s * STEP4 + nb * 64 + lane];
+                for (int nb0 = 0; nb0 < NB; nb0 += G) {
+                    f32x4 av[G];
+#pragma unroll
+                    for (int u = 0; u < G; ++u)
+                        if (nb0 + u < NB) av[u] = w[s * STEP4 + (nb0 + u) * 64 + lane];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        zA[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], accA[kb < NB ? kb : 0][r], zA[nb], 0, 0, 0);
-                        zB[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], accB[kb < NB ? kb : 0][r], zB[nb], 0, 0, 0);
+#pragma unroll
+                        for (int u = 0; u < G; ++u) {
+                            if (nb0 + u < NB) {
+                                zA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], accA[kb < NB ? kb : 0][r], zA[nb0 + u], 0, 0, 0);
+                                zB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], accB[kb < NB ? kb : 0][r], zB[nb0 + u], 0, 0, 0);
+                            }
+                        }
                     }
                 }
             }
