@@ -151,3 +151,42 @@ def test_non_finite_rows_stay_in_their_own_scores(hip_lib, D0, D, B):
     z, _ = ops.embed(torch.from_numpy(x1).cuda(), packed)
     zf = np.isfinite(z.cpu().numpy()[:, :D]).all(axis=1)
     assert not zf[bad1].any() and zf[np.setdiff1d(np.arange(B), bad1)].all()
+
+
+def test_full_size_batch_properties(hip_lib):
+    """BASELINE cfg1 at full size (1 048 576 trial pairs, 512 -> 150 -> 150) through size-independent properties:
+    a sample against the oracle, independence of a pair's score from where it sits in the batch (halves, a permutation:
+    bit-exact), swap symmetry and agreement with the embed-once / score-by-index path (tolerance)."""
+    from neuralplda_amd import ops
+    B, D0, D = 1 << 20, 512, 150
+    rng = np.random.default_rng(2024)
+    p = rand_params(rng, D0, D, D)
+    packed = ops.pack_params(*to_dev(p))
+    gen = torch.Generator(device="cuda").manual_seed(7)
+    x1 = torch.randn(B, D0, device="cuda", generator=gen)
+    x2 = torch.randn(B, D0, device="cuda", generator=gen)
+    s = ops.score_pairs(x1, x2, packed)
+    assert s.shape == (B,) and bool(torch.isfinite(s).all())
+    # (1) sample vs the fp64 oracle
+    idx = torch.from_numpy(rng.choice(B, 4096, replace=False)).cuda()
+    ref = orc.forward(x1[idx].cpu().numpy(), x2[idx].cpu().numpy(), p, np.float64)
+    got = s[idx].cpu().numpy()
+    assert np.all(np.abs(got - ref) <= ATOL + RTOL * np.abs(ref)), np.abs(got - ref).max()
+    # (2) position independence, bit-exact: the two halves scored separately, and a permuted batch
+    h = B // 2
+    assert torch.equal(torch.cat([ops.score_pairs(x1[:h], x2[:h], packed), ops.score_pairs(x1[h:], x2[h:], packed)]), s)
+    perm = torch.randperm(B, device="cuda", generator=gen)
+    assert torch.equal(ops.score_pairs(x1[perm], x2[perm], packed), s[perm])
+    # (3) swap symmetry of the score (the fused z1^2 + z2^2 rounds differently under a swap: tolerance)
+    sw = ops.score_pairs(x2, x1, packed)
+    assert float((sw - s).abs().max()) <= ATOL + RTOL * float(s.abs().max())
+    # (4) the embed-once / score-by-index path gives the same scores
+    z1, q1 = ops.embed(x1[:65536], packed)
+    z2, q2 = ops.embed(x2[:65536], packed)
+    z, q = torch.cat([z1, z2]), torch.cat([q1, q2])
+    i1 = torch.arange(65536, device="cuda")
+    si = ops.score_indexed(z, q, i1, i1 + 65536, packed)
+    assert float((si - s[:65536]).abs().max()) <= ATOL + RTOL * float(s.abs().max())
+    # (5) checksum of checksums: 16 block sums add up to the total (fp64)
+    parts = s.double().reshape(16, -1).sum(1)
+    assert abs(float(parts.sum()) - float(s.double().sum())) <= 1e-6 * max(1.0, abs(float(s.double().sum())))
