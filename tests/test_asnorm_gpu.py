@@ -131,3 +131,44 @@ def test_asnorm_scores_pipeline(hip_lib):
     zr, zc = orc.extract_plda_embeddings(xr, p, np.float64), orc.extract_plda_embeddings(xc, p, np.float64)
     ref = orc.asnorm_apply(raw, ie, it, orc.cohort_stats(orc.cohort_scores(zr, zc, p, np.float64), 200))
     np.testing.assert_allclose(out.cpu().numpy(), ref, rtol=5e-4, atol=5e-4)
+
+
+def test_cfg3_full_size_properties(hip_lib):
+    """BASELINE cfg3 at full size on one GPU — 22 000 enroll/test rows x 10 000 cohort utterances, top-500, 2 M trials,
+    D = 170 — through size-independent properties: sampled rows and trials against the fp64 oracle, row-order
+    independence (bit-exact), and ordering invariants of the statistics."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(33)
+    D, R, M, T, topn = 170, 22000, 10000, 2_000_000, 500
+    p = rand_params(rng, 512, D, D)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    gen = torch.Generator(device="cuda").manual_seed(5)
+    xr = torch.randn(R, 512, device="cuda", generator=gen)
+    xc = torch.randn(M, 512, device="cuda", generator=gen)
+    zr, qr = ops.embed(xr, packed)
+    zc, qc = ops.embed(xc, packed)
+    stats = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn)
+    assert stats.shape == (R, 4) and stats.dtype == torch.float64 and bool(torch.isfinite(stats).all())
+    st = stats.cpu().numpy()
+    # the 500 smallest of 10 000 scores: mean below the row mean, spread below the row spread
+    assert (st[:, 2] < st[:, 0]).all() and (st[:, 3] < st[:, 1]).all() and (st[:, 1] > 0).all()
+    # sampled rows vs the oracle (fp64 scores of the expanded pair list, sort-then-slice)
+    rows = rng.choice(R, 48, replace=False)
+    z_r = orc.extract_plda_embeddings(xr[torch.from_numpy(rows).cuda()].cpu().numpy(), p, np.float64)
+    z_c = orc.extract_plda_embeddings(xc.cpu().numpy(), p, np.float64)
+    ref = orc.cohort_stats(orc.cohort_scores(z_r, z_c, p, np.float64), topn)
+    np.testing.assert_allclose(st[rows], ref, atol=2e-5, rtol=2e-5)
+    # a row's statistics do not depend on where the row sits
+    perm = torch.randperm(R, device="cuda", generator=gen)
+    assert torch.equal(ops.cohort_stats(zr[perm], qr[perm], zc, qc, packed, topn=topn), stats[perm])
+    # 2 M trials normalised on the device; a sample vs the oracle
+    ie = torch.randint(0, 2000, (T,), device="cuda", generator=gen)
+    it = torch.randint(2000, R, (T,), device="cuda", generator=gen)
+    raw = ops.score_indexed(zr, qr, ie, it, packed).double()
+    out = ops.asnorm_apply(raw, ie, it, stats)
+    assert out.shape == (T, 4) and bool(torch.isfinite(out).all())
+    k = torch.from_numpy(rng.choice(T, 5000, replace=False)).cuda()
+    refn = orc.asnorm_apply(raw[k].cpu().numpy(), ie[k].cpu().numpy(), it[k].cpu().numpy(), st)
+    np.testing.assert_allclose(out[k].cpu().numpy(), refn, rtol=1e-12, atol=1e-12)
+    # snorm is the mean of znorm and tnorm for every trial
+    assert float((out[:, 2] - (out[:, 0] + out[:, 1]) / 2).abs().max()) < 1e-12

@@ -355,3 +355,51 @@ def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
     for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
     assert step.step_count.item() == 5
+
+
+def test_cfg2_full_size_minibatch_from_a_voxceleb_scale_table(hip_lib):
+    """BASELINE cfg2 at full size: 4096-pair minibatches gathered from a 1.2 M-utterance resident table (2.4 GB),
+    512 -> 150 -> 150, SoftCdet, three fused optimiser steps.  Properties: the device gather equals plain indexing bit
+    for bit, the loss and gradient of the first step agree with the fp64 oracle, and the fused step follows
+    autograd + torch.optim.Adam."""
+    from neuralplda_amd import ops, train
+    rng = np.random.default_rng(77)
+    N, B, D = 1_200_000, 4096, 150
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    table = torch.randn(N, 512, device="cuda", generator=gen)
+    p = rand_params(rng, 512, D, D)
+    batches = []
+    for _ in range(3):
+        i1 = torch.randint(0, N, (B,), device="cuda", generator=gen)
+        i2 = torch.randint(0, N, (B,), device="cuda", generator=gen)
+        t = (torch.rand(B, device="cuda", generator=gen) < 0.1).float()
+        x1, x2 = ops.gather_rows(table, i1), ops.gather_rows(table, i2)
+        assert torch.equal(x1, table[i1]) and torch.equal(x2, table[i2])
+        batches.append((x1, x2, t))
+    m_ref = model_from(p, NC(D1=D, D2=D, loss="SoftCdet"), thetas=[-0.5, -0.3], theta_xent=0.1)
+    x1, x2, t = batches[0]
+    L = m_ref.loss(m_ref(x1, x2), t)
+    L.backward()
+    sref = orc.forward(x1.cpu().numpy(), x2.cpu().numpy(), p, np.float64)
+    Lref = orc.softcdet(sref, t.cpu().numpy(), [-0.5, -0.3], [99.0, 199.0], 15.0, np.float64)
+    gs, _ = orc.softcdet_grad(sref, t.cpu().numpy(), [-0.5, -0.3], [99.0, 199.0], 15.0)
+    gref = orc.backward(x1.cpu().numpy(), x2.cpu().numpy(), gs, p)
+    assert abs(L.item() - float(Lref)) <= 1e-4 * abs(float(Lref))
+    for name, prm in (("W1", m_ref.centering_and_LDA.weight), ("W2", m_ref.centering_and_wccn_plda.weight),
+                      ("Q", m_ref.Q), ("P_sqrt", m_ref.P_sqrt)):
+        np.testing.assert_allclose(prm.grad.cpu().numpy(), gref[name], atol=1e-4 * np.abs(gref[name]).max(), rtol=1e-3)
+    m_ref.zero_grad()
+    opt = train.make_optimizer(m_ref, 1e-4)
+    ref_losses = []
+    for x1, x2, t in batches:
+        opt.zero_grad()
+        L = m_ref.loss(m_ref(x1, x2), t)
+        L.backward()
+        opt.step()
+        ref_losses.append(L.item())
+    m = model_from(p, NC(D1=D, D2=D, loss="SoftCdet"), thetas=[-0.5, -0.3], theta_xent=0.1)
+    step = train.FusedTrainStep(m, 1e-4, weight_decay=1e-5, batch_size=B, graph=True)
+    losses = [step(x1, x2, t).item() for x1, x2, t in batches]
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
