@@ -241,9 +241,10 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_bf16x3_kernel(const B
     };
     // x of one k32-step: 8 consecutive floats per lane per side (two float4), D0 % 4 == 0
     auto loadx = [&](const float* p, const float* psafe, int kc, bool live, f32x4& lo, f32x4& hi) {
+        (void)p; (void)live;  // columns past D0 (or past the last chunk) read the row's last float4: see load_x4c
         const int k0 = 32 * kc + 8 * g;
-        lo = load_x4s<false>(p + 32 * kc, psafe, live && (k0 < D0));
-        hi = load_x4s<false>(p + 32 * kc + 4, psafe, live && (k0 + 4 < D0));
+        lo = load_x4c<false>(psafe, k0, D0);
+        hi = load_x4c<false>(psafe, k0 + 4, D0);
     };
 
     // ---- prologue --------------------------------------------------------------------------------------------

@@ -64,21 +64,23 @@ __device__ __forceinline__ f32x4 load_x4(const float* p, bool ok) {
     return v;
 }
 
-// Branch-free form: always loads — from `psafe` (the start of the SAME row, always valid and 16-byte aligned) when !ok —
-// and returns what it loaded, WITHOUT zeroing the !ok case.  That is sound because every consumer multiplies these
-// values into weight fragments that are zero wherever ok is false for a real reason (k >= D0: the packed image pads W1's
-// k range with zeros), and the stand-in values come from the same input row, so a non-finite value can only reach the
-// score of the row it belongs to.  It matters: a `ok ? v : 0` select after the load is scheduled by hipcc at the end of
-// the chunk that ISSUED the load (the selected value is what the loop carries), behind an `s_waitcnt vmcnt(0)` — i.e.
-// every chunk ended by waiting out the full HBM latency of the x prefetch it had just issued (16 % of the kernel;
-// found in the ISA in front of s_barrier, profiles/r01s_*).
+// Branch-free x load: the float4 at column min(koff, D0 - 4) of the row that starts at `row` (koff % 4 == 0,
+// D0 % 4 == 0), returned as loaded — no predicate, no select, no zero fill.
+//  * Columns >= D0 (the padded tail of the last k16-step, or a prefetch past the last chunk) read the row's LAST float4
+//    instead; that is sound because every consumer multiplies these values into weight fragments that are zero there
+//    (the packed image pads W1's k range with zeros), and the stand-in comes from the same input row, so a non-finite
+//    value can only reach the score of the row it belongs to.
+//  * Why not `ok ? v : 0`: hipcc schedules such a select at the end of the chunk that ISSUED the load (the selected
+//    value is what the loop carries), behind `s_waitcnt vmcnt(0)` — every chunk then ends by waiting out the full HBM
+//    latency of the x prefetch it has just issued (16 % of the kernel; found in the ISA in front of s_barrier,
+//    profiles/r01s_*).  Why not `ok ? p : psafe` either: hipcc may turn the address select into two predicated loads,
+//    i.e. branches with their own vmcnt(0).  A clamped offset is plain arithmetic.
 template <bool NT>
-__device__ __forceinline__ f32x4 load_x4s(const float* p, const float* psafe, bool ok) {
-    const f32x4* q = reinterpret_cast<const f32x4*>(ok ? p : psafe);
-    f32x4 v;
-    if (NT) v = __builtin_nontemporal_load(q);
-    else v = *q;
-    return v;
+__device__ __forceinline__ f32x4 load_x4c(const float* row, int koff, int D0) {
+    const int o = koff < D0 - 4 ? koff : D0 - 4;
+    const f32x4* q = reinterpret_cast<const f32x4*>(row + o);
+    if (NT) return __builtin_nontemporal_load(q);
+    return *q;
 }
 
 struct FwdArgs {
@@ -149,8 +151,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
         const int kk = 16 * s + 4 * g;
-        xa[s] = load_x4s<NT>(pa + 16 * s, sa, kk < D0);
-        xb[s] = load_x4s<NT>(pb + 16 * s, sb, kk < D0);
+        xa[s] = load_x4c<NT>(sa, kk, D0);
+        xb[s] = load_x4c<NT>(sb, kk, D0);
     }
 
     f32x4 accA[NB], accB[NB];
@@ -173,10 +175,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 #pragma unroll
         for (int s = 0; s < KPB; ++s) {
             const int ks = KPB * (c + 1) + s;
-            const bool ok = more && (16 * ks + 4 * g < D0);
             if (ABL & 4) { xan[s] = xa[s]; xbn[s] = xb[s]; continue; }
-            xan[s] = load_x4s<NT>(pa + 16 * ks, sa, ok);
-            xbn[s] = load_x4s<NT>(pb + 16 * ks, sb, ok);
+            xan[s] = load_x4c<NT>(sa, 16 * ks + 4 * g, D0);
+            xbn[s] = load_x4c<NT>(sb, 16 * ks + 4 * g, D0);
         }
         const f32x4* w = wbuf[cur];
 #pragma unroll

@@ -77,9 +77,8 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a
             const int nb = wave + NW * i;
             wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
         }
-        const bool ok = in && (16 * ks + 4 * g < D0);
-        xa[slot] = load_x4s<false>(pa + 16 * ks, sa, ok);
-        xb[slot] = load_x4s<false>(pb + 16 * ks, sb, ok);
+        xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
+        xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch1(s, s);

@@ -4,7 +4,7 @@
 // MFMA peak, the barrier + weight-staging work at 10 % and the x loads at 4 %; LDS fragment reads cost nothing.
 // v2 therefore keeps v1's structure but
 //  * streams KPB k16-steps of weights per barrier (product: 2; 4 was best before the post-load select was removed,
-//    see load_x4s) through two
+//    see load_x4c) through two
 //    LDS buffers, staging each chunk through registers in TWO halves (load first half at chunk start, store it
 //    and load the second half mid-chunk, store that at the end) so the staging registers do not grow;
 //  * gives x its own 4-slot ring: slot s is reloaded with k16-step s of the NEXT chunk right after its last
@@ -92,8 +92,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
     f32x4 xa[KPB], xb[KPB];
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
-        xa[s] = load_x4s<NT>(pa + 16 * s, sa, 16 * s + 4 * g < D0);
-        xb[s] = load_x4s<NT>(pb + 16 * s, sb, 16 * s + 4 * g < D0);
+        xa[s] = load_x4c<NT>(sa, 16 * s + 4 * g, D0);
+        xb[s] = load_x4c<NT>(sb, 16 * s + 4 * g, D0);
     }
     f32x4 accA[NB], accB[NB];
 #pragma unroll
@@ -139,9 +139,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
             }
             {   // slot s is free: fetch k16-step s of the next chunk (a whole chunk ahead of its use)
                 const int ks = KPB * (c + 1) + s;
-                const bool ok = more && (16 * ks + 4 * g < D0);
-                xa[s] = load_x4s<NT>(pa + 16 * ks, sa, ok);
-                xb[s] = load_x4s<NT>(pb + 16 * ks, sb, ok);
+                xa[s] = load_x4c<NT>(sa, 16 * ks + 4 * g, D0);
+                xb[s] = load_x4c<NT>(sb, 16 * ks + 4 * g, D0);
             }
             if (s == SMID - 1) {
                 store1(wbuf[cur ^ 1]);

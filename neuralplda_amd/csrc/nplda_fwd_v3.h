@@ -97,8 +97,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
     f32x4 xa[KPB], xb[KPB];
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
-        xa[s] = load_x4s<NT>(sa + 4 * g + 16 * s, sa, 16 * s + 4 * g < D0);
-        xb[s] = load_x4s<NT>(sb + 4 * g + 16 * s, sb, 16 * s + 4 * g < D0);
+        xa[s] = load_x4c<NT>(sa, 16 * s + 4 * g, D0);
+        xb[s] = load_x4c<NT>(sb, 16 * s + 4 * g, D0);
     }
     store1(wbuf[0]);
     load2(0);
@@ -160,9 +160,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
                 const int ks = more ? KPB * (c + 1) + s : s;
                 const float* ra = more ? sa : sa_n;
                 const float* rb = more ? sb : sb_n;
-                const bool ok = 16 * ks + 4 * g < D0;
-                xa[s] = load_x4s<NT>(ra + 4 * g + 16 * ks, ra, ok);
-                xb[s] = load_x4s<NT>(rb + 4 * g + 16 * ks, rb, ok);
+                xa[s] = load_x4c<NT>(ra, 16 * ks + 4 * g, D0);
+                xb[s] = load_x4c<NT>(rb, 16 * ks + 4 * g, D0);
             }
             if (s == SMID - 1) {
                 store1(wbuf[cur ^ 1]);
