@@ -58,10 +58,18 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
     const float* sb = a.xb + rowB * a.ldx;
 
     const f32x4* Wall = reinterpret_cast<const f32x4*>(a.packed);
-    const f32x4* b1p = reinterpret_cast<const f32x4*>(a.packed + a.ob1);
-    const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
-    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
-    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    // b1, b2, Q, P (NB * 16 floats each) are needed once per tile: a persistent block keeps them in LDS instead of
+    // paying an exposed L2 round trip at every tile start / epilogue
+    __shared__ f32x4 cvec[4][NB * 4];
+    for (int i = tid; i < 4 * NB * 4; i += THREADS) {
+        const int v = i / (NB * 4), e = i % (NB * 4);
+        const size_t o = v == 0 ? a.ob1 : (v == 1 ? a.ob2 : (v == 2 ? a.oQ : a.oP));
+        cvec[v][e] = reinterpret_cast<const f32x4*>(a.packed + o)[e];
+    }
+    const f32x4* b1p = cvec[0];
+    const f32x4* b2p = cvec[1];
+    const f32x4* Qp = cvec[2];
+    const f32x4* Pp = cvec[3];
     const int KS1 = a.KS1;
     const int D0 = a.D0;
     const int NC1 = (KS1 + KPB - 1) / KPB;

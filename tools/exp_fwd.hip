@@ -75,14 +75,14 @@ void launch_a(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((nplda_fwd_kernel<NB, MODE_PAIR, WAVES, NT, KPB, ABL>), grid, block, 0, st, a);
 }
 
-template <int NB, int WAVES, bool NT, int KPB, int G = 2>
+template <int NB, int WAVES, bool NT, int KPB, int G = 4>
 void launch_2(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
     dim3 grid((unsigned)((B + per_block - 1) / per_block)), block(WAVES * 64);
     hipLaunchKernelGGL((nplda_fwd_v2_kernel<NB, MODE_PAIR, WAVES, NT, KPB, G>), grid, block, 0, st, a);
 }
 
-template <int NB, int WAVES, bool NT, int KPB, int BPC, int G = 2>
+template <int NB, int WAVES, bool NT, int KPB, int BPC, int G = 4>
 void launch_3(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
     const int ntiles = (int)((B + per_block - 1) / per_block);
@@ -137,13 +137,11 @@ int main(int argc, char** argv) {
     std::vector<float> sref(1 << 16);
     std::vector<Variant> vs;
     if (L.NB == 10) {
-        vs = { {"v3 w8 kpb2 g2", launch_3<10, 8, false, 2, 1, 2>}, {"v3 w8 kpb2 g3", launch_3<10, 8, false, 2, 1, 3>},
-               {"v3 w8 kpb2 g4", launch_3<10, 8, false, 2, 1, 4>}, {"v2 w8 kpb2 g4", launch_2<10, 8, false, 2, 4>},
-               {"v2 w8 kpb2 g3", launch_2<10, 8, false, 2, 3>}, {"v2 w8 kpb4 g4", launch_2<10, 8, false, 4, 4>},
-               {"v3 w8 kpb4 g4", launch_3<10, 8, false, 4, 1, 4>} };
+        vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v2 w8 kpb2", launch_2<10, 8, false, 2>},
+               {"v2 w4 kpb2", launch_2<10, 4, false, 2>}, {"v1 w8 kpb2", launch_v<10, 8, false, 2>} };
     } else {
-        vs = { {"v2 w8 kpb2 g4", launch_2<11, 8, false, 2, 4>}, {"v2 w8 kpb2 g3", launch_2<11, 8, false, 2, 3>},
-               {"v2 w8 kpb4 g4", launch_2<11, 8, false, 4, 4>}, {"v2 w4 kpb2 g4", launch_2<11, 4, false, 2, 4>} };
+        vs = { {"v2 w8 kpb2", launch_2<11, 8, false, 2>}, {"v3 w8 kpb2", launch_3<11, 8, false, 2, 1>},
+               {"v2 w4 kpb2", launch_2<11, 4, false, 2>}, {"v1 w8 kpb2", launch_v<11, 8, false, 2>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
