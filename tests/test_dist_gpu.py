@@ -1,0 +1,77 @@
+"""The RCCL ("nccl") code path of neuralplda_amd.dist on real hardware with a one-rank group (the GPU box has one GPU;
+world_size 2 runs on gloo in tests/test_dist_cpu.py): process-group init with device_id, sharded scoring + all-gather,
+AS-norm row statistics gathered across the group, and a data-parallel training step (all-reduce of the loss sums and of the
+flat gradient) must reproduce the single-process results bit for bit."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+class NC:
+    xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+    beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
+
+
+@pytest.fixture()
+def one_rank_group():
+    import torch.distributed as td
+    from neuralplda_amd import dist as ndist
+    if td.is_initialized():
+        pytest.skip("a process group already exists")
+    os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
+                       "MASTER_PORT": "29533"})
+    ndist.init("nccl")
+    yield ndist
+    td.destroy_process_group()
+
+
+def test_rccl_single_rank_paths(hip_lib, one_rank_group):
+    ndist = one_rank_group
+    from neuralplda_amd import adaptive_score_normalization as asn, models, train
+    import torch.distributed as td
+    assert ndist.world() == (0, 1) and td.get_backend() == "nccl"
+    torch.manual_seed(0)
+    m = models.NeuralPlda(NC()).cuda()
+    gen = torch.Generator(device="cuda").manual_seed(1)
+    x1 = torch.randn(5000, 512, device="cuda", generator=gen)
+    x2 = torch.randn(5000, 512, device="cuda", generator=gen)
+    with torch.no_grad():
+        ref = m(x1, x2)
+        got = ndist.sharded_apply(lambda lo, hi: m(x1[lo:hi], x2[lo:hi]), 5000)
+    assert torch.equal(got, ref)
+    # collectives on device tensors through RCCL
+    t = torch.arange(10, dtype=torch.float64, device="cuda")
+    ndist.allreduce_sum_(t)
+    assert torch.equal(t, torch.arange(10, dtype=torch.float64, device="cuda"))
+    rows = torch.randn(7, 4, dtype=torch.float64, device="cuda", generator=gen)
+    assert torch.equal(ndist.all_gather_rows(rows, 7), rows)
+    # AS-norm with the group argument == without
+    xr = torch.randn(64, 512, device="cuda", generator=gen)
+    xc = torch.randn(900, 512, device="cuda", generator=gen)
+    ie, it = np.arange(200) % 20, 20 + np.arange(200) % 44
+    with torch.no_grad():
+        raw = m(xr[torch.from_numpy(ie).cuda()], xr[torch.from_numpy(it).cuda()]).double().cpu().numpy()
+    a = asn.asnorm_scores(m, xr, xc, raw, ie, it, topN=100)
+    b = asn.asnorm_scores(m, xr, xc, raw, ie, it, topN=100, group=td.group.WORLD)
+    assert torch.equal(a, b)
+    # data-parallel wrapper: loss and gradients equal the plain model's
+    tgt = (torch.rand(5000, device="cuda", generator=gen) < 0.2).float()
+    m2 = models.NeuralPlda(NC()).cuda()
+    m2.load_state_dict(m.state_dict())
+    ndist.make_data_parallel(m2)
+    L1 = m.loss(m(x1, x2), tgt)
+    L1.backward()
+    xs1, xs2, ts = ndist.shard_batch((x1, x2, tgt))
+    L2 = m2.loss(m2(xs1, xs2), ts)
+    L2.backward()
+    assert L1.item() == L2.item()
+    for (k, p1), (_, p2) in zip(m.named_parameters(), m2.named_parameters()):
+        assert (p1.grad is None) == (p2.grad is None), k
+        if p1.grad is not None:
+            assert torch.equal(p1.grad, p2.grad), k
+    step = train.FusedTrainStep(m2, 1e-4, batch_size=5000, graph=False)
+    assert np.isfinite(step(xs1, xs2, ts).item())
