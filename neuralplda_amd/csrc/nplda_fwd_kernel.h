@@ -249,7 +249,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
         // (M11 y1 + M12 y2, M21 y1 + M22 y2) fed straight from the layer-1 accumulators, then
         // S = y1.t1 + y2.t2 + c.  Packed image: a.oW2 -> G[h_out][h_in][kb][nb] fragments,
         // a.ob2 -> v (two padded halves), a.oQ -> c.
-        static_assert(MODE != MODE_GB || KPB == 1, "GB mode streams one k16-step per barrier");
+        static_assert(MODE != MODE_GB || (2 * NB) % KPB == 0, "a chunk of G steps must not straddle the two output halves");
         if (a.out_z != nullptr) {  // forward_getpaired: (n, 2 D1) rows [y1 | y2]
             const int D1 = (int)a.ldz / 2;
 #pragma unroll
@@ -273,32 +273,37 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) t[nb] = vp[(ho * NB + nb) * 4 + g];
 #pragma unroll
-            for (int hk = 0; hk < 2 * NB; ++hk) {
-                const int q = ho * 2 * NB + hk;
-                const int hi = hk / NB, kb = hk % NB;
-                const int cur = (NC1 + q) & 1;
-                if (q + 1 < 4 * NB) {
-                    const long long nbase = w2base4 + (long long)(q + 1) * CH;
+            for (int hc = 0; hc < 2 * NB / KPB; ++hc) {   // chunks of KPB G-steps (one step = one (h_in, kb) k-block)
+                const int qc = ho * (2 * NB / KPB) + hc;   // chunk index within the G stream
+                const int cur = (NC1 + qc) & 1;
+                const bool moreg = qc + 1 < 4 * NB / KPB;
+                if (moreg) {
+                    const long long nbase = w2base4 + (long long)(qc + 1) * CH;
                     chunk_load<CH, THREADS, NSLOT>(Wall + nbase, total4 - nbase, st, tid);
                 }
                 const f32x4* w = wbuf[cur];
-                // groups of 4 output blocks: 4 independent accumulator chains per fragment quartet
 #pragma unroll
-                for (int nb0 = 0; nb0 < NB; nb0 += 4) {
-                    f32x4 av[4];
+                for (int s = 0; s < KPB; ++s) {
+                    const int hk = hc * KPB + s;
+                    const int hi = hk / NB, kb = hk % NB;
+                    // groups of 4 output blocks: 4 independent accumulator chains per fragment quartet
 #pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (nb0 + u < NB) av[u] = w[(nb0 + u) * 64 + lane];
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float bv = hi == 0 ? accA[kb][r] : accB[kb][r];
+                    for (int nb0 = 0; nb0 < NB; nb0 += 4) {
+                        f32x4 av[4];
 #pragma unroll
                         for (int u = 0; u < 4; ++u)
-                            if (nb0 + u < NB)
-                                t[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], bv, t[nb0 + u], 0, 0, 0);
+                            if (nb0 + u < NB) av[u] = w[s * STEP4 + (nb0 + u) * 64 + lane];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            const float bv = hi == 0 ? accA[kb][r] : accB[kb][r];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u)
+                                if (nb0 + u < NB)
+                                    t[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], bv, t[nb0 + u], 0, 0, 0);
+                        }
                     }
                 }
-                if (q + 1 < 4 * NB) {
+                if (moreg) {
                     chunk_store<CH, THREADS, NSLOT>(wbuf[cur ^ 1], st, tid);
                     __syncthreads();
                 }

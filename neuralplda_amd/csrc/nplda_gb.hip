@@ -27,7 +27,7 @@ GbLayout gb_layout(int D0, int D1) {
     L.ob1 = L.oG + 4 * (size_t)L.NB * L.NB * 256;
     L.ov = L.ob1 + (size_t)L.NB * 16;
     L.oc = L.ov + 2 * (size_t)L.NB * 16;
-    L.total = L.oc + 4 + (size_t)L.NB * 256;  // + one k16-step of slack (unconditional chunk loads)
+    L.total = L.oc + 4 + (size_t)2 * L.NB * 256;  // + one 2-step chunk of slack (unconditional chunk loads)
     return L;
 }
 
@@ -154,7 +154,7 @@ int launch_gb(FwdArgs a, const GbLayout& L, hipStream_t st) {
     const long long blocks = (a.n + per_block - 1) / per_block;
     if (blocks > 0x7fffffffLL) return NPLDA_EINVAL;
     dim3 grid((unsigned)blocks), block(WAVES * 64);
-#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_kernel<NBV, MODE_GB, WAVES, NT, 1>), grid, block, 0, st, a)
+#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_kernel<NBV, MODE_GB, WAVES, NT, 2>), grid, block, 0, st, a)
     switch (L.NB) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
@@ -270,7 +270,7 @@ static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ld
     a.out_s = s; a.out_z = paired; a.ldz = 2 * (long long)D1;
     a.no_norm = no_norm;
     if (B <= 256 * 64) return launch_gb_small(a, L, (hipStream_t)stream);
-    return launch_gb<8, true>(a, L, (hipStream_t)stream);
+    return launch_gb<8, false>(a, L, (hipStream_t)stream);
 }
 
 }  // extern "C"
