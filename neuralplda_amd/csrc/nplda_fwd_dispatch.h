@@ -12,31 +12,11 @@ namespace nplda {
 //  * large batches, pair scoring, NB <= 10: the persistent continuous-stream schedule (nplda_fwd_v3.h),
 //    8 waves/block, one block per CU, 2 k16-steps of weights per barrier, LDS fragments read 4 feature blocks at a
 //    time: 0.82 of the fp32 MFMA peak at D = 150;
-//  * large batches otherwise (NB = 11, embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
+//  * large batches otherwise (NB >= 11, embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
 //    per barrier, x prefetched a whole chunk ahead, plain (cached) x loads: 0.81 at D = 150, 0.84 at D = 170
 //    (v3 spills at NB = 11; v1 with non-temporal loads was 0.72 / 0.75);
 //  * batches of <= 16 384 pairs: the feature-split small-batch schedule (nplda_fwd_small.h): 4 waves share one
 //    16-pair tile, so a 4096-pair training minibatch runs on all 1024 SIMDs (forward 105 us -> see DESIGN.md).
-template <int MODE, int WAVES, bool NT>
-static inline int launch_fwd_v1(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
-    const long long per_block = (MODE == MODE_EMBED ? 32 : 16) * WAVES;
-    const long long blocks = (a.n + per_block - 1) / per_block;
-    if (blocks > 0x7fffffffLL) return NPLDA_EINVAL;
-    dim3 grid((unsigned)blocks), block(WAVES * 64);
-#define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_kernel<NBV, MODE, WAVES, NT, 1>), grid, block, 0, st, a)
-    switch (L.NB) {
-        case 2: NPLDA_LAUNCH(2); break;
-        case 4: NPLDA_LAUNCH(4); break;
-        case 8: NPLDA_LAUNCH(8); break;
-        case 10: NPLDA_LAUNCH(10); break;
-        case 11: NPLDA_LAUNCH(11); break;
-        case 12: NPLDA_LAUNCH(12); break;
-        default: return NPLDA_EUNSUPPORTED;
-    }
-#undef NPLDA_LAUNCH
-    return nplda_launch_status();
-}
-
 template <int MODE>
 static inline int launch_fwd_v2(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     constexpr int WAVES = 8;
@@ -111,7 +91,6 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
     const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);
     if (units <= 256 * 64) return launch_fwd_small<MODE>(a, L, st);  // 4 waves share a 16-pair tile
-    if (L.NB == 12) return launch_fwd_v1<MODE, 8, true>(a, L, st);  // v2 spills a few registers at NB = 12
     if constexpr (MODE == MODE_PAIR) {  // embed / train modes spill in v3
         if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
     }

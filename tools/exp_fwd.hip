@@ -159,7 +159,8 @@ int main(int argc, char** argv) {
     } else if (L.NB == 8) {
         vs = { {"v3 w8 kpb2 nb8", launch_3<8, 8, false, 2, 1>}, {"v2 w8 kpb2 nb8", launch_2<8, 8, false, 2>} };
     } else {
-        vs = { {"v2 w8 kpb2", launch_2<12, 8, false, 2>} };
+        vs = { {"v1 w8 nt kpb1", launch_v<12, 8, true, 1>}, {"v1 w8 pl kpb2", launch_v<12, 8, false, 2>},
+               {"v2 w8 kpb2", launch_2<12, 8, false, 2>}, {"v1 w4 pl kpb2", launch_v<12, 4, false, 2>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
