@@ -42,7 +42,7 @@ __device__ __forceinline__ void tile_of(int t, int T, int& mt, int& nt) {
 }
 
 template <int NC>
-__global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
+__global__ __launch_bounds__(256, 2) void moments_kernel(const MomArgs a) {
     __shared__ f32x4 red[4][16 * 64];  // [wave][(ca*4+cb)*64 + lane]  (64 KB), reused per class
     __shared__ f32x4 rede[4][NC][16];
     __shared__ float redc[4][NC];
