@@ -101,7 +101,8 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
 // K8b
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowThreads = 512;
-constexpr int kMaxRowLds = 40000;  // floats of one row kept in LDS (160 000 B < 160 KiB)
+constexpr int kListCap = 512;       // candidate keys of the quantile shortcut
+constexpr int kMaxRowLds = 38000;  // floats of one row kept in LDS (with the shortcut's lists: < 160 KiB)
 
 __device__ __forceinline__ unsigned f2key(float f) {
     const unsigned u = __float_as_uint(f);
@@ -179,6 +180,94 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     if (N < 1) N = 1;
     const unsigned want = (unsigned)N;
 
+    // ---- shortcut for well-behaved rows: bracket the N-th smallest key with the normal quantile of (mean, std), count
+    // once, and if the bracket holds the rank and few enough keys, finish EXACTLY on that short list (rank by counting,
+    // values written to their rank slot so that the fp64 sums are order-independent): 3 passes over the row instead of
+    // ~16.  Anything else (heavy tails, ties, tiny rows) falls through to the general search below, started from the
+    // bracket when it is valid.
+    bool done = false;
+    double t1 = 0.0, t2 = 0.0;
+    if (use_lds && M >= 64 && var > 0.0) {
+        unsigned* list = cnt + 64 + 2 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
+        float* sel = reinterpret_cast<float*>(list + kListCap);
+        unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
+        const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
+        const double sd = sqrt(var);
+        const double t0 = mean + normcdfinv(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q)) * sd;
+        const float fa = (float)(t0 - 0.08 * sd), fb = (float)(t0 + 0.08 * sd);
+        unsigned ka = f2key(fa), kb = f2key(fb);
+        if (!lowest) { const unsigned t = ~ka; ka = ~kb; kb = t; }
+        unsigned ca = 0, cb2 = 0;
+        for (long long i = tid; i < M; i += kRowThreads) {
+            const unsigned k = keys[i];
+            ca += k < ka;
+            cb2 += k <= kb;
+        }
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) {
+            ca += __shfl_xor(ca, m, 64);
+            cb2 += __shfl_xor(cb2, m, 64);
+        }
+        if (lane == 0) { cnt[wave * 4] = ca; cnt[wave * 4 + 1] = cb2; }
+        if (tid == 0) *nlist = 0;
+        __syncthreads();
+        ca = cb2 = 0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) { ca += cnt[w * 4]; cb2 += cnt[w * 4 + 1]; }
+        __syncthreads();
+        if (ca < want && want <= cb2) {
+            lo = ka; hi = kb;  // a valid (much narrower) bracket for the general search, should the list be too long
+            if (cb2 - ca <= (unsigned)kListCap) {
+                // collect the bracket's keys; sum everything strictly below it
+                for (long long i = tid; i < M; i += kRowThreads) {
+                    const unsigned k = keys[i];
+                    if (k < ka) {
+                        const double v = (double)key2f(lowest ? k : ~k);
+                        t1 += v;
+                        t2 += v * v;
+                    } else if (k <= kb) {
+                        list[atomicAdd(nlist, 1u)] = k;
+                    }
+                }
+                __syncthreads();
+                const unsigned L = *nlist, need = want - ca;
+                for (unsigned i = tid; i < L; i += kRowThreads) {
+                    const unsigned k = list[i];
+                    unsigned rank = 0;
+                    for (unsigned jx = 0; jx < L; ++jx) {
+                        const unsigned kj = list[jx];
+                        rank += (kj < k) || (kj == k && jx < i);
+                    }
+                    sel[rank] = key2f(lowest ? k : ~k);
+                }
+                __syncthreads();
+                double u1 = 0.0, u2 = 0.0;
+                for (unsigned i = tid; i < need; i += kRowThreads) {  // rank slots: a fixed summation order
+                    const double v = (double)sel[i];
+                    u1 += v;
+                    u2 += v * v;
+                }
+                t1 = block_sum_d(t1 + u1, red);
+                t2 = block_sum_d(t2 + u2, red);
+                done = true;
+            }
+        }
+    }
+    if (done) {
+        if (tid == 0) {
+            const double nn = (double)N;
+            const double mt = t1 / nn;
+            double vt = t2 / nn - mt * mt;
+            if (vt < 0.0) vt = 0.0;
+            double* o = stats + row * 4;
+            o[0] = mean;
+            o[1] = sqrt(var);
+            o[2] = mt;
+            o[3] = sqrt(vt);
+        }
+        return;
+    }
+
     // N-th smallest key T by 4-ary search on the integer key space: every iteration counts, for three pivots,
     // the keys <= pivot (register counters + shuffle/LDS reduction — no atomics: cohort scores of one row share
     // their leading bits, which serialises an LDS-histogram radix select) and keeps the quarter that holds rank N.
@@ -215,7 +304,8 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     float tval = key2f(lowest ? tkey : ~tkey);
 
     // selected sums: everything strictly below tkey, plus (N - #less) copies of the threshold value (ties)
-    double t1 = 0.0, t2 = 0.0, nless = 0.0;
+    double nless = 0.0;
+    t1 = t2 = 0.0;
     for (long long i = tid; i < M; i += kRowThreads) {
         unsigned k;
         if (use_lds) k = keys[i];
@@ -312,7 +402,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -339,7 +429,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
