@@ -172,3 +172,35 @@ def test_cfg3_full_size_properties(hip_lib):
     np.testing.assert_allclose(out[k].cpu().numpy(), refn, rtol=1e-12, atol=1e-12)
     # snorm is the mean of znorm and tnorm for every trial
     assert float((out[:, 2] - (out[:, 0] + out[:, 1]) / 2).abs().max()) < 1e-12
+
+
+@pytest.mark.parametrize("select", ["lowest", "highest"])
+def test_row_stats_shapes_that_defeat_the_quantile_shortcut(hip_lib, select):
+    """The quantile-bracket shortcut of row_stats_kernel only fires when its bracket provably holds the rank; rows
+    built to defeat it (bimodal, heavy-tailed, coarse quantisation with thousands of ties, a spike exactly at the
+    selection boundary, mostly-constant rows) must take the general search and still equal sort-then-slice."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(17)
+    M, topn = 10000, 500
+    rows = [
+        np.concatenate([rng.normal(-50, 0.1, M // 2), rng.normal(80, 0.1, M - M // 2)]),          # bimodal
+        rng.standard_cauchy(M) * 3,                                                                # heavy tails
+        np.round(rng.standard_normal(M) * 2) / 2,                                                  # ~20 distinct values
+        np.where(rng.random(M) < 0.9, 1.5, rng.standard_normal(M)),                                # 90 % constant
+        np.concatenate([np.full(400, -3.0), np.full(300, -2.999), rng.standard_normal(M - 700)]),  # spike at the boundary
+        np.concatenate([rng.standard_normal(M - 700), np.full(400, 3.0), np.full(300, 2.999)]),    # ... for "highest"
+        rng.exponential(1.0, M),                                                                   # skewed
+        rng.standard_normal(M) * 1e-30,                                                            # tiny magnitudes
+        np.sort(rng.standard_normal(M)),                                                           # plain normal (shortcut)
+    ]
+    S = np.stack(rows).astype(np.float32)
+    S[:, ::997] += 0.0  # keep dtype
+    got = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
+    ref = orc.cohort_stats(S, topn, select)
+    scale = np.abs(S).max(axis=1) + 1e-30
+    np.testing.assert_allclose(got[:, 0], ref[:, 0], atol=1e-9 * scale.max(), rtol=1e-10)
+    assert np.all(np.abs(got[:, 2] - ref[:, 2]) <= 1e-9 * scale)
+    assert np.all(np.abs(got[:, 1] - ref[:, 1]) <= 2e-7 * scale)
+    assert np.all(np.abs(got[:, 3] - ref[:, 3]) <= 2e-7 * scale)
+    again = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
+    assert np.array_equal(got, again)  # bit-reproducible (rank-slot summation, no atomics on values)
