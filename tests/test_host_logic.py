@@ -286,3 +286,24 @@ def test_abi_argument_validation_needs_no_gpu(hip_lib):
     assert L.nplda_cohort_workspace_bytes(22000, 10000) == 22000 * 10000 * 4
     assert L.nplda_cohort_workspace_bytes(10 ** 7, 10 ** 4) <= (4 << 30)
     assert L.gb_packed_bytes(512, 170) > 4 * 176 * 176 * 4 and L.nplda_bf16x3_packed_bytes(512, 150, 150) > 0
+
+
+def test_trial_loader_fast_iterator_equals_torch_dataloader():
+    """TrialLoader's vectorised iterator yields exactly the batches torch's DataLoader(shuffle=True) machinery yields
+    under the same RNG state, for several epochs, including the short last batch."""
+    from torch.utils.data import DataLoader
+    from neuralplda_amd import sv_trials_loaders as svl
+    n = 1000
+    ds = svl.TrialIndexDataset(torch.arange(n), torch.arange(n) * 2, (torch.arange(n) % 3 == 0).float())
+    for bs in (64, 1000, 1024, 7):
+        torch.manual_seed(123)
+        ref = DataLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate)
+        ref_batches = [b for _ in range(3) for b in ref]
+        ref_next = torch.rand(1)
+        torch.manual_seed(123)
+        fast = svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate)
+        fast_batches = [b for _ in range(3) for b in fast]
+        assert torch.equal(torch.rand(1), ref_next)  # the same amount of global RNG state was consumed
+        assert len(fast) == len(ref) and len(fast_batches) == len(ref_batches)
+        for a, b in zip(fast_batches, ref_batches):
+            assert all(torch.equal(x, y) for x, y in zip(a, b))
