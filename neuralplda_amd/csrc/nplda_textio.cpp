@@ -13,7 +13,9 @@
 #include <cstdint>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nplda_hip.h"
@@ -246,6 +248,95 @@ inline void for_rows(const char* text, size_t len, int64_t skip_rows, F&& fn) {
     }
 }
 
+// ---- line-aligned chunks for the host threads ------------------------------------------------------------------------
+// Large tables (a cfg3-scale cohort score file has 2.2e8 lines) are cut at line boundaries into one chunk per thread; a
+// first parallel pass counts the data rows of every chunk, so that each thread knows the global index of its first row
+// and all outputs keep the file order.  NPLDA_TEXT_THREADS overrides the thread count (default: min(16, cores), one
+// thread per 2 MB of text at least).
+struct Chunk {
+    const char* b;
+    const char* e;
+    int64_t row0;   // global index (before skip_rows) of the chunk's first data row
+    int64_t rows;   // data rows in the chunk
+    int cols;       // columns of its rows, -1 if they disagree, 0 if it has none
+};
+
+inline int text_threads(size_t len) {
+    int want = 0;
+    if (const char* env = getenv("NPLDA_TEXT_THREADS")) want = atoi(env);
+    if (want > 0) return want > 64 ? 64 : want;  // explicit: honoured as is (tests force several threads on tiny files)
+    const unsigned hw = std::thread::hardware_concurrency();
+    want = hw == 0 ? 4 : (hw > 16 ? 16 : (int)hw);
+    const size_t by_size = len / (2u << 20) + 1;
+    if ((size_t)want > by_size) want = (int)by_size;
+    return want < 1 ? 1 : want;
+}
+
+template <typename F>
+inline void run_threads(int n, F&& fn) {
+    if (n <= 1) { fn(0); return; }
+    std::vector<std::thread> th;
+    th.reserve((size_t)n - 1);
+    for (int t = 1; t < n; ++t) th.emplace_back([&fn, t]() { fn(t); });
+    fn(0);
+    for (auto& x : th) x.join();
+}
+
+inline std::vector<Chunk> make_chunks(const char* text, size_t len) {
+    const int nt = text_threads(len);
+    std::vector<Chunk> ch((size_t)nt);
+    const char* end = text + len;
+    const char* p = text;
+    for (int t = 0; t < nt; ++t) {
+        const char* target = t + 1 == nt ? end : text + (len / (size_t)nt) * (size_t)(t + 1);
+        const char* q = target;
+        if (q < p) q = p;
+        if (q < end) {
+            const char* nl = (const char*)memchr(q, '\n', (size_t)(end - q));
+            q = nl ? nl + 1 : end;
+        }
+        ch[(size_t)t] = Chunk{p, q, 0, 0, 0};
+        p = q;
+    }
+    run_threads(nt, [&](int t) {
+        Chunk& c = ch[(size_t)t];
+        const char* p2 = c.b;
+        while (p2 < c.e) {
+            const char* nl = (const char*)memchr(p2, '\n', (size_t)(c.e - p2));
+            const char* e2 = nl ? nl : c.e;
+            Tok dummy;
+            const int n = split_line(p2, e2, &dummy, 1);
+            if (n > 0) {
+                if (c.rows == 0) c.cols = n;
+                else if (n != c.cols) c.cols = -1;
+                ++c.rows;
+            }
+            p2 = nl ? nl + 1 : c.e;
+        }
+    });
+    int64_t r = 0;
+    for (auto& c : ch) { c.row0 = r; r += c.rows; }
+    return ch;
+}
+
+// visit the data rows of one chunk: fn(global_row_index_after_skip, tokens, ntokens) -> false stops this chunk
+template <typename F>
+inline void for_chunk_rows(const Chunk& c, int64_t skip_rows, F&& fn) {
+    const char* p = c.b;
+    int64_t row = c.row0;
+    Tok tk[64];
+    while (p < c.e) {
+        const char* nl = (const char*)memchr(p, '\n', (size_t)(c.e - p));
+        const char* e = nl ? nl : c.e;
+        const int n = split_line(p, e, tk, 64);
+        p = nl ? nl + 1 : c.e;
+        if (n == 0) continue;
+        const int64_t r = row++;
+        if (r < skip_rows) continue;
+        if (!fn(r - skip_rows, tk, n < 64 ? n : 64)) return;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -255,26 +346,28 @@ int nplda_format_f64(double v, char* out) { return format_np<double>(v, out); }
 
 int nplda_text_column_f64(const char* text, size_t len, int64_t skip_rows, int col, double* out, int64_t n) {
     if ((!text && len) || (!out && n) || n < 0 || col < -64 || col > 63) return NPLDA_EINVAL;
-    int rc = NPLDA_OK;
-    int64_t got = 0;
-    for_rows(text, len, skip_rows, [&](int64_t r, const Tok* tk, int nt) {
-        if (r >= n) return false;
-        const int c = col < 0 ? nt + col : col;
-        if (c < 0 || c >= nt || !parse_f64(tk[c], &out[r])) { rc = NPLDA_EINVAL; return false; }
-        got = r + 1;
-        return true;
+    const std::vector<Chunk> ch = make_chunks(text, len);
+    const int64_t total = ch.empty() ? 0 : ch.back().row0 + ch.back().rows;
+    if (total - (skip_rows < total ? skip_rows : total) != n) return NPLDA_EINVAL;  // fewer / more rows than asked
+    std::vector<int> bad(ch.size(), 0);
+    run_threads((int)ch.size(), [&](int t) {
+        for_chunk_rows(ch[(size_t)t], skip_rows, [&](int64_t r, const Tok* tk, int nt) {
+            const int c = col < 0 ? nt + col : col;
+            if (c < 0 || c >= nt || !parse_f64(tk[c], &out[r])) { bad[(size_t)t] = 1; return false; }
+            return true;
+        });
     });
-    if (rc == NPLDA_OK && got != n) rc = NPLDA_EINVAL;
-    return rc;
+    for (int v : bad) if (v) return NPLDA_EINVAL;
+    return NPLDA_OK;
 }
 
-int nplda_text_count_unique(const char* text, size_t len, int64_t skip_rows, int col, int64_t* n_unique) {
-    if ((!text && len) || !n_unique || col < -64 || col > 63) return NPLDA_EINVAL;
-    std::vector<Tok> slot(1 << 12, Tok{nullptr, 0});
-    uint64_t mask = slot.size() - 1;
+namespace {
+struct TokSet {
+    std::vector<Tok> slot;
+    uint64_t mask;
     int64_t count = 0;
-    int rc = NPLDA_OK;
-    auto insert = [&](std::vector<Tok>& tab, uint64_t m, Tok t) -> bool {  // true if new
+    TokSet() : slot(1 << 12, Tok{nullptr, 0}), mask((1 << 12) - 1) {}
+    static bool put(std::vector<Tok>& tab, uint64_t m, Tok t) {  // true if new
         uint64_t h = hash_bytes(t.p, t.n) & m;
         while (true) {
             Tok& s = tab[h];
@@ -282,24 +375,41 @@ int nplda_text_count_unique(const char* text, size_t len, int64_t skip_rows, int
             if (s.n == t.n && memcmp(s.p, t.p, t.n) == 0) return false;
             h = (h + 1) & m;
         }
-    };
-    for_rows(text, len, skip_rows, [&](int64_t, const Tok* tk, int nt) {
-        const int c = col < 0 ? nt + col : col;
-        if (c < 0 || c >= nt) { rc = NPLDA_EINVAL; return false; }
-        if (insert(slot, mask, tk[c])) {
-            if ((uint64_t)(++count) * 2 > mask) {  // grow
-                std::vector<Tok> bigger(slot.size() * 2, Tok{nullptr, 0});
-                const uint64_t bm = bigger.size() - 1;
-                for (const Tok& t : slot)
-                    if (t.p) insert(bigger, bm, t);
-                slot.swap(bigger);
-                mask = bm;
-            }
+    }
+    void insert(Tok t) {
+        if (!put(slot, mask, t)) return;
+        if ((uint64_t)(++count) * 2 > mask) {
+            std::vector<Tok> bigger(slot.size() * 2, Tok{nullptr, 0});
+            const uint64_t bm = bigger.size() - 1;
+            for (const Tok& x : slot)
+                if (x.p) put(bigger, bm, x);
+            slot.swap(bigger);
+            mask = bm;
         }
-        return true;
+    }
+};
+}  // namespace
+
+int nplda_text_count_unique(const char* text, size_t len, int64_t skip_rows, int col, int64_t* n_unique) {
+    if ((!text && len) || !n_unique || col < -64 || col > 63) return NPLDA_EINVAL;
+    const std::vector<Chunk> ch = make_chunks(text, len);
+    std::vector<TokSet> sets(ch.size());
+    std::vector<int> bad(ch.size(), 0);
+    run_threads((int)ch.size(), [&](int t) {
+        TokSet& set = sets[(size_t)t];
+        for_chunk_rows(ch[(size_t)t], skip_rows, [&](int64_t, const Tok* tk, int nt) {
+            const int c = col < 0 ? nt + col : col;
+            if (c < 0 || c >= nt) { bad[(size_t)t] = 1; return false; }
+            set.insert(tk[c]);
+            return true;
+        });
     });
-    *n_unique = count;
-    return rc;
+    for (int v : bad) if (v) return NPLDA_EINVAL;
+    for (size_t t = 1; t < sets.size(); ++t)
+        for (const Tok& x : sets[t].slot)
+            if (x.p) sets[0].insert(x);
+    *n_unique = sets.empty() ? 0 : sets[0].count;
+    return NPLDA_OK;
 }
 
 int nplda_text_column_spans(const char* text, size_t len, int64_t skip_rows, int col, int64_t stride, int64_t* start,
@@ -324,21 +434,14 @@ int nplda_text_column_spans(const char* text, size_t len, int64_t skip_rows, int
 
 int64_t nplda_text_scan(const char* text, size_t len, int* ncols) {
     if ((!text && len) || !ncols) return NPLDA_EINVAL;
-    const char* p = text;
-    const char* end = text + len;
-    int64_t rows = 0;
+    const std::vector<Chunk> ch = make_chunks(text, len);
     int cols = 0;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* e = nl ? nl : end;
-        Tok dummy;
-        const int n = split_line(p, e, &dummy, 1);
-        if (n > 0) {
-            if (rows == 0) cols = n;
-            else if (n != cols) return NPLDA_EINVAL;  // genfromtxt: "Some errors were detected" (ragged rows)
-            ++rows;
-        }
-        p = nl ? nl + 1 : end;
+    int64_t rows = 0;
+    for (const Chunk& c : ch) {
+        if (c.rows == 0) continue;
+        if (c.cols < 0 || (cols != 0 && c.cols != cols)) return NPLDA_EINVAL;  // genfromtxt: ragged rows are an error
+        cols = c.cols;
+        rows += c.rows;
     }
     *ncols = cols;
     return rows;
@@ -351,38 +454,45 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
     if (mode1 < 0 || mode1 > 3 || mode2 < 0 || mode2 > 3 || label_col > 62) return NPLDA_EINVAL;
     if (label_col >= 0 && !label) return NPLDA_EINVAL;
     const IdTable tab(ids, id_off, n_ids);
-    const char* p = text;
-    const char* end = text + len;
-    int64_t row = 0, kept = 0, bad = -1;
-    Tok tk[64];
-    std::string scratch;
+    const std::vector<Chunk> ch = make_chunks(text, len);
     const int need = label_col >= 0 ? (label_col + 1 > 2 ? label_col + 1 : 2) : 2;
-    while (p < end) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* e = nl ? nl : end;
-        const int n = split_line(p, e, tk, 64);
-        p = nl ? nl + 1 : end;
-        if (n == 0) continue;
-        const int64_t r = row++;
-        if (r < skip_rows) continue;
-        bool ok = n >= need;
-        int64_t a = -1, b = -1;
-        float lab = 0.f;
-        if (ok) {
-            a = tab.find(normalise(tk[0], mode1, &scratch));
-            b = tab.find(normalise(tk[1], mode2, &scratch));
-            ok = a >= 0 && b >= 0;
-            if (ok && label_col >= 0) ok = parse_label(tk[label_col], &lab);
+    struct Part { std::vector<int64_t> a, b, src; std::vector<float> lab; int64_t bad = -1; };
+    std::vector<Part> parts(ch.size());
+    run_threads((int)ch.size(), [&](int t) {
+        Part& P = parts[(size_t)t];
+        std::string scratch;
+        for_chunk_rows(ch[(size_t)t], skip_rows, [&](int64_t r, const Tok* tk, int n) {
+            bool ok = n >= need;
+            int64_t a2 = -1, b2 = -1;
+            float lab = 0.f;
+            if (ok) {
+                a2 = tab.find(normalise(tk[0], mode1, &scratch));
+                b2 = tab.find(normalise(tk[1], mode2, &scratch));
+                ok = a2 >= 0 && b2 >= 0;
+                if (ok && label_col >= 0) ok = parse_label(tk[label_col], &lab);
+            }
+            if (!ok) {
+                if (P.bad < 0) P.bad = r;
+                return true;
+            }
+            P.a.push_back(id_num ? id_num[a2] : a2);
+            P.b.push_back(id_num ? id_num[b2] : b2);
+            if (label_col >= 0) P.lab.push_back(lab);
+            P.src.push_back(r);
+            return true;
+        });
+    });
+    int64_t kept = 0, bad = -1;
+    for (const Part& P : parts) {
+        const size_t k = P.a.size();
+        if (k) {
+            memcpy(i1 + kept, P.a.data(), k * sizeof(int64_t));
+            memcpy(i2 + kept, P.b.data(), k * sizeof(int64_t));
+            if (label_col >= 0) memcpy(label + kept, P.lab.data(), k * sizeof(float));
+            if (row_of) memcpy(row_of + kept, P.src.data(), k * sizeof(int64_t));
+            kept += (int64_t)k;
         }
-        if (!ok) {
-            if (bad < 0) bad = r - skip_rows;
-            continue;
-        }
-        i1[kept] = id_num ? id_num[a] : a;
-        i2[kept] = id_num ? id_num[b] : b;
-        if (label_col >= 0) label[kept] = lab;
-        if (row_of) row_of[kept] = r - skip_rows;
-        ++kept;
+        if (bad < 0 && P.bad >= 0) bad = P.bad;
     }
     *n_kept = kept;
     if (first_bad_row) *first_bad_row = bad;
@@ -392,46 +502,39 @@ int nplda_text_lookup(const char* text, size_t len, int64_t skip_rows, int mode1
 int nplda_scores_write(const char* path, const char* text, size_t len, int64_t skip_rows, int keep_cols,
                        const char* header, const void* scores, int scores_f64, int64_t n) {
     if (!path || (!text && len) || (!scores && n) || n < 0 || keep_cols < 1 || keep_cols > 64) return NPLDA_EINVAL;
+    const std::vector<Chunk> ch = make_chunks(text, len);
+    const int64_t total = ch.empty() ? 0 : ch.back().row0 + ch.back().rows;
+    if (total - (skip_rows < total ? skip_rows : total) < n) return NPLDA_EINVAL;  // fewer data rows than scores
+    std::vector<std::string> bufs(ch.size());
+    std::vector<int> bad(ch.size(), 0);
+    run_threads((int)ch.size(), [&](int t) {
+        std::string& buf = bufs[(size_t)t];
+        buf.reserve((size_t)(ch[(size_t)t].e - ch[(size_t)t].b) + (size_t)ch[(size_t)t].rows * 16);
+        char num[48];
+        for_chunk_rows(ch[(size_t)t], skip_rows, [&](int64_t r, const Tok* tk, int nt) {
+            if (r >= n) return false;
+            if (nt < keep_cols) { bad[(size_t)t] = 1; return false; }
+            for (int c = 0; c < keep_cols; ++c) {
+                buf.append(tk[c].p, tk[c].n);
+                buf.push_back('\t');
+            }
+            const int k = scores_f64 ? format_np<double>(((const double*)scores)[r], num)
+                                     : format_np<float>(((const float*)scores)[r], num);
+            buf.append(num, (size_t)k);
+            buf.push_back('\n');
+            return true;
+        });
+    });
+    for (int v : bad) if (v) return NPLDA_EINVAL;
     FILE* f = fopen(path, "wb");
     if (!f) return NPLDA_EINVAL;
-    std::vector<char> buf;
-    buf.reserve(1 << 22);
-    auto flush = [&]() -> bool {
-        const bool ok = buf.empty() || fwrite(buf.data(), 1, buf.size(), f) == buf.size();
-        buf.clear();
-        return ok;
-    };
-    if (header) {
-        buf.insert(buf.end(), header, header + strlen(header));
-        buf.push_back('\n');
-    }
-    const char* p = text;
-    const char* end = text + len;
-    int64_t row = 0, out = 0;
-    Tok tk[64];
-    char num[48];
     int rc = NPLDA_OK;
-    while (p < end && out < n) {
-        const char* nl = (const char*)memchr(p, '\n', (size_t)(end - p));
-        const char* e = nl ? nl : end;
-        const int nt = split_line(p, e, tk, 64);
-        p = nl ? nl + 1 : end;
-        if (nt == 0) continue;
-        if (row++ < skip_rows) continue;
-        if (nt < keep_cols) { rc = NPLDA_EINVAL; break; }
-        for (int c = 0; c < keep_cols; ++c) {
-            buf.insert(buf.end(), tk[c].p, tk[c].p + tk[c].n);
-            buf.push_back('\t');
-        }
-        const int k = scores_f64 ? format_np<double>(((const double*)scores)[out], num)
-                                 : format_np<float>(((const float*)scores)[out], num);
-        ++out;
-        buf.insert(buf.end(), num, num + k);
-        buf.push_back('\n');
-        if (buf.size() > (1u << 22) - 4096 && !flush()) { rc = NPLDA_EINVAL; break; }
+    if (header) {
+        const size_t hl = strlen(header);
+        if (fwrite(header, 1, hl, f) != hl || fputc('\n', f) == EOF) rc = NPLDA_EINVAL;
     }
-    if (rc == NPLDA_OK && out != n) rc = NPLDA_EINVAL;  // fewer data rows than scores
-    if (rc == NPLDA_OK && !flush()) rc = NPLDA_EINVAL;
+    for (const std::string& buf : bufs)
+        if (rc == NPLDA_OK && !buf.empty() && fwrite(buf.data(), 1, buf.size(), f) != buf.size()) rc = NPLDA_EINVAL;
     if (fclose(f) != 0 && rc == NPLDA_OK) rc = NPLDA_EINVAL;
     return rc;
 }

@@ -207,3 +207,36 @@ def test_format_f64_and_f64_writer(tmp_path):
                fmt="%s", delimiter="\t")
     textio.write_scores(out_p, text, sc, skip_rows=1, keep_cols=3, header="# " + "\t".join(["modelid", "segmentid", "side", "LLR"]))
     assert out_p.read_bytes() == ref_p.read_bytes()
+
+
+@pytest.mark.parametrize("threads", [2, 5, 13])
+def test_threaded_chunks_give_the_single_thread_results(tmp_path, monkeypatch, threads):
+    """The file is cut at line boundaries into one chunk per host thread; results must not depend on the thread count
+    (forced here on a small file with blank lines, comments and dropped rows so that chunks start mid-structure)."""
+    rng = np.random.default_rng(threads)
+    ids = [f"spk{u // 3:03d}-utt{u:04d}" for u in range(200)]
+    path = _make_file(tmp_path, rng, 3000, ids)
+    text = open(path, "rb").read()
+    blob = textio.IdBlob(ids)
+    monkeypatch.setenv("NPLDA_TEXT_THREADS", "1")
+    base_scan = textio.scan(text)
+    base = textio.lookup(text, blob, 2, textio.BASENAME_SPLITEXT, textio.BASENAME_SPLITEXT, label_col=2)
+    sc = rng.standard_normal(base_scan[0] - 2).astype(np.float32)
+    textio.write_scores(tmp_path / "one.tsv", text, sc, skip_rows=2, keep_cols=2, header="a\tb\tLLR")
+    nuniq = textio.count_unique(text, 1)
+    monkeypatch.setenv("NPLDA_TEXT_THREADS", str(threads))
+    assert textio.scan(text) == base_scan
+    got = textio.lookup(text, blob, 2, textio.BASENAME_SPLITEXT, textio.BASENAME_SPLITEXT, label_col=2)
+    for a, b in zip(base[:4], got[:4]):
+        assert np.array_equal(a, b, equal_nan=True)
+    assert got[4] == base[4]
+    textio.write_scores(tmp_path / "many.tsv", text, sc, skip_rows=2, keep_cols=2, header="a\tb\tLLR")
+    assert (tmp_path / "many.tsv").read_bytes() == (tmp_path / "one.tsv").read_bytes()
+    assert textio.count_unique(text, 1) == nuniq
+    with pytest.raises(ValueError):
+        textio.scan(text + b"one two three four five\n")  # a ragged row in the last chunk
+    # numeric column, several threads
+    vals = rng.standard_normal(5000)
+    t2 = "\n".join(f"e{k} c{k % 50} {float(v)!r}" for k, v in enumerate(vals)) + "\n"
+    assert np.array_equal(textio.column_f64(t2, -1, 5000), vals)
+    assert textio.count_unique(t2, 1) == 50
