@@ -152,7 +152,8 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     if (L.NB == 10 && S.LO == 6) {
         vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v2 w8 kpb2", launch_2<10, 8, false, 2>},
-               {"v4 9+6 w8 kpb2 (exp)", launch_4<9, 6, 8, 2>}, {"v1 w8 kpb2", launch_v<10, 8, false, 2>} };
+               {"v3 w4 kpb2 x2", launch_3<10, 4, false, 2, 2>}, {"v3 w4 kpb4 x2", launch_3<10, 4, false, 4, 2>},
+               {"v3 w8 kpb2 g2", launch_3<10, 8, false, 2, 1, 2>}, {"v3 w8 kpb2 g5", launch_3<10, 8, false, 2, 1, 5>} };
     } else if (L.NB == 11 && S.LO == 10) {
         vs = { {"v2 w8 kpb2", launch_2<11, 8, false, 2>}, {"v3 w8 kpb2", launch_3<11, 8, false, 2, 1>},
                {"v4 10+10 w8 kpb2 (exp)", launch_4<10, 10, 8, 2>} };
