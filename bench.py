@@ -105,8 +105,8 @@ def cpu_baseline(params_np, D0, budget_s=12.0, buf_pairs=102400, chunk=10240):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--pairs", type=int, default=1 << 20, help="trial pairs per GPU per step")
     ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
     ap.add_argument("--no-cpu-baseline", action="store_true")
