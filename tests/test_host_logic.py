@@ -281,6 +281,22 @@ def test_abi_argument_validation_needs_no_gpu(hip_lib):
     assert L.nplda_gather_rows_f32(p16, 512, 10, p16, 4, 510, p16, 512, None) == EINVAL
     assert L.gb_pack_params_f32(p16, p16, p16, p16, p16, p16, 512, 500, p16, 1 << 30, None) == EUNSUP
     assert L.nplda_adam_step_f32(None, None, None, None, None, 3, p16, 1e-3, 0.9, 0.999, 1e-8, 0.0, None) == EINVAL
+    # entry points added later: moments, quadratic-form images, detection-cost sweep
+    assert L.nplda_weighted_moments_f32(p16, -1, 340, 340, p16, None, p16, p16, p16, 0, p16, 1 << 30, None) == EINVAL
+    assert L.nplda_weighted_moments_f32(p16, 8, 340, 342, p16, None, p16, p16, p16, 0, p16, 1 << 30, None) == EUNSUP   # n % 4
+    assert L.nplda_weighted_moments_f32(p16, 8, 340, 388, p16, None, p16, p16, p16, 0, p16, 1 << 30, None) == EUNSUP   # n > 384
+    assert L.nplda_weighted_moments_f32(p16, 8, 338, 340, p16, None, p16, p16, p16, 0, p16, 1 << 30, None) == EINVAL   # ldx < n
+    assert L.nplda_weighted_moments_f32(p16, 8, 340, 340, p16, None, p16, p16, p16, 0, p16, 16, None) == -28
+    assert L.nplda_moments_workspace_bytes(2048, 340) > 0 and L.nplda_moments_workspace_bytes(2048, 342) == 0
+    assert L.gb_pack_quadform_f32(p16, p16, None, None, 0.0, 512, 170, p16, 1 << 30, None) == EINVAL
+    assert L.gb_pack_dplda_f32(p16, p16, p16, None, 512, 170, p16, 1 << 30, None) == EINVAL
+    assert L.gb_pack_dplda_f32(p16, p16, p16, p16, 512, 170, p16, 16, None) == -28
+    assert L.gb_score_rows_f32(None, None, 0, 172, None, 172, 170, None, None) == 0
+    assert L.gb_score_rows_f32(p16, p16, 4, 170, p16, 172, 170, p16, None) == EINVAL                 # ldy < D0
+    betas = (ctypes.c_float * 9)(*([99.0] * 9))
+    assert L.nplda_detcost_sweep_f32(p16, p16, -1, betas, 2, 0, p16, p16, p16, None, p16, 1 << 30, None) == EINVAL
+    assert L.nplda_detcost_sweep_f32(p16, p16, 8, betas, 9, 0, p16, p16, p16, None, p16, 1 << 30, None) == EUNSUP      # K > 8
+    assert L.nplda_detcost_workspace_bytes(-1) == 0  # (sizes of real inputs come from rocPRIM and need a device)
     # sizes
     assert L.nplda_backward_workspace_bytes(4096, 512, 150, 150) > 2 * 8192 * 160 * 4
     assert L.nplda_cohort_workspace_bytes(22000, 10000) == 22000 * 10000 * 4
