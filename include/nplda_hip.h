@@ -227,7 +227,8 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
  *   exact = 1: the true minimum of P_miss(th) + beta P_fa(th) over every distinct score and +inf ("target" iff
  *              s >= th), in fp64; eer (optional) = the equal error rate by linear interpolation at the crossing.
  * Labels: target iff t > 0.5, non-target iff t < 0.5 (as :407-408).  minc, thr (K), minc_avg (1), eer (1 or NULL)
- * are DEVICE floats.  N < 2^31. */
+ * are DEVICE floats.  N < 2^31.  The workspace size includes rocPRIM's temporary storage, whose size query needs a HIP
+ * device: nplda_detcost_workspace_bytes returns 0 when there is none (or N is out of range). */
 size_t nplda_detcost_workspace_bytes(int64_t N);
 int nplda_detcost_sweep_f32(const float* scores, const float* target, int64_t N, const float* betas, int K, int exact,
                             float* minc, float* thr, float* minc_avg, float* eer, void* workspace,
