@@ -36,15 +36,26 @@ struct CohortGemmArgs {
     const float* P;    // padded (>= 16 * NBK) floats, zero beyond D2
     long long R, M, ldz, lds;  // lds = row stride of S (>= M)
     int ksteps;        // k16-steps = padded D2 / 16
+    int nxp;           // column tiles per XCD band = min(ceil(ceil(M / 128) / 8), 24)
+    int ny;            // row tiles = ceil(R / 128)
     float* S;
 };
 
 __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i16 = lane & 15, g4 = lane >> 4;
-    // block tile 128 x 128 = 2 x 2 waves of 64 x 64
-    const long long r0 = (long long)blockIdx.y * 128 + (wave >> 1) * 64;
-    const long long m0 = (long long)blockIdx.x * 128 + (wave & 1) * 64;
+    // block tile 128 x 128 = 2 x 2 waves of 64 x 64.  XCD-aware tile order: workgroup b is dispatched to XCD b % 8
+    // (observed; speed only, nothing depends on it), so XCD x owns the band of nxp consecutive column tiles
+    // [x nxp, (x + 1) nxp) for every row tile.  Its slice of the cohort table (nxp * 128 rows, < 1 MB) then stays in that
+    // XCD's 4 MB L2 while the row table streams through once per XCD; with the plain 2-D grid every XCD cycled through
+    // the whole cohort table (7 MB at cfg3) once per wave of resident blocks.  Bands are capped at 24 tiles (2.3 MB of
+    // a 192-wide table); a wider cohort is covered by several super-bands of 8 bands, one after the other.
+    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+    const int per_sb = a.nxp * a.ny;
+    const int sb = slot / per_sb, rem = slot - sb * per_sb;
+    const int ty = rem / a.nxp, tx = (sb * 8 + xcd) * a.nxp + (rem - ty * a.nxp);
+    const long long r0 = (long long)ty * 128 + (wave >> 1) * 64;
+    const long long m0 = (long long)tx * 128 + (wave & 1) * 64;
     if (r0 >= a.R || m0 >= a.M) return;
 
     const float* pa[4];
@@ -429,8 +440,12 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
         CohortGemmArgs a;
         a.zr = z_rows + r0 * ldz; a.qr = q_rows + r0; a.zc = z_coh; a.qc = q_coh;
         a.P = (const float*)packed + L.oP; a.R = rc; a.M = M; a.ldz = ldz; a.lds = lds; a.ksteps = L.NB; a.S = (float*)ws;
-        dim3 grid((unsigned)((M + 127) / 128), (unsigned)((rc + 127) / 128));
-        hipLaunchKernelGGL(cohort_gemm_kernel, grid, dim3(256), 0, st, a);
+        const long long nx = (M + 127) / 128, ny = (rc + 127) / 128;
+        a.nxp = (int)((nx + 7) / 8 < 24 ? (nx + 7) / 8 : 24);
+        a.ny = (int)ny;
+        const long long nsb = (nx + 8LL * a.nxp - 1) / (8LL * a.nxp);
+        if (8LL * a.nxp * ny * nsb > 0x7fffffffLL) return NPLDA_EINVAL;
+        hipLaunchKernelGGL(cohort_gemm_kernel, dim3((unsigned)(8LL * a.nxp * ny * nsb)), dim3(256), 0, st, a);
         if (int rc2 = nplda_launch_status()) return rc2;
         hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)rc), dim3(kRowThreads), shmem, st, (const float*)ws,
                            (long long)lds, (long long)M, topn, select_lowest ? 1 : 0, use_lds, stats + 4 * r0);

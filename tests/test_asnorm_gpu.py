@@ -43,7 +43,7 @@ def test_row_stats_matches_sort_then_slice(hip_lib, R, M, topn, select):
 
 
 @pytest.mark.parametrize("D", [150, 170])
-@pytest.mark.parametrize("R,M", [(200, 1000), (130, 257)])
+@pytest.mark.parametrize("R,M", [(200, 1000), (130, 257), (140, 24700)])  # the last spans two super-bands of column tiles
 def test_cohort_stats_full_pipeline(hip_lib, D, R, M):
     from neuralplda_amd import ops
     rng = np.random.default_rng(D + R)
