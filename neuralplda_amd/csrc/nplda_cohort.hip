@@ -75,21 +75,24 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // the self terms of this lane's 16 output rows and 4 output columns: fetched before the k loop so that their
-    // latency hides under it (loading them in the epilogue exposed a full L2 round trip per tile)
-    float qrv[4][4], qmv[4];
+    // The MFMAs below take the cohort fragment as the A operand, so the lane (i16, g4) of block (ca, cb) ends up with
+    // row r0 + 16 ca + i16 and the FOUR CONSECUTIVE columns m0 + 16 cb + 4 g4 + r: one 16-byte store per block instead
+    // of four 4-byte ones (the epilogue is store-issue bound).  The self terms of those 4 rows and 16 columns are
+    // fetched before the k loop so that their latency hides under it.
+    float qrv[4];
+    f32x4 qmv[4];
 #pragma unroll
-    for (int ca = 0; ca < 4; ++ca)
+    for (int ca = 0; ca < 4; ++ca) {
+        const long long row = r0 + 16 * ca + i16;
+        qrv[ca] = a.qr[row < a.R ? row : a.R - 1];
+    }
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-            const long long row = r0 + 16 * ca + 4 * g4 + r;
-            qrv[ca][r] = a.qr[row < a.R ? row : a.R - 1];
+            const long long m = m0 + 16 * cb + 4 * g4 + r;
+            qmv[cb][r] = a.qc[m < a.M ? m : a.M - 1];
         }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb) {
-        const long long m = m0 + 16 * cb + i16;
-        qmv[cb] = a.qc[m < a.M ? m : a.M - 1];
-    }
 
     for (int ks = 0; ks < a.ksteps; ++ks) {
         const f32x4 p2 = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 16 * ks + 4 * g4);
@@ -105,22 +108,18 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
             for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
-                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ca][kk], fb[cb][kk], acc[ca][cb], 0, 0, 0);
+                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
     }
-    // epilogue: lane (j = i16, g4) of block (ca, cb) holds rows r0 + 16 ca + 4 g4 + r, column m0 + 16 cb + j.
-    // One running row pointer per (ca, r), the four column blocks at constant offsets: VALU instructions are paid in
-    // MFMA time on this chip, a 64-bit multiply-add per stored element was ~7 % of the tile.
+    // epilogue: S rows are padded to a multiple of 4 floats (lds), so a 16-byte store that starts below M stays in its row
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca) {
+        const long long row = r0 + 16 * ca + i16;
+        if (row >= a.R) continue;
+        float* srow = a.S + row * a.lds + m0 + 4 * g4;
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long row = r0 + 16 * ca + 4 * g4 + r;
-            if (row >= a.R) continue;
-            float* srow = a.S + row * a.lds + m0 + i16;
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb)
-                if (m0 + 16 * cb + i16 < a.M) srow[16 * cb] = acc[ca][cb][r] + (qrv[ca][r] + qmv[cb]);
-        }
+        for (int cb = 0; cb < 4; ++cb)
+            if (m0 + 16 * cb + 4 * g4 < a.M)
+                *reinterpret_cast<f32x4*>(srow + 16 * cb) = acc[ca][cb] + (qmv[cb] + qrv[ca]);
     }
 }
 
