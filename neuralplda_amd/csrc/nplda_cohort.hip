@@ -41,8 +41,22 @@ struct CohortGemmArgs {
     float* S;
 };
 
-__global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+__global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArgs a) {
+    // Both operands go through LDS in k16 stages (128 rows x 64 B each, two buffers, 32 KB).  Reading the MFMA
+    // fragments straight from the row-major tables (lane i16 + 16 g4 <- row i16, 16-byte chunk g4) hands the texture
+    // addresser 64 different 16-byte pieces per wave instruction in lane order, and with 8 such loads per 64 MFMAs the
+    // address path, not the matrix pipe, set the pace (0.66 of the MFMA rate in the k loop).  Staged, four consecutive
+    // lanes fetch one row's 64 contiguous bytes, each element is fetched once per block instead of once per wave, and the
+    // fragments come from LDS by ds_read_b128.
+    //
+    // LDS image of a stage: row-major, 4 chunks of 16 B per row, chunk c of row r stored at chunk c ^ ((r >> 2) & 2).
+    // ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and the same + 32): rows 0-3 and 12-15
+    // of chunk g4 together with rows 4-11 of chunk g4 + 1; unswizzled, rows r and r + 4 share their four banks, with
+    // the swizzle the 16 lanes of a group cover the 16 slots of the 256-byte bank row exactly once.  The stores
+    // (8 consecutive lanes = 2 rows x 4 chunks = 128 contiguous bytes) are conflict-free under any in-row permutation.
+    __shared__ f32x4 tile[2][2][512];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
     // block tile 128 x 128 = 2 x 2 waves of 64 x 64.  XCD-aware tile order: workgroup b is dispatched to XCD b % 8
     // (observed; speed only, nothing depends on it), so XCD x owns the band of nxp consecutive column tiles
@@ -54,31 +68,16 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
     const int per_sb = a.nxp * a.ny;
     const int sb = slot / per_sb, rem = slot - sb * per_sb;
     const int ty = rem / a.nxp, tx = (sb * 8 + xcd) * a.nxp + (rem - ty * a.nxp);
-    const long long r0 = (long long)ty * 128 + (wave >> 1) * 64;
-    const long long m0 = (long long)tx * 128 + (wave & 1) * 64;
-    if (r0 >= a.R || m0 >= a.M) return;
-
-    const float* pa[4];
-    const float* pb[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-        long long r = r0 + 16 * c + i16;
-        long long m = m0 + 16 * c + i16;
-        if (r >= a.R) r = a.R - 1;
-        if (m >= a.M) m = a.M - 1;
-        pa[c] = a.zr + r * a.ldz + 4 * g4;
-        pb[c] = a.zc + m * a.ldz + 4 * g4;
-    }
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const long long rb = (long long)ty * 128, mb = (long long)tx * 128;
+    if (rb >= a.R || mb >= a.M) return;  // whole block (uniform): no barrier is skipped
+    const long long r0 = rb + (wave >> 1) * 64;
+    const long long m0 = mb + (wave & 1) * 64;
 
     // The MFMAs below take the cohort fragment as the A operand, so the lane (i16, g4) of block (ca, cb) ends up with
     // row r0 + 16 ca + i16 and the FOUR CONSECUTIVE columns m0 + 16 cb + 4 g4 + r: one 16-byte store per block instead
     // of four 4-byte ones (the epilogue is store-issue bound).  The self terms of those 4 rows and 16 columns are
-    // fetched before the k loop so that their latency hides under it.
+    // fetched first so that their latency hides under the k loop (and every later vmcnt wait covers them: the
+    // epilogue stores must not wait on the memory counter, see below).
     float qrv[4];
     f32x4 qmv[4];
 #pragma unroll
@@ -94,13 +93,63 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
             qmv[cb][r] = a.qc[m < a.M ? m : a.M - 1];
         }
 
+    // staging: thread t moves chunk q = t & 3 of tile rows (t >> 2) and 64 + (t >> 2), of both operands
+    const int q = tid & 3;
+    const float* ga[2];
+    const float* gb[2];
+    int wo[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int row = (tid >> 2) + 64 * i;
+        long long r = rb + row, m = mb + row;
+        if (r >= a.R) r = a.R - 1;
+        if (m >= a.M) m = a.M - 1;
+        ga[i] = a.zr + r * a.ldz + 4 * q;
+        gb[i] = a.zc + m * a.ldz + 4 * q;
+        wo[i] = row * 4 + (q ^ ((row >> 2) & 2));
+    }
+    const float* pq = a.P + 4 * q;
+    // fragment reads: row 64 (wave half) + 16 c + i16, chunk g4
+    const int fo = i16 * 4 + (g4 ^ ((i16 >> 2) & 2));
+    const f32x4* fra = &tile[0][0][(wave >> 1) * 256 + fo];
+    const f32x4* frb = &tile[0][1][(wave & 1) * 256 + fo];
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    f32x4 sa[2], sbv[2], pn;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        sa[i] = *reinterpret_cast<const f32x4*>(ga[i]);
+        sbv[i] = *reinterpret_cast<const f32x4*>(gb[i]);
+    }
+    pn = *reinterpret_cast<const f32x4*>(pq);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        tile[0][0][wo[i]] = sa[i] * (2.0f * pn);  // the 2 P_d factor rides on the row operand
+        tile[0][1][wo[i]] = sbv[i];
+    }
+    __syncthreads();
+
     for (int ks = 0; ks < a.ksteps; ++ks) {
-        const f32x4 p2 = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 16 * ks + 4 * g4);
+        const int cur = ks & 1;
+        const bool more = ks + 1 < a.ksteps;
+        if (more) {  // a real (uniform) branch: keeps the loads up here, a whole stage ahead of the LDS stores below
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                sa[i] = *reinterpret_cast<const f32x4*>(ga[i] + 16 * (ks + 1));
+                sbv[i] = *reinterpret_cast<const f32x4*>(gb[i] + 16 * (ks + 1));
+            }
+            pn = *reinterpret_cast<const f32x4*>(pq + 16 * (ks + 1));
+        }
         f32x4 fa[4], fb[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            fa[c] = *reinterpret_cast<const f32x4*>(pa[c] + 16 * ks) * p2;
-            fb[c] = *reinterpret_cast<const f32x4*>(pb[c] + 16 * ks);
+            fa[c] = fra[cur * 1024 + c * 64];
+            fb[c] = frb[cur * 1024 + c * 64];
         }
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk)
@@ -109,7 +158,21 @@ __global__ __launch_bounds__(256) void cohort_gemm_kernel(const CohortGemmArgs a
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
                     acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
+        if (more) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                tile[cur ^ 1][0][wo[i]] = sa[i] * (2.0f * pn);
+                tile[cur ^ 1][1][wo[i]] = sbv[i];
+            }
+        }
+        __syncthreads();
     }
+
+    // Nothing is outstanding here (the last stage issues no loads), but hipcc's wait-count bookkeeping cannot prove
+    // that across the loop and otherwise protects the registers it recycles with vmcnt(0) BETWEEN the stores below,
+    // which on gfx9 also waits for every store issued so far: a store round trip per 64 output rows.  An explicit
+    // vmcnt(0) up front (free at run time) resets the bookkeeping.
+    __builtin_amdgcn_s_waitcnt(0x0F70);
     // epilogue: S rows are padded to a multiple of 4 floats (lds), so a 16-byte store that starts below M stays in its row
 #pragma unroll
     for (int ca = 0; ca < 4; ++ca) {
