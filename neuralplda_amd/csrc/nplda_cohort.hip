@@ -54,7 +54,10 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
     // of chunk g4 together with rows 4-11 of chunk g4 + 1; unswizzled, rows r and r + 4 share their four banks, with
     // the swizzle the 16 lanes of a group cover the 16 slots of the 256-byte bank row exactly once.  The stores
     // (8 consecutive lanes = 2 rows x 4 chunks = 128 contiguous bytes) are conflict-free under any in-row permutation.
-    __shared__ f32x4 tile[2][2][512];
+    // ONE __shared__ object: with a second one hipcc drains the memory counter before the first ds_read of every stage
+    __shared__ f32x4 smem[2 * 2 * 512 + 48];
+    f32x4 (*tile)[2][512] = reinterpret_cast<f32x4 (*)[2][512]>(smem);
+    f32x4* p2s = smem + 2048;  // 2 P_d, NB <= 12 k16-steps
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -93,22 +96,36 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
             qmv[cb][r] = a.qc[m < a.M ? m : a.M - 1];
         }
 
-    // staging: thread t moves chunk q = t & 3 of tile rows (t >> 2) and 64 + (t >> 2), of both operands
-    const int q = tid & 3;
+    // staging by LDS-DMA (global_load_lds_dwordx4: the destination is a wave-uniform LDS base + 16 * lane, so a wave
+    // instruction fills one 1 KB piece = 16 rows of a stage, and the swizzle is applied to the SOURCE address: lane l
+    // of piece pc fetches row 16 pc + (l >> 2), chunk (l & 3) ^ ((l >> 4) & 2)).  No staging registers, no ds_write
+    // pass, and the wait for the data moves from the middle of the stage to the barrier that ends it.  A stage is
+    // 8 + 8 pieces; wave w fills pieces 2 w and 2 w + 1 of both operands.
+    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 2);
     const float* ga[2];
     const float* gb[2];
-    int wo[2];
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const int row = (tid >> 2) + 64 * i;
+        const int row = 16 * (2 * wave + i) + srow;
         long long r = rb + row, m = mb + row;
         if (r >= a.R) r = a.R - 1;
         if (m >= a.M) m = a.M - 1;
-        ga[i] = a.zr + r * a.ldz + 4 * q;
-        gb[i] = a.zc + m * a.ldz + 4 * q;
-        wo[i] = row * 4 + (q ^ ((row >> 2) & 2));
+        ga[i] = a.zr + r * a.ldz + 4 * sq;
+        gb[i] = a.zc + m * a.ldz + 4 * sq;
     }
-    const float* pq = a.P + 4 * q;
+    auto stage_in = [&](int ks, int buf) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + 16 * ks),
+                                             (__attribute__((address_space(3))) void*)&tile[buf][0][64 * (2 * wave + i)],
+                                             16, 0, 0);
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + 16 * ks),
+                                             (__attribute__((address_space(3))) void*)&tile[buf][1][64 * (2 * wave + i)],
+                                             16, 0, 0);
+        }
+    };
+    // 2 P_d, read back per stage as the fragment-shaped float4 (k = 16 ks + 4 g4 ...): it rides on the row operand
+    if (tid < 4 * a.ksteps) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
     // fragment reads: row 64 (wave half) + 16 c + i16, chunk g4
     const int fo = i16 * 4 + (g4 ^ ((i16 >> 2) & 2));
     const f32x4* fra = &tile[0][0][(wave >> 1) * 256 + fo];
@@ -120,35 +137,17 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    f32x4 sa[2], sbv[2], pn;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        sa[i] = *reinterpret_cast<const f32x4*>(ga[i]);
-        sbv[i] = *reinterpret_cast<const f32x4*>(gb[i]);
-    }
-    pn = *reinterpret_cast<const f32x4*>(pq);
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        tile[0][0][wo[i]] = sa[i] * (2.0f * pn);  // the 2 P_d factor rides on the row operand
-        tile[0][1][wo[i]] = sbv[i];
-    }
-    __syncthreads();
+    stage_in(0, 0);
+    __syncthreads();  // hipcc drains the memory counter (the DMA is a pending LDS write) before the barrier
 
     for (int ks = 0; ks < a.ksteps; ++ks) {
         const int cur = ks & 1;
-        const bool more = ks + 1 < a.ksteps;
-        if (more) {  // a real (uniform) branch: keeps the loads up here, a whole stage ahead of the LDS stores below
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                sa[i] = *reinterpret_cast<const f32x4*>(ga[i] + 16 * (ks + 1));
-                sbv[i] = *reinterpret_cast<const f32x4*>(gb[i] + 16 * (ks + 1));
-            }
-            pn = *reinterpret_cast<const f32x4*>(pq + 16 * (ks + 1));
-        }
+        if (ks + 1 < a.ksteps) stage_in(ks + 1, cur ^ 1);
         f32x4 fa[4], fb[4];
+        const f32x4 pf = p2s[4 * ks + g4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            fa[c] = fra[cur * 1024 + c * 64];
+            fa[c] = fra[cur * 1024 + c * 64] * pf;
             fb[c] = frb[cur * 1024 + c * 64];
         }
 #pragma unroll
@@ -158,14 +157,12 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb)
                     acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
-        if (more) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                tile[cur ^ 1][0][wo[i]] = sa[i] * (2.0f * pn);
-                tile[cur ^ 1][1][wo[i]] = sbv[i];
-            }
-        }
-        __syncthreads();
+        // end of stage: this wave's pieces of the next stage have landed (vmcnt), then everybody's (barrier).  Raw
+        // builtins pinned behind the MFMAs: __syncthreads() may legally be hoisted above them (they touch no
+        // memory), which puts the wait for the DMA right after its issue.
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0F70);
+        __builtin_amdgcn_s_barrier();
     }
 
     // Nothing is outstanding here (the last stage issues no loads), but hipcc's wait-count bookkeeping cannot prove
