@@ -140,7 +140,9 @@ int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int6
 
 /* ---- adaptive score normalisation (utils/adaptive_score_normalization.py:27-73) ------------------ */
 
-/* Bytes of workspace for the spilled cohort score matrix (whole matrix up to 4 GiB, else row chunks). */
+/* Bytes of workspace: a 256-byte control block (tile counters of the score GEMM) followed by the spilled
+ * cohort score matrix (whole matrix up to 4 GiB, else row chunks).  Any ws_bytes >= 256 + one padded score
+ * row (4 * ceil(M / 4) * 4 bytes) is accepted by nplda_cohort_stats_f32; less gives NPLDA_ENOSPC. */
 size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M);
 
 /* Cohort score matrix + per-row statistics.  z_rows (R, ldz) / q_rows (R) and z_coh (M, ldz) / q_coh (M)

@@ -38,81 +38,88 @@ struct CohortGemmArgs {
     int ksteps;        // k16-steps = padded D2 / 16
     int nxp;           // column tiles per XCD band = min(ceil(ceil(M / 128) / 8), 24)
     int ny;            // row tiles = ceil(R / 128)
+    int nx, nsb;       // column tiles = ceil(M / 128); super-bands of 8 bands
+    unsigned* ctr;     // 8 tile counters (one per XCD), zero at launch
     float* S;
 };
 
 __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArgs a) {
-    // Both operands go through LDS in k16 stages (128 rows x 64 B each, two buffers, 32 KB).  Reading the MFMA
+    // Block tile 128 x 128 = 2 x 2 waves of 64 x 64, K = 16 * ksteps.
+    //
+    // Operands.  Both go through LDS in k16 stages (128 rows x 64 B each, two buffers, 32 KB).  Reading the MFMA
     // fragments straight from the row-major tables (lane i16 + 16 g4 <- row i16, 16-byte chunk g4) hands the texture
     // addresser 64 different 16-byte pieces per wave instruction in lane order, and with 8 such loads per 64 MFMAs the
-    // address path, not the matrix pipe, set the pace (0.66 of the MFMA rate in the k loop).  Staged, four consecutive
-    // lanes fetch one row's 64 contiguous bytes, each element is fetched once per block instead of once per wave, and the
-    // fragments come from LDS by ds_read_b128.
+    // address path, not the matrix pipe, set the pace.  Staged, four consecutive lanes fetch one row's 64 contiguous
+    // bytes, each element is fetched once per block instead of once per wave, and the fragments come from LDS by
+    // ds_read_b128.  The stages are filled by LDS-DMA (global_load_lds_dwordx4: the destination is a wave-uniform LDS
+    // base + 16 * lane, so one wave instruction fills a 1 KB piece = 16 rows, and the swizzle below is applied to the
+    // SOURCE address): no staging registers, no ds_write pass, and the wait for the data sits at the barrier that ends
+    // the stage, a whole stage of MFMAs after the issue.  A stage is 8 + 8 pieces; wave w fills pieces 2 w, 2 w + 1
+    // of both operands.
     //
     // LDS image of a stage: row-major, 4 chunks of 16 B per row, chunk c of row r stored at chunk c ^ ((r >> 2) & 2).
     // ds_read_b128 serves the lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} (and the same + 32): rows 0-3 and 12-15
     // of chunk g4 together with rows 4-11 of chunk g4 + 1; unswizzled, rows r and r + 4 share their four banks, with
-    // the swizzle the 16 lanes of a group cover the 16 slots of the 256-byte bank row exactly once.  The stores
-    // (8 consecutive lanes = 2 rows x 4 chunks = 128 contiguous bytes) are conflict-free under any in-row permutation.
-    // ONE __shared__ object: with a second one hipcc drains the memory counter before the first ds_read of every stage
-    __shared__ f32x4 smem[2 * 2 * 512 + 48];
+    // the swizzle the 16 lanes of a group cover the 16 slots of the 256-byte bank row exactly once (SQ_LDS_BANK_CONFLICT
+    // = 0 measured).
+    //
+    // Tiles.  Persistent blocks: identical tiles keep the blocks that share a CU in lockstep, so with one tile per
+    // block their prologues (first stage in flight, nothing to multiply), epilogues and the relaunch all fell
+    // together.  Here a block walks tiles and, during the LAST stage of a tile, already fetches the first stage and the
+    // self terms of the next one; the stores of a tile drain under the next tile's MFMAs.  Tiles are handed out by a
+    // per-XCD counter (one returning atomic per tile, requested a tile ahead): the matrix pipe serves the blocks of a
+    // CU unevenly (lifetimes of 580 ... 730 us were measured for equal static shares), and with static shares the
+    // kernel ended with one block per CU finishing alone.
+    //
+    // XCD-aware tile order: workgroup b is dispatched to XCD b % 8 (observed; speed only, nothing depends on it), so
+    // XCD x owns the band of nxp consecutive column tiles [x nxp, (x + 1) nxp) for every row tile.  Its slice of the
+    // cohort table (nxp * 128 rows, < 1 MB at cfg3) then stays in that XCD's 4 MB L2 while the row table streams
+    // through once per XCD; with a plain 2-D grid every XCD cycled through the whole cohort table (7 MB) once per
+    // wave of resident blocks.  Bands are capped at 24 tiles (2.3 MB of a 192-wide table); a wider cohort is covered
+    // by several super-bands of 8 bands, one after the other.  The grid is a multiple of 8, so a block keeps its XCD.
+    //
+    // ONE __shared__ object: with a second one hipcc drains the memory counter before the first ds_read of every stage.
+    __shared__ f32x4 smem[2 * 2 * 512 + 48 + 128 + 1];
     f32x4 (*tile)[2][512] = reinterpret_cast<f32x4 (*)[2][512]>(smem);
-    f32x4* p2s = smem + 2048;  // 2 P_d, NB <= 12 k16-steps
+    f32x4* p2s = smem + 2048;                             // 2 P_d as fragment-shaped float4, NB <= 12 k16-steps
+    float* qs = reinterpret_cast<float*>(smem + 2096);    // self terms [tile parity][q_r 128 | q_m 128]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
-    // block tile 128 x 128 = 2 x 2 waves of 64 x 64.  XCD-aware tile order: workgroup b is dispatched to XCD b % 8
-    // (observed; speed only, nothing depends on it), so XCD x owns the band of nxp consecutive column tiles
-    // [x nxp, (x + 1) nxp) for every row tile.  Its slice of the cohort table (nxp * 128 rows, < 1 MB) then stays in that
-    // XCD's 4 MB L2 while the row table streams through once per XCD; with the plain 2-D grid every XCD cycled through
-    // the whole cohort table (7 MB at cfg3) once per wave of resident blocks.  Bands are capped at 24 tiles (2.3 MB of
-    // a 192-wide table); a wider cohort is covered by several super-bands of 8 bands, one after the other.
-    const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
-    const int per_sb = a.nxp * a.ny;
-    const int sb = slot / per_sb, rem = slot - sb * per_sb;
-    const int ty = rem / a.nxp, tx = (sb * 8 + xcd) * a.nxp + (rem - ty * a.nxp);
-    const long long rb = (long long)ty * 128, mb = (long long)tx * 128;
-    if (rb >= a.R || mb >= a.M) return;  // whole block (uniform): no barrier is skipped
-    const long long r0 = rb + (wave >> 1) * 64;
-    const long long m0 = mb + (wave & 1) * 64;
-
-    // The MFMAs below take the cohort fragment as the A operand, so the lane (i16, g4) of block (ca, cb) ends up with
-    // row r0 + 16 ca + i16 and the FOUR CONSECUTIVE columns m0 + 16 cb + 4 g4 + r: one 16-byte store per block instead
-    // of four 4-byte ones (the epilogue is store-issue bound).  The self terms of those 4 rows and 16 columns are
-    // fetched first so that their latency hides under the k loop (and every later vmcnt wait covers them: the
-    // epilogue stores must not wait on the memory counter, see below).
-    float qrv[4];
-    f32x4 qmv[4];
-#pragma unroll
-    for (int ca = 0; ca < 4; ++ca) {
-        const long long row = r0 + 16 * ca + i16;
-        qrv[ca] = a.qr[row < a.R ? row : a.R - 1];
-    }
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const long long m = m0 + 16 * cb + 4 * g4 + r;
-            qmv[cb][r] = a.qc[m < a.M ? m : a.M - 1];
+    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    // tile `slot` of this XCD: super-band by super-band, row tile by row tile, the band's column tiles innermost
+    auto decode = [&](int slot, long long& rb, long long& mb) {
+        for (int sb = 0; sb < a.nsb; ++sb) {
+            const int tx0 = (sb * 8 + xcd) * a.nxp;
+            int w = a.nx - tx0;
+            if (w > a.nxp) w = a.nxp;
+            if (w <= 0) break;
+            if (slot < w * a.ny) {
+                const int ty = slot / w;
+                rb = (long long)ty * 128;
+                mb = (long long)(tx0 + slot - ty * w) * 128;
+                return true;
+            }
+            slot -= w * a.ny;
         }
+        return false;
+    };
 
-    // staging by LDS-DMA (global_load_lds_dwordx4: the destination is a wave-uniform LDS base + 16 * lane, so a wave
-    // instruction fills one 1 KB piece = 16 rows of a stage, and the swizzle is applied to the SOURCE address: lane l
-    // of piece pc fetches row 16 pc + (l >> 2), chunk (l & 3) ^ ((l >> 4) & 2)).  No staging registers, no ds_write
-    // pass, and the wait for the data moves from the middle of the stage to the barrier that ends it.  A stage is
-    // 8 + 8 pieces; wave w fills pieces 2 w and 2 w + 1 of both operands.
+    // staging: lane l of piece pc fetches row 16 pc + (l >> 2), chunk (l & 3) ^ ((l >> 4) & 2)
     const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 2);
     const float* ga[2];
     const float* gb[2];
+    auto set_ptrs = [&](long long rb, long long mb) {
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        const int row = 16 * (2 * wave + i) + srow;
-        long long r = rb + row, m = mb + row;
-        if (r >= a.R) r = a.R - 1;
-        if (m >= a.M) m = a.M - 1;
-        ga[i] = a.zr + r * a.ldz + 4 * sq;
-        gb[i] = a.zc + m * a.ldz + 4 * sq;
-    }
+        for (int i = 0; i < 2; ++i) {
+            const int row = 16 * (2 * wave + i) + srow;
+            long long r = rb + row, m = mb + row;
+            if (r >= a.R) r = a.R - 1;
+            if (m >= a.M) m = a.M - 1;
+            ga[i] = a.zr + r * a.ldz + 4 * sq;
+            gb[i] = a.zc + m * a.ldz + 4 * sq;
+        }
+    };
     auto stage_in = [&](int ks, int buf) {
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
@@ -124,62 +131,114 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
                                              16, 0, 0);
         }
     };
-    // 2 P_d, read back per stage as the fragment-shaped float4 (k = 16 ks + 4 g4 ...): it rides on the row operand
+    auto q_in = [&](long long rb, long long mb, int par) {  // waves 0, 1: q_r of the 128 rows; waves 2, 3: q_m of the 128 columns
+        const bool isr = wave < 2;
+        long long j = (isr ? rb : mb) + 64 * (wave & 1) + lane;
+        const long long lim = isr ? a.R : a.M;
+        if (j >= lim) j = lim - 1;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((isr ? a.qr : a.qc) + j),
+                                         (__attribute__((address_space(3))) void*)&qs[par * 256 + 64 * wave], 4, 0, 0);
+    };
+
+    long long rb, mb, nrb = 0, nmb = 0;
+    if (!decode(blockIdx.x >> 3, rb, mb)) return;  // the first tile is static; whole block (uniform)
+    unsigned* nxt_s = reinterpret_cast<unsigned*>(smem + 2224);  // the next tile's slot, wave 0 -> everybody
     if (tid < 4 * a.ksteps) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
     // fragment reads: row 64 (wave half) + 16 c + i16, chunk g4
     const int fo = i16 * 4 + (g4 ^ ((i16 >> 2) & 2));
     const f32x4* fra = &tile[0][0][(wave >> 1) * 256 + fo];
     const f32x4* frb = &tile[0][1][(wave & 1) * 256 + fo];
 
-    f32x4 acc[4][4];
-#pragma unroll
-    for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
+    set_ptrs(rb, mb);
     stage_in(0, 0);
+    q_in(rb, mb, 0);
     __syncthreads();  // hipcc drains the memory counter (the DMA is a pending LDS write) before the barrier
+    int gpar = 0, qpar = 0;
 
-    for (int ks = 0; ks < a.ksteps; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < a.ksteps) stage_in(ks + 1, cur ^ 1);
-        f32x4 fa[4], fb[4];
-        const f32x4 pf = p2s[4 * ks + g4];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-            fa[c] = fra[cur * 1024 + c * 64] * pf;
-            fb[c] = frb[cur * 1024 + c * 64];
+    for (;;) {
+        // ask for the tile after this one; the answer is published at the end of the first stage, used in the last
+        unsigned pend = 0;
+        if (tid == 0) pend = atomicAdd(a.ctr + xcd, 1u);
+        if (a.ksteps == 1) {
+            if (tid == 0) *nxt_s = pend;
+            __syncthreads();
         }
+        bool have_next = false;
+        f32x4 acc[4][4];
 #pragma unroll
-        for (int kk = 0; kk < 4; ++kk)
+        for (int ca = 0; ca < 4; ++ca)
 #pragma unroll
-            for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-                for (int cb = 0; cb < 4; ++cb)
-                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
-        // end of stage: this wave's pieces of the next stage have landed (vmcnt), then everybody's (barrier).  Raw
-        // builtins pinned behind the MFMAs: __syncthreads() may legally be hoisted above them (they touch no
-        // memory), which puts the wait for the DMA right after its issue.
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_waitcnt(0x0F70);
-        __builtin_amdgcn_s_barrier();
-    }
+            for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-    // Nothing is outstanding here (the last stage issues no loads), but hipcc's wait-count bookkeeping cannot prove
-    // that across the loop and otherwise protects the registers it recycles with vmcnt(0) BETWEEN the stores below,
-    // which on gfx9 also waits for every store issued so far: a store round trip per 64 output rows.  An explicit
-    // vmcnt(0) up front (free at run time) resets the bookkeeping.
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    // epilogue: S rows are padded to a multiple of 4 floats (lds), so a 16-byte store that starts below M stays in its row
+        for (int ks = 0; ks < a.ksteps; ++ks) {
+            const int cur = gpar;
+            if (ks + 1 < a.ksteps) {
+                stage_in(ks + 1, cur ^ 1);
+            } else {  // last stage: the next tile's first stage and self terms
+                const int nslot = stride + __builtin_amdgcn_readfirstlane((int)*nxt_s);
+                have_next = decode(nslot, nrb, nmb);
+                if (have_next) {
+                    set_ptrs(nrb, nmb);
+                    stage_in(0, cur ^ 1);
+                    q_in(nrb, nmb, qpar ^ 1);
+                }
+            }
+            f32x4 fa[4], fb[4];
+            const f32x4 pf = p2s[4 * ks + g4];
 #pragma unroll
-    for (int ca = 0; ca < 4; ++ca) {
-        const long long row = r0 + 16 * ca + i16;
-        if (row >= a.R) continue;
-        float* srow = a.S + row * a.lds + m0 + 4 * g4;
+            for (int c = 0; c < 4; ++c) {
+                fa[c] = fra[cur * 1024 + c * 64] * pf;  // the 2 P_d factor rides on the row operand
+                fb[c] = frb[cur * 1024 + c * 64];
+            }
+            // the cohort fragment is the A operand, so the lane (i16, g4) of block (ca, cb) ends up with row
+            // 16 ca + i16 and the FOUR CONSECUTIVE columns 16 cb + 4 g4 + r: 16-byte stores in the epilogue
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb)
-            if (m0 + 16 * cb + 4 * g4 < a.M)
-                *reinterpret_cast<f32x4*>(srow + 16 * cb) = acc[ca][cb] + (qmv[cb] + qrv[ca]);
+            for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                    for (int cb = 0; cb < 4; ++cb)
+                        acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
+            // end of stage: this wave's pieces of the next stage have landed (vmcnt), then everybody's (barrier).  Raw
+            // builtins pinned behind the MFMAs: __syncthreads() may legally be hoisted above them (they touch no
+            // memory), which puts the wait for the DMA right after its issue.
+            __builtin_amdgcn_sched_barrier(0);
+            __builtin_amdgcn_s_waitcnt(0x0F70);
+            if (ks == 0 && a.ksteps > 1) {
+                if (tid == 0) *nxt_s = pend;
+                __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): the LDS store is done before the barrier releases
+            }
+            __builtin_amdgcn_s_barrier();
+            gpar ^= 1;
+        }
+
+        // epilogue: S rows are padded to a multiple of 4 floats (lds), so a 16-byte store that starts below M stays in
+        // its row.  (On gfx9 the stores sit on the same counter as the loads: nothing here may wait on it, or every
+        // group of stores would pay a store round trip; the stage-end wait above keeps hipcc's bookkeeping clean.)
+        const long long r0 = rb + (wave >> 1) * 64;
+        const long long m0 = mb + (wave & 1) * 64;
+        const float* qr_s = qs + qpar * 256 + (wave >> 1) * 64 + i16;
+        const float* qm_s = qs + qpar * 256 + 128 + (wave & 1) * 64 + 4 * g4;
+        f32x4 qmv[4];
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) qmv[cb] = *reinterpret_cast<const f32x4*>(qm_s + 16 * cb);
+#pragma unroll
+        for (int ca = 0; ca < 4; ++ca) {
+            const long long row = r0 + 16 * ca + i16;
+            const float qrv = qr_s[16 * ca];
+            if (row >= a.R) continue;
+            float* srow = a.S + row * a.lds + m0 + 4 * g4;
+#pragma unroll
+            for (int cb = 0; cb < 4; ++cb)
+                if (m0 + 16 * cb + 4 * g4 < a.M)
+                    *reinterpret_cast<f32x4*>(srow + 16 * cb) = acc[ca][cb] + (qmv[cb] + qrv);
+        }
+        if (!have_next) break;
+        // with a single stage per tile the self-term buffer of this parity is refilled during the very next stage
+        if (a.ksteps == 1) __syncthreads();
+        rb = nrb;
+        mb = nmb;
+        qpar ^= 1;
     }
 }
 
@@ -453,6 +512,9 @@ __global__ __launch_bounds__(256) void asnorm_apply_kernel(const double* __restr
 
 extern "C" {
 
+// the workspace starts with the tile counters of the GEMM (one per XCD), the spilled score rows follow
+static constexpr size_t kCohortCtlBytes = 256;
+
 size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
     if (R <= 0 || M <= 0) return 0;
     // whole matrix if it is below 4 GiB, else row chunks of at least 128 rows
@@ -464,7 +526,7 @@ size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
         if (rows < 128) rows = 128;
         rows = rows / 128 * 128;
     }
-    return (size_t)(rows * row);
+    return (size_t)(rows * row) + kCohortCtlBytes;
 }
 
 int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
@@ -483,8 +545,8 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
         return NPLDA_EINVAL;
     const long long lds = (M + 3) / 4 * 4;
     const size_t row_bytes = (size_t)lds * sizeof(float);
-    long long rows_per = (long long)(ws_bytes / row_bytes);
-    if (rows_per < 1) return NPLDA_ENOSPC;
+    if (ws_bytes < kCohortCtlBytes + row_bytes) return NPLDA_ENOSPC;
+    long long rows_per = (long long)((ws_bytes - kCohortCtlBytes) / row_bytes);
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
@@ -494,19 +556,36 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
                                            (int)shmem);
         if (e != hipSuccess) return (int)e;
     }
+    // persistent tile walkers: as many blocks as are resident at once, a multiple of 8 so that a block keeps its XCD
+    long long resident = 0;
+    {
+        int dev = 0, cus = 0, per_cu = 0;
+        if (hipGetDevice(&dev) != hipSuccess ||
+            hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_gemm_kernel, 256, 0) != hipSuccess)
+            return NPLDA_EINVAL;
+        resident = (long long)cus * per_cu / 8 * 8;
+        if (resident < 8) resident = 8;
+    }
     for (long long r0 = 0; r0 < R; r0 += rows_per) {
         const long long rc = (R - r0 < rows_per) ? R - r0 : rows_per;
         CohortGemmArgs a;
         a.zr = z_rows + r0 * ldz; a.qr = q_rows + r0; a.zc = z_coh; a.qc = q_coh;
-        a.P = (const float*)packed + L.oP; a.R = rc; a.M = M; a.ldz = ldz; a.lds = lds; a.ksteps = L.NB; a.S = (float*)ws;
+        a.P = (const float*)packed + L.oP; a.R = rc; a.M = M; a.ldz = ldz; a.lds = lds; a.ksteps = L.NB; a.S = (float*)((char*)ws + kCohortCtlBytes);
         const long long nx = (M + 127) / 128, ny = (rc + 127) / 128;
         a.nxp = (int)((nx + 7) / 8 < 24 ? (nx + 7) / 8 : 24);
         a.ny = (int)ny;
         const long long nsb = (nx + 8LL * a.nxp - 1) / (8LL * a.nxp);
-        if (8LL * a.nxp * ny * nsb > 0x7fffffffLL) return NPLDA_EINVAL;
-        hipLaunchKernelGGL(cohort_gemm_kernel, dim3((unsigned)(8LL * a.nxp * ny * nsb)), dim3(256), 0, st, a);
+        if (nx > 0x00ffffffLL || ny > 0x00ffffffLL || (long long)a.nxp * ny * nsb > 0x0fffffffLL) return NPLDA_EINVAL;
+        a.nx = (int)nx;
+        a.nsb = (int)nsb;
+        a.ctr = (unsigned*)ws;
+        long long grid = 8LL * a.nxp * ny;  // at most one block per tile of the busiest XCD
+        if (grid > resident) grid = resident;
+        if (hipMemsetAsync(ws, 0, kCohortCtlBytes, st) != hipSuccess) return NPLDA_EINVAL;
+        hipLaunchKernelGGL(cohort_gemm_kernel, dim3((unsigned)grid), dim3(256), 0, st, a);
         if (int rc2 = nplda_launch_status()) return rc2;
-        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)rc), dim3(kRowThreads), shmem, st, (const float*)ws,
+        hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)rc), dim3(kRowThreads), shmem, st, (const float*)((const char*)ws + kCohortCtlBytes),
                            (long long)lds, (long long)M, topn, select_lowest ? 1 : 0, use_lds, stats + 4 * r0);
         if (int rc2 = nplda_launch_status()) return rc2;
     }

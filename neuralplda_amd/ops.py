@@ -333,7 +333,7 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
         return stats
     wsb = lib.nplda_cohort_workspace_bytes(R, M)
     if max_ws_bytes is not None:
-        wsb = max(min(wsb, int(max_ws_bytes)), ((M + 3) // 4 * 4) * 4)
+        wsb = max(min(wsb, int(max_ws_bytes)), 256 + ((M + 3) // 4 * 4) * 4)  # control block + one score row
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),
