@@ -271,35 +271,97 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
     return s;
 }
 
-// keys live in LDS when the row fits (use_lds), else they are re-read from global every pass
+// two fp64 block sums with one pair of barriers
+__device__ __forceinline__ void block_sum_d2(double& a, double& b, double* red) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+        a += __shfl_xor(a, m, 64);
+        b += __shfl_xor(b, m, 64);
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
+    __syncthreads();
+    a = b = 0.0;
+#pragma unroll
+    for (int w = 0; w < kRowThreads / 64; ++w) { a += red[2 * w]; b += red[2 * w + 1]; }
+}
+
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// The row is handled in 16-byte groups (S rows are 16-byte aligned and padded to a multiple of 4 floats): the keys of
+// group g are keys4[g]; elements past M carry the key 0xffffffff, which no pivot reaches (pivots are capped at
+// 0xfffffffe; only a NaN with the payload 0x7fffffff maps there, and a row holding one has NaN statistics anyway).
+// Keys live in LDS when the row fits (use_lds), else they are rebuilt from global memory every pass.
+__device__ __forceinline__ u32x4 row_keys(const f32x4 v, long long g, long long M, int lowest) {
+    u32x4 k;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned x = f2key(v[e]);
+        if (!lowest) x = ~x;  // N largest == N smallest of the reversed order
+        k[e] = (4 * g + e < M) ? x : 0xffffffffu;
+    }
+    return k;
+}
+
+template <class F>
+__device__ __forceinline__ void for_row_keys(int use_lds, const u32x4* keys4, const f32x4* src4, long long nvec,
+                                             long long M, int lowest, F f) {
+    if (use_lds) {
+        for (long long g = threadIdx.x; g < nvec; g += kRowThreads) f(keys4[g]);
+    } else {
+        for (long long g = threadIdx.x; g < nvec; g += kRowThreads) f(row_keys(src4[g], g, M, lowest));
+    }
+}
+
 __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __restrict__ S, long long lds_stride,
                                                                 long long M, int topn, int lowest, int use_lds,
                                                                 double* __restrict__ stats) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
     unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);                  // [M] when use_lds
+    u32x4* keys4 = reinterpret_cast<u32x4*>(smem_raw);
     unsigned* cnt = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                  // [2][8][4] count partials
-    double* red = reinterpret_cast<double*>(cnt + 64);                         // [8]
+    double* red = reinterpret_cast<double*>(cnt + 64);                         // [2][8]
     constexpr int NWV = kRowThreads / 64;
 
     const long long row = blockIdx.x;
-    const float* src = S + row * lds_stride;
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(S + row * lds_stride);
+    const long long nvec = (M + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // pass 0: load, full-row sums, key range
+    // pass 0: load, full-row sums, key range.  Batches of U independent 16-byte loads per thread (clamped index, so
+    // that no load sits behind a branch): with one 4-byte load per iteration the compiler waited out every load before
+    // issuing the next, ~20 memory round trips per row.
     double s1 = 0.0, s2 = 0.0;
     unsigned kmin = 0xffffffffu, kmax = 0u;
-    for (long long i = tid; i < M; i += kRowThreads) {
-        const float v = src[i];
-        unsigned k = f2key(v);
-        if (!lowest) k = ~k;  // N largest == N smallest of the reversed order
-        if (use_lds) keys[i] = k;
-        kmin = k < kmin ? k : kmin;
-        kmax = k > kmax ? k : kmax;
-        s1 += (double)v;
-        s2 += (double)v * (double)v;
+    constexpr int U = 5;
+    for (long long base = tid; base < nvec; base += (long long)kRowThreads * U) {
+        f32x4 v[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long g = base + (long long)kRowThreads * u;
+            v[u] = src4[g < nvec ? g : nvec - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const long long g = base + (long long)kRowThreads * u;
+            if (g < nvec) {
+                const u32x4 k = row_keys(v[u], g, M, lowest);
+                if (use_lds) keys4[g] = k;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    if (4 * g + e < M) {
+                        kmin = k[e] < kmin ? k[e] : kmin;
+                        kmax = k[e] > kmax ? k[e] : kmax;
+                        const double d = (double)v[u][e];
+                        s1 += d;
+                        s2 += d * d;
+                    }
+                }
+            }
+        }
     }
-    s1 = block_sum_d(s1, red);
-    s2 = block_sum_d(s2, red);
+    block_sum_d2(s1, s2, red);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         const unsigned a = __shfl_xor(kmin, m, 64), b = __shfl_xor(kmax, m, 64);
@@ -314,6 +376,8 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
         hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
     }
+    if (hi > 0xfffffffeu) hi = 0xfffffffeu;
+    if (lo > hi) lo = hi;
     __syncthreads();
     const double n = (double)M;
     const double mean = s1 / n;
@@ -333,7 +397,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
     if (use_lds && M >= 64 && var > 0.0) {
-        unsigned* list = cnt + 64 + 2 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
+        unsigned* list = cnt + 64 + 4 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
         float* sel = reinterpret_cast<float*>(list + kListCap);
         unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
         const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
@@ -342,12 +406,15 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         const float fa = (float)(t0 - 0.08 * sd), fb = (float)(t0 + 0.08 * sd);
         unsigned ka = f2key(fa), kb = f2key(fb);
         if (!lowest) { const unsigned t = ~ka; ka = ~kb; kb = t; }
+        if (kb > 0xfffffffeu) kb = 0xfffffffeu;
         unsigned ca = 0, cb2 = 0;
-        for (long long i = tid; i < M; i += kRowThreads) {
-            const unsigned k = keys[i];
-            ca += k < ka;
-            cb2 += k <= kb;
-        }
+        for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                ca += k[e] < ka;
+                cb2 += k[e] <= kb;
+            }
+        });
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             ca += __shfl_xor(ca, m, 64);
@@ -364,26 +431,54 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             lo = ka; hi = kb;  // a valid (much narrower) bracket for the general search, should the list be too long
             if (cb2 - ca <= (unsigned)kListCap) {
                 // collect the bracket's keys; sum everything strictly below it
-                for (long long i = tid; i < M; i += kRowThreads) {
-                    const unsigned k = keys[i];
-                    if (k < ka) {
-                        const double v = (double)key2f(lowest ? k : ~k);
-                        t1 += v;
-                        t2 += v * v;
-                    } else if (k <= kb) {
-                        list[atomicAdd(nlist, 1u)] = k;
+                for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k4) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const unsigned k = k4[e];
+                        if (k < ka) {
+                            const double v = (double)key2f(lowest ? k : ~k);
+                            t1 += v;
+                            t2 += v * v;
+                        } else if (k <= kb) {
+                            list[atomicAdd(nlist, 1u)] = k;
+                        }
                     }
-                }
+                });
                 __syncthreads();
                 const unsigned L = *nlist, need = want - ca;
-                for (unsigned i = tid; i < L; i += kRowThreads) {
+                const unsigned L4 = (L + 3) / 4 * 4;
+                if (tid < L4 - L) list[L + tid] = 0xffffffffu;  // pad to whole 16-byte groups (above every candidate)
+                __syncthreads();
+                // rank by counting, the list read 16 bytes at a time; `split` threads share one candidate when the
+                // candidates are few enough (the usual case: ~170 at N / M = 0.05 -> 2), their partial ranks meet in rk
+                const unsigned sh = (L * 4 <= (unsigned)kRowThreads) ? 2u : (L * 2 <= (unsigned)kRowThreads) ? 1u : 0u;
+                const unsigned split = 1u << sh;
+                unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // L <= 256 here: clear of the rank slots
+                if (sh) {
+                    for (unsigned i = tid; i < L; i += kRowThreads) rk[i] = 0u;
+                    __syncthreads();
+                }
+                for (unsigned t = tid; t < L * split; t += kRowThreads) {
+                    const unsigned i = t >> sh, part = t & (split - 1u);
                     const unsigned k = list[i];
+                    const unsigned ng = L4 / 4;
+                    const unsigned g0 = part * ng / split, g1 = (part + 1) * ng / split;
                     unsigned rank = 0;
-                    for (unsigned jx = 0; jx < L; ++jx) {
-                        const unsigned kj = list[jx];
-                        rank += (kj < k) || (kj == k && jx < i);
+                    const u32x4* list4 = reinterpret_cast<const u32x4*>(list);
+                    for (unsigned gx = g0; gx < g1; ++gx) {
+                        const u32x4 kj = list4[gx];
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) rank += (kj[e] < k) || (kj[e] == k && 4 * gx + e < i);
                     }
-                    sel[rank] = key2f(lowest ? k : ~k);
+                    if (sh) atomicAdd(rk + i, rank);
+                    else sel[rank] = key2f(lowest ? k : ~k);
+                }
+                if (sh) {
+                    __syncthreads();
+                    if ((unsigned)tid < L) {
+                        const unsigned k = list[tid];
+                        sel[rk[tid]] = key2f(lowest ? k : ~k);
+                    }
                 }
                 __syncthreads();
                 double u1 = 0.0, u2 = 0.0;
@@ -392,8 +487,9 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                     u1 += v;
                     u2 += v * v;
                 }
-                t1 = block_sum_d(t1 + u1, red);
-                t2 = block_sum_d(t2 + u2, red);
+                t1 += u1;
+                t2 += u2;
+                block_sum_d2(t1, t2, red);
                 done = true;
             }
         }
@@ -420,14 +516,14 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         const unsigned long long span = (unsigned long long)hi - lo;
         const unsigned p1 = lo + (unsigned)(span / 4), p2 = lo + (unsigned)(span / 2), p3 = lo + (unsigned)(span / 4 * 3);
         unsigned c1 = 0, c2 = 0, c3 = 0;
-        for (long long i = tid; i < M; i += kRowThreads) {
-            unsigned k;
-            if (use_lds) k = keys[i];
-            else { k = f2key(src[i]); if (!lowest) k = ~k; }
-            c1 += k <= p1;
-            c2 += k <= p2;
-            c3 += k <= p3;
-        }
+        for_row_keys(use_lds, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                c1 += k[e] <= p1;
+                c2 += k[e] <= p2;
+                c3 += k[e] <= p3;
+            }
+        });
 #pragma unroll
         for (int m = 32; m >= 1; m >>= 1) {
             c1 += __shfl_xor(c1, m, 64);
@@ -451,19 +547,19 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // selected sums: everything strictly below tkey, plus (N - #less) copies of the threshold value (ties)
     double nless = 0.0;
     t1 = t2 = 0.0;
-    for (long long i = tid; i < M; i += kRowThreads) {
-        unsigned k;
-        if (use_lds) k = keys[i];
-        else { k = f2key(src[i]); if (!lowest) k = ~k; }
-        if (k < tkey) {
-            const double v = (double)key2f(lowest ? k : ~k);
-            t1 += v;
-            t2 += v * v;
-            nless += 1.0;
+    for_row_keys(use_lds, keys4, src4, nvec, M, lowest, [&](const u32x4 k4) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const unsigned k = k4[e];
+            if (k < tkey) {
+                const double v = (double)key2f(lowest ? k : ~k);
+                t1 += v;
+                t2 += v * v;
+                nless += 1.0;
+            }
         }
-    }
-    t1 = block_sum_d(t1, red);
-    t2 = block_sum_d(t2, red);
+    });
+    block_sum_d2(t1, t2, red);
     nless = block_sum_d(nless, red);
     if (tid == 0) {
         const double ties_taken = (double)N - nless;
@@ -550,7 +646,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 16 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -598,7 +694,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 8 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 16 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
