@@ -179,6 +179,31 @@ def main():
     if not np.isfinite(checksum):
         raise SystemExit("non-finite scores")
 
+    # Untimed extra pass: the shader clock the chip holds under this kernel.  A one-wave probe (nplda_clock_probe) sits
+    # on a side stream next to 12 more launches and compares the shader-cycle counter with the constant 100 MHz counter.
+    sclk_mhz = None
+    if rank == 0:
+        try:
+            from neuralplda_amd import _lib
+            lib = _lib.load()
+            ticks = torch.zeros(2, dtype=torch.int64, device=dev)
+            side = torch.cuda.Stream(device=dev)
+            reps = 12
+            torch.cuda.synchronize()
+            for _ in range(2):
+                s = step()
+            with torch.cuda.stream(side):
+                code = lib.nplda_clock_probe(_lib.ptr(ticks), max(int(kern_ms * 1e3 * (reps - 4)), 100), _lib.current_stream())
+            _lib.check(code, "nplda_clock_probe")
+            for _ in range(reps):
+                s = step()
+            torch.cuda.synchronize()
+            tk = ticks.cpu().numpy()
+            if tk[1] > 0:
+                sclk_mhz = 100.0 * float(tk[0]) / float(tk[1])
+        except Exception as e:  # the probe is reporting only
+            sys.stderr.write(f"clock probe skipped: {e}\n")
+
     alt = None
     if rank == 0 and args.precision == "fp32" and not args.no_alt:
         # the opt-in split-bf16 scoring kernel on the same inputs (reported beside, never as `value`)
@@ -232,6 +257,10 @@ def main():
                          "flop_per_pair_algorithmic": flops,
                          "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
         }
+        if sclk_mhz is not None:
+            # reporting only: `frac` above stays priced at the nominal 2.4 GHz peak
+            out["roofline"]["sclk_mhz_under_kernel"] = sclk_mhz
+            out["roofline"]["frac_at_measured_clock"] = achieved / (FP32_MFMA_PEAK_TFLOPS * sclk_mhz / 2400.0)
         if args.precision == "bf16x3":
             out["dtype"] = "bf16x3"
             out["roofline"]["kernel"] = "nplda_fwd_bf16x3_kernel (6 bf16 MFMA passes per fp32 product)"

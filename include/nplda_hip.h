@@ -310,6 +310,14 @@ int nplda_score_pairs_bf16x3(const float* x1, const float* x2, int64_t B, int64_
 int nplda_embed_bf16x3(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
                        float* z, int64_t ldz, float* q, nplda_stream_t stream);
 
+/* ---- measurement utility ------------------------------------------------------------------------------------- */
+
+/* Shader-clock probe for bench.py (no reference counterpart): one wave that stays resident for window_us microseconds
+ * on `stream` and writes out2[0] = shader cycles elapsed (s_memtime), out2[1] = ticks of the constant 100 MHz counter
+ * (s_memrealtime) to DEVICE memory; MHz = 100 * out2[0] / out2[1].  Launched on a side stream next to the kernel under
+ * test it reports the clock the chip actually holds under that kernel (the roofline peak assumes 2.4 GHz). */
+int nplda_clock_probe(uint64_t* out2, unsigned window_us, nplda_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

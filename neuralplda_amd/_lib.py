@@ -39,6 +39,7 @@ SIGNATURES = {
                                          _c_int, _c_int, _c_f32p, _c_vp]),
     "nplda_score_embeddings_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p,
                                             _c_f32p, _c_vp]),
+    "nplda_clock_probe": (_c_int, [_c_vp, ctypes.c_uint, _c_vp]),
     "nplda_gather_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_f32p, _c_i64, _c_vp]),
     "nplda_cohort_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "nplda_cohort_stats_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int,
