@@ -86,7 +86,7 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
-    const int xcd = blockIdx.x & 7, stride = gridDim.x >> 3;
+    const int xcd = blockIdx.x & 7;
     // tile `slot` of this XCD: super-band by super-band, row tile by row tile, the band's column tiles innermost
     auto decode = [&](int slot, long long& rb, long long& mb) {
         for (int sb = 0; sb < a.nsb; ++sb) {
@@ -141,8 +141,12 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
     };
 
     long long rb, mb, nrb = 0, nmb = 0;
-    if (!decode(blockIdx.x >> 3, rb, mb)) return;  // the first tile is static; whole block (uniform)
     unsigned* nxt_s = reinterpret_cast<unsigned*>(smem + 2224);  // the next tile's slot, wave 0 -> everybody
+    // every tile comes from the counter, the first one included: a block that only becomes resident once the others
+    // have drained the counter (should the occupancy query ever over-count) finds nothing and leaves
+    if (tid == 0) *nxt_s = atomicAdd(a.ctr + xcd, 1u);
+    __syncthreads();
+    if (!decode(__builtin_amdgcn_readfirstlane((int)*nxt_s), rb, mb)) return;  // whole block (uniform)
     if (tid < 4 * a.ksteps) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
     // fragment reads: row 64 (wave half) + 16 c + i16, chunk g4
     const int fo = i16 * 4 + (g4 ^ ((i16 >> 2) & 2));
@@ -175,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
             if (ks + 1 < a.ksteps) {
                 stage_in(ks + 1, cur ^ 1);
             } else {  // last stage: the next tile's first stage and self terms
-                const int nslot = stride + __builtin_amdgcn_readfirstlane((int)*nxt_s);
+                const int nslot = __builtin_amdgcn_readfirstlane((int)*nxt_s);
                 have_next = decode(nslot, nrb, nmb);
                 if (have_next) {
                     set_ptrs(nrb, nmb);

@@ -206,7 +206,79 @@ void runt(int waves_per_simd) {
            flops / (ms * 1e-3) / 1e12, flops / (ms * 1e-3) / 1e12 / 157.3);
 }
 
+// The same tile loop with its 8 fragments re-read from LDS every iteration (read-only image, no barrier): what do
+// ds_read_b128 -> MFMA operand hand-offs cost?  MODE 0: all 8 reads up front; 1: reads for the NEXT iteration issued
+// before this iteration's MFMAs (software pipelined, 64 fragment registers).
+template <int MODE>
+__global__ __launch_bounds__(256) void kl(const float* in, float* out, int iters) {
+    __shared__ f32x4 img[2][512];
+    for (int i = threadIdx.x; i < 1024; i += 256) (&img[0][0])[i] = *reinterpret_cast<const f32x4*>(in + 4 * (i & 127));
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const f32x4* fra = &img[0][(wave >> 1) * 256 + lane];
+    const f32x4* frb = &img[1][(wave & 1) * 256 + lane];
+    f32x4 acc[4][4], fa[4], fb[4], na[4], nb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        fa[i] = fra[64 * i]; fb[i] = frb[64 * i];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int it = 0; it < iters; ++it) {
+        if (MODE == 0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[i] = fra[64 * i]; fb[i] = frb[64 * i]; }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { na[i] = fra[64 * i]; nb[i] = frb[64 * i]; }
+        }
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+            for (int ca = 0; ca < 4; ++ca)
+#pragma unroll
+                for (int cb = 0; cb < 4; ++cb)
+                    acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
+        if (MODE == 1) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { fa[i] = na[i]; fb[i] = nb[i]; }
+        }
+        asm volatile("" ::: "memory");
+    }
+    f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += acc[i][j];
+    if (s[0] == 123.f) out[threadIdx.x] = s[1];
+}
+
+template <int MODE>
+void runl(int waves_per_simd) {
+    float *in, *out;
+    hipMalloc(&in, 512 * 4); hipMalloc(&out, 4096);
+    float h[512];
+    unsigned x = 12345u;
+    for (int i = 0; i < 512; ++i) { x = x * 1664525u + 1013904223u; h[i] = (float)(x >> 8) / 16777216.0f - 0.5f; }
+    hipMemcpy(in, h, sizeof h, hipMemcpyHostToDevice);
+    const int iters = 4000;
+    dim3 grid(256 * waves_per_simd), block(256);
+    hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+    hipLaunchKernelGGL(kl<MODE>, grid, block, 0, 0, in, out, iters);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    for (int rep = 0; rep < 5; ++rep) hipLaunchKernelGGL(kl<MODE>, grid, block, 0, 0, in, out, iters);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1); ms /= 5;
+    const double flops = (double)grid.x * 4 * iters * 64 * 2048.0;
+    printf("tile loop + 8 ds_read_b128 per 64 MFMAs (%s), waves/SIMD %d: %.3f ms  %.1f TFLOP/s  frac %.3f\n",
+           MODE ? "pipelined" : "read then multiply", waves_per_simd, ms, flops / (ms * 1e-3) / 1e12,
+           flops / (ms * 1e-3) / 1e12 / 157.3);
+}
+
 int main() {
+    runl<0>(1); runl<0>(2); runl<0>(3); runl<1>(2); runl<1>(3);
     runt<0>(1); runt<0>(2); runt<0>(3); runt<2>(2); runt<1>(2);
     rund<8>(2, false, 4000, 5); rund<8>(2, true, 4000, 5); rund<8>(2, false, 40000, 20); rund<8>(2, true, 40000, 20);
     rund<16>(3, true, 20000, 20);
