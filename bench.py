@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")
     ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the shader-clock probe pass (use under rocprofv3: the profiler serialises kernels)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
     args = ap.parse_args()
 
@@ -182,7 +184,7 @@ def main():
     # Untimed extra pass: the shader clock the chip holds under this kernel.  A one-wave probe (nplda_clock_probe) sits
     # on a side stream next to 12 more launches and compares the shader-cycle counter with the constant 100 MHz counter.
     sclk_mhz = None
-    if rank == 0:
+    if rank == 0 and not args.no_clock_probe:
         try:
             from neuralplda_amd import _lib
             lib = _lib.load()
