@@ -262,9 +262,58 @@ __device__ __forceinline__ float key2f(unsigned k) {
     return __uint_as_float(u);
 }
 
-__device__ __forceinline__ double block_sum_d(double v, double* red) {
+// Wave64 reductions on the DPP path: xor 1 and xor 2 by quad_perm, then rotations by 4 and 8 inside each row of 16
+// lanes (every lane of a row then holds the row's result), and the four row results meet through v_readlane.  __shfl_xor
+// compiles to ds_bpermute_b32 — a round trip through the LDS crossbar per step and per 32-bit half, 126 of them in the
+// first version of this kernel, a fifth of its time.
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int CTRL>
+__device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;
+
+__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
+    v += dpp_u32<kDppXor1>(v);
+    v += dpp_u32<kDppXor2>(v);
+    v += dpp_u32<kDppRor4>(v);
+    v += dpp_u32<kDppRor8>(v);
+    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
+           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+}
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
+    unsigned t;
+    t = dpp_u32<kDppXor1>(v); v = t < v ? t : v;
+    t = dpp_u32<kDppXor2>(v); v = t < v ? t : v;
+    t = dpp_u32<kDppRor4>(v); v = t < v ? t : v;
+    t = dpp_u32<kDppRor8>(v); v = t < v ? t : v;
+    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
+                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
+    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
+    return ab < cd ? ab : cd;
+}
+__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~wave_min_u32(~v); }
+// fixed association ((r0 + r1) + r2) + r3 over the four rows of 16 lanes: deterministic
+__device__ __forceinline__ double wave_sum_f64(double v) {
+    v += dpp_f64<kDppXor1>(v);
+    v += dpp_f64<kDppXor2>(v);
+    v += dpp_f64<kDppRor4>(v);
+    v += dpp_f64<kDppRor8>(v);
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    double r[4];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) v += __shfl_xor(v, m, 64);
+    for (int q = 0; q < 4; ++q)
+        r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
+    return ((r[0] + r[1]) + r[2]) + r[3];
+}
+
+__device__ __forceinline__ double block_sum_d(double v, double* red) {
+    v = wave_sum_f64(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) red[wave] = v;
@@ -277,11 +326,8 @@ __device__ __forceinline__ double block_sum_d(double v, double* red) {
 
 // two fp64 block sums with one pair of barriers
 __device__ __forceinline__ void block_sum_d2(double& a, double& b, double* red) {
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        a += __shfl_xor(a, m, 64);
-        b += __shfl_xor(b, m, 64);
-    }
+    a = wave_sum_f64(a);
+    b = wave_sum_f64(b);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     __syncthreads();
     if (lane == 0) { red[2 * wave] = a; red[2 * wave + 1] = b; }
@@ -339,39 +385,39 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     double s1 = 0.0, s2 = 0.0;
     unsigned kmin = 0xffffffffu, kmax = 0u;
     constexpr int U = 5;
-    for (long long base = tid; base < nvec; base += (long long)kRowThreads * U) {
+    const int nv = (int)nvec, Mi = (int)M;  // M < 2^31 (checked on the host)
+    for (int base = tid; base < nv; base += kRowThreads * U) {
         f32x4 v[U];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long g = base + (long long)kRowThreads * u;
-            v[u] = src4[g < nvec ? g : nvec - 1];
+            const int g = base + kRowThreads * u;
+            v[u] = src4[g < nv ? g : nv - 1];
         }
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const long long g = base + (long long)kRowThreads * u;
-            if (g < nvec) {
-                const u32x4 k = row_keys(v[u], g, M, lowest);
-                if (use_lds) keys4[g] = k;
+            const int g = base + kRowThreads * u;
+            if (g < nv) {
+                const int nvalid = Mi - 4 * g;  // >= 4 except in the row's last group
+                u32x4 k;
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    if (4 * g + e < M) {
-                        kmin = k[e] < kmin ? k[e] : kmin;
-                        kmax = k[e] > kmax ? k[e] : kmax;
-                        const double d = (double)v[u][e];
-                        s1 += d;
-                        s2 += d * d;
-                    }
+                    unsigned x = f2key(v[u][e]);
+                    if (!lowest) x = ~x;  // N largest == N smallest of the reversed order
+                    const bool ok = e < nvalid;
+                    k[e] = ok ? x : 0xffffffffu;
+                    kmin = (ok && x < kmin) ? x : kmin;
+                    kmax = (ok && x > kmax) ? x : kmax;
+                    const double d = ok ? (double)v[u][e] : 0.0;
+                    s1 += d;
+                    s2 += d * d;
                 }
+                if (use_lds) keys4[g] = k;
             }
         }
     }
     block_sum_d2(s1, s2, red);
-#pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        const unsigned a = __shfl_xor(kmin, m, 64), b = __shfl_xor(kmax, m, 64);
-        kmin = a < kmin ? a : kmin;
-        kmax = b > kmax ? b : kmax;
-    }
+    kmin = wave_min_u32(kmin);
+    kmax = wave_max_u32(kmax);
     if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
     __syncthreads();
     unsigned lo = 0xffffffffu, hi = 0u;
@@ -419,11 +465,8 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 cb2 += k[e] <= kb;
             }
         });
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            ca += __shfl_xor(ca, m, 64);
-            cb2 += __shfl_xor(cb2, m, 64);
-        }
+        ca = wave_sum_u32(ca);
+        cb2 = wave_sum_u32(cb2);
         if (lane == 0) { cnt[wave * 4] = ca; cnt[wave * 4 + 1] = cb2; }
         if (tid == 0) *nlist = 0;
         __syncthreads();
@@ -457,7 +500,9 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 // candidates are few enough (the usual case: ~170 at N / M = 0.05 -> 2), their partial ranks meet in rk
                 const unsigned sh = (L * 4 <= (unsigned)kRowThreads) ? 2u : (L * 2 <= (unsigned)kRowThreads) ? 1u : 0u;
                 const unsigned split = 1u << sh;
-                unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // L <= 256 here: clear of the rank slots
+                // Ties need no order: equal keys are equal values, so a candidate with `lt` keys below it and `le` keys at
+                // or below it owns the rank slots [lt, le) and every one of them receives the same value.
+                unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // [L] lt | le << 16; L <= 256 when shared
                 if (sh) {
                     for (unsigned i = tid; i < L; i += kRowThreads) rk[i] = 0u;
                     __syncthreads();
@@ -467,21 +512,30 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                     const unsigned k = list[i];
                     const unsigned ng = L4 / 4;
                     const unsigned g0 = part * ng / split, g1 = (part + 1) * ng / split;
-                    unsigned rank = 0;
+                    unsigned lt = 0, le = 0;
                     const u32x4* list4 = reinterpret_cast<const u32x4*>(list);
                     for (unsigned gx = g0; gx < g1; ++gx) {
                         const u32x4 kj = list4[gx];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) rank += (kj[e] < k) || (kj[e] == k && 4 * gx + e < i);
+                        for (int e = 0; e < 4; ++e) {
+                            lt += kj[e] < k;
+                            le += kj[e] <= k;
+                        }
                     }
-                    if (sh) atomicAdd(rk + i, rank);
-                    else sel[rank] = key2f(lowest ? k : ~k);
+                    if (sh) {
+                        atomicAdd(rk + i, lt | (le << 16));  // both partial counts <= 512: no carry between the halves
+                    } else {
+                        const float v = key2f(lowest ? k : ~k);
+                        for (unsigned r = lt; r < le; ++r) sel[r] = v;
+                    }
                 }
                 if (sh) {
                     __syncthreads();
                     if ((unsigned)tid < L) {
                         const unsigned k = list[tid];
-                        sel[rk[tid]] = key2f(lowest ? k : ~k);
+                        const float v = key2f(lowest ? k : ~k);
+                        const unsigned c = rk[tid];
+                        for (unsigned r = c & 0xffffu; r < (c >> 16); ++r) sel[r] = v;
                     }
                 }
                 __syncthreads();
@@ -528,12 +582,9 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 c3 += k[e] <= p3;
             }
         });
-#pragma unroll
-        for (int m = 32; m >= 1; m >>= 1) {
-            c1 += __shfl_xor(c1, m, 64);
-            c2 += __shfl_xor(c2, m, 64);
-            c3 += __shfl_xor(c3, m, 64);
-        }
+        c1 = wave_sum_u32(c1);
+        c2 = wave_sum_u32(c2);
+        c3 = wave_sum_u32(c3);
         unsigned* cb = cnt + (it & 1) * 32;
         if (lane == 0) { cb[wave * 4] = c1; cb[wave * 4 + 1] = c2; cb[wave * 4 + 2] = c3; }
         __syncthreads();
@@ -637,7 +688,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
     if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
     if (R == 0) return NPLDA_OK;
-    if (M == 0) return NPLDA_EINVAL;
+    if (M == 0 || M > 0x7ffffff0LL) return NPLDA_EINVAL;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
     if (!z_rows || !q_rows || !z_coh || !q_coh || !packed || !stats || !ws) return NPLDA_EINVAL;
     if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z_rows) || !nplda_aligned16(z_coh) ||
@@ -704,7 +755,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
                                            (int)shmem);
         if (e != hipSuccess) return (int)e;
     }
-    if (R > 0x7fffffffLL) return NPLDA_EINVAL;
+    if (R > 0x7fffffffLL || M > 0x7ffffff0LL) return NPLDA_EINVAL;  // 32-bit group indices inside the kernel
     hipLaunchKernelGGL(row_stats_kernel, dim3((unsigned)R), dim3(kRowThreads), shmem, (hipStream_t)stream, S,
                        (long long)lds, (long long)M, topn, select_lowest ? 1 : 0, use_lds, stats);
     return nplda_launch_status();
