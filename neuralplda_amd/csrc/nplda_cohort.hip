@@ -371,7 +371,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);                  // [M] when use_lds
     u32x4* keys4 = reinterpret_cast<u32x4*>(smem_raw);
     unsigned* cnt = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                  // [2][8][4] count partials
-    double* red = reinterpret_cast<double*>(cnt + 64);                         // [2][8]
+    double* red = reinterpret_cast<double*>(cnt + 64);                         // [2][2][8]
     constexpr int NWV = kRowThreads / 64;
 
     const long long row = blockIdx.x;
@@ -415,20 +415,40 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             }
         }
     }
-    block_sum_d2(s1, s2, red);
+    // Barriers are the expensive part of this kernel (three rows share a CU: a barrier waits for the slowest of eight
+    // waves, each queued behind the other rows' arithmetic), so every exchange below is ONE barrier: the partial results
+    // of a phase go to LDS slots that no other phase uses (cnt[0..31] / cnt[32..63], red[0..15] / red[16..31]), and the
+    // scratch of the shortcut (sentinel-filled candidate list, zeroed rank counters) is prepared here, two barriers
+    // ahead of its use.
+    unsigned* list = cnt + 64 + 8 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
+    float* sel = reinterpret_cast<float*>(list + kListCap);
+    unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
+    unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // [<= 256] rank counts lt | le << 16
+    s1 = wave_sum_f64(s1);
+    s2 = wave_sum_f64(s2);
     kmin = wave_min_u32(kmin);
     kmax = wave_max_u32(kmax);
-    if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
+    if (lane == 0) {
+        red[2 * wave] = s1;
+        red[2 * wave + 1] = s2;
+        cnt[wave * 4] = kmin;
+        cnt[wave * 4 + 1] = kmax;
+    }
+    for (int i = tid; i < kListCap; i += kRowThreads) list[i] = 0xffffffffu;  // above every candidate
+    for (int i = tid; i < kListCap / 2; i += kRowThreads) rk[i] = 0u;
+    if (tid == 0) *nlist = 0;
     __syncthreads();
     unsigned lo = 0xffffffffu, hi = 0u;
+    s1 = s2 = 0.0;
 #pragma unroll
     for (int w = 0; w < NWV; ++w) {
         lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
         hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
+        s1 += red[2 * w];
+        s2 += red[2 * w + 1];
     }
     if (hi > 0xfffffffeu) hi = 0xfffffffeu;
     if (lo > hi) lo = hi;
-    __syncthreads();
     const double n = (double)M;
     const double mean = s1 / n;
     double var = s2 / n - mean * mean;
@@ -447,9 +467,6 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
     if (use_lds && M >= 64 && var > 0.0) {
-        unsigned* list = cnt + 64 + 4 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
-        float* sel = reinterpret_cast<float*>(list + kListCap);
-        unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
         const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
         const double sd = sqrt(var);
         const double t0 = mean + normcdfinv(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q)) * sd;
@@ -467,13 +484,11 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         });
         ca = wave_sum_u32(ca);
         cb2 = wave_sum_u32(cb2);
-        if (lane == 0) { cnt[wave * 4] = ca; cnt[wave * 4 + 1] = cb2; }
-        if (tid == 0) *nlist = 0;
+        if (lane == 0) { cnt[32 + wave * 4] = ca; cnt[32 + wave * 4 + 1] = cb2; }
         __syncthreads();
         ca = cb2 = 0;
 #pragma unroll
-        for (int w = 0; w < NWV; ++w) { ca += cnt[w * 4]; cb2 += cnt[w * 4 + 1]; }
-        __syncthreads();
+        for (int w = 0; w < NWV; ++w) { ca += cnt[32 + w * 4]; cb2 += cnt[32 + w * 4 + 1]; }
         if (ca < want && want <= cb2) {
             lo = ka; hi = kb;  // a valid (much narrower) bracket for the general search, should the list be too long
             if (cb2 - ca <= (unsigned)kListCap) {
@@ -493,20 +508,14 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 });
                 __syncthreads();
                 const unsigned L = *nlist, need = want - ca;
-                const unsigned L4 = (L + 3) / 4 * 4;
-                if (tid < L4 - L) list[L + tid] = 0xffffffffu;  // pad to whole 16-byte groups (above every candidate)
-                __syncthreads();
+                const unsigned L4 = (L + 3) / 4 * 4;  // whole 16-byte groups: the list was sentinel-filled
                 // rank by counting, the list read 16 bytes at a time; `split` threads share one candidate when the
                 // candidates are few enough (the usual case: ~170 at N / M = 0.05 -> 2), their partial ranks meet in rk
                 const unsigned sh = (L * 4 <= (unsigned)kRowThreads) ? 2u : (L * 2 <= (unsigned)kRowThreads) ? 1u : 0u;
                 const unsigned split = 1u << sh;
                 // Ties need no order: equal keys are equal values, so a candidate with `lt` keys below it and `le` keys at
                 // or below it owns the rank slots [lt, le) and every one of them receives the same value.
-                unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // [L] lt | le << 16; L <= 256 when shared
-                if (sh) {
-                    for (unsigned i = tid; i < L; i += kRowThreads) rk[i] = 0u;
-                    __syncthreads();
-                }
+                // (rk: [L] lt | le << 16, L <= 256 when shared, zeroed above)
                 for (unsigned t = tid; t < L * split; t += kRowThreads) {
                     const unsigned i = t >> sh, part = t & (split - 1u);
                     const unsigned k = list[i];
@@ -545,9 +554,13 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                     u1 += v;
                     u2 += v * v;
                 }
-                t1 += u1;
-                t2 += u2;
-                block_sum_d2(t1, t2, red);
+                t1 = wave_sum_f64(t1 + u1);
+                t2 = wave_sum_f64(t2 + u2);
+                if (lane == 0) { red[16 + 2 * wave] = t1; red[16 + 2 * wave + 1] = t2; }
+                __syncthreads();
+                t1 = t2 = 0.0;
+#pragma unroll
+                for (int w = 0; w < NWV; ++w) { t1 += red[16 + 2 * w]; t2 += red[16 + 2 * w + 1]; }
                 done = true;
             }
         }
@@ -570,6 +583,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // N-th smallest key T by 4-ary search on the integer key space: every iteration counts, for three pivots,
     // the keys <= pivot (register counters + shuffle/LDS reduction — no atomics: cohort scores of one row share
     // their leading bits, which serialises an LDS-histogram radix select) and keeps the quarter that holds rank N.
+    __syncthreads();  // the count slots are reused below
     for (int it = 0; lo < hi; ++it) {
         const unsigned long long span = (unsigned long long)hi - lo;
         const unsigned p1 = lo + (unsigned)(span / 4), p2 = lo + (unsigned)(span / 2), p3 = lo + (unsigned)(span / 4 * 3);
@@ -701,7 +715,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 16 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -749,7 +763,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 16 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
