@@ -464,42 +464,59 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     for (int i = tid; i < kListCap / 2; i += kRowThreads) rk[i] = 0u;
     if (tid == 0) *nlist = 0;
     __syncthreads();
-    unsigned lo = 0xffffffffu, hi = 0u;
-    s1 = s2 = 0.0;
-#pragma unroll
-    for (int w = 0; w < NWV; ++w) {
-        lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
-        hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
-        s1 += red[2 * w];
-        s2 += red[2 * w + 1];
-    }
-    if (hi > 0xfffffffeu) hi = 0xfffffffeu;
-    if (lo > hi) lo = hi;
-    const double n = (double)M;
-    const double mean = s1 / n;
-    double var = s2 / n - mean * mean;
-    if (var < 0.0) var = 0.0;
-
     long long N = topn;
     if (N > M) N = M;
     if (N < 1) N = 1;
     const unsigned want = (unsigned)N;
+    const double n = (double)M;
 
+    // The scalar follow-up (totals, mean / variance, the quantile bracket: ~250 instructions, most of them fp64
+    // divisions) is done by wave 0 alone and handed over through `ctl`: evaluated by all eight waves it was a sixth
+    // of the kernel's VALU instructions, and the VALU is what bounds this kernel (SQ_ACTIVE_INST_VALU ~ 95 %).
     // ---- shortcut for well-behaved rows: bracket the N-th smallest key with the normal quantile of (mean, std), count
     // once, and if the bracket holds the rank and few enough keys, finish EXACTLY on that short list (rank by counting,
     // values written to their rank slot so that the fp64 sums are order-independent): 3 passes over the row instead of
     // ~16.  Anything else (heavy tails, ties, tiny rows) falls through to the general search below, started from the
     // bracket when it is valid.
+    unsigned* ctl = nlist + 4;  // lo, hi, ka, kb, shortcut
+    double mean = 0.0, var = 0.0;  // kept by wave 0 (thread 0 writes the result)
+    if (wave == 0) {
+        unsigned lo0 = 0xffffffffu, hi0 = 0u;
+        s1 = s2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            lo0 = cnt[w * 4] < lo0 ? cnt[w * 4] : lo0;
+            hi0 = cnt[w * 4 + 1] > hi0 ? cnt[w * 4 + 1] : hi0;
+            s1 += red[2 * w];
+            s2 += red[2 * w + 1];
+        }
+        if (hi0 > 0xfffffffeu) hi0 = 0xfffffffeu;
+        if (lo0 > hi0) lo0 = hi0;
+        mean = s1 / n;
+        var = s2 / n - mean * mean;
+        if (var < 0.0) var = 0.0;
+        unsigned ka0 = 0, kb0 = 0, ok0 = 0;
+        if (use_lds && M >= 64 && var > 0.0) {
+            const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
+            const double sd = sqrt(var);
+            const double t0 = mean + (double)fast_normcdfinv((float)(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q))) * sd;
+            const float fa = (float)(t0 - 0.06 * sd), fb = (float)(t0 + 0.06 * sd);
+            ka0 = f2key(fa);
+            kb0 = f2key(fb);
+            if (!lowest) { const unsigned t = ~ka0; ka0 = ~kb0; kb0 = t; }
+            if (kb0 > 0xfffffffeu) kb0 = 0xfffffffeu;
+            ok0 = 1;
+        }
+        if (lane == 0) { ctl[0] = lo0; ctl[1] = hi0; ctl[2] = ka0; ctl[3] = kb0; ctl[4] = ok0; }
+    }
+    __syncthreads();
+    unsigned lo = ctl[0], hi = ctl[1];
+    const unsigned ka = ctl[2], kb = ctl[3];
+    const bool shortcut = ctl[4] != 0;
+
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
-    if (use_lds && M >= 64 && var > 0.0) {
-        const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
-        const double sd = sqrt(var);
-        const double t0 = mean + (double)fast_normcdfinv((float)(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q))) * sd;
-        const float fa = (float)(t0 - 0.06 * sd), fb = (float)(t0 + 0.06 * sd);
-        unsigned ka = f2key(fa), kb = f2key(fb);
-        if (!lowest) { const unsigned t = ~ka; ka = ~kb; kb = t; }
-        if (kb > 0xfffffffeu) kb = 0xfffffffeu;
+    if (shortcut) {
         unsigned ca = 0, cb2 = 0;
         for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
 #pragma unroll
@@ -584,9 +601,11 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 t2 = wave_sum_f64(t2 + u2);
                 if (lane == 0) { red[16 + 2 * wave] = t1; red[16 + 2 * wave + 1] = t2; }
                 __syncthreads();
-                t1 = t2 = 0.0;
+                if (tid == 0) {
+                    t1 = t2 = 0.0;
 #pragma unroll
-                for (int w = 0; w < NWV; ++w) { t1 += red[16 + 2 * w]; t2 += red[16 + 2 * w + 1]; }
+                    for (int w = 0; w < NWV; ++w) { t1 += red[16 + 2 * w]; t2 += red[16 + 2 * w + 1]; }
+                }
                 done = true;
             }
         }
@@ -741,7 +760,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 48;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -789,7 +808,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 16;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 48;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
