@@ -517,12 +517,24 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
     if (shortcut) {
+        // ONE pass over the keys: count below / inside the bracket, sum everything strictly below it, and already
+        // collect the bracket's keys (bounded by the list capacity); the counts then say whether the list is usable.
         unsigned ca = 0, cb2 = 0;
-        for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
+        for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                ca += k[e] < ka;
-                cb2 += k[e] <= kb;
+                const unsigned k = k4[e];
+                const bool below = k < ka, upto = k <= kb;
+                ca += below;
+                cb2 += upto;
+                if (below) {
+                    const double v = (double)key2f(lowest ? k : ~k);
+                    t1 += v;
+                    t2 += v * v;
+                } else if (upto) {
+                    const unsigned pos = atomicAdd(nlist, 1u);
+                    if (pos < (unsigned)kListCap) list[pos] = k;
+                }
             }
         });
         ca = wave_sum_u32(ca);
@@ -535,22 +547,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         if (ca < want && want <= cb2) {
             lo = ka; hi = kb;  // a valid (much narrower) bracket for the general search, should the list be too long
             if (cb2 - ca <= (unsigned)kListCap) {
-                // collect the bracket's keys; sum everything strictly below it
-                for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k4) {
-#pragma unroll
-                    for (int e = 0; e < 4; ++e) {
-                        const unsigned k = k4[e];
-                        if (k < ka) {
-                            const double v = (double)key2f(lowest ? k : ~k);
-                            t1 += v;
-                            t2 += v * v;
-                        } else if (k <= kb) {
-                            list[atomicAdd(nlist, 1u)] = k;
-                        }
-                    }
-                });
-                __syncthreads();
-                const unsigned L = *nlist, need = want - ca;
+                const unsigned L = cb2 - ca, need = want - ca;  // == *nlist: every candidate found its slot
                 const unsigned L4 = (L + 3) / 4 * 4;  // whole 16-byte groups: the list was sentinel-filled
                 // rank by counting, the list read 16 bytes at a time; `split` threads share one candidate when the
                 // candidates are few enough (the usual case: ~170 at N / M = 0.05 -> 2), their partial ranks meet in rk
