@@ -251,6 +251,7 @@ __global__ __launch_bounds__(256, 2) void cohort_gemm_kernel(const CohortGemmArg
 // ------------------------------------------------------------------------------------------------
 constexpr int kRowThreads = 512;
 constexpr int kListCap = 512;       // candidate keys of the quantile shortcut
+constexpr unsigned kUnwritten = 0xffffffffu;  // a rank slot nobody wrote (as a float: one particular NaN)
 constexpr int kMaxRowLds = 38000;  // floats of one row kept in LDS (with the shortcut's lists: < 160 KiB)
 
 __device__ __forceinline__ unsigned f2key(float f) {
@@ -392,11 +393,10 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     const long long nvec = (M + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
-    // pass 0: load, full-row sums, key range.  Batches of U independent 16-byte loads per thread (clamped index, so
+    // pass 0: load, full-row sums (the key range is only needed by the general search: computed there).  Batches of U independent 16-byte loads per thread (clamped index, so
     // that no load sits behind a branch): with one 4-byte load per iteration the compiler waited out every load before
     // issuing the next, ~20 memory round trips per row.
     double s1 = 0.0, s2 = 0.0;
-    unsigned kmin = 0xffffffffu, kmax = 0u;
     constexpr int U = 5;
     const int nv = (int)nvec, Mi = (int)M;  // M < 2^31 (checked on the host)
     const unsigned flip = lowest ? 0u : 0xffffffffu;
@@ -418,8 +418,6 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                     for (int e = 0; e < 4; ++e) {
                         const unsigned x = f2key(v[u][e]) ^ flip;  // N largest == N smallest of the reversed order
                         k[e] = x;
-                        kmin = x < kmin ? x : kmin;
-                        kmax = x > kmax ? x : kmax;
                         const double d = (double)v[u][e];
                         s1 += d;
                         s2 += d * d;
@@ -430,8 +428,6 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                         const unsigned x = f2key(v[u][e]) ^ flip;
                         const bool ok = e < nvalid;
                         k[e] = ok ? x : 0xffffffffu;
-                        kmin = (ok && x < kmin) ? x : kmin;
-                        kmax = (ok && x > kmax) ? x : kmax;
                         const double d = ok ? (double)v[u][e] : 0.0;
                         s1 += d;
                         s2 += d * d;
@@ -449,18 +445,18 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     unsigned* list = cnt + 64 + 8 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
     float* sel = reinterpret_cast<float*>(list + kListCap);
     unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
-    unsigned* rk = reinterpret_cast<unsigned*>(sel) + kListCap / 2;  // [<= 256] rank counts lt | le << 16
+    unsigned* ctl = nlist + 4;                     // ka, kb, shortcut
+    unsigned* rk = ctl + 8;                        // [kListCap / 2] shared rank counts
     s1 = wave_sum_f64(s1);
     s2 = wave_sum_f64(s2);
-    kmin = wave_min_u32(kmin);
-    kmax = wave_max_u32(kmax);
     if (lane == 0) {
         red[2 * wave] = s1;
         red[2 * wave + 1] = s2;
-        cnt[wave * 4] = kmin;
-        cnt[wave * 4 + 1] = kmax;
     }
-    for (int i = tid; i < kListCap; i += kRowThreads) list[i] = 0xffffffffu;  // above every candidate
+    for (int i = tid; i < kListCap; i += kRowThreads) {
+        list[i] = 0xffffffffu;                           // above every candidate
+        reinterpret_cast<unsigned*>(sel)[i] = kUnwritten;  // rank slots: "not written" (see the tie rule below)
+    }
     for (int i = tid; i < kListCap / 2; i += kRowThreads) rk[i] = 0u;
     if (tid == 0) *nlist = 0;
     __syncthreads();
@@ -478,20 +474,14 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // values written to their rank slot so that the fp64 sums are order-independent): 3 passes over the row instead of
     // ~16.  Anything else (heavy tails, ties, tiny rows) falls through to the general search below, started from the
     // bracket when it is valid.
-    unsigned* ctl = nlist + 4;  // lo, hi, ka, kb, shortcut
     double mean = 0.0, var = 0.0;  // kept by wave 0 (thread 0 writes the result)
     if (wave == 0) {
-        unsigned lo0 = 0xffffffffu, hi0 = 0u;
         s1 = s2 = 0.0;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) {
-            lo0 = cnt[w * 4] < lo0 ? cnt[w * 4] : lo0;
-            hi0 = cnt[w * 4 + 1] > hi0 ? cnt[w * 4 + 1] : hi0;
             s1 += red[2 * w];
             s2 += red[2 * w + 1];
         }
-        if (hi0 > 0xfffffffeu) hi0 = 0xfffffffeu;
-        if (lo0 > hi0) lo0 = hi0;
         mean = s1 / n;
         var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
@@ -507,12 +497,13 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             if (kb0 > 0xfffffffeu) kb0 = 0xfffffffeu;
             ok0 = 1;
         }
-        if (lane == 0) { ctl[0] = lo0; ctl[1] = hi0; ctl[2] = ka0; ctl[3] = kb0; ctl[4] = ok0; }
+        if (lane == 0) { ctl[0] = ka0; ctl[1] = kb0; ctl[2] = ok0; }
     }
     __syncthreads();
-    unsigned lo = ctl[0], hi = ctl[1];
-    const unsigned ka = ctl[2], kb = ctl[3];
-    const bool shortcut = ctl[4] != 0;
+    const unsigned ka = ctl[0], kb = ctl[1];
+    const bool shortcut = ctl[2] != 0;
+    unsigned lo = 0u, hi = 0u;
+    bool have_range = false;  // [lo, hi] brackets the N-th smallest key
 
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
@@ -545,7 +536,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
 #pragma unroll
         for (int w = 0; w < NWV; ++w) { ca += cnt[32 + w * 4]; cb2 += cnt[32 + w * 4 + 1]; }
         if (ca < want && want <= cb2) {
-            lo = ka; hi = kb;  // a valid (much narrower) bracket for the general search, should the list be too long
+            lo = ka; hi = kb; have_range = true;  // a valid (much narrower) bracket for the general search, should the list be too long
             if (cb2 - ca <= (unsigned)kListCap) {
                 const unsigned L = cb2 - ca, need = want - ca;  // == *nlist: every candidate found its slot
                 const unsigned L4 = (L + 3) / 4 * 4;  // whole 16-byte groups: the list was sentinel-filled
@@ -553,44 +544,37 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 // candidates are few enough (the usual case: ~170 at N / M = 0.05 -> 2), their partial ranks meet in rk
                 const unsigned sh = (L * 4 <= (unsigned)kRowThreads) ? 2u : (L * 2 <= (unsigned)kRowThreads) ? 1u : 0u;
                 const unsigned split = 1u << sh;
-                // Ties need no order: equal keys are equal values, so a candidate with `lt` keys below it and `le` keys at
-                // or below it owns the rank slots [lt, le) and every one of them receives the same value.
-                // (rk: [L] lt | le << 16, L <= 256 when shared, zeroed above)
+                // A candidate goes to the rank slot `lt` = number of keys below it.  Ties share that slot and leave the
+                // following ones unwritten; equal keys are equal values, so an unwritten slot simply takes the value of
+                // the nearest written slot below it (slot 0 is always written).  Only `lt` is counted: half the compares.
                 for (unsigned t = tid; t < L * split; t += kRowThreads) {
                     const unsigned i = t >> sh, part = t & (split - 1u);
                     const unsigned k = list[i];
                     const unsigned ng = L4 / 4;
                     const unsigned g0 = part * ng / split, g1 = (part + 1) * ng / split;
-                    unsigned lt = 0, le = 0;
+                    unsigned lt = 0;
                     const u32x4* list4 = reinterpret_cast<const u32x4*>(list);
                     for (unsigned gx = g0; gx < g1; ++gx) {
                         const u32x4 kj = list4[gx];
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            lt += kj[e] < k;
-                            le += kj[e] <= k;
-                        }
+                        for (int e = 0; e < 4; ++e) lt += kj[e] < k;
                     }
-                    if (sh) {
-                        atomicAdd(rk + i, lt | (le << 16));  // both partial counts <= 512: no carry between the halves
-                    } else {
-                        const float v = key2f(lowest ? k : ~k);
-                        for (unsigned r = lt; r < le; ++r) sel[r] = v;
-                    }
+                    if (sh) atomicAdd(rk + i, lt);
+                    else sel[lt] = key2f(lowest ? k : ~k);
                 }
                 if (sh) {
                     __syncthreads();
                     if ((unsigned)tid < L) {
                         const unsigned k = list[tid];
-                        const float v = key2f(lowest ? k : ~k);
-                        const unsigned c = rk[tid];
-                        for (unsigned r = c & 0xffffu; r < (c >> 16); ++r) sel[r] = v;
+                        sel[rk[tid]] = key2f(lowest ? k : ~k);
                     }
                 }
                 __syncthreads();
                 double u1 = 0.0, u2 = 0.0;
                 for (unsigned i = tid; i < need; i += kRowThreads) {  // rank slots: a fixed summation order
-                    const double v = (double)sel[i];
+                    unsigned j = i;
+                    while (reinterpret_cast<const unsigned*>(sel)[j] == kUnwritten) --j;
+                    const double v = (double)sel[j];
                     u1 += v;
                     u2 += v * v;
                 }
@@ -626,6 +610,32 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // the keys <= pivot (register counters + shuffle/LDS reduction — no atomics: cohort scores of one row share
     // their leading bits, which serialises an LDS-histogram radix select) and keeps the quarter that holds rank N.
     __syncthreads();  // the count slots are reused below
+    if (!have_range) {  // key range of the row
+        unsigned kmin = 0xffffffffu, kmax = 0u;
+        for_row_keys(use_lds, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                if (k[e] != 0xffffffffu) {  // padding
+                    kmin = k[e] < kmin ? k[e] : kmin;
+                    kmax = k[e] > kmax ? k[e] : kmax;
+                }
+            }
+        });
+        kmin = wave_min_u32(kmin);
+        kmax = wave_max_u32(kmax);
+        if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
+        __syncthreads();
+        lo = 0xffffffffu;
+        hi = 0u;
+#pragma unroll
+        for (int w = 0; w < NWV; ++w) {
+            lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
+            hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
+        }
+        if (hi > 0xfffffffeu) hi = 0xfffffffeu;
+        if (lo > hi) lo = hi;
+        __syncthreads();
+    }
     for (int it = 0; lo < hi; ++it) {
         const unsigned long long span = (unsigned long long)hi - lo;
         const unsigned p1 = lo + (unsigned)(span / 4), p2 = lo + (unsigned)(span / 2), p3 = lo + (unsigned)(span / 4 * 3);
@@ -757,7 +767,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 48;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4 + 8 + kListCap / 2) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
@@ -805,7 +815,7 @@ int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int t
     if (R == 0) return NPLDA_OK;
     if (M == 0 || !S || !stats || lds < M) return NPLDA_EINVAL;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
-    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4) * 4 + 48;
+    const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4 + 8 + kListCap / 2) * 4 + 16;
     if (use_lds && shmem > 64 * 1024) {
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);

@@ -193,6 +193,13 @@ def test_row_stats_shapes_that_defeat_the_quantile_shortcut(hip_lib, select):
         rng.standard_normal(M) * 1e-30,                                                            # tiny magnitudes
         np.sort(rng.standard_normal(M)),                                                           # plain normal (shortcut)
     ]
+    # normal rows with a run of equal values straddling the selection boundary on either end: the shortcut fires and
+    # its rank slots must resolve the ties (unwritten-slot rule of the kernel)
+    z = np.sort(rng.standard_normal(M))
+    z[495:504] = z[499]
+    z[M - 504:M - 495] = z[M - 500]
+    z[470:474] = z[471]
+    rows.append(rng.permutation(z))
     S = np.stack(rows).astype(np.float32)
     S[:, ::997] += 0.0  # keep dtype
     got = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
