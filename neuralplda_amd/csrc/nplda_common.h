@@ -68,6 +68,19 @@ static inline int nplda_launch_status() {
 
 static inline bool nplda_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// v + (v of lane ^ mask).  For mask = 16 / 32 (whole rows of 16 lanes: the MFMA k-groups) gfx950 exchanges rows on the
+// VALU: v_permlane16_swap(a, b) swaps the odd rows of a with the even rows of b, v_permlane32_swap the upper half of a
+// with the lower half of b; with a = b = v the two results are (own, partner) in some order, and the sum is bit-identical
+// to the shuffle form.  __shfl_xor is ds_bpermute_b32: a round trip through the LDS crossbar in front of dependent MFMAs.
 __device__ __forceinline__ float wave_xor_add(float v, int mask) {
+    const unsigned u = __float_as_uint(v);
+    if (mask == 16) {
+        const auto r = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
+    if (mask == 32) {
+        const auto r = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+        return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+    }
     return v + __shfl_xor(v, mask, 64);
 }
