@@ -295,8 +295,9 @@ def score_embeddings(z1, z2, P_sqrt, Q):
     return s
 
 
-def gather_rows(table, idx):
-    """nplda_gather_rows_f32: out[r] = table[idx[r]] for a resident (N, D0) float32 matrix."""
+def gather_rows(table, idx, out=None):
+    """nplda_gather_rows_f32: out[r] = table[idx[r]] for a resident (N, D0) float32 matrix.  `out`: an existing
+    contiguous (B, D0) float32 device tensor to fill (static buffers of a captured step)."""
     lib = _lib.load()
     _require_dev_f32(table, "table")
     if table.dim() != 2 or table.stride(1) != 1 or table.stride(0) % 4 != 0 or table.shape[1] % 4 != 0:
@@ -304,7 +305,12 @@ def gather_rows(table, idx):
     dev = table.device
     idx = _idx(idx, "idx", dev)
     B, D0 = idx.shape[0], table.shape[1]
-    out = torch.empty((B, D0), dtype=torch.float32, device=dev)
+    if out is None:
+        out = torch.empty((B, D0), dtype=torch.float32, device=dev)
+    else:
+        _require_dev_f32(out, "out")
+        if out.shape != (B, D0) or not out.is_contiguous() or out.device != dev:
+            raise ValueError("out must be a contiguous (len(idx), D0) float32 tensor on the table's device")
     if B == 0:
         return out
     with torch.cuda.device(dev):

@@ -22,8 +22,8 @@ import torch.optim as optim
 
 from .models import NeuralPlda
 from .NpldaConf import NpldaConf
-from .sv_trials_loaders import (combine_trials_and_get_loader, get_trials_loaders_dict,
-                                load_xvec_trials_from_numbatch)
+from .sv_trials_loaders import (TrialIndexDataset, TrialLoader, combine_trials_and_get_loader,
+                                get_trials_loaders_dict, load_xvec_trials_from_numbatch, xvector_table)
 
 __all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "main_kaldiplda", "main_dplda",
            "train_gaussian_backend"]
@@ -35,7 +35,33 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
     step (e.g. a GraphedTrainStep); the loss is read back once per logging interval, not every step."""
     model.train()
     losses = []
-    for batch_idx, (data1, data2, target) in enumerate(train_loader):
+    device = torch.device(device)
+    # Device-resident epoch: with the vectorised loader and the fused step the whole epoch's index arrays go to the device
+    # once (mapped to x-vector table rows there), every batch is a view, and the gather runs inside the captured step
+    # (FusedTrainStep.step_rows).  Same batches, same arithmetic as the generic path below — the host just stops being
+    # the bottleneck (13 launches + 3 host-to-device copies per step otherwise).
+    fast = (isinstance(step_fn, FusedTrainStep) and isinstance(train_loader, TrialLoader) and device.type == "cuda"
+            and isinstance(train_loader.dataset, TrialIndexDataset) and train_loader.num_workers == 0
+            and not train_loader.drop_last)
+    if fast:
+        tab = xvector_table(mega_xvec_dict)
+        table = tab.on(device)
+        _, m, devmaps = tab.rows_from_nums(num_to_id_dict)
+        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+        if key not in devmaps:
+            devmaps[key] = torch.from_numpy(m).to(device)
+        batches = ((r1, r2, t, None, None) for r1, r2, t in train_loader.device_batches(device, devmaps[key]))
+    else:
+        batches = ((None, None, t, d1, d2) for d1, d2, t in train_loader)
+    for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
+        if fast:
+            data1 = rows1  # len(data1) below
+            loss = step_fn.step_rows(table, rows1, rows2, target)
+            losses.append(loss.detach())
+            if batch_idx % nc.log_interval == 0:
+                _log_train(nc, epoch, batch_idx, len(data1), train_loader, losses)
+                losses = []
+            continue
         data1, data2, target = data1.to(device), data2.to(device), target.to(device)
         data1_xvec, data2_xvec = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
         if step_fn is not None and (isinstance(step_fn, FusedTrainStep)
@@ -49,13 +75,18 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             optimizer.step()
         losses.append(loss.detach())
         if batch_idx % nc.log_interval == 0:
-            mean_loss = float(torch.stack([l.reshape(()).float() for l in losses]).mean().item())
-            msg = 'Train Epoch: {} [{}/{} ({:.0f}%)]\t {}: {:.6f}'.format(
-                epoch, batch_idx * len(data1), len(train_loader.dataset), 100. * batch_idx / len(train_loader),
-                nc.loss, mean_loss)
-            print(msg)
-            logging.info(msg)
+            _log_train(nc, epoch, batch_idx, len(data1), train_loader, losses)
             losses = []
+
+
+def _log_train(nc, epoch, batch_idx, batch_len, train_loader, losses):
+    """The progress line of xvector_NeuralPlda_pytorch.py:44-50 (mean of the losses since the previous line)."""
+    mean_loss = float(torch.stack([l.reshape(()).float() for l in losses]).mean().item())
+    msg = 'Train Epoch: {} [{}/{} ({:.0f}%)]\t {}: {:.6f}'.format(
+        epoch, batch_idx * batch_len, len(train_loader.dataset), 100. * batch_idx / len(train_loader),
+        nc.loss, mean_loss)
+    print(msg)
+    logging.info(msg)
 
 
 def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, update_thresholds=False):
@@ -183,6 +214,10 @@ class FusedTrainStep:
         self.use_graph = bool(graph) and batch_size is not None
         self._graph = None
         self._loss = None
+        self._graph_rows = None
+        self._loss_rows = None
+        self._graph_table = None
+        self.i1 = self.i2 = None
         self.reduce_sums = getattr(model, "_reduce_sums", None)
         self.reduce_flat = getattr(model, "_reduce_flat", None)
         if self.use_graph and (self.reduce_sums is not None or self.reduce_flat is not None):
@@ -226,14 +261,15 @@ class FusedTrainStep:
             self._lib.check(code, "nplda_adam_step_f32")
         return loss
 
-    def _capture(self):
+    def _capture_fn(self, fn):
+        """Warm `fn` up on a side stream (optimiser state restored afterwards), then capture one call of it."""
         state = [q.detach().clone() for q in self.params + self.thetas]
         m0, v0, s0 = self.m.clone(), self.v.clone(), self.step_count.clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
             for _ in range(2):
-                self._eager(self.x1, self.x2, self.t)
+                fn()
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
         with torch.no_grad():
@@ -242,9 +278,42 @@ class FusedTrainStep:
             self.m.copy_(m0)
             self.v.copy_(v0)
             self.step_count.copy_(s0)
-        self._graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self._graph):
-            self._loss = self._eager(self.x1, self.x2, self.t)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = fn()
+        return graph, loss
+
+    def _capture(self):
+        self._graph, self._loss = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
+
+    def step_rows(self, table, rows1, rows2, target):
+        """One step on the pairs (table[rows1], table[rows2]): `table` is the resident (N, D0) x-vector matrix, rows
+        int64 device tensors.  With graph replay the two gathers are part of the captured step and read their indices
+        from static buffers, so a step costs three small device copies and one graph launch on the host."""
+        ops = self._ops
+        B = rows1.shape[0]
+        if not self.use_graph or B != self.batch_size:
+            return self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
+        if self._graph_rows is None or self._graph_table != (table.data_ptr(), table.shape, table.stride(0)):
+            self._capture_rows(table)
+        self.i1.copy_(rows1, non_blocking=True)
+        self.i2.copy_(rows2, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self._graph_rows.replay()
+        return self._loss_rows
+
+    def _eager_rows(self, table):
+        self._ops.gather_rows(table, self.i1, out=self.x1)
+        self._ops.gather_rows(table, self.i2, out=self.x2)
+        return self._eager(self.x1, self.x2, self.t)
+
+    def _capture_rows(self, table):
+        if self.i1 is None:
+            self.i1 = torch.zeros(self.batch_size, dtype=torch.int64, device=self.dev)
+            self.i2 = torch.zeros(self.batch_size, dtype=torch.int64, device=self.dev)
+        self._graph_rows, self._loss_rows = self._capture_fn(lambda: self._eager_rows(table))
+        self._graph_table = (table.data_ptr(), table.shape, table.stride(0))
+        self._table_ref = table  # keeps the captured pointer alive
 
     def __call__(self, x1, x2, target):
         if not self.use_graph or x1.shape[0] != self.batch_size:

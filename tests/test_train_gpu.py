@@ -403,3 +403,60 @@ def test_cfg2_full_size_minibatch_from_a_voxceleb_scale_table(hip_lib):
     np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
     for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
+    """train() with the vectorised loader + FusedTrainStep keeps the epoch's index arrays on the device and gathers inside
+    the captured step (TrialLoader.device_batches, FusedTrainStep.step_rows).  It must visit the same batches and leave
+    the same parameters as the generic loop (host batches -> load_xvec_trials_from_numbatch -> step), bit for bit,
+    including the ragged last batch (eager fall-back of the graph path)."""
+    import contextlib
+    import io
+    from neuralplda_amd import sv_trials_loaders as svl, train
+    rng = np.random.default_rng(5)
+    n_utt, n_trials, B = 300, 1000, 128
+    ids = [f"spk{u // 3:03d}-utt{u:04d}" for u in range(n_utt)]
+    xv = rng.standard_normal((n_utt, 512)).astype(np.float32)
+    mega = {u: xv[i] for i, u in enumerate(ids)}
+    num_to_id = dict(enumerate(ids))
+    id_to_num = {u: i for i, u in num_to_id.items()}
+    a, b = rng.integers(0, n_utt, n_trials), rng.integers(0, n_utt, n_trials)
+    lab = (a // 3 == b // 3).astype(int)
+    lab[rng.random(n_trials) < 0.15] = 1
+    tf = tmp_path / "train.tsv"
+    tf.write_text("\n".join(f"{ids[i]}\t{ids[j]}\t{l}" for i, j, l in zip(a, b, lab)) + "\n")
+    loader = svl.combine_trials_and_get_loader([str(tf)], id_to_num, subsample_factors=[1.01], batch_size=B)
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    nc.log_interval = 3
+
+    def run(fast):
+        m = model_from(p, nc, thetas=[-0.5, -0.3])
+        step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+        torch.manual_seed(11)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            if fast:
+                train.train(nc, m, torch.device("cuda"), loader, mega, num_to_id, None, 1, step_fn=step)
+            else:  # the same batches handed over as a plain iterable: generic path
+                batches = list(loader)
+
+                class Plain(list):
+                    dataset = loader.dataset
+                train.train(nc, m, torch.device("cuda"), Plain(batches), mega, num_to_id, None, 1, step_fn=step)
+        return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, out.getvalue(), step
+
+    sd_fast, log_fast, step_fast = run(True)
+    sd_gen, log_gen, _ = run(False)
+    assert step_fast._graph_rows is not None and step_fast.step_count.item() == 8  # 7 replays + 1 ragged eager step
+    assert log_fast == log_gen and log_fast.count("Train Epoch") == 3
+    for k in sd_gen:
+        assert np.array_equal(sd_fast[k], sd_gen[k]), k
+    # an index that maps to no utterance raises like the reference-shaped gather
+    bad = dict(num_to_id)
+    bad[0] = "nobody"
+    with pytest.raises(KeyError):
+        m = model_from(p, nc, thetas=[-0.5, -0.3])
+        step = train.FusedTrainStep(m, 1e-3, batch_size=B, graph=True)
+        with contextlib.redirect_stdout(io.StringIO()):
+            train.train(nc, m, torch.device("cuda"), loader, mega, bad, None, 1, step_fn=step)
