@@ -44,13 +44,8 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             and isinstance(train_loader.dataset, TrialIndexDataset) and train_loader.num_workers == 0
             and not train_loader.drop_last)
     if fast:
-        tab = xvector_table(mega_xvec_dict)
-        table = tab.on(device)
-        _, m, devmaps = tab.rows_from_nums(num_to_id_dict)
-        key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
-        if key not in devmaps:
-            devmaps[key] = torch.from_numpy(m).to(device)
-        batches = ((r1, r2, t, None, None) for r1, r2, t in train_loader.device_batches(device, devmaps[key]))
+        table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
+        batches = ((r1, r2, t, None, None) for r1, r2, t in train_loader.device_batches(device, row_map))
     else:
         batches = ((None, None, t, d1, d2) for d1, d2, t in train_loader)
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
@@ -79,6 +74,16 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             losses = []
 
 
+def _device_table(mega_xvec_dict, num_to_id_dict, device):
+    """(resident x-vector matrix, int64 device map trial number -> table row) of a mega dict / num_to_id dict pair."""
+    tab = xvector_table(mega_xvec_dict)
+    _, m, devmaps = tab.rows_from_nums(num_to_id_dict)
+    key = (device.type, device.index if device.index is not None else torch.cuda.current_device())
+    if key not in devmaps:
+        devmaps[key] = torch.from_numpy(m).to(device)
+    return tab.on(device), devmaps[key]
+
+
 def _log_train(nc, epoch, batch_idx, batch_len, train_loader, losses):
     """The progress line of xvector_NeuralPlda_pytorch.py:44-50 (mean of the losses since the previous line)."""
     mean_loss = float(torch.stack([l.reshape(()).float() for l in losses]).mean().item())
@@ -94,11 +99,22 @@ def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, upd
     model.eval()
     with torch.no_grad():
         targets, scores = [], []
-        for data1, data2, target in data_loader:
-            data1, data2, target = data1.to(device), data2.to(device), target.to(device)
-            x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
-            targets.append(target)
-            scores.append(model.forward(x1, x2))
+        device = torch.device(device)
+        if (isinstance(data_loader, TrialLoader) and device.type == "cuda"
+                and isinstance(data_loader.dataset, TrialIndexDataset) and data_loader.num_workers == 0
+                and not data_loader.drop_last):
+            # device-resident pass (see train()): same batches, same forward launches, no per-batch host copies
+            from . import ops
+            table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
+            for rows1, rows2, target in data_loader.device_batches(device, row_map):
+                targets.append(target)
+                scores.append(model.forward(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2)))
+        else:
+            for data1, data2, target in data_loader:
+                data1, data2, target = data1.to(device), data2.to(device), target.to(device)
+                x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
+                targets.append(target)
+                scores.append(model.forward(x1, x2))
         targets, scores = torch.cat(targets), torch.cat(scores)
         soft_cdet_loss = model.softcdet(scores, targets)
         cdet_mdl = model.cdet(scores, targets)

@@ -405,16 +405,10 @@ def test_cfg2_full_size_minibatch_from_a_voxceleb_scale_table(hip_lib):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
 
 
-def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
-    """train() with the vectorised loader + FusedTrainStep keeps the epoch's index arrays on the device and gathers inside
-    the captured step (TrialLoader.device_batches, FusedTrainStep.step_rows).  It must visit the same batches and leave
-    the same parameters as the generic loop (host batches -> load_xvec_trials_from_numbatch -> step), bit for bit,
-    including the ragged last batch (eager fall-back of the graph path)."""
-    import contextlib
-    import io
-    from neuralplda_amd import sv_trials_loaders as svl, train
-    rng = np.random.default_rng(5)
-    n_utt, n_trials, B = 300, 1000, 128
+def _tiny_trial_set(tmp_path, rng, B):
+    """300 utterances, 1000 trials in a TSV, the vectorised loader over it (ragged last batch at B = 128)."""
+    from neuralplda_amd import sv_trials_loaders as svl
+    n_utt, n_trials = 300, 1000
     ids = [f"spk{u // 3:03d}-utt{u:04d}" for u in range(n_utt)]
     xv = rng.standard_normal((n_utt, 512)).astype(np.float32)
     mega = {u: xv[i] for i, u in enumerate(ids)}
@@ -426,6 +420,20 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
     tf = tmp_path / "train.tsv"
     tf.write_text("\n".join(f"{ids[i]}\t{ids[j]}\t{l}" for i, j, l in zip(a, b, lab)) + "\n")
     loader = svl.combine_trials_and_get_loader([str(tf)], id_to_num, subsample_factors=[1.01], batch_size=B)
+    return mega, num_to_id, loader
+
+
+def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
+    """train() with the vectorised loader + FusedTrainStep keeps the epoch's index arrays on the device and gathers inside
+    the captured step (TrialLoader.device_batches, FusedTrainStep.step_rows).  It must visit the same batches and leave
+    the same parameters as the generic loop (host batches -> load_xvec_trials_from_numbatch -> step), bit for bit,
+    including the ragged last batch (eager fall-back of the graph path)."""
+    import contextlib
+    import io
+    from neuralplda_amd import train
+    rng = np.random.default_rng(5)
+    B = 128
+    mega, num_to_id, loader = _tiny_trial_set(tmp_path, rng, B)
     p = rand_params(rng, 512, 150, 150)
     nc = NC(D1=150, D2=150, loss="SoftCdet")
     nc.log_interval = 3
@@ -460,3 +468,30 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
         step = train.FusedTrainStep(m, 1e-3, batch_size=B, graph=True)
         with contextlib.redirect_stdout(io.StringIO()):
             train.train(nc, m, torch.device("cuda"), loader, mega, bad, None, 1, step_fn=step)
+
+
+def test_validate_device_resident_pass_equals_the_generic_loop(hip_lib, tmp_path):
+    """validate() over the vectorised loader gathers from the resident table on the device; scores, metrics, thresholds
+    written back and the printed report must equal the generic loop's (same batches -> same forward launches)."""
+    import contextlib
+    import io
+    from neuralplda_amd import train
+    rng = np.random.default_rng(6)
+    mega, num_to_id, loader = _tiny_trial_set(tmp_path, rng, 128)
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+
+    def run(fast):
+        m = model_from(p, nc, thetas=[-0.5, -0.3])
+        torch.manual_seed(3)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            if fast:
+                mc, th = train.validate(nc, m, torch.device("cuda"), mega, num_to_id, loader, update_thresholds=True)
+            else:
+                mc, th = train.validate(nc, m, torch.device("cuda"), mega, num_to_id, list(loader), update_thresholds=True)
+        return float(mc), {k: float(v) for k, v in th.items()}, out.getvalue(), [float(m.threshold[b].detach()) for b in m.beta]
+
+    fast, gen = run(True), run(False)
+    assert fast == gen
+    assert fast[3] == [fast[1][b] for b in nc.beta]  # update_thresholds wrote the arg-min scores into Th{beta}
