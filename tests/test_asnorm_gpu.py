@@ -42,7 +42,7 @@ def test_row_stats_matches_sort_then_slice(hip_lib, R, M, topn, select):
         assert got[1, 1] < 1e-7 and got[1, 3] < 1e-7
 
 
-@pytest.mark.parametrize("D", [150, 170])
+@pytest.mark.parametrize("D", [150, 170, 16, 24])  # 16 / 24: one / two k16 stages per tile (the single-stage pipeline)
 @pytest.mark.parametrize("R,M", [(200, 1000), (130, 257), (140, 24700)])  # the last spans two super-bands of column tiles
 def test_cohort_stats_full_pipeline(hip_lib, D, R, M):
     from neuralplda_amd import ops
