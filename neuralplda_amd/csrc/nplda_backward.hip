@@ -285,7 +285,7 @@ struct WgradArgs {
     int nw;               // total work items
 };
 
-constexpr int kPF = 8;  // k4-steps of operand prefetch per wave (HBM/L2 latency ~ 8 x 16 MFMAs)
+constexpr int kPF = 4;  // k4-steps of operand prefetch per wave (8 needed 330 registers: one block per CU; at 4 two are resident)
 
 // One block = one (problem, 64x64 tile, k-group) work item; its 4 waves take the 4 quarters of the k-group's
 // rows, then reduce their accumulators through LDS in a fixed order (deterministic) so that only ONE slab per
@@ -434,7 +434,7 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProble
     }
 }
 
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
+__global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __shared__ f32x4 red[4][16 * 64];   // [wave][(ca*4+cb)*64 + lane]  (64 KB)
     __shared__ f32x4 rede[4][3][16];    // column-sum partials
     int w = blockIdx.x;
@@ -519,7 +519,7 @@ WsLayout ws_layout(long long B, const NpldaLayout& L) {
     if (ks * tiles > 512) ks = 512 / tiles;
     if (ks < 1) ks = 1;
     long long rps = (K + ks - 1) / ks;
-    rps = (rps + 127) / 128 * 128;  // 4 quarters, each a multiple of 4 * kPF rows
+    rps = (rps + 16 * kPF - 1) / (16 * kPF) * (16 * kPF);  // 4 quarters, each a multiple of 4 * kPF rows
     w.ksplit = (int)((K + rps - 1) / rps);
     if (w.ksplit < 1) w.ksplit = 1;
     w.rows_per_split = rps;
