@@ -29,8 +29,10 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// `single`: the launch is ONE block that covers the whole batch — it stores its sums (no zero-fill of `out` before the
+// launch, no atomics: one graph node less in the training step and a fixed summation order).
 template <int NS>
-__device__ __forceinline__ void block_reduce_add(double (&acc)[NS], double* out) {
+__device__ __forceinline__ void block_reduce_add(double (&acc)[NS], double* out, int single) {
     __shared__ double red[kThreads / 64][NS];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -43,15 +45,44 @@ __device__ __forceinline__ void block_reduce_add(double (&acc)[NS], double* out)
         double v = 0.0;
 #pragma unroll
         for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
-        atomicAdd(out + threadIdx.x, v);
+        if (single) out[threadIdx.x] = v;
+        else atomicAdd(out + threadIdx.x, v);
     }
+}
+
+// One block over a whole (16-byte aligned) batch: float4 groups, four groups per thread loaded as one batch with clamped
+// indices (a scalar one-load-per-iteration loop is waited out load by load), then the < 4 tail elements.
+constexpr long long kSingleBlockMax = 4096;
+template <class F>
+__device__ __forceinline__ void sums_single_block(const float* __restrict__ s, const float* __restrict__ t, long long B,
+                                                  F accumulate) {
+    const int nv = (int)(B / 4);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(s);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+    for (int base = threadIdx.x; base < nv; base += kThreads * 4) {
+        f32x4 sv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gidx = base + kThreads * u;
+            sv[u] = s4[gidx < nv ? gidx : nv - 1];
+            tv[u] = t4[gidx < nv ? gidx : nv - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (base + kThreads * u < nv) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) accumulate(sv[u][e], tv[u][e]);
+            }
+        }
+    }
+    for (long long i = 4LL * nv + threadIdx.x; i < B; i += kThreads) accumulate(s[i], t[i]);
 }
 
 // kind 0 = SoftCdet, 1 = BCE, 2 = hard Cdet (utils/models.py:401-404: step functions, strict < / >)
 template <int K, bool HARD>
 __global__ __launch_bounds__(kThreads) void loss_sums_softcdet(const float* __restrict__ s,
                                                                const float* __restrict__ t, long long B,
-                                                               ThetaPtrs th, float alpha, double* sums) {
+                                                               ThetaPtrs th, float alpha, double* sums, int single) {
     constexpr int NS = 2 + 4 * K;
     double acc[NS];
 #pragma unroll
@@ -59,9 +90,8 @@ __global__ __launch_bounds__(kThreads) void loss_sums_softcdet(const float* __re
     float theta[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
-    const long long stride = (long long)gridDim.x * kThreads;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
-        const float si = s[i], ti = t[i], ni = 1.0f - ti;
+    auto accumulate = [&](float si, float ti) {
+        const float ni = 1.0f - ti;
         acc[0] += ti;
         acc[1] += ni;
 #pragma unroll
@@ -86,17 +116,21 @@ __global__ __launch_bounds__(kThreads) void loss_sums_softcdet(const float* __re
             acc[2 + 4 * k + 2] += d * ti;
             acc[2 + 4 * k + 3] += d * ni;
         }
+    };
+    if (single) {
+        sums_single_block(s, t, B, accumulate);
+    } else {
+        const long long stride = (long long)gridDim.x * kThreads;
+        for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) accumulate(s[i], t[i]);
     }
-    block_reduce_add<NS>(acc, sums);
+    block_reduce_add<NS>(acc, sums, single);
 }
 
 __global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restrict__ s, const float* __restrict__ t,
-                                                          long long B, ThetaPtrs th, double* sums) {
+                                                          long long B, ThetaPtrs th, double* sums, int single) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const float theta = th.p[0][0];
-    const long long stride = (long long)gridDim.x * kThreads;
-    for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
-        const float si = s[i], ti = t[i];
+    auto accumulate = [&](float si, float ti) {
         // F.binary_cross_entropy(sigmoid(s - theta), t): log terms clamped at -100 (utils/models.py:390-393)
         const float p = 1.0f / (1.0f + expf(-(si - theta)));
         const float lp = fmaxf(logf(p), -100.0f);
@@ -105,8 +139,14 @@ __global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restric
         acc[1] += 1.0f - ti;
         acc[2] += -(ti * lp + (1.0f - ti) * lq);
         acc[3] += p - ti;
+    };
+    if (single) {
+        sums_single_block(s, t, B, accumulate);
+    } else {
+        const long long stride = (long long)gridDim.x * kThreads;
+        for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) accumulate(s[i], t[i]);
     }
-    block_reduce_add<4>(acc, sums);
+    block_reduce_add<4>(acc, sums, single);
 }
 
 struct BetaVals { float b[kMaxK]; };
@@ -201,25 +241,28 @@ int nplda_loss_sums_f32(const float* s, const float* t, int64_t B, const float* 
         th.p[k] = theta[k];
     }
     hipStream_t st = (hipStream_t)stream;
-    hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * ns, st);
-    if (e != hipSuccess) return (int)e;
+    const int single = (B > 0 && B <= kSingleBlockMax && nplda_aligned16(s) && nplda_aligned16(t)) ? 1 : 0;
+    if (!single) {
+        hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * ns, st);
+        if (e != hipSuccess) return (int)e;
+    }
     if (B == 0) return NPLDA_OK;
-    const dim3 grid(grid_for(B)), block(kThreads);
+    const dim3 grid(single ? 1u : grid_for(B)), block(kThreads);
     if (kind == 1) {
-        hipLaunchKernelGGL(loss_sums_bce, grid, block, 0, st, s, t, (long long)B, th, sums);
+        hipLaunchKernelGGL(loss_sums_bce, grid, block, 0, st, s, t, (long long)B, th, sums, single);
     } else if (kind == 2) {
         switch (K) {
-            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            default: hipLaunchKernelGGL((loss_sums_softcdet<4, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            default: hipLaunchKernelGGL((loss_sums_softcdet<4, true>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
         }
     } else {
         switch (K) {
-            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
-            default: hipLaunchKernelGGL((loss_sums_softcdet<4, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums); break;
+            case 1: hipLaunchKernelGGL((loss_sums_softcdet<1, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            case 2: hipLaunchKernelGGL((loss_sums_softcdet<2, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            case 3: hipLaunchKernelGGL((loss_sums_softcdet<3, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
+            default: hipLaunchKernelGGL((loss_sums_softcdet<4, false>), grid, block, 0, st, s, t, (long long)B, th, alpha, sums, single); break;
         }
     }
     return nplda_launch_status();
