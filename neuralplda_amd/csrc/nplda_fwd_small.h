@@ -19,7 +19,7 @@
 namespace nplda {
 
 template <int NB, int MODE>
-__global__ __launch_bounds__(256, 1) void nplda_fwd_small_kernel(const FwdArgs a) {
+__global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a) {
     static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN || MODE == MODE_GB, "small kernel modes");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
