@@ -146,7 +146,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 // fragments read straight from the L2-resident image through a register ring, and the y.dy dot product of the
 // normalize backward is reduced across the waves through LDS.
 template <int NB>
-__global__ __launch_bounds__(256, 1) void bwd_data_small_kernel(const BwdArgs a) {
+__global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a) {
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;
     constexpr int PF = 4;
