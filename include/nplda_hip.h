@@ -289,8 +289,10 @@ int nplda_text_column_spans(const char* text, size_t len, int64_t skip_rows, int
 
 /* torch.optim.Adam's update (xvector_NeuralPlda_pytorch.py:139: lr, weight_decay = 1e-5 as L2 term, no amsgrad)
  * applied to nseg <= 12 (param, grad, exp_avg, exp_avg_sq) segments in one launch.  The four pointer arrays and
- * numel are HOST arrays of nseg entries (device pointers / element counts).  step: DEVICE float holding the number
- * of steps taken so far; it is incremented first, then used for the bias correction (graph-replay safe). */
+ * numel are HOST arrays of nseg entries (device pointers / element counts).  step: DEVICE buffer of TWO 4-byte words,
+ * zero-initialised by the caller: step[0] is the number of steps taken so far as a float (incremented by the launch,
+ * the new value is the one used for the bias correction), step[1] is scratch of the launch (an arrival counter, zero
+ * between launches).  Graph-replay safe: nothing about the step lives on the host. */
 int nplda_adam_step_f32(float* const* params, const float* const* grads, float* const* exp_avg,
                         float* const* exp_avg_sq, const int64_t* numel, int nseg, float* step, float lr,
                         float beta1, float beta2, float eps, float weight_decay, nplda_stream_t stream);

@@ -200,7 +200,7 @@ class FusedTrainStep:
     """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser:
     pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat gradient) -> one-launch Adam
     (nplda_adam_step_f32, same update rule as torch.optim.Adam(lr, weight_decay) of the reference,
-    xvector_NeuralPlda_pytorch.py:139) — nine launches, optionally replayed from a HIP graph.
+    xvector_NeuralPlda_pytorch.py:139) — eight launches (nine above 4096 pairs: the loss sums are zero-filled first), optionally replayed from a HIP graph.
     With `reduce_sums` / `reduce_flat` callables (neuralplda_amd.dist) it is the data-parallel step (eager only)."""
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
@@ -225,7 +225,7 @@ class FusedTrainStep:
         K = len(self.thetas)
         self.m = torch.zeros(n + K, device=self.dev)
         self.v = torch.zeros(n + K, device=self.dev)
-        self.step_count = torch.zeros(1, device=self.dev)
+        self.step_count = torch.zeros(2, device=self.dev)  # [steps taken, launch scratch] (nplda_adam_step_f32)
         self.batch_size = batch_size
         self.use_graph = bool(graph) and batch_size is not None
         self._graph = None
