@@ -25,7 +25,7 @@ from .NpldaConf import NpldaConf
 from .sv_trials_loaders import (TrialIndexDataset, TrialLoader, combine_trials_and_get_loader,
                                 get_trials_loaders_dict, load_xvec_trials_from_numbatch, xvector_table)
 
-__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "main_kaldiplda", "main_dplda",
+__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "FusedDPldaStep", "main_kaldiplda", "main_dplda",
            "train_gaussian_backend"]
 
 
@@ -262,20 +262,25 @@ class FusedTrainStep:
                 flat = self.reduce_flat(flat)
             # segments: the six tensors of the flat gradient, then one scalar per threshold
             grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
-            tensors = prm + ths
-            nseg = len(tensors)
-            arr = lambda ptrs: (ctypes.c_void_p * nseg)(*ptrs)  # noqa: E731
-            offs, o = [], 0
-            for q in tensors:
-                offs.append(o)
-                o += q.numel()
-            code = lib.nplda_adam_step_f32(
-                arr([q.data_ptr() for q in tensors]), arr([gq.data_ptr() for gq in grads]),
-                arr([self.m.data_ptr() + 4 * of for of in offs]), arr([self.v.data_ptr() + 4 * of for of in offs]),
-                (ctypes.c_int64 * nseg)(*[q.numel() for q in tensors]), nseg, self.step_count.data_ptr(), self.lr,
-                self.betas[0], self.betas[1], self.eps, self.wd, self._lib.current_stream())
-            self._lib.check(code, "nplda_adam_step_f32")
+            self._adam(prm + ths, grads)
         return loss
+
+    def _adam(self, tensors, grads):
+        """One nplda_adam_step_f32 launch over `tensors` (moments in self.m / self.v, segment by segment)."""
+        import ctypes
+        lib = self._lib.load()
+        nseg = len(tensors)
+        arr = lambda ptrs: (ctypes.c_void_p * nseg)(*ptrs)  # noqa: E731
+        offs, o = [], 0
+        for q in tensors:
+            offs.append(o)
+            o += q.numel()
+        code = lib.nplda_adam_step_f32(
+            arr([q.data_ptr() for q in tensors]), arr([gq.data_ptr() for gq in grads]),
+            arr([self.m.data_ptr() + 4 * of for of in offs]), arr([self.v.data_ptr() + 4 * of for of in offs]),
+            (ctypes.c_int64 * nseg)(*[q.numel() for q in tensors]), nseg, self.step_count.data_ptr(), self.lr,
+            self.betas[0], self.betas[1], self.eps, self.wd, self._lib.current_stream())
+        self._lib.check(code, "nplda_adam_step_f32")
 
     def _capture_fn(self, fn):
         """Warm `fn` up on a side stream (optimiser state restored afterwards), then capture one call of it."""
@@ -341,6 +346,61 @@ class FusedTrainStep:
         self.t.copy_(target, non_blocking=True)
         self._graph.replay()
         return self._loss
+
+
+class FusedDPldaStep(FusedTrainStep):
+    """The recipe step of DPlda (xvector_DPlda_pytorch.py:140-152: LDA frozen, Adam on the linear unit and the
+    thresholds) as direct launches: quadratic-form image -> fused LDA + normalise + score (saving the paired rows)
+    -> loss sums / finish -> weighted moments sum_k g_k x x^T -> fold into d wlr, d bias -> one-launch Adam.
+    Same interface as FusedTrainStep (call, step_rows, graph replay); follows the autograd + torch.optim.Adam
+    trajectory of models.DPlda (tests/test_dplda_gpu.py)."""
+
+    def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
+        from . import _lib, ops
+        from .models import _loss_kind
+        self._lib, self._ops = _lib, ops
+        p = model.logistic_regres.weight
+        if not p.is_cuda:
+            raise ValueError("FusedDPldaStep needs the model on a HIP device")
+        if model.centering_and_LDA.weight.requires_grad or model.centering_and_LDA.bias.requires_grad:
+            raise ValueError("DPlda trains with centering_and_LDA frozen (xvector_DPlda_pytorch.py:140-147): "
+                             "set requires_grad = False on its weight and bias")
+        self.model, self.dev = model, p.device
+        self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
+        self.kind = _loss_kind(model.lossfn)
+        self.thetas = ([model.threshold[b] for b in model.beta] if self.kind == ops.LOSS_SOFTCDET
+                       else [model.threshold_Xent])
+        self.betas_loss = [float(b) for b in model.beta] if self.kind == ops.LOSS_SOFTCDET else []
+        self.alpha = float(model.alpha) if self.kind == ops.LOSS_SOFTCDET else 0.0
+        self.params = [model.logistic_regres.weight, model.logistic_regres.bias]
+        D0, self.D1 = model.centering_and_LDA.in_features, model.centering_and_LDA.out_features
+        n = sum(q.numel() for q in self.params) + len(self.thetas)
+        self.m = torch.zeros(n, device=self.dev)
+        self.v = torch.zeros(n, device=self.dev)
+        self.step_count = torch.zeros(2, device=self.dev)
+        self.batch_size = batch_size
+        self.use_graph = bool(graph) and batch_size is not None
+        self._graph = self._loss = self._graph_rows = self._loss_rows = self._graph_table = None
+        self.i1 = self.i2 = None
+        self.reduce_sums = self.reduce_flat = None
+        if self.use_graph:
+            self.x1 = torch.zeros(batch_size, D0, device=self.dev)
+            self.x2 = torch.zeros(batch_size, D0, device=self.dev)
+            self.t = torch.zeros(batch_size, device=self.dev)
+            self.t[::2] = 1
+
+    def _eager(self, x1, x2, t):
+        ops, mdl = self._ops, self.model
+        with torch.no_grad():
+            wlr, blr = (q.detach() for q in self.params)
+            packed = ops.dplda_pack(mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach(), wlr, blr)
+            s, paired = ops._gb_call(x1, x2, packed, True, True)
+            ths = [th.detach() for th in self.thetas]
+            sums = ops.loss_sums(s, t, ths, self.alpha, self.kind)
+            loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
+            dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1)
+            self._adam([wlr, blr] + ths, [dw.contiguous(), db.contiguous()] + [dth[k:k + 1] for k in range(len(ths))])
+        return loss
 
 
 def train_gaussian_backend(nc, model, train_loader, mega_xvec_dict, num_to_id_dict, device=None):
@@ -428,7 +488,7 @@ def main_kaldiplda(configfile='conf/voices_config.cfg', use_graph=True):
     return model
 
 
-def main_dplda(configfile='conf/voices_config.cfg'):
+def main_dplda(configfile='conf/voices_config.cfg', use_graph=True):
     """xvector_DPlda_pytorch.py:88-189: the same driver around DPlda — Kaldi LDA loaded and frozen (:131-147), Adam
     over logistic_regres + thresholds, eager steps (forward = fused quadratic form, backward = weighted moments)."""
     from .models import DPlda
@@ -464,11 +524,14 @@ def main_dplda(configfile='conf/voices_config.cfg'):
             updatable.append(prm)
     lr = nc.lr
     optimizer = optim.Adam(updatable, lr=lr, weight_decay=1e-5)
+    on_gpu = torch.device(device).type == "cuda"
+    step_fn = (FusedDPldaStep(model, lr, weight_decay=1e-5, batch_size=nc.batch_size, graph=use_graph)
+               if on_gpu else None)
     validate(nc, model, device, mega_xvec_dict, num_to_id_dict, valid_loaders[nc.heldout_set_for_th_init],
              update_thresholds=True)
     all_losses = []
     for epoch in range(1, nc.n_epochs + 1):
-        train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch)
+        train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, step_fn=step_fn)
         val_losses = {}
         for val_set, loader in valid_loaders.items():
             val_losses[val_set], _ = validate(nc, model, device, mega_xvec_dict, num_to_id_dict, loader)
@@ -481,7 +544,9 @@ def main_dplda(configfile='conf/voices_config.cfg'):
         if len(all_losses) >= 3 and all_losses[-1] > all_losses[-2] > all_losses[-3]:
             lr = lr / 2
             logging.info("REDUCING LEARNING RATE to {} since loss trend looks like {}".format(lr, all_losses[-3:]))
-            optimizer = optim.Adam(updatable, lr=lr, weight_decay=1e-5)
+            optimizer = optim.Adam(updatable, lr=lr, weight_decay=1e-5)  # moments reset, as the reference re-creates Adam
+            if on_gpu:
+                step_fn = FusedDPldaStep(model, lr, weight_decay=1e-5, batch_size=nc.batch_size, graph=use_graph)
     return model
 
 

@@ -197,3 +197,40 @@ def test_dplda_adam_steps_match_torch_recipe(hip_lib):
     assert float(dw.mean()) < 2e-5 and float(dw.max()) < 2.1e-3
     for b, th in zip((99.0, 199.0), ref_th):
         assert abs(float(m.threshold[b]) - float(th)) < 1e-5
+
+
+@pytest.mark.parametrize("graph", [False, True])
+def test_fused_dplda_step_follows_the_autograd_recipe(hip_lib, graph):
+    """train.FusedDPldaStep (direct launches + one-launch Adam, optionally a HIP-graph replay) against the autograd +
+    torch.optim.Adam recipe on models.DPlda: same losses, same parameters after five steps."""
+    from neuralplda_amd import train
+    rg = np.random.default_rng(8)
+    D0, D1, B = 128, 40, 512
+    W1 = (rg.standard_normal((D1, D0)) / np.sqrt(D0)).astype(np.float32)
+    b1 = (0.1 * rg.standard_normal(D1)).astype(np.float32)
+    wlr = (0.05 * rg.standard_normal((1, 2 * D1 * D1 + D1))).astype(np.float32)
+    batches = [(torch.from_numpy(rg.standard_normal((B, D0)).astype(np.float32)).cuda(),
+                torch.from_numpy(rg.standard_normal((B, D0)).astype(np.float32)).cuda(),
+                torch.from_numpy((rg.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(5)]
+    m_ref = make(D0, D1, W1, b1, wlr, [0.0])
+    _freeze_lda(m_ref)
+    opt = torch.optim.Adam([p for p in m_ref.parameters() if p.requires_grad], lr=1e-3, weight_decay=1e-5)
+    ref_losses = []
+    for x1, x2, t in batches:
+        opt.zero_grad()
+        with torch.enable_grad():
+            L = m_ref.loss(m_ref(x1, x2), t)
+            L.backward()
+        opt.step()
+        ref_losses.append(float(L))
+    m = make(D0, D1, W1, b1, wlr, [0.0])
+    _freeze_lda(m)
+    step = train.FusedDPldaStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+    losses = [float(step(x1, x2, t)) for x1, x2, t in batches]
+    np.testing.assert_allclose(losses, ref_losses, rtol=2e-5)
+    for (k, a), (_, b) in zip(m.state_dict().items(), m_ref.state_dict().items()):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+    assert step.step_count[0].item() == 5
+    m2 = make(D0, D1, W1, b1, wlr, [0.0])  # LDA not frozen: refused up front
+    with pytest.raises(ValueError):
+        train.FusedDPldaStep(m2, 1e-3, batch_size=B)

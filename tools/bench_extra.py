@@ -147,7 +147,11 @@ def main():
         L.backward()
         opt.step()
     ms_ds = timeit(dstep, reps=20)
-    out["dplda_D170"] = {"score_pairs_per_s": Bg / ms_d * 1e3, "score_ms_512k": ms_d, "train_step_ms_B2048": ms_ds}
+    from neuralplda_amd import train as _train
+    fstep = _train.FusedDPldaStep(dp, 1e-4, weight_decay=1e-5, batch_size=2048, graph=True)
+    ms_df = timeit(lambda: fstep(xa, xb, tt), reps=50, warm=5)
+    out["dplda_D170"] = {"score_pairs_per_s": Bg / ms_d * 1e3, "score_ms_512k": ms_d,
+                         "train_step_eager_autograd_torchAdam_ms_B2048": ms_ds, "train_step_fused_ms_B2048": ms_df}
     # validation metrics: minc (reference semantics) / exact min-DCF + EER over N scores
     from neuralplda_amd import metrics
     for N in (1 << 20, 10_000_000):
