@@ -5,19 +5,21 @@
 // are COMPUTED (new functionality; oracle = NeuralPlda.forward on the expanded pair list) and reduced:
 //
 //  K8a cohort_gemm_kernel   S[r, m] = q_r + q_m + 2 sum_d P_d z_r,d z_m,d as an fp32-MFMA tile GEMM
-//                           (K = padded D2 <= 192, so it is MFMA/write-bound, AI ~ 80 FLOP/B): wave
-//                           tile 64 x 64, operands read as float4 straight from the row-major
-//                           embedding tables with the k-permutation trick of the forward kernel, the
-//                           2 P_d factor folded into the A operand, q_r + q_m added in the epilogue.
-//                           S is spilled (R_chunk x M fp32; 0.88 GB for the whole 22 k x 10 k of
-//                           BASELINE cfg3, far below 288 GB) because the per-row top-N needs whole rows.
+//                           (K = padded D2 <= 192, so it is MFMA/write-bound, AI ~ 80 FLOP/B): block tile
+//                           128 x 128 (2 x 2 waves of 64 x 64), both operands staged through LDS by LDS-DMA in
+//                           swizzled k16 stages, persistent blocks pulling XCD-banded tiles from per-XCD
+//                           counters, the 2 P_d factor folded into the row operand, q_r + q_m added in the
+//                           epilogue (16-byte stores).  S is spilled (R_chunk x M fp32; 0.88 GB for the whole
+//                           22 k x 10 k of BASELINE cfg3, far below 288 GB) because the per-row top-N needs
+//                           whole rows.
 //  K8b row_stats_kernel     one workgroup per row: the row is loaded once into LDS (<= 160 KB) as
-//                           order-preserving integer keys; sum and sum of squares in fp64; the N-th
-//                           smallest (reference semantics: ascending sort then [:N],
-//                           adaptive_score_normalization.py:32-36) or N-th largest
-//                           key is found by a 4-ary search on the integer key space (three pivot counts per
-//                           pass in registers, shuffle + LDS reduction, no atomics); a last pass accumulates the
-//                           selected values (ties resolved by count, so the result equals sort-then-slice exactly).
+//                           order-preserving integer keys; sum and sum of squares in fp64.  The N-th smallest
+//                           (reference semantics: ascending sort then [:N], adaptive_score_normalization.py:32-36)
+//                           or N-th largest key: a normal-quantile bracket of the row's (mean, std) is counted and
+//                           its <= 512 keys ranked exactly (one pass over the keys); rows the bracket misses take
+//                           a 4-ary search on the integer key space (three pivot counts per pass in registers,
+//                           DPP + LDS reduction, no atomics) and a last pass over the selected values.  Either way
+//                           ties are resolved by count, so the result equals sort-then-slice exactly.
 //                           Output (mean, std, mean_top, std_top), population std (ddof = 0), fp64.
 //  K9  asnorm_apply_kernel  per trial: z-norm, t-norm, s-norm, as-norm1 from the two rows' statistics
 //                           (adaptive_score_normalization.py:65-73), fp64, ~100 B/trial: HBM-bound.
