@@ -439,11 +439,10 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             }
         }
     }
-    // Barriers are the expensive part of this kernel (three rows share a CU: a barrier waits for the slowest of eight
-    // waves, each queued behind the other rows' arithmetic), so every exchange below is ONE barrier: the partial results
-    // of a phase go to LDS slots that no other phase uses (cnt[0..31] / cnt[32..63], red[0..15] / red[16..31]), and the
-    // scratch of the shortcut (sentinel-filled candidate list, zeroed rank counters) is prepared here, two barriers
-    // ahead of its use.
+    // Every exchange below is ONE barrier: the partial results of a phase go to LDS slots that no other phase uses
+    // (cnt[0..31] / cnt[32..63], red[0..15] / red[16..31]), and the scratch of the shortcut (sentinel-filled candidate
+    // list, "unwritten" rank slots, zeroed rank counters) is prepared here, two barriers ahead of its use.  (Measured:
+    // halving the barrier count this way changed nothing by itself — the kernel is bound by its VALU instructions.)
     unsigned* list = cnt + 64 + 8 * NWV;          // [kListCap] candidate keys, then [kListCap] floats by rank
     float* sel = reinterpret_cast<float*>(list + kListCap);
     unsigned* nlist = reinterpret_cast<unsigned*>(sel + kListCap);
