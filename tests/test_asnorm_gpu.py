@@ -211,3 +211,33 @@ def test_row_stats_shapes_that_defeat_the_quantile_shortcut(hip_lib, select):
     assert np.all(np.abs(got[:, 3] - ref[:, 3]) <= 2e-7 * scale)
     again = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
     assert np.array_equal(got, again)  # bit-reproducible (rank-slot summation, no atomics on values)
+
+
+def test_row_stats_random_sweep(hip_lib):
+    """Random (M, topn, distribution, select) sweep against sort-then-slice: odd row lengths (16-byte tail groups), rows at
+    the LDS / no-LDS boundary, top-N from 1 to beyond M, mixtures with exact duplicates."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(99)
+    Ms = [64, 65, 66, 67, 101, 513, 2047, 4099, 10239, 10241, 20003, 37999, 38001, 38005]
+    for M in Ms:
+        for _ in range(2):
+            topn = int(rng.choice([1, 2, 7, max(1, M // 20), max(1, M // 2), M - 1, M, M + 5]))
+            kind = int(rng.integers(0, 4))
+            if kind == 0:
+                row = rng.standard_normal((3, M))
+            elif kind == 1:
+                row = rng.uniform(-5, 5, (3, M))
+            elif kind == 2:
+                row = np.round(rng.standard_normal((3, M)) * 4) / 4 + rng.standard_normal((3, 1))
+            else:
+                row = np.where(rng.random((3, M)) < 0.3, rng.standard_normal((3, 1)), rng.standard_normal((3, M)) * 3)
+            S = row.astype(np.float32)
+            for select in ("lowest", "highest"):
+                got = ops.row_stats(torch.from_numpy(S).cuda(), topn=topn, select=select).cpu().numpy()
+                ref = orc.cohort_stats(S, topn, select)
+                scale = np.abs(S).max(axis=1) + 1
+                msg = f"M={M} topn={topn} kind={kind} {select}"
+                np.testing.assert_allclose(got[:, 0], ref[:, 0], rtol=1e-11, atol=1e-11, err_msg=msg)
+                np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=1e-11, atol=1e-11, err_msg=msg)
+                assert np.all(np.abs(got[:, 1] - ref[:, 1]) <= 2e-7 * scale), msg
+                assert np.all(np.abs(got[:, 3] - ref[:, 3]) <= 2e-7 * scale), msg
