@@ -241,3 +241,24 @@ def test_row_stats_random_sweep(hip_lib):
                 np.testing.assert_allclose(got[:, 2], ref[:, 2], rtol=1e-11, atol=1e-11, err_msg=msg)
                 assert np.all(np.abs(got[:, 1] - ref[:, 1]) <= 2e-7 * scale), msg
                 assert np.all(np.abs(got[:, 3] - ref[:, 3]) <= 2e-7 * scale), msg
+
+
+def test_cohort_stats_shape_sweep(hip_lib):
+    """Row / cohort counts around the 128-wide tile edges, single rows / columns, cohort sizes that are not a multiple of
+    4 (padded score rows) — the persistent, counter-driven GEMM must cover every tile exactly once."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(41)
+    D = 24
+    p = rand_params(rng, 512, D, D)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    for R in (1, 7, 127, 128, 129, 300):
+        for M in (1, 3, 127, 128, 129, 1025):
+            xr = rng.standard_normal((R, 512)).astype(np.float32)
+            xc = rng.standard_normal((M, 512)).astype(np.float32)
+            zr, qr = ops.embed(torch.from_numpy(xr).cuda(), packed)
+            zc, qc = ops.embed(torch.from_numpy(xc).cuda(), packed)
+            topn = min(5, M)
+            got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn).cpu().numpy()
+            C = orc.cohort_scores(orc.extract_plda_embeddings(xr, p, np.float64),
+                                  orc.extract_plda_embeddings(xc, p, np.float64), p, np.float64)
+            np.testing.assert_allclose(got, orc.cohort_stats(C, topn), atol=2e-5, rtol=2e-5, err_msg=f"R={R} M={M}")
