@@ -103,6 +103,14 @@ int nplda_loss_finish_f32(const float* s, const float* t, int64_t B, const float
                           const float* beta, int K, float alpha, int kind, const double* sums,
                           float* loss, float* g, float* dtheta, nplda_stream_t stream);
 
+/* Both passes in one call for a batch that is NOT sharded (no all-reduce of the sums in between): sums, loss, g and
+ * dtheta as nplda_loss_sums_f32 followed by nplda_loss_finish_f32 would give them, bit for bit (all four outputs are
+ * required; kinds 0 and 1).  A batch of <= 4096 16-byte aligned scores runs as ONE single-block launch — the training
+ * step's loss (utils/models.py:384-393 + its autograd) in one graph node; anything else takes the two passes. */
+int nplda_loss_fwd_bwd_f32(const float* s, const float* t, int64_t B, const float* const* theta, const float* beta,
+                           int K, float alpha, int kind, double* sums, float* loss, float* g, float* dtheta,
+                           nplda_stream_t stream);
+
 /* Floats in the flat gradient [dW1 (D1,D0) | db1 (D1) | dW2 (D2,D1) | db2 (D2) | dP_sqrt (D2) | dQ (D2)]. */
 size_t nplda_grad_floats(int D0, int D1, int D2);
 /* Bytes of caller-provided workspace nplda_backward_f32 needs for a batch of B pairs. */

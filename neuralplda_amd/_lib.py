@@ -35,6 +35,9 @@ SIGNATURES = {
     "nplda_loss_finish_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, ctypes.POINTER(ctypes.c_void_p),
                                        ctypes.POINTER(ctypes.c_float), _c_int, ctypes.c_float, _c_int, _c_vp,
                                        _c_f32p, _c_f32p, _c_f32p, _c_vp]),
+    "nplda_loss_fwd_bwd_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, ctypes.POINTER(ctypes.c_void_p),
+                                        ctypes.POINTER(ctypes.c_float), _c_int, ctypes.c_float, _c_int, _c_vp,
+                                        _c_f32p, _c_f32p, _c_f32p, _c_vp]),
     "nplda_score_indexed_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_int,
                                          _c_int, _c_int, _c_f32p, _c_vp]),
     "nplda_score_embeddings_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p,

@@ -20,6 +20,7 @@ constexpr int kMaxK = 4;
 constexpr int kThreads = 256;
 
 struct ThetaPtrs { const float* p[kMaxK]; };
+struct BetaVals { float b[kMaxK]; };
 
 __device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
@@ -149,7 +150,38 @@ __global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restric
     block_reduce_add<4>(acc, sums, single);
 }
 
-struct BetaVals { float b[kMaxK]; };
+// dL/ds_i of SoftCdet given the batch constants (shared by the two-pass finish kernel and the fused small-batch kernel)
+template <int K>
+__device__ __forceinline__ float softcdet_gi(float si, float ti, const float (&theta)[K], const float (&cn)[K], float ct,
+                                             float alpha) {
+    const float ni = 1.0f - ti;
+    float gi = 0.f;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        const float v = alpha * (theta[k] - si);
+        const float e = __expf(-fabsf(v));
+        const float inv = 1.0f / (1.0f + e);
+        const float d = e * inv * inv;
+        gi = fmaf(d, fmaf(ct, ti, cn[k] * ni), gi);  // explicit contraction: the same bits wherever this is inlined
+    }
+    return gi;
+}
+
+// loss and dL/dtheta from the sums (one thread)
+template <int K>
+__device__ __forceinline__ void softcdet_scalars(const double* sums, const BetaVals& beta, float alpha, float* loss,
+                                                 float* dtheta) {
+    const double Nt = sums[0], Nn = sums[1];
+    double L = 0.0;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+        L += sums[2 + 4 * k] / Nt + (double)beta.b[k] * sums[2 + 4 * k + 1] / Nn;
+        if (dtheta)
+            dtheta[k] = (float)(((double)alpha * sums[2 + 4 * k + 2] / Nt -
+                                 (double)beta.b[k] * alpha * sums[2 + 4 * k + 3] / Nn) / K);
+    }
+    if (loss) loss[0] = (float)(L / K);
+}
 
 template <int K>
 __global__ __launch_bounds__(kThreads) void loss_finish_softcdet(const float* __restrict__ s,
@@ -158,17 +190,7 @@ __global__ __launch_bounds__(kThreads) void loss_finish_softcdet(const float* __
                                                                  const double* __restrict__ sums, float* loss,
                                                                  float* __restrict__ g, float* dtheta) {
     const double Nt = sums[0], Nn = sums[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        double L = 0.0;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            L += sums[2 + 4 * k] / Nt + (double)beta.b[k] * sums[2 + 4 * k + 1] / Nn;
-            if (dtheta)
-                dtheta[k] = (float)(((double)alpha * sums[2 + 4 * k + 2] / Nt -
-                                     (double)beta.b[k] * alpha * sums[2 + 4 * k + 3] / Nn) / K);
-        }
-        if (loss) loss[0] = (float)(L / K);
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) softcdet_scalars<K>(sums, beta, alpha, loss, dtheta);
     if (g == nullptr) return;
     float theta[K], cn[K];
 #pragma unroll
@@ -179,17 +201,7 @@ __global__ __launch_bounds__(kThreads) void loss_finish_softcdet(const float* __
     const float ct = (float)(-(double)alpha / (Nt * K));
     const long long stride = (long long)gridDim.x * kThreads;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
-        const float si = s[i], ti = t[i], ni = 1.0f - ti;
-        float gi = 0.f;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float v = alpha * (theta[k] - si);
-            const float e = __expf(-fabsf(v));
-            const float inv = 1.0f / (1.0f + e);
-            const float d = e * inv * inv;
-            gi += d * (ct * ti + cn[k] * ni);
-        }
-        g[i] = gi;
+        g[i] = softcdet_gi<K>(s[i], t[i], theta, cn, ct, alpha);
     }
 }
 
@@ -210,6 +222,127 @@ __global__ __launch_bounds__(kThreads) void loss_finish_bce(const float* __restr
         const float p = 1.0f / (1.0f + expf(-(s[i] - theta)));
         g[i] = (p - t[i]) * invN;
     }
+}
+
+// ---- fused small-batch loss: sums, loss, dL/ds and dL/dtheta in ONE single-block launch (B <= kSingleBlockMax) -----------
+// Same arithmetic, in the same order, as loss_sums (single-block form) followed by loss_finish: the block's totals stay
+// in LDS, the batch stays in registers (four 16-byte groups per thread), so the gradient pass needs no second launch.
+template <int NS>
+__device__ __forceinline__ void block_totals(double (&acc)[NS], double* tot, double* sums_out) {
+    __shared__ double red[kThreads / 64][NS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const double v = wave_sum_d(acc[i]);
+        if (lane == 0) red[wave][i] = v;
+    }
+    __syncthreads();
+    if (threadIdx.x < NS) {
+        double v = 0.0;
+#pragma unroll
+        for (int w = 0; w < kThreads / 64; ++w) v += red[w][threadIdx.x];
+        tot[threadIdx.x] = v;
+        sums_out[threadIdx.x] = v;
+    }
+    __syncthreads();
+}
+
+template <class F>
+__device__ __forceinline__ void grad_single_block(const float* __restrict__ s, const float* __restrict__ t,
+                                                  float* __restrict__ g, long long B, F gi) {
+    const int nv = (int)(B / 4);
+    const f32x4* s4 = reinterpret_cast<const f32x4*>(s);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(t);
+    f32x4* g4 = reinterpret_cast<f32x4*>(g);
+    for (int base = threadIdx.x; base < nv; base += kThreads * 4) {
+        f32x4 sv[4], tv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gidx = base + kThreads * u;
+            sv[u] = s4[gidx < nv ? gidx : nv - 1];
+            tv[u] = t4[gidx < nv ? gidx : nv - 1];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int gidx = base + kThreads * u;
+            if (gidx < nv) {
+                f32x4 o;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) o[e] = gi(sv[u][e], tv[u][e]);
+                g4[gidx] = o;
+            }
+        }
+    }
+    for (long long i = 4LL * nv + threadIdx.x; i < B; i += kThreads) g[i] = gi(s[i], t[i]);
+}
+
+template <int K>
+__global__ __launch_bounds__(kThreads) void loss_fused_softcdet(const float* __restrict__ s, const float* __restrict__ t,
+                                                                long long B, ThetaPtrs th, BetaVals beta, float alpha,
+                                                                double* sums, float* loss, float* __restrict__ g,
+                                                                float* dtheta) {
+    constexpr int NS = 2 + 4 * K;
+    __shared__ double tot[NS];
+    double acc[NS];
+#pragma unroll
+    for (int i = 0; i < NS; ++i) acc[i] = 0.0;
+    float theta[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
+    sums_single_block(s, t, B, [&](float si, float ti) {
+        const float ni = 1.0f - ti;
+        acc[0] += ti;
+        acc[1] += ni;
+#pragma unroll
+        for (int k = 0; k < K; ++k) {
+            const float v = alpha * (theta[k] - si);
+            const float e = __expf(-fabsf(v));
+            const float inv = 1.0f / (1.0f + e);
+            const float sm = v >= 0.f ? inv : e * inv;
+            const float sf = v >= 0.f ? e * inv : inv;
+            const float d = e * inv * inv;
+            acc[2 + 4 * k + 0] += sm * ti;
+            acc[2 + 4 * k + 1] += sf * ni;
+            acc[2 + 4 * k + 2] += d * ti;
+            acc[2 + 4 * k + 3] += d * ni;
+        }
+    });
+    block_totals<NS>(acc, tot, sums);
+    if (threadIdx.x == 0) softcdet_scalars<K>(tot, beta, alpha, loss, dtheta);
+    const double Nt = tot[0], Nn = tot[1];
+    float cn[K];
+#pragma unroll
+    for (int k = 0; k < K; ++k) cn[k] = (float)((double)beta.b[k] * alpha / (Nn * K));
+    const float ct = (float)(-(double)alpha / (Nt * K));
+    grad_single_block(s, t, g, B, [&](float si, float ti) { return softcdet_gi<K>(si, ti, theta, cn, ct, alpha); });
+}
+
+__global__ __launch_bounds__(kThreads) void loss_fused_bce(const float* __restrict__ s, const float* __restrict__ t,
+                                                           long long B, ThetaPtrs th, double* sums, float* loss,
+                                                           float* __restrict__ g, float* dtheta) {
+    __shared__ double tot[4];
+    double acc[4] = {0.0, 0.0, 0.0, 0.0};
+    const float theta = th.p[0][0];
+    sums_single_block(s, t, B, [&](float si, float ti) {
+        const float p = 1.0f / (1.0f + expf(-(si - theta)));
+        const float lp = fmaxf(logf(p), -100.0f);
+        const float lq = fmaxf(logf(1.0f - p), -100.0f);
+        acc[0] += ti;
+        acc[1] += 1.0f - ti;
+        acc[2] += -(ti * lp + (1.0f - ti) * lq);
+        acc[3] += p - ti;
+    });
+    block_totals<4>(acc, tot, sums);
+    const double N = tot[0] + tot[1];
+    if (threadIdx.x == 0) {
+        if (loss) loss[0] = (float)(tot[2] / N);
+        if (dtheta) dtheta[0] = (float)(-tot[3] / N);
+    }
+    const float invN = (float)(1.0 / N);
+    grad_single_block(s, t, g, B, [&](float si, float ti) {
+        const float p = 1.0f / (1.0f + expf(-(si - theta)));
+        return (p - ti) * invN;
+    });
 }
 
 unsigned grid_for(long long B) {
@@ -294,6 +427,42 @@ int nplda_loss_finish_f32(const float* s, const float* t, int64_t B, const float
             case 2: hipLaunchKernelGGL(loss_finish_softcdet<2>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
             case 3: hipLaunchKernelGGL(loss_finish_softcdet<3>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
             default: hipLaunchKernelGGL(loss_finish_softcdet<4>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+        }
+    }
+    return nplda_launch_status();
+}
+
+int nplda_loss_fwd_bwd_f32(const float* s, const float* t, int64_t B, const float* const* theta, const float* beta,
+                           int K, float alpha, int kind, double* sums, float* loss, float* g, float* dtheta,
+                           nplda_stream_t stream) {
+    const int ns = nplda_loss_nsums(K, kind);
+    if (ns == 0) return (kind >= 0 && kind <= 2) ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
+    if (kind == 2) return NPLDA_EINVAL;  // the hard cost has no gradient: use the two passes
+    if (B < 0 || !sums || !theta || !loss || !g || !dtheta) return NPLDA_EINVAL;
+    if (B > 0 && (!s || !t)) return NPLDA_EINVAL;
+    if (kind != 1 && !beta) return NPLDA_EINVAL;
+    const bool fused = B > 0 && B <= kSingleBlockMax && nplda_aligned16(s) && nplda_aligned16(t) && nplda_aligned16(g);
+    if (!fused) {
+        if (int rc = nplda_loss_sums_f32(s, t, B, theta, K, alpha, kind, sums, stream)) return rc;
+        return nplda_loss_finish_f32(s, t, B, theta, beta, K, alpha, kind, sums, loss, g, dtheta, stream);
+    }
+    ThetaPtrs th = {};
+    BetaVals bv = {};
+    for (int k = 0; k < (kind == 1 ? 1 : K); ++k) {
+        if (!theta[k]) return NPLDA_EINVAL;
+        th.p[k] = theta[k];
+        if (kind != 1) bv.b[k] = beta[k];
+    }
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid(1), block(kThreads);
+    if (kind == 1) {
+        hipLaunchKernelGGL(loss_fused_bce, grid, block, 0, st, s, t, (long long)B, th, sums, loss, g, dtheta);
+    } else {
+        switch (K) {
+            case 1: hipLaunchKernelGGL(loss_fused_softcdet<1>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            case 2: hipLaunchKernelGGL(loss_fused_softcdet<2>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            case 3: hipLaunchKernelGGL(loss_fused_softcdet<3>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
+            default: hipLaunchKernelGGL(loss_fused_softcdet<4>, grid, block, 0, st, s, t, (long long)B, th, bv, alpha, sums, loss, g, dtheta); break;
         }
     }
     return nplda_launch_status();

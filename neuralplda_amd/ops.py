@@ -233,6 +233,34 @@ def loss_finish(s, t, thetas, betas, alpha, kind, sums, want_grad=True):
     return loss, g, dth
 
 
+def loss_fwd_bwd(s, t, thetas, betas, alpha, kind):
+    """nplda_loss_fwd_bwd_f32: (loss 0-d tensor, g, dtheta (K,), sums) of an unsharded batch — both loss passes in one
+    call (one launch up to 4096 pairs), bit-identical to loss_sums + loss_finish."""
+    import ctypes
+    lib = _lib.load()
+    _require_dev_f32(s, "output")
+    _require_dev_f32(t, "target")
+    s, t = s.contiguous(), t.contiguous()
+    if s.shape != t.shape or s.dim() != 1:
+        raise ValueError("output and target must be 1-D tensors of the same length")
+    K = len(thetas)
+    ns = lib.nplda_loss_nsums(K, kind)
+    if ns == 0 or kind == LOSS_HARD_CDET:
+        raise _lib.NpldaHipError("loss_fwd_bwd: unsupported loss kind / number of thresholds")
+    dev = s.device
+    sums = torch.empty(ns, dtype=torch.float64, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    g = torch.empty_like(s)
+    dth = torch.empty(K, dtype=torch.float32, device=dev)
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(dev):
+        code = lib.nplda_loss_fwd_bwd_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), barr, K,
+                                          float(alpha), kind, _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(g),
+                                          _lib.ptr(dth), _lib.current_stream())
+    _lib.check(code, "nplda_loss_fwd_bwd_f32")
+    return loss, g, dth, sums
+
+
 # ---- indexed scoring / gather -------------------------------------------------------------------
 
 def _idx(t, name, dev):

@@ -200,7 +200,7 @@ class FusedTrainStep:
     """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser:
     pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat gradient) -> one-launch Adam
     (nplda_adam_step_f32, same update rule as torch.optim.Adam(lr, weight_decay) of the reference,
-    xvector_NeuralPlda_pytorch.py:139) — eight launches (nine above 4096 pairs: the loss sums are zero-filled first), optionally replayed from a HIP graph.
+    xvector_NeuralPlda_pytorch.py:139) — seven launches up to 4096 pairs (the loss is one launch there; ten beyond), optionally replayed from a HIP graph.
     With `reduce_sums` / `reduce_flat` callables (neuralplda_amd.dist) it is the data-parallel step (eager only)."""
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
@@ -253,10 +253,11 @@ class FusedTrainStep:
             packed = ops.pack_params(*prm)
             s, saved = ops.forward_train(x1, x2, packed)
             ths = [th.detach() for th in self.thetas]
-            sums = ops.loss_sums(s, t, ths, self.alpha, self.kind)
-            if self.reduce_sums is not None:
-                sums = self.reduce_sums(sums)
-            loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
+            if self.reduce_sums is None:
+                loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
+            else:
+                sums = self.reduce_sums(ops.loss_sums(s, t, ths, self.alpha, self.kind))
+                loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
             flat = ops.backward(saved, g, packed, prm[4])
             if self.reduce_flat is not None:
                 flat = self.reduce_flat(flat)
@@ -396,8 +397,7 @@ class FusedDPldaStep(FusedTrainStep):
             packed = ops.dplda_pack(mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach(), wlr, blr)
             s, paired = ops._gb_call(x1, x2, packed, True, True)
             ths = [th.detach() for th in self.thetas]
-            sums = ops.loss_sums(s, t, ths, self.alpha, self.kind)
-            loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
+            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
             dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1)
             self._adam([wlr, blr] + ths, [dw.contiguous(), db.contiguous()] + [dth[k:k + 1] for k in range(len(ths))])
         return loss

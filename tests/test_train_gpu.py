@@ -495,3 +495,32 @@ def test_validate_device_resident_pass_equals_the_generic_loop(hip_lib, tmp_path
     fast, gen = run(True), run(False)
     assert fast == gen
     assert fast[3] == [fast[1][b] for b in nc.beta]  # update_thresholds wrote the arg-min scores into Th{beta}
+
+
+@pytest.mark.parametrize("B", [1, 3, 255, 4096, 4097, 9000])
+@pytest.mark.parametrize("kind", ["SoftCdet", "crossentropy"])
+def test_loss_fwd_bwd_equals_the_two_passes(hip_lib, B, kind):
+    """nplda_loss_fwd_bwd_f32 (one launch up to 4096 scores) gives the bits of loss_sums + loss_finish; a misaligned
+    view takes the two-pass route inside the library."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(B)
+    s = torch.from_numpy((rng.standard_normal(B + 1) * 2).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(B + 1) < 0.3).astype(np.float32)).cuda()
+    t[0], t[-1] = 1.0, 0.0
+    k = ops.LOSS_SOFTCDET if kind == "SoftCdet" else ops.LOSS_BCE
+    ths = [torch.tensor([-0.4], device="cuda"), torch.tensor([0.2], device="cuda")] if k == ops.LOSS_SOFTCDET \
+        else [torch.tensor([0.1], device="cuda")]
+    betas = [99.0, 199.0] if k == ops.LOSS_SOFTCDET else []
+    for sv, tv in ((s[:B], t[:B]), (s[1:], t[1:])):  # aligned, then offset by 4 bytes
+        if tv.sum() == 0 or tv.sum() == B:
+            continue
+        sums = ops.loss_sums(sv, tv, ths, 15.0, k)
+        L, g, dth = ops.loss_finish(sv, tv, ths, betas, 15.0, k, sums)
+        L2, g2, dth2, sums2 = ops.loss_fwd_bwd(sv, tv, ths, betas, 15.0, k)
+        if sv.data_ptr() % 16 == 0 and B <= 4096:  # single-block forms on both sides: deterministic, same bits
+            assert torch.equal(sums, sums2) and torch.equal(L, L2) and torch.equal(g, g2) and torch.equal(dth, dth2)
+        else:  # multi-block sums meet through fp64 atomics: equal up to the order of those additions
+            torch.testing.assert_close(sums, sums2, rtol=1e-12, atol=1e-12)
+            torch.testing.assert_close(L, L2, rtol=1e-6, atol=1e-7)
+            torch.testing.assert_close(g, g2, rtol=1e-5, atol=1e-9)
+            torch.testing.assert_close(dth, dth2, rtol=1e-5, atol=1e-9)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""FusedTrainStep replays at B = 4096 (BASELINE cfg2) for rocprofv3 --kernel-trace: what the graph's eight launches cost."""
+"""FusedTrainStep replays at B = 4096 (BASELINE cfg2) for rocprofv3 --kernel-trace: what the graph's launches cost."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
