@@ -7,7 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NPLDA_ABI_VERSION 1
+#define NPLDA_ABI_VERSION 2  // 2: cohort workspace starts with a 256-byte control block; Adam step buffer is two words
 #define NPLDA_MAX_NB 12            // 12 x 16 = 192 features per layer
 #define NPLDA_MAX_DIM (NPLDA_MAX_NB * 16)
 
