@@ -245,8 +245,7 @@ class FusedTrainStep:
             self.t[::2] = 1
 
     def _eager(self, x1, x2, t):
-        import ctypes
-        ops, lib = self._ops, self._lib.load()
+        ops = self._ops
         D0, D1, D2 = self.dims
         with torch.no_grad():
             prm = [q.detach() for q in self.params]

@@ -8,7 +8,6 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
-import numpy as np  # noqa: E402
 import torch  # noqa: E402
 
 from neuralplda_amd import models, ops  # noqa: E402
@@ -153,7 +152,6 @@ def main():
     out["dplda_D170"] = {"score_pairs_per_s": Bg / ms_d * 1e3, "score_ms_512k": ms_d,
                          "train_step_eager_autograd_torchAdam_ms_B2048": ms_ds, "train_step_fused_ms_B2048": ms_df}
     # validation metrics: minc (reference semantics) / exact min-DCF + EER over N scores
-    from neuralplda_amd import metrics
     for N in (1 << 20, 10_000_000):
         sc = torch.randn(N, device=dev, generator=gen)
         tg = (torch.rand(N, device=dev, generator=gen) < 0.05).float()

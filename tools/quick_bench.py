@@ -1,7 +1,6 @@
 """Throw-away style micro timing of the fused forward (used while iterating on the kernel)."""
-import sys, os, time
+import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import numpy as np
 import torch
 from neuralplda_amd import ops
 
