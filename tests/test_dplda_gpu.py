@@ -234,3 +234,50 @@ def test_fused_dplda_step_follows_the_autograd_recipe(hip_lib, graph):
     m2 = make(D0, D1, W1, b1, wlr, [0.0])  # LDA not frozen: refused up front
     with pytest.raises(ValueError):
         train.FusedDPldaStep(m2, 1e-3, batch_size=B)
+
+
+def test_dplda_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
+    """train() + FusedDPldaStep over the vectorised loader (epoch resident on the device, gathers inside the captured
+    step) leaves the same parameters as the generic host-batch loop, bit for bit (ragged last batch included)."""
+    import contextlib
+    import io
+    from neuralplda_amd import sv_trials_loaders as svl, train
+    rng = np.random.default_rng(12)
+    n_utt, n_trials, B, D0, D1 = 200, 700, 128, 128, 24
+    ids = [f"u{u:04d}" for u in range(n_utt)]
+    xv = rng.standard_normal((n_utt, D0)).astype(np.float32)
+    mega = {u: xv[i] for i, u in enumerate(ids)}
+    num_to_id = dict(enumerate(ids))
+    id_to_num = {u: i for i, u in num_to_id.items()}
+    a, b = rng.integers(0, n_utt, n_trials), rng.integers(0, n_utt, n_trials)
+    lab = (rng.random(n_trials) < 0.2).astype(int)
+    tf = tmp_path / "train.tsv"
+    tf.write_text("\n".join(f"{ids[i]}\t{ids[j]}\t{l}" for i, j, l in zip(a, b, lab)) + "\n")
+    loader = svl.combine_trials_and_get_loader([str(tf)], id_to_num, subsample_factors=[1.01], batch_size=B)
+    W1 = (rng.standard_normal((D1, D0)) / np.sqrt(D0)).astype(np.float32)
+    b1 = (0.1 * rng.standard_normal(D1)).astype(np.float32)
+    wlr = (0.05 * rng.standard_normal((1, 2 * D1 * D1 + D1))).astype(np.float32)
+    nc = NC(D0, D1)
+    nc.log_interval = 2
+
+    def run(fast):
+        m = make(D0, D1, W1, b1, wlr, [0.0])
+        _freeze_lda(m)
+        step = train.FusedDPldaStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+        torch.manual_seed(4)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            if fast:
+                train.train(nc, m, torch.device("cuda"), loader, mega, num_to_id, None, 1, step_fn=step)
+            else:
+                class Plain(list):
+                    dataset = loader.dataset
+                train.train(nc, m, torch.device("cuda"), Plain(list(loader)), mega, num_to_id, None, 1, step_fn=step)
+        return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, out.getvalue(), step
+
+    sd_fast, log_fast, step_fast = run(True)
+    sd_gen, log_gen, _ = run(False)
+    assert step_fast._graph_rows is not None and step_fast.step_count[0].item() == 6  # 5 replays + 1 ragged eager step
+    assert log_fast == log_gen
+    for k in sd_gen:
+        assert np.array_equal(sd_fast[k], sd_gen[k]), k
