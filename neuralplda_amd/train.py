@@ -407,14 +407,23 @@ def train_gaussian_backend(nc, model, train_loader, mega_xvec_dict, num_to_id_di
     sums and second moments of the paired rows, then the closed-form means / inverse covariances.  The x-vectors are
     gathered on the device (the reference's script feeds the index batches to forward_getpaired, :41 — a bug; the
     x-vector batches it built one line above are what is meant)."""
-    from .sv_trials_loaders import load_xvec_trials_from_numbatch
-    device = device or next(model.parameters()).device
+    device = torch.device(device or next(model.parameters()).device)
     model.eval()
     stats = None
     with torch.no_grad():
-        for data1, data2, target in train_loader:
-            x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
-            stats = model.accumulate_statistics(x1, x2, target.to(device), stats)
+        if (isinstance(train_loader, TrialLoader) and device.type == "cuda"
+                and isinstance(train_loader.dataset, TrialIndexDataset) and train_loader.num_workers == 0
+                and not train_loader.drop_last):
+            # device-resident pass (see train()): the same batches, gathered from the resident table
+            from . import ops
+            table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
+            for rows1, rows2, target in train_loader.device_batches(device, row_map):
+                stats = model.accumulate_statistics(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2),
+                                                    target, stats)
+        else:
+            for data1, data2, target in train_loader:
+                x1, x2 = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
+                stats = model.accumulate_statistics(x1, x2, target.to(device), stats)
     if stats is None:
         raise ValueError("empty training loader")
     return model.fit_statistics(stats)
