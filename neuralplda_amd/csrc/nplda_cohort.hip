@@ -476,6 +476,21 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // ~16.  Anything else (heavy tails, ties, tiny rows) falls through to the general search below, started from the
     // bracket when it is valid.
     double mean = 0.0, var = 0.0;  // kept by wave 0 (thread 0 writes the result)
+    // The bracket is proposed by wave 0 in "ordered" values w (w = v when the N smallest are wanted, w = -v for the N
+    // largest: the key order) and refined, when a proposal misses, by interpolating the probit z = Phi^-1(count / M)
+    // between the tightest points known below and above the target rank — the first proposal is the normal model of
+    // the row (points at mean -+ 6 sd), every later one uses the row's own counts, so skewed / heavy-tailed / bimodal
+    // rows converge in two or three passes instead of dropping to the 16-pass key search (3.7x slower, measured).
+    float wl = 0.f, zl = 0.f, wu = 0.f, zu = 0.f, zt = 0.f, pa = 0.f, pb = 0.f, dens = 0.f;
+    auto propose = [&](float center, float half) {  // wave 0: the next bracket [center - half, center + half] -> ctl
+        pa = center - half;
+        pb = center + half;
+        unsigned ka0 = lowest ? f2key(pa) : ~f2key(-pa), kb0 = lowest ? f2key(pb) : ~f2key(-pb);
+        if (kb0 > 0xfffffffeu) kb0 = 0xfffffffeu;
+        if (ka0 > kb0) ka0 = kb0;
+        if (lane == 0) { ctl[0] = ka0; ctl[1] = kb0; }
+    };
+    constexpr float kHalfCount = 64.f;  // candidates wanted on either side of the target rank
     if (wave == 0) {
         s1 = s2 = 0.0;
 #pragma unroll
@@ -486,32 +501,35 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         mean = s1 / n;
         var = s2 / n - mean * mean;
         if (var < 0.0) var = 0.0;
-        unsigned ka0 = 0, kb0 = 0, ok0 = 0;
+        unsigned ok0 = 0;
         if (use_lds && M >= 64 && var > 0.0) {
-            const double q = lowest ? (double)N / n : 1.0 - (double)N / n;
-            const double sd = sqrt(var);
-            const double t0 = mean + (double)fast_normcdfinv((float)(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q))) * sd;
-            const float fa = (float)(t0 - 0.06 * sd), fb = (float)(t0 + 0.06 * sd);
-            ka0 = f2key(fa);
-            kb0 = f2key(fb);
-            if (!lowest) { const unsigned t = ~ka0; ka0 = ~kb0; kb0 = t; }
-            if (kb0 > 0xfffffffeu) kb0 = 0xfffffffeu;
+            const float sd = (float)sqrt(var), mw = (float)(lowest ? mean : -mean);
+            const double q = (double)N / n;
+            zt = fast_normcdfinv((float)(q < 1e-9 ? 1e-9 : (q > 1.0 - 1e-9 ? 1.0 - 1e-9 : q)));
+            dens = (float)n * __expf(-0.5f * zt * zt) * 0.3989423f;  // keys per unit of z around the target
+            wl = mw - 6.f * sd; zl = -6.f;  // provisional anchors: replaced by the row's extremes after a first miss
+            wu = mw + 6.f * sd; zu = 6.f;
+            float half = kHalfCount * sd / fmaxf(dens, 1e-3f);
+            half = fminf(fmaxf(half, 1e-6f * sd), 3.f * sd);
+            propose(mw + zt * sd, half);
             ok0 = 1;
         }
-        if (lane == 0) { ctl[0] = ka0; ctl[1] = kb0; ctl[2] = ok0; }
+        if (lane == 0) ctl[2] = ok0;
     }
     __syncthreads();
-    const unsigned ka = ctl[0], kb = ctl[1];
     const bool shortcut = ctl[2] != 0;
-    unsigned lo = 0u, hi = 0u;
-    bool have_range = false;  // [lo, hi] brackets the N-th smallest key
+    unsigned lo = 0u, hi = 0xfffffffeu;  // the N-th smallest key lies in [lo, hi]; have_* : that side comes from a count
+    bool have_lo = false, have_hi = false;
 
     bool done = false;
     double t1 = 0.0, t2 = 0.0;
-    if (shortcut) {
+    constexpr int kAttempts = 5;
+    for (int att = 0; shortcut && att < kAttempts; ++att) {
+        const unsigned ka = ctl[0], kb = ctl[1];
         // ONE pass over the keys: count below / inside the bracket, sum everything strictly below it, and already
         // collect the bracket's keys (bounded by the list capacity); the counts then say whether the list is usable.
         unsigned ca = 0, cb2 = 0;
+        t1 = t2 = 0.0;
         for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k4) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -536,9 +554,13 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         ca = cb2 = 0;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) { ca += cnt[32 + w * 4]; cb2 += cnt[32 + w * 4 + 1]; }
-        if (ca < want && want <= cb2) {
-            lo = ka; hi = kb; have_range = true;  // a valid (much narrower) bracket for the general search, should the list be too long
-            if (cb2 - ca <= (unsigned)kListCap) {
+        // what the two counts say about the key T of the N-th smallest element (kept for the general search below)
+        if (ca < want) { if (!have_lo || ka > lo) lo = ka; have_lo = true; }
+        else { if (!have_hi || ka - 1 < hi) hi = ka - 1; have_hi = true; }
+        if (cb2 >= want) { if (!have_hi || kb < hi) hi = kb; have_hi = true; }
+        else { if (!have_lo || kb + 1 > lo) lo = kb + 1; have_lo = true; }
+        if (ca < want && want <= cb2 && cb2 - ca <= (unsigned)kListCap) {
+            {
                 const unsigned L = cb2 - ca, need = want - ca;  // == *nlist: every candidate found its slot
                 const unsigned L4 = (L + 3) / 4 * 4;  // whole 16-byte groups: the list was sentinel-filled
                 // rank by counting, the list read 16 bytes at a time; `split` threads share one candidate when the
@@ -590,7 +612,81 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
                 }
                 done = true;
             }
+            break;
         }
+        if (att + 1 == kAttempts) break;
+        // missed (or too many candidates): clean the list, refine the bracket from the counts, go again
+        for (int i = tid; i < kListCap; i += kRowThreads) list[i] = 0xffffffffu;
+        if (tid == 0) *nlist = 0;
+        const bool off_edge = cb2 == 0 || ca >= (unsigned)M;  // the bracket fell entirely below / above the data
+        if (off_edge) {  // find the row's extreme keys: the next bracket starts at that edge (hard-edged distributions)
+            unsigned kmin = 0xffffffffu, kmax = 0u;
+            for_row_keys(1, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    kmin = k[e] < kmin ? k[e] : kmin;
+                    kmax = (k[e] != 0xffffffffu && k[e] > kmax) ? k[e] : kmax;
+                }
+            });
+            kmin = wave_min_u32(kmin);
+            kmax = wave_max_u32(kmax);
+            if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
+            __syncthreads();
+        }
+        if (wave == 0 && off_edge) {
+            unsigned kmin = 0xffffffffu, kmax = 0u;
+#pragma unroll
+            for (int w = 0; w < NWV; ++w) {
+                kmin = cnt[w * 4] < kmin ? cnt[w * 4] : kmin;
+                kmax = cnt[w * 4 + 1] > kmax ? cnt[w * 4 + 1] : kmax;
+            }
+            const float zedge = fast_normcdfinv(0.5f / (float)n);
+            const float hprev = 0.5f * (pb - pa);
+            if (cb2 == 0) {  // below everything: same width, lower end at the smallest value
+                wl = lowest ? key2f(kmin) : -key2f(~kmin);
+                zl = zedge;
+                propose(wl + hprev, hprev * 1.0001f + 1e-30f);
+            } else {         // above everything
+                wu = lowest ? key2f(kmax) : -key2f(~kmax);
+                zu = -zedge;
+                propose(wu - hprev, hprev * 1.0001f + 1e-30f);
+            }
+        } else if (wave == 0) {
+            const float fa = fminf(fmaxf((float)ca / (float)n, 0.5f / (float)n), 1.f - 0.5f / (float)n);
+            const float fb = fminf(fmaxf((float)cb2 / (float)n, 0.5f / (float)n), 1.f - 0.5f / (float)n);
+            const float za = fast_normcdfinv(fa), zb = fast_normcdfinv(fb);
+            // a point replaces an end of the interpolation interval only if it is tighter (a bracket that fell outside the
+            // data carries a count of 0 or M and says nothing the extremes do not)
+            if (ca < want) { if (pa > wl) { wl = pa; zl = za; } } else if (pa < wu) { wu = pa; zu = za; }
+            if (cb2 >= want) { if (pb < wu) { wu = pb; zu = zb; } } else if (pb > wl) { wl = pb; zl = zb; }
+            const float span = wu - wl;
+            float center, half;
+            const bool same_side = (ca >= want) || (cb2 < want);
+            if (!same_side) {
+                // the bracket holds the rank but too many keys: inside a bracket this narrow the density is flat —
+                // interpolate the rank linearly and shrink to the wanted candidate count
+                const float frac = ((float)(want - ca) - 0.5f) / (float)(cb2 - ca);
+                center = pa + frac * (pb - pa);
+                half = fmaxf((pb - pa) * (kHalfCount / (float)(cb2 - ca)), 1e-7f * fabsf(center));
+            } else if (ca > 0 && cb2 < (unsigned)M && cb2 > ca + 8 && zb > za) {
+                // both ends of the missed bracket carry counts: step from its nearer end with ITS slope (Newton-like)
+                const float slope = (zb - za) / (pb - pa);
+                const float from = ca >= want ? pa : pb, zfrom = ca >= want ? za : zb;
+                center = fminf(fmaxf(from + (zt - zfrom) / slope, wl), wu);
+                half = fminf(kHalfCount / fmaxf(dens * slope, 1e-30f), 0.5f * span);
+            } else if (span > 0.f && zu > zl) {
+                const float slope = (zu - zl) / span;  // dz / dw between the two points
+                center = wl + (zt - zl) / slope;
+                half = kHalfCount / fmaxf(dens * slope, 1e-30f);
+                center = fminf(fmaxf(center, wl), wu);
+                half = fminf(half, 0.5f * span);
+            } else {
+                center = 0.5f * (wl + wu);
+                half = 0.25f * fabsf(span);
+            }
+            propose(center, fmaxf(half, 1e-7f * fabsf(center)));
+        }
+        __syncthreads();
     }
     if (done) {
         if (tid == 0) {
@@ -611,7 +707,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     // the keys <= pivot (register counters + shuffle/LDS reduction — no atomics: cohort scores of one row share
     // their leading bits, which serialises an LDS-histogram radix select) and keeps the quarter that holds rank N.
     __syncthreads();  // the count slots are reused below
-    if (!have_range) {  // key range of the row
+    if (!have_lo || !have_hi) {  // key range of the row (for the side no count has bounded)
         unsigned kmin = 0xffffffffu, kmax = 0u;
         for_row_keys(use_lds, keys4, src4, nvec, M, lowest, [&](const u32x4 k) {
 #pragma unroll
@@ -626,14 +722,16 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         kmax = wave_max_u32(kmax);
         if (lane == 0) { cnt[wave * 4] = kmin; cnt[wave * 4 + 1] = kmax; }
         __syncthreads();
-        lo = 0xffffffffu;
-        hi = 0u;
+        unsigned rlo = 0xffffffffu, rhi = 0u;
 #pragma unroll
         for (int w = 0; w < NWV; ++w) {
-            lo = cnt[w * 4] < lo ? cnt[w * 4] : lo;
-            hi = cnt[w * 4 + 1] > hi ? cnt[w * 4 + 1] : hi;
+            rlo = cnt[w * 4] < rlo ? cnt[w * 4] : rlo;
+            rhi = cnt[w * 4 + 1] > rhi ? cnt[w * 4 + 1] : rhi;
         }
-        if (hi > 0xfffffffeu) hi = 0xfffffffeu;
+        if (rhi > 0xfffffffeu) rhi = 0xfffffffeu;
+        if (rlo > rhi) rlo = rhi;
+        if (!have_lo) lo = rlo;
+        if (!have_hi) hi = rhi;
         if (lo > hi) lo = hi;
         __syncthreads();
     }
