@@ -16,7 +16,8 @@
 //                           order-preserving integer keys; sum and sum of squares in fp64.  The N-th smallest
 //                           (reference semantics: ascending sort then [:N], adaptive_score_normalization.py:32-36)
 //                           or N-th largest key: a normal-quantile bracket of the row's (mean, std) is counted and
-//                           its <= 512 keys ranked exactly (one pass over the keys); rows the bracket misses take
+//                           its <= 512 keys ranked exactly (one pass over the keys; a miss refines the bracket from its counts, up to five
+//                           passes); rows that still miss take
 //                           a 4-ary search on the integer key space (three pivot counts per pass in registers,
 //                           DPP + LDS reduction, no atomics) and a last pass over the selected values.  Either way
 //                           ties are resolved by count, so the result equals sort-then-slice exactly.
