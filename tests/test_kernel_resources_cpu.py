@@ -1,0 +1,43 @@
+"""Register-budget guards for two kernels whose speed depends on it (training step): the weight-gradient kernel
+must keep TWO blocks resident per CU (its grid is sized for that: at 330 registers it silently ran as two rounds) and
+the small-batch forward must not split its registers between VGPRs and AGPRs (146 cross-file moves per 96 MFMAs).
+hipcc cross-compiles for gfx950 without a GPU, so this runs in the CPU suite."""
+import os
+import re
+import shutil
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "neuralplda_amd", "csrc")
+
+
+def _resources(src):
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not os.path.exists(hipcc):
+        pytest.skip("hipcc not available")
+    err = subprocess.run([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-I" + os.path.join(ROOT, "include"),
+                          "-I" + CSRC, "-c", os.path.join(CSRC, src), "-o", os.devnull,
+                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True, timeout=900).stderr
+    out, cur = {}, None
+    for line in err.splitlines():
+        m = re.search(r"remark: +(Function Name|VGPRs|AGPRs|ScratchSize \[bytes/lane\]|Occupancy \[waves/SIMD\]): +(\S+)", line)
+        if not m:
+            continue
+        if m.group(1) == "Function Name":
+            cur = out.setdefault(m.group(2), {})
+        elif cur is not None:
+            cur[m.group(1).split(" ")[0]] = int(m.group(2))
+    return out
+
+
+def test_register_budgets_of_the_training_kernels():
+    res = _resources("nplda_backward.hip")
+    wgrad = [v for k, v in res.items() if "wgrad_kernel" in k]
+    assert len(wgrad) == 1
+    assert wgrad[0]["Occupancy"] >= 2 and wgrad[0]["ScratchSize"] == 0 and wgrad[0]["VGPRs"] + wgrad[0]["AGPRs"] <= 256
+    small = {k: v for k, v in res.items() if "nplda_fwd_small_kernel" in k}
+    assert small, "the training-mode small forward is instantiated in this translation unit"
+    for k, v in small.items():
+        assert v["AGPRs"] == 0 and v["ScratchSize"] == 0, (k, v)
