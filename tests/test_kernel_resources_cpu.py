@@ -41,3 +41,10 @@ def test_register_budgets_of_the_training_kernels():
     assert small, "the training-mode small forward is instantiated in this translation unit"
     for k, v in small.items():
         assert v["AGPRs"] == 0 and v["ScratchSize"] == 0, (k, v)
+
+
+def test_register_budget_of_the_cohort_gemm():
+    """Three blocks per CU: <= 168 registers, no scratch (the stage loop has no room for spills)."""
+    res = _resources("nplda_cohort.hip")
+    gemm = [v for k, v in res.items() if "cohort_gemm_kernel" in k]
+    assert len(gemm) == 1 and gemm[0]["Occupancy"] >= 3 and gemm[0]["ScratchSize"] == 0
