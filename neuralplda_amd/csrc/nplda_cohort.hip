@@ -391,7 +391,9 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
     double* red = reinterpret_cast<double*>(cnt + 64);                         // [2][2][8]
     constexpr int NWV = kRowThreads / 64;
 
-    const long long row = blockIdx.x;
+    // newest rows first: in the cohort pipeline the GEMM has just written the matrix row tile by row tile, so the last rows
+    // are the ones still held by the memory-side cache
+    const long long row = (long long)gridDim.x - 1 - blockIdx.x;
     const f32x4* src4 = reinterpret_cast<const f32x4*>(S + row * lds_stride);
     const long long nvec = (M + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
