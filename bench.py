@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
-"""bench.py — scored trial-pairs/s of the fused NPLDA forward on MI355X (BASELINE.json metric).
+"""bench.py — throughput of the NPLDA hot path on MI355X (BASELINE.json metric: scored trial-pairs/s).
 
-A "step" is one pass of the hot path (nplda_score_pairs_f32, the NeuralPlda.forward(x1, x2)
-replacement) over one batch of synthetic trial pairs that is already resident in HBM.  Workload
-at every N: BASELINE.json configs[1] — 1 M trial pairs of 512-d x-vectors through a 512->150->150
-NPLDA, scoring only — PER GPU (weak scaling: the trial list shards across ranks with no data-path
-collective).  `value` = pairs all ranks scored / max-over-ranks wall time.
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg3] [--scaling weak|strong] [--dim D]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--pairs P] [--dim D]
-    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+Workloads (BASELINE.json `configs`):
+  cfg1 (default; the configuration `metric` is quoted on): one step = nplda_score_pairs_f32 — the fused
+        NeuralPlda.forward(x1, x2) — over a batch of synthetic trial pairs already resident in HBM, 512->150->150.
+        --scaling weak  : 1 048 576 pairs PER GPU per step (the trial list shards across ranks, no data-path collective);
+        --scaling strong: BASELINE's "1 M trial pairs" in total, split N ways (131 072 pairs per GPU at N = 8).
+  cfg3  adaptive score normalisation, 10 000-utterance cohort x 22 000 enroll/test rows x 2 M trials: one step =
+        embed this rank's row shard and the cohort -> cohort score matrix + per-row statistics (nplda_cohort_stats_f32)
+        -> the ONE collective of the path, an all-gather of the (R, 4) fp64 statistics over RCCL -> normalise this rank's
+        trial shard (nplda_asnorm_apply_f64).  The collective is timed separately (`config.allgather_ms`).
+`value` = units all ranks processed / max-over-ranks wall time of exactly K steps between barrier + synchronize pairs.
 
-Extra objects on the JSON line (tier contract): `roofline` (dominant kernel vs the fp32-MFMA peak,
-per-launch duration from HIP events on the launch stream) and `cpu_baseline` (the NumPy oracle of
-the same arithmetic timed on this box's host cores on a bounded sample; rank 0, N=1 only).
+--gpus N without a torchrun environment re-launches this script under torch.distributed.run with N ranks (one per
+GPU, RCCL); it exits non-zero if the box has fewer than N devices.  NPLDA_BENCH_BACKEND=gloo is a plumbing dry run on a
+box with fewer GPUs than ranks (ranks share devices; timings meaningless).
+
+Extra objects on the JSON line (tier contract): `roofline` (dominant kernel vs its peak, per-launch duration from HIP
+events on the launch stream), `alt_d170` (the same kernel at the reference's shipped 512->170->170 shape) and
+`cpu_baseline` (the reference's forward restated as torch CPU ops, timed on this box's host cores; rank 0, N = 1 only).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -29,6 +40,7 @@ import torch  # noqa: E402
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD
 HBM_PEAK_TBPS = 8.0
+METRIC_CFG1 = "scored trial-pairs/sec (512-d xvec)"
 
 
 def algorithmic_flops_per_pair(D0, D1, D2):
@@ -55,128 +67,181 @@ def make_params(D, device, seed=1234):
     return [torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(device) for a in arrs], src
 
 
-def cpu_baseline(params_np, D0, budget_s=12.0, buf_pairs=102400, chunk=10240):
-    """The oracle (NumPy fp32 restatement of utils/models.py:366-382) on the host cores: same arithmetic, the
-    reference driver's chunking (5*2048 pairs, xvector_NeuralPlda_pytorch.py:172).  The BLAS thread count is
-    calibrated first (more threads than ~32 hurts these 10240x512x150 GEMMs); then a bounded sample sweeps a
-    resident buffer of `buf_pairs` pairs for ~`budget_s` seconds."""
-    from oracle import nplda_oracle as orc
-    p = orc.Params(*params_np)
-    rng = np.random.default_rng(99)
-    x1 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
-    x2 = rng.standard_normal((buf_pairs, D0), dtype=np.float32)
+# ---------------------------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's forward as torch CPU ops, all physical cores and one core, D = 150 and
+# 170, the reference driver's chunking (5 * 2048 pairs), median of >= 10 repetitions; plus the gather-inclusive figure.
+# ---------------------------------------------------------------------------------------------------------------------
 
-    def sweep(n_pairs):
-        for lo in range(0, n_pairs, chunk):
-            orc.forward(x1[lo:lo + chunk], x2[lo:lo + chunk], p)
-
-    ncpu = os.cpu_count() or 1
-    threads, limiter = ncpu, None
+def _cpu_model():
     try:
-        from threadpoolctl import threadpool_limits
-        best = (0.0, ncpu)
-        for nt in sorted({min(ncpu, t) for t in (8, 16, 32, 64, ncpu)}):
-            with threadpool_limits(limits=nt, user_api="blas"):
-                sweep(2 * chunk)  # warm-up at this width
-                t0 = time.perf_counter()
-                sweep(4 * chunk)
-                rate = 4 * chunk / (time.perf_counter() - t0)
-            if rate > best[0]:
-                best = (rate, nt)
-        threads = best[1]
-        limiter = threadpool_limits(limits=threads, user_api="blas")
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                return ln.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _physical_cores():
+    try:
+        import psutil
+        n = psutil.cpu_count(logical=False)
+        if n:
+            # a container may see fewer cpus than the host has cores
+            return max(1, min(int(n), len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else int(n)))
     except Exception:
-        sweep(chunk)
-    done, t0 = 0, time.perf_counter()
-    while True:
-        sweep(buf_pairs)
-        done += buf_pairs
-        el = time.perf_counter() - t0
-        if el >= budget_s:
-            break
-    if limiter is not None:
-        limiter.restore_original_limits() if hasattr(limiter, "restore_original_limits") else None
-    return {"value": done / el, "unit": "pairs/s", "cores": int(threads), "kind": "port",
-            "sample": f"{done} pairs ({el:.1f} s) as sweeps of a {buf_pairs}-pair buffer in chunks of {chunk}; "
-                      f"numpy fp32 oracle, BLAS threads={threads} (best of a calibration sweep), "
-                      f"{ncpu} logical cpus visible"}
+        pass
+    return max(1, (os.cpu_count() or 2) // 2)
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
-    ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--pairs", type=int, default=1 << 20, help="trial pairs per GPU per step")
-    ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
-                    help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")
-    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 measurement")
-    ap.add_argument("--no-clock-probe", action="store_true",
-                    help="skip the shader-clock probe pass (use under rocprofv3: the profiler serialises kernels)")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
-    args = ap.parse_args()
+def cpu_baseline(dims, D0, headline_dim, budget_s=12.0, chunk=10240):
+    from oracle import nplda_oracle_torch as ot
+    ncores = _physical_cores()
+    rng = np.random.default_rng(99)
+    nbuf = 4 * chunk
+    x1 = torch.from_numpy(rng.standard_normal((nbuf, D0), dtype=np.float32))
+    x2 = torch.from_numpy(rng.standard_normal((nbuf, D0), dtype=np.float32))
+    prev_threads = torch.get_num_threads()
+    share = budget_s / (2 * len(dims) + 1)
+    detail = {}
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if not torch.cuda.is_available():
-        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
-    # NPLDA_BENCH_BACKEND=gloo is a plumbing dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks
-    # share devices, timing meaningless); the driver's runs use the default: RCCL, one rank per GPU
+    def measure(p, chunks_per_rep, min_reps=10):
+        def sweep():
+            with torch.no_grad():
+                for c in range(chunks_per_rep):
+                    lo = (c * chunk) % nbuf
+                    ot.forward(x1[lo:lo + chunk], x2[lo:lo + chunk], p)
+        sweep()  # warm-up (thread pool, allocator)
+        times = []
+        t_end = time.perf_counter() + share
+        while len(times) < min_reps or (time.perf_counter() < t_end and len(times) < 200):
+            t0 = time.perf_counter()
+            sweep()
+            times.append(time.perf_counter() - t0)
+        return chunks_per_rep * chunk / float(np.median(times)), len(times)
+
+    for D in dims:
+        prm, _ = make_params(D, "cpu")
+        p = ot.TorchParams(*[t.numpy() for t in prm])
+        for nt, tag in ((ncores, "all_cores"), (1, "one_core")):
+            torch.set_num_threads(nt)
+            rate, reps = measure(p, 4 if nt > 1 else 1)
+            detail[f"d{D}_{tag}"] = {"pairs_per_s": rate, "threads": nt, "reps": reps}
+    # gather-inclusive (utils/sv_trials_loaders.py:418-426 + forward), all cores, headline dim: what the reference's
+    # scoring / training loops actually sustain per batch
+    torch.set_num_threads(ncores)
+    prm, _ = make_params(headline_dim, "cpu")
+    p = ot.TorchParams(*[t.numpy() for t in prm])
+    nutt = 20000
+    tab = rng.standard_normal((nutt, D0), dtype=np.float32)
+    mega = {f"utt{i:06d}": tab[i] for i in range(nutt)}
+    n2i = {i: f"utt{i:06d}" for i in range(nutt)}
+    d1, d2 = rng.integers(0, nutt, chunk), rng.integers(0, nutt, chunk)
+    times = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        a, b = ot.gather_numbatch(mega, n2i, d1, d2)
+        with torch.no_grad():
+            ot.forward(a, b, p)
+        times.append(time.perf_counter() - t0)
+    detail["gather_inclusive_all_cores"] = {"pairs_per_s": chunk / float(np.median(times)), "threads": ncores, "reps": 3}
+    torch.set_num_threads(prev_threads)
+    head = detail[f"d{headline_dim}_all_cores"]
+    return {"value": head["pairs_per_s"], "unit": "pairs/s", "cores": int(ncores), "kind": "port",
+            "sample": f"median of {head['reps']} sweeps of {4 * chunk} pairs in chunks of {chunk} (the reference driver's "
+                      f"5*2048), the reference's forward restated as torch CPU ops (oracle/nplda_oracle_torch.py), "
+                      f"torch.set_num_threads({ncores}) = physical cores; 512->{headline_dim}->{headline_dim}",
+            "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "detail": detail}
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_spawn(args):
+    """`python bench.py --gpus N` outside torchrun: launch the N ranks ourselves (one per GPU over RCCL)."""
     backend = os.environ.get("NPLDA_BENCH_BACKEND", "nccl")
-    if backend != "nccl":
-        local_rank %= torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
-        else:
-            dist.init_process_group(backend)
+    ndev = torch.cuda.device_count() if torch.cuda.is_available() else 0
+    if ndev == 0:
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    if backend == "nccl" and ndev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but only {ndev} HIP device(s) are visible")
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.call(cmd, env=env))
 
-    from neuralplda_amd import _lib, ops
-    _lib.load()  # fail loudly if libnplda_hip.so is missing
 
-    D0, D = 512, args.dim
-    params, psrc = make_params(D, dev)
-    packed = ops.pack_params(*params, precision=args.precision)
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # each rank scores its own shard
-    B = args.pairs
-    x1 = torch.randn(B, D0, device=dev, generator=gen)
-    x2 = torch.randn(B, D0, device=dev, generator=gen)
+class Ctx:
+    pass
 
-    def step():
-        return ops.score_pairs(x1, x2, packed)
 
-    for _ in range(args.warmup):
-        s = step()
+def timed_steps(ctx, step, steps, warmup, per_step_events=True):
+    """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (elapsed max over ranks,
+    mean HIP-event duration of a step on the launch stream, last result)."""
+    dist = ctx.dist
+    out = None
+    for _ in range(warmup):
+        out = step()
     torch.cuda.synchronize()
-
-    # Timed region: exactly K steps bracketed by barrier + synchronize on both sides.  The HIP events
-    # bracketing each launch are recorded on the stream the kernel is launched on (torch's current stream).
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for k in range(args.steps):
+    for k in range(steps):
         evs[k][0].record()
-        s = step()
+        out = step()
         evs[k][1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist is not None:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    return elapsed, kern_ms, out
+
+
+def kernel_ms_of(fn, reps=10):
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        out = fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps, out
+
+
+def run_cfg1(args, ctx):
+    from neuralplda_amd import _lib, ops
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    D0, D = 512, args.dim
+    params, psrc = make_params(D, dev)
+    packed = ops.pack_params(*params, precision=args.precision)
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)  # each rank scores its own shard
+    if args.scaling == "strong":
+        lo, hi = (args.pairs * rank) // world, (args.pairs * (rank + 1)) // world
+        B = hi - lo
+    else:
+        B = args.pairs
+    x1 = torch.randn(B, D0, device=dev, generator=gen)
+    x2 = torch.randn(B, D0, device=dev, generator=gen)
+
+    def step():
+        return ops.score_pairs(x1, x2, packed)
+
+    elapsed, kern_ms, s = timed_steps(ctx, step, args.steps, args.warmup)
     checksum = float(s.double().sum().item())
     if not np.isfinite(checksum):
         raise SystemExit("non-finite scores")
@@ -186,7 +251,6 @@ def main():
     sclk_mhz = None
     if rank == 0 and not args.no_clock_probe:
         try:
-            from neuralplda_amd import _lib
             lib = _lib.load()
             ticks = torch.zeros(2, dtype=torch.int64, device=dev)
             side = torch.cuda.Stream(device=dev)
@@ -206,73 +270,238 @@ def main():
         except Exception as e:  # the probe is reporting only
             sys.stderr.write(f"clock probe skipped: {e}\n")
 
-    alt = None
+    alt = alt170 = None
     if rank == 0 and args.precision == "fp32" and not args.no_alt:
         # the opt-in split-bf16 scoring kernel on the same inputs (reported beside, never as `value`)
         pk3 = ops.pack_params(*params, precision="bf16x3")
-        s3 = ops.score_pairs(x1, x2, pk3)
-        torch.cuda.synchronize()
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-        for _ in range(10):
-            s3 = ops.score_pairs(x1, x2, pk3)
-        e1.record()
-        torch.cuda.synchronize()
-        ms3 = e0.elapsed_time(e1) / 10
+        ms3, s3 = kernel_ms_of(lambda: ops.score_pairs(x1, x2, pk3))
         nb = (D + 15) // 16
         issued = 6 * 2 * 2 * (32 * ((D0 + 31) // 32) + 32 * ((nb + 1) // 2)) * 16 * nb  # bf16 MFMA FLOPs per pair
         alt = {"precision": "bf16x3 (3-way bf16 split, 6 MFMA passes, fp32-class accuracy)", "kernel_ms": ms3,
                "pairs_per_s_1gpu": B / (ms3 * 1e-3), "max_abs_diff_vs_fp32_scores": float((s3 - s).abs().max().item()),
                "bf16_mfma_TFLOPs_issued": B * issued / (ms3 * 1e-3) / 1e12, "bf16_dense_peak_TFLOPs": 2500.0}
+        if D != 170:
+            # the reference's shipped shape (every conf/*.cfg and Kaldi_Models/ is 512->170->170), same inputs
+            p170, _ = make_params(170, dev)
+            pk170 = ops.pack_params(*p170)
+            ms170, s170 = kernel_ms_of(lambda: ops.score_pairs(x1, x2, pk170))
+            f170 = algorithmic_flops_per_pair(D0, 170, 170)
+            ach = B * f170 / (ms170 * 1e-3) / 1e12
+            alt170 = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": ms170,
+                      "pairs_per_s_1gpu": B / (ms170 * 1e-3), "flop_per_pair_algorithmic": f170,
+                      "workload": f"{B} trial pairs, 512->170->170 (conf/voices_config.cfg:14-16), scoring only",
+                      "checksum_finite": bool(torch.isfinite(s170).all().item())}
 
+    if rank != 0:
+        return None
+    total_pairs = (args.pairs if args.scaling == "strong" else B * world) * args.steps
+    flops = algorithmic_flops_per_pair(D0, D, D)
+    achieved = B * flops / (kern_ms * 1e-3) / 1e12
+    traffic = None
+    tfile = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the PMC passes
+    if os.path.exists(tfile):
+        try:
+            traffic = json.load(open(tfile)).get(f"score_pairs_D{D}_B{B}")
+        except Exception:
+            traffic = None
+    out = {
+        "metric": METRIC_CFG1,
+        "value": total_pairs / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": (f"cfg1: {B} trial pairs/GPU/step" if args.scaling == "weak" else
+                                f"cfg1: {args.pairs} trial pairs/step in total, {B} on rank 0") +
+                               f", 512->{D}->{D} NPLDA, scoring only (fused NeuralPlda.forward, inputs resident in HBM)",
+                   "pairs_per_gpu_per_step": B, "xvector_dim": D0, "layer1_LDA_dim": D,
+                   "layer2_PLDA_spkfactor_dim": D, "params": psrc, "parallelism": f"trial-list shard x{world}",
+                   "backend": ctx.backend if world > 1 else "single process"},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
+                     "kernel": "nplda_fwd_v3_kernel<NB, PAIR, 8 waves, 2 k16-steps/barrier> (persistent)", "kernel_ms": kern_ms,
+                     "flop_per_pair_algorithmic": flops,
+                     "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
+    }
+    if sclk_mhz is not None:
+        # reporting only: `frac` above stays priced at the nominal 2.4 GHz peak
+        out["roofline"]["sclk_mhz_under_kernel"] = sclk_mhz
+        out["roofline"]["frac_at_measured_clock"] = achieved / (FP32_MFMA_PEAK_TFLOPS * sclk_mhz / 2400.0)
+    if args.precision == "bf16x3":
+        out["dtype"] = "bf16x3"
+        out["roofline"]["kernel"] = "nplda_fwd_bf16x3_kernel (6 bf16 MFMA passes per fp32 product)"
+    if alt is not None:
+        out["alt_bf16x3"] = alt
+    if alt170 is not None:
+        out["alt_d170"] = alt170
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(sorted({D, 170}), D0, D, args.cpu_seconds)
+    return out
+
+
+def run_cfg3(args, ctx):
+    """BASELINE configs[3]: 10k-utterance cohort x 2 M trials, rows sharded across ranks, one all-gather."""
+    from neuralplda_amd import dist as ndist
+    from neuralplda_amd import ops
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    D0, D = 512, args.dim
+    M, n_enroll, n_test, T, topn = args.cohort, args.enroll, args.test, args.trials, 500
+    R = n_enroll + n_test
+    params, psrc = make_params(D, dev)
+    packed = ops.pack_params(*params)
+    gen = torch.Generator(device=dev).manual_seed(4321)  # the same data on every rank; each takes its shard
+    x_rows = torch.randn(R, D0, device=dev, generator=gen)
+    x_coh = torch.randn(M, D0, device=dev, generator=gen)
+    ie = torch.randint(0, n_enroll, (T,), device=dev, generator=gen)
+    it = n_enroll + torch.randint(0, n_test, (T,), device=dev, generator=gen)
+    raw = torch.randn(T, device=dev, generator=gen, dtype=torch.float64) * 0.3 - 1.0  # raw trial scores are an INPUT
+    rlo, rhi = ndist.shard_bounds(R, world, rank)                                      # (the reference reads a TSV)
+    tlo, thi = ndist.shard_bounds(T, world, rank)
+    raw_s, ie_s, it_s = raw[tlo:thi].contiguous(), ie[tlo:thi].contiguous(), it[tlo:thi].contiguous()
+    chunk = (R + world - 1) // world
+    ag_in = torch.zeros((chunk, 4), dtype=torch.float64, device=dev)
+    ag_out = torch.empty((world * chunk, 4), dtype=torch.float64, device=dev)
+    ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in ("stats", "ag", "apply")}
+    acc = {"stats": 0.0, "ag": 0.0, "apply": 0.0, "n": 0}
+
+    def step():
+        zc, qc = ops.embed(x_coh, packed)
+        zr, qr = ops.embed(x_rows[rlo:rhi], packed)
+        ev["stats"][0].record()
+        local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn)
+        ev["stats"][1].record()
+        ev["ag"][0].record()
+        if ctx.dist is not None:
+            ag_in[: rhi - rlo] = local
+            if ctx.backend == "nccl":
+                ctx.dist.all_gather_into_tensor(ag_out, ag_in)
+                stats = ag_out[:R]
+            else:  # gloo dry run: through the host
+                o = torch.empty(ag_out.shape, dtype=torch.float64)
+                ctx.dist.all_gather_into_tensor(o, ag_in.cpu())
+                stats = o[:R].to(dev)
+        else:
+            stats = local
+        ev["ag"][1].record()
+        ev["apply"][0].record()
+        out = ops.asnorm_apply(raw_s, ie_s, it_s, stats)
+        ev["apply"][1].record()
+        return out
+
+    elapsed, step_ms, out = timed_steps(ctx, step, args.steps, args.warmup)
+    # phase times: three extra synchronised passes after the timed region (the phase events are reused per step)
+    for _ in range(3):
+        step()
+        torch.cuda.synchronize()
+        for k in ("stats", "ag", "apply"):
+            acc[k] += ev[k][0].elapsed_time(ev[k][1])
+        acc["n"] += 1
+    if not torch.isfinite(out).all():
+        raise SystemExit("non-finite normalised scores")
+    if rank != 0:
+        return None
+    stats_ms, ag_ms, apply_ms = (acc[k] / acc["n"] for k in ("stats", "ag", "apply"))
+    rows_local = rhi - rlo
+    flops = 2.0 * D * rows_local * M  # SURVEY.md §8d: 2 D2 FLOP per cohort score
+    achieved = flops / (stats_ms * 1e-3) / 1e12
+    return {
+        "metric": "AS-normalised trials/sec (10k-utterance cohort, top-500)",
+        "value": T * args.steps / elapsed,
+        "unit": "trials/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": "strong",
+        "vs_baseline": None,
+        "dtype": "f32 scores, f64 statistics",
+        "data": "synthetic",
+        "config": {"workload": f"cfg3: cohort {M} x rows {R} ({n_enroll} enroll + {n_test} test) x {T} trials, top-{topn} "
+                               f"lowest, 512->{D}->{D}; rows and trials sharded x{world}, one all-gather of (R, 4) fp64",
+                   "cohort": M, "rows": R, "trials": T, "rows_per_gpu": rows_local, "trials_per_gpu": thi - tlo,
+                   "parallelism": f"row shard + trial shard x{world}", "backend": ctx.backend if world > 1 else "single process",
+                   "cohort_scores_per_s": R * M * args.steps / elapsed, "stats_ms": stats_ms, "allgather_ms": ag_ms,
+                   "allgather_bytes": int(world * chunk * 32), "apply_ms": apply_ms, "params": psrc},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "nplda_cohort_stats_f32 (cohort score GEMM + per-row statistics), whole call",
+                     "kernel_ms": stats_ms, "flop_per_score_algorithmic": 2 * D},
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--workload", choices=["cfg1", "cfg3"], default="cfg1")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
+                    help="cfg1: weak = --pairs per GPU (default), strong = --pairs in total split over the ranks")
+    ap.add_argument("--pairs", type=int, default=1 << 20, help="cfg1: trial pairs per GPU (weak) / in total (strong) per step")
+    ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
+    ap.add_argument("--cohort", type=int, default=10000, help="cfg3: cohort utterances")
+    ap.add_argument("--enroll", type=int, default=2000, help="cfg3: enroll ids")
+    ap.add_argument("--test", type=int, default=20000, help="cfg3: test ids")
+    ap.add_argument("--trials", type=int, default=2000000, help="cfg3: trials")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
+                    help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")
+    ap.add_argument("--no-alt", action="store_true", help="skip the extra bf16x3 / D = 170 measurements")
+    ap.add_argument("--no-clock-probe", action="store_true",
+                    help="skip the shader-clock probe pass (use under rocprofv3: the profiler serialises kernels)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="wall budget of the CPU baseline sample")
+    args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        self_spawn(args)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s)")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (there is no CPU fallback of the product path)")
+    # NPLDA_BENCH_BACKEND=gloo is a plumbing dry run of the N > 1 path on a box with fewer GPUs than ranks (ranks
+    # share devices, timing meaningless); the driver's runs use the default: RCCL, one rank per GPU
+    backend = os.environ.get("NPLDA_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= torch.cuda.device_count()
+    elif local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"bench.py: rank {rank} has no HIP device ({torch.cuda.device_count()} visible)")
+    torch.cuda.set_device(local_rank)
+    ctx = Ctx()
+    ctx.dev = torch.device("cuda", local_rank)
+    ctx.rank, ctx.world, ctx.backend, ctx.dist = rank, world, backend, None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=ctx.dev)
+        else:
+            dist.init_process_group(backend)
+        if dist.get_world_size() != world:
+            raise SystemExit("process group size does not match WORLD_SIZE")
+        ctx.dist = dist
+
+    from neuralplda_amd import _lib
+    _lib.load()  # fail loudly if libnplda_hip.so is missing
+
+    out = run_cfg1(args, ctx) if args.workload == "cfg1" else run_cfg3(args, ctx)
     if rank == 0:
-        total_pairs = B * world * args.steps
-        flops = algorithmic_flops_per_pair(D0, D, D)
-        achieved = B * flops / (kern_ms * 1e-3) / 1e12
-        traffic = None
-        tfile = os.path.join(ROOT, "profiles", "traffic.json")  # per-launch HBM bytes from the PMC passes
-        if os.path.exists(tfile):
-            try:
-                traffic = json.load(open(tfile)).get(f"score_pairs_D{D}_B{B}")
-            except Exception:
-                traffic = None
-        out = {
-            "metric": "scored trial-pairs/sec (512-d xvec)",
-            "value": total_pairs / elapsed,
-            "unit": "pairs/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "f32",
-            "data": "synthetic",
-            "config": {"workload": f"cfg1: {B} trial pairs/GPU/step, 512->{D}->{D} NPLDA, scoring only "
-                                   "(fused NeuralPlda.forward, inputs resident in HBM)",
-                       "pairs_per_gpu_per_step": B, "xvector_dim": D0, "layer1_LDA_dim": D,
-                       "layer2_PLDA_spkfactor_dim": D, "params": psrc, "parallelism": f"trial-list shard x{world}"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                         "kernel": "nplda_fwd_v3_kernel<NB, PAIR, 8 waves, 2 k16-steps/barrier> (persistent; v2 at D = 170)", "kernel_ms": kern_ms,
-                         "flop_per_pair_algorithmic": flops,
-                         "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
-        }
-        if sclk_mhz is not None:
-            # reporting only: `frac` above stays priced at the nominal 2.4 GHz peak
-            out["roofline"]["sclk_mhz_under_kernel"] = sclk_mhz
-            out["roofline"]["frac_at_measured_clock"] = achieved / (FP32_MFMA_PEAK_TFLOPS * sclk_mhz / 2400.0)
-        if args.precision == "bf16x3":
-            out["dtype"] = "bf16x3"
-            out["roofline"]["kernel"] = "nplda_fwd_bf16x3_kernel (6 bf16 MFMA passes per fp32 product)"
-        if alt is not None:
-            out["alt_bf16x3"] = alt
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline([p.cpu().numpy() for p in params], D0, args.cpu_seconds)
+        out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
         print(json.dumps(out), flush=True)
-    if dist is not None:
-        dist.destroy_process_group()
+    if ctx.dist is not None:
+        ctx.dist.destroy_process_group()
 
 
 if __name__ == "__main__":

@@ -125,6 +125,67 @@ int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
                        const float* rn, int64_t ldz, const float* P_sqrt, void* ws, size_t ws_bytes,
                        float* grad_flat, nplda_stream_t stream);
 
+/* nplda_backward_f32 plus the gradient w.r.t. the INPUTS: dx1, dx2 (B, D0) with row stride lddx, both or neither
+ * NULL — dL/dx = du . W1, what autograd hands to an x-vector extractor trained jointly with the head (the E2E model,
+ * utils/models.py:251-268, feeds extractor outputs through the same two layers).  One more MFMA GEMM on the `du` rows the
+ * backward already holds (csrc/nplda_matmul.hip).  Workspace: nplda_backward_ex_workspace_bytes(2 B, ..., want_dx). */
+size_t nplda_backward_ex_workspace_bytes(int64_t rows, int D0, int D1, int D2, int want_dx);
+int nplda_backward_ex_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
+                          int D0, int D1, int D2, const float* g, const float* y, const float* z,
+                          const float* rn, int64_t ldz, const float* P_sqrt, void* ws, size_t ws_bytes,
+                          float* grad_flat, float* dx1, float* dx2, int64_t lddx, nplda_stream_t stream);
+
+/* NeuralPlda.extract_plda_embeddings (utils/models.py:366-370) with what ITS backward needs: z (N, ldz) as
+ * nplda_embed_f32, y (N, ldz) = normalised layer-1 rows, rn (N) = 1 / max(||u||, 1e-12); ldz = nplda_padded_dim. */
+int nplda_embed_train_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
+                          float* z, float* y, float* rn, int64_t ldz, nplda_stream_t stream);
+
+/* Backward of z = extract_plda_embeddings(x) given gz = dL/dz (N, D2) with row stride ldgz (any stride >= D2):
+ * grad_flat as nplda_backward_f32 lays it out (dP_sqrt = dQ = 0: z does not depend on them) and, when dx != NULL,
+ * dL/dx (N, D0).  y, rn from nplda_embed_train_f32.  Workspace: nplda_backward_ex_workspace_bytes(N, ..., dx != NULL). */
+int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
+                             const float* gz, int64_t ldgz, const float* y, const float* rn, int64_t ldz,
+                             void* ws, size_t ws_bytes, float* grad_flat, float* dx, int64_t lddx,
+                             nplda_stream_t stream);
+
+/* Backward of s = NeuralPlda.forward_from_plda_embeddings(z1, z2) (utils/models.py:372-376) given g = dL/ds:
+ * dz1 = 2 g (Q z1 + P z2), dz2 = 2 g (Q z2 + P z1) (either may be NULL), dQ = sum g (z1^2 + z2^2),
+ * dP_sqrt = 4 P_sqrt sum g z1 z2 (either may be NULL); column sums in a fixed order (deterministic). */
+size_t nplda_score_embeddings_bwd_workspace_bytes(int64_t B, int D2);
+int nplda_score_embeddings_bwd_f32(const float* z1, int64_t ld1, const float* z2, int64_t ld2, int64_t B, int D2,
+                                   const float* P_sqrt, const float* Q, const float* g, float* dz1, int64_t ldd1,
+                                   float* dz2, int64_t ldd2, float* dP_sqrt, float* dQ, void* ws, size_t ws_bytes,
+                                   nplda_stream_t stream);
+
+/* ---- small resident-matrix GEMM on row batches (input gradients; csrc/nplda_matmul.hip) ---------------------- */
+
+/* MFMA-fragment image of a K x N matrix Wm (K <= 512, N % 4 == 0) for nplda_rows_matmul_f32.  mode 0: Wm = src (K, N)
+ * row-major with stride ldw; 1: Wm = src^T (src is (N, K)); 2: Wm = src + src^T (K == N). */
+size_t nplda_matrix_frag_bytes(int K, int N);
+int nplda_pack_matrix_f32(const float* src, int64_t ldw, int K, int N, int mode, void* frag, size_t frag_bytes,
+                          nplda_stream_t stream);
+/* out[r, :] = rowscale[r] * (in[r, :K] . Wm + bias) for R rows; bias (N) and rowscale (R) may be NULL.  With
+ * Wm = M + M^T, bias = v, rowscale = dL/ds this is the gradient of DPlda's quadratic form x^T M x + x^T v + c
+ * (utils/models.py:484-495) w.r.t. the paired rows x = [y1; y2]. */
+int nplda_rows_matmul_f32(const float* in, int64_t ldin, int64_t R, int K, const void* frag, int N,
+                          const float* bias, const float* rowscale, float* out, int64_t ldout,
+                          nplda_stream_t stream);
+/* F.normalize backward on paired rows: du[h B + k, :] = (dy - y (y . dy)) * rn[h B + k], dy = dpaired[k, h D1 : (h+1) D1],
+ * y = paired[k, h D1 : (h+1) D1]; du is (2 B, ldz) with zero padding columns (the layout nplda_backward's wgrad and
+ * nplda_rows_matmul_f32 consume).  rn (2 B) from gb_score_pairs_ex_f32. */
+int nplda_normalize_bwd_paired_f32(const float* dpaired, int64_t lddp, const float* paired, int64_t ldp,
+                                   const float* rn, int64_t B, int D1, float* du, int64_t ldz,
+                                   nplda_stream_t stream);
+/* dW1 (D1, D0) and db1 (D1) of an LDA layer from du (2 B, ldz) and the inputs x1, x2 (B, D0): the wgrad half of
+ * nplda_backward_f32 alone (DPlda / GaussianBackend heads have no second layer).  out: D1 * D0 + D1 floats. */
+size_t nplda_lda_wgrad_workspace_bytes(int64_t B, int D0, int D1);
+int nplda_lda_wgrad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* du, int64_t ldz,
+                        int D0, int D1, void* ws, size_t ws_bytes, float* out, nplda_stream_t stream);
+/* dx1, dx2 (B, D0) = du . W1 for the same heads (W1 (D1, D0) row-major raw parameter; frag workspace inside ws). */
+size_t nplda_lda_dgrad_workspace_bytes(int D0, int D1);
+int nplda_lda_dgrad_f32(const float* du, int64_t ldz, int64_t B, const float* W1, int D0, int D1, void* ws,
+                        size_t ws_bytes, float* dx1, float* dx2, int64_t lddx, nplda_stream_t stream);
+
 /* ---- indexed scoring (embed each utterance once, then score index pairs) --------------------- */
 
 /* utils/models.py:372-376 on rows of a pre-embedded table: s[p] = q[i1[p]] + q[i2[p]] +
@@ -204,6 +265,11 @@ int gb_pack_dplda_f32(const float* W1, const float* b1, const float* wlr, const 
  * Either output pointer may be NULL (not both). */
 int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
                        int D0, int D1, float* s, float* paired, nplda_stream_t stream);
+
+/* gb_score_pairs_f32 that also returns rn (2 B) = 1 / max(||LDA x||, 1e-12) (x1 side rows, then x2 side): what a
+ * backward through the LDA layer needs next to the paired rows.  rn may be NULL. */
+int gb_score_pairs_ex_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed,
+                          int D0, int D1, float* s, float* paired, float* rn, nplda_stream_t stream);
 
 /* The same score WITHOUT the normalisation step: rows of y1/y2 are used as layer-1 inputs as they are, i.e.
  * s = x^T M x + x^T v + c with x = [W1 y1 + b1; W1 y2 + b1].  With W1 = I (D0 = padded D1), b1 = 0 this is

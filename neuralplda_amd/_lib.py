@@ -86,6 +86,32 @@ SIGNATURES = {
     "nplda_backward_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
     "nplda_backward_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,
                                     _c_f32p, _c_f32p, _c_f32p, _c_i64, _c_f32p, _c_vp, _c_sz, _c_f32p, _c_vp]),
+    "nplda_backward_ex_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
+    "nplda_backward_ex_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,
+                                       _c_f32p, _c_f32p, _c_f32p, _c_i64, _c_f32p, _c_vp, _c_sz, _c_f32p, _c_f32p,
+                                       _c_f32p, _c_i64, _c_vp]),
+    "nplda_embed_train_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_f32p,
+                                       _c_f32p, _c_i64, _c_vp]),
+    "nplda_embed_backward_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
+                                          _c_f32p, _c_f32p, _c_i64, _c_vp, _c_sz, _c_f32p, _c_f32p, _c_i64, _c_vp]),
+    "nplda_score_embeddings_bwd_workspace_bytes": (_c_sz, [_c_i64, _c_int]),
+    "nplda_score_embeddings_bwd_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p,
+                                                _c_f32p, _c_f32p, _c_i64, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_vp,
+                                                _c_sz, _c_vp]),
+    "nplda_matrix_frag_bytes": (_c_sz, [_c_int, _c_int]),
+    "nplda_pack_matrix_f32": (_c_int, [_c_f32p, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "nplda_rows_matmul_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_vp, _c_int, _c_f32p, _c_f32p, _c_f32p,
+                                       _c_i64, _c_vp]),
+    "nplda_normalize_bwd_paired_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_f32p, _c_i64, _c_int, _c_f32p,
+                                                _c_i64, _c_vp]),
+    "nplda_lda_wgrad_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int]),
+    "nplda_lda_wgrad_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_f32p, _c_i64, _c_int, _c_int, _c_vp, _c_sz,
+                                     _c_f32p, _c_vp]),
+    "nplda_lda_dgrad_workspace_bytes": (_c_sz, [_c_int, _c_int]),
+    "nplda_lda_dgrad_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_f32p, _c_int, _c_int, _c_vp, _c_sz, _c_f32p, _c_f32p,
+                                     _c_i64, _c_vp]),
+    "gb_score_pairs_ex_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
+                                       _c_f32p, _c_vp]),
 }
 
 _lib = None

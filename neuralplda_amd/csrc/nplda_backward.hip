@@ -19,6 +19,12 @@
 //         buffer a data-parallel all-reduce needs.
 #include "nplda_fwd_dispatch.h"
 
+namespace nplda {  // nplda_matmul.hip
+int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
+                       float* frag, float* dx0, float* dx1, long long nsplit, long long lddx, hipStream_t st);
+int pad_rows(const float* in, long long ldin, long long N, int D, float* out, long long ldo, hipStream_t st);
+}  // namespace nplda
+
 namespace {
 
 using namespace nplda;
@@ -26,20 +32,23 @@ using namespace nplda;
 // ------------------------------------------------------------------------------------------------
 // K-A
 // ------------------------------------------------------------------------------------------------
+// Row bookkeeping: a tile holds 16 "A" rows t0 + j (< nA) and 16 "B" rows offB + t0 + j (t0 + j < nB).  Pair scoring:
+// nA = nB = offB = B (x1 side, x2 side).  Embedding rows (GIVEN): N rows split into two halves, nA = ceil(N / 2),
+// nB = N - nA, offB = nA — the same kernels, the pairing is then just a way to fill both MFMA row groups.
 struct BwdArgs {
-    const float* g;       // (n)
-    const float* z;       // (2n, ldz)
-    const float* y;       // (2n, ldz)
-    const float* rn;      // (2n)
+    const float* g;       // (nA) dL/ds per pair                       [unused when GIVEN]
+    const float* z;       // (rows, ldz)                               [unused when GIVEN]
+    const float* y;       // (rows, ldz)
+    const float* rn;      // (rows)
     const float* packed;
-    long long n, ldz;
+    long long nA, nB, offB, ldz;
     size_t oW2T, oQ, oP, total;
-    float* dz;            // (2n, ldz)
-    float* du;            // (2n, ldz)
-    int ntb;              // tile-blocks = ceil(n / (16 * WAVES))
+    float* dz;            // (rows, ldz): written, or READ when GIVEN (upstream dL/dz, zero-padded columns)
+    float* du;            // (rows, ldz)
+    int ntb;              // tile-blocks = ceil(nA / (16 * WAVES))
 };
 
-template <int NB, int WAVES>
+template <int NB, int WAVES, bool GIVEN>
 __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a) {
     constexpr int THREADS = WAVES * 64;
     constexpr int CH = NB * 64;
@@ -54,27 +63,35 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 
     for (int tb = blockIdx.x; tb < a.ntb; tb += gridDim.x) {
         const long long t0 = ((long long)tb * WAVES + wave) * 16;
-        const bool ok = t0 + j < a.n;
-        const long long rA = ok ? t0 + j : a.n - 1;
-        const long long rB = a.n + rA;
+        const bool okA = t0 + j < a.nA, okB = t0 + j < a.nB;
+        const long long rA = okA ? t0 + j : a.nA - 1;
+        const long long rB = a.offB + (okB ? t0 + j : (a.nB > 0 ? a.nB - 1 : 0));
         f32x4 st[NSLOT];
         if (WAVES > 1) {
             __syncthreads();  // every wave is done reading wbuf from the previous tile
             chunk_load<CH, THREADS, NSLOT>(W2T, avail, st, tid);
         }
-        const float gi = ok ? a.g[rA] : 0.f;
         f32x4 dzA[NB], dzB[NB];
+        if (GIVEN) {
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
-            const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
-            const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
-            const float tg = 2.0f * gi;
-            dzA[nb] = tg * (q * zA + p * zB);
-            dzB[nb] = tg * (q * zB + p * zA);
-            if (ok) {
-                *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dzA[nb];
-                *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dzB[nb];
+            for (int nb = 0; nb < NB; ++nb) {
+                dzA[nb] = *reinterpret_cast<const f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4);
+                dzB[nb] = *reinterpret_cast<const f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4);
+            }
+        } else {
+            const float gi = okA ? a.g[rA] : 0.f;
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
+                const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
+                const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
+                const float tg = 2.0f * gi;
+                dzA[nb] = tg * (q * zA + p * zB);
+                dzB[nb] = tg * (q * zB + p * zA);
+                if (okA) {
+                    *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dzA[nb];
+                    *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dzB[nb];
+                }
             }
         }
         if (WAVES > 1) {
@@ -132,10 +149,8 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
         for (int nb = 0; nb < NB; ++nb) {
             const f32x4 yA = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nb + 4 * g4);
             const f32x4 yB = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
-            if (ok) {
-                *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA * dotA) * rnA;
-                *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB * dotB) * rnB;
-            }
+            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA * dotA) * rnA;
+            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB * dotB) * rnB;
         }
     }
 }
@@ -145,7 +160,7 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 // accumulator layout (= the B operand of the chained MFMA), computes ITS dy blocks from all of dz with W2^T
 // fragments read straight from the L2-resident image through a register ring, and the y.dy dot product of the
 // normalize backward is reduced across the waves through LDS.
-template <int NB>
+template <int NB, bool GIVEN>
 __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a) {
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;
@@ -159,9 +174,9 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
 
     const long long t0 = (long long)blockIdx.x * 16;
-    const bool ok = t0 + j < a.n;
-    const long long rA = ok ? t0 + j : a.n - 1;
-    const long long rB = a.n + rA;
+    const bool okA = t0 + j < a.nA, okB = t0 + j < a.nB;
+    const long long rA = okA ? t0 + j : a.nA - 1;
+    const long long rB = a.offB + (okB ? t0 + j : (a.nB > 0 ? a.nB - 1 : 0));
 
     f32x4 wf[PF][NBW];
     auto fetch = [&](int slot, int kb) {
@@ -175,21 +190,26 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch(s, s);
 
-    const float tg = ok ? 2.0f * a.g[rA] : 0.f;
+    const float tg = (!GIVEN && okA) ? 2.0f * a.g[rA] : 0.f;
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
-            const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
-            const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
-            const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
-            const f32x4 dA = tg * (q * zA + p * zB);
-            const f32x4 dB = tg * (q * zB + p * zA);
-            dzlds[0][nb][lane] = dA;
-            dzlds[1][nb][lane] = dB;
-            if (ok) {
-                *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dA;
-                *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dB;
+            if (GIVEN) {
+                dzlds[0][nb][lane] = *reinterpret_cast<const f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4);
+                dzlds[1][nb][lane] = *reinterpret_cast<const f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4);
+            } else {
+                const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
+                const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
+                const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
+                const f32x4 dA = tg * (q * zA + p * zB);
+                const f32x4 dB = tg * (q * zB + p * zA);
+                dzlds[0][nb][lane] = dA;
+                dzlds[1][nb][lane] = dB;
+                if (okA) {
+                    *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dA;
+                    *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dB;
+                }
             }
         }
     }
@@ -248,9 +268,9 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int nb = wave + NW * i;
-        if (nb < NB && ok) {
-            *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[i] - yA[i] * dotA) * rnA;
-            *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[i] - yB[i] * dotB) * rnB;
+        if (nb < NB) {
+            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[i] - yA[i] * dotA) * rnA;
+            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[i] - yB[i] * dotB) * rnB;
         }
     }
 }
@@ -268,12 +288,13 @@ struct WgradProblem {
     int MT, NT;           // 64-wide tiles
     float* slab;          // [ksplit][Mp][Np]
     int Mp, Np;
-    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}
+    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}, 3 = {db2 from A; dQ = dP = 0}
 };
 
 struct WgradArgs {
     WgradProblem p[2];
-    long long n;          // pairs; K = 2n
+    long long K;          // rows of the "A^T B" products (2 B for pair scoring, N for embedding rows)
+    long long nsplit;     // rows [0, nsplit) of B come from B0, the rest from B1 (= pairs for pair scoring)
     int ksplit;
     long long rows_per_split;  // multiple of 4
     const float* z;       // (2n, ldz)
@@ -301,14 +322,14 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProble
     const float* __restrict__ PA = P.A;
     const float* __restrict__ PB0 = P.B0;
     const float* __restrict__ PB1 = P.B1;
-    const long long lda = P.lda, ldb = P.ldb, npairs = a.n, ldz = a.ldz;
+    const long long lda = P.lda, ldb = P.ldb, npairs = a.nsplit, ldz = a.ldz;
     const float* __restrict__ zptr = a.z;
     const float* __restrict__ gptr = a.g;
     const int ks = w % a.ksplit;
     const int tile = w / a.ksplit;
     const int nt = tile % P.NT, mt = tile / P.NT;
     const int m0 = mt * 64, n0 = nt * 64;
-    const long long K = 2 * a.n;
+    const long long K = a.K;
     const long long quarter = a.rows_per_split / 4;
     const long long k0 = (long long)ks * a.rows_per_split + wave * quarter;
     long long k1 = k0 + quarter;
@@ -446,7 +467,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     const int ext = (nt == 0) ? P.extras : 0;  // block-uniform: one specialised body per block
     if (ext == 0) wgrad_body<0>(a, P, w, red, rede);
     else if (ext == 1) wgrad_body<1>(a, P, w, red, rede);
-    else wgrad_body<2>(a, P, w, red, rede);
+    else if (ext == 2) wgrad_body<2>(a, P, w, red, rede);
+    else wgrad_body<3>(a, P, w, red, rede);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -488,7 +510,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs a) {
         const int row = which == 0 ? 2 : (which == 1 ? 1 : 0);
         src = a.ext + row * a.Mp + f;
         stride = 4 * (size_t)a.Mp;
-        if (which == 1) scale = 4.0f * a.P_sqrt[f];
+        if (which == 1) scale = a.P_sqrt ? 4.0f * a.P_sqrt[f] : 0.f;  // no P_sqrt: embedding rows, dP = 0
     }
     float sum = 0.f;
     for (int k = 0; k < a.ksplit; ++k) sum += src[k * stride];
@@ -499,17 +521,17 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs a) {
 constexpr int kBwdWaves = 4;
 
 struct WsLayout {
-    size_t dz, du, slab1, slab2, ext, total;  // float offsets
+    size_t dz, du, slab1, slab2, ext, frag, total;  // float offsets
     int ksplit;
     long long rows_per_split;
     int Mp, Np1;
 };
 
-WsLayout ws_layout(long long B, const NpldaLayout& L) {
+// K = rows of the A^T B products (2 B for pair scoring).  want_dx adds room for the W1 fragment image of dx = du W1.
+WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     WsLayout w;
     w.Mp = 16 * L.NB;
     w.Np1 = (L.D0 + 3) / 4 * 4;
-    const long long K = 2 * B;
     // k-groups (slabs): each group = one block of 4 waves x >= 128 rows.  A block holds 68 KB of LDS, so 2 are
     // resident per CU: keep (64x64 tiles) x (k-groups) <= 512 blocks so that the grid is a single resident wave
     // (528 blocks ran as 512 + a 16-block tail at twice the time).
@@ -520,17 +542,87 @@ WsLayout ws_layout(long long B, const NpldaLayout& L) {
     if (ks < 1) ks = 1;
     long long rps = (K + ks - 1) / ks;
     rps = (rps + 16 * kPF - 1) / (16 * kPF) * (16 * kPF);  // 4 quarters, each a multiple of 4 * kPF rows
+    if (rps < 16 * kPF) rps = 16 * kPF;
     w.ksplit = (int)((K + rps - 1) / rps);
     if (w.ksplit < 1) w.ksplit = 1;
     w.rows_per_split = rps;
-    const size_t rows = (size_t)(2 * B) * w.Mp;
+    const size_t rows = (size_t)(K + (K & 1)) * w.Mp;  // an odd row count is padded by one (never-read) row
     w.dz = 0;
     w.du = w.dz + rows;
     w.slab1 = w.du + rows;
     w.slab2 = w.slab1 + (size_t)w.ksplit * w.Mp * w.Np1;
     w.ext = w.slab2 + (size_t)w.ksplit * w.Mp * w.Mp;
-    w.total = w.ext + (size_t)w.ksplit * 4 * w.Mp;
+    w.frag = w.ext + (size_t)w.ksplit * 4 * w.Mp;
+    w.total = w.frag + (want_dx ? (size_t)L.NB * L.KS1 * 256 : 0);
     return w;
+}
+
+// The three launches (+ the input-gradient GEMM when dx is asked for) behind every backward entry point.
+//   given == false: pair scoring — dz is formed from g, z (rows [0,B) = x1 side, [B,2B) = x2 side);
+//   given == true : `K` embedding rows whose upstream gradient dL/dz already sits, zero-padded, in the workspace.
+int backward_launch(bool given, const float* xa, const float* xb, long long K, long long nsplit, long long ldx,
+                    const float* packed, const NpldaLayout& L, const float* g, const float* y, const float* z,
+                    const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
+                    float* dx0, float* dx1, long long lddx, hipStream_t st) {
+    BwdArgs b = {};
+    b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = packed; b.ldz = ldz;
+    if (given) {
+        b.nA = (K + 1) / 2; b.nB = K - b.nA; b.offB = b.nB > 0 ? b.nA : 0;
+    } else {
+        b.nA = b.nB = b.offB = nsplit;
+    }
+    b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
+    b.dz = wsf + W.dz; b.du = wsf + W.du;
+    const long long ntb = (b.nA + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
+    if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
+    b.ntb = (int)ntb;
+    {
+        // small batches: 4 waves share a 16-pair tile (feature split), so a 4096-pair minibatch fills 256 CUs
+        const bool small = b.nA <= 16 * 1024;
+        dim3 grid(small ? (unsigned)((b.nA + 15) / 16) : (unsigned)(ntb < 2048 ? ntb : 2048)), block(256);
+#define NPLDA_LAUNCH2(NBV, GV)                                                                  \
+    if (small) hipLaunchKernelGGL((bwd_data_small_kernel<NBV, GV>), grid, block, 0, st, b);      \
+    else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves, GV>), grid, block, 0, st, b)
+#define NPLDA_LAUNCH(NBV) if (given) { NPLDA_LAUNCH2(NBV, true); } else { NPLDA_LAUNCH2(NBV, false); }
+        switch (L.NB) {
+            case 2: NPLDA_LAUNCH(2); break;
+            case 4: NPLDA_LAUNCH(4); break;
+            case 8: NPLDA_LAUNCH(8); break;
+            case 10: NPLDA_LAUNCH(10); break;
+            case 11: NPLDA_LAUNCH(11); break;
+            case 12: NPLDA_LAUNCH(12); break;
+            default: return NPLDA_EUNSUPPORTED;
+        }
+#undef NPLDA_LAUNCH
+#undef NPLDA_LAUNCH2
+        if (int rc = nplda_launch_status()) return rc;
+    }
+    // K-B
+    WgradArgs wa = {};
+    wa.K = K; wa.nsplit = nsplit; wa.ksplit = W.ksplit; wa.rows_per_split = W.rows_per_split;
+    wa.z = z; wa.g = g; wa.ldz = ldz; wa.ext = wsf + W.ext; wa.Mp = W.Mp;
+    WgradProblem& p1 = wa.p[0];  // dW1 = du^T [x1; x2]
+    p1.A = wsf + W.du; p1.lda = ldz; p1.B0 = xa; p1.B1 = xb; p1.ldb = ldx; p1.M = W.Mp; p1.N = L.D0;
+    p1.MT = (W.Mp + 63) / 64; p1.NT = (L.D0 + 63) / 64; p1.slab = wsf + W.slab1; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
+    WgradProblem& p2 = wa.p[1];  // dW2 = dz^T [y1; y2]
+    p2.A = wsf + W.dz; p2.lda = ldz; p2.B0 = y; p2.B1 = y + (size_t)nsplit * ldz; p2.ldb = ldz; p2.M = W.Mp; p2.N = W.Mp;
+    p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp;
+    p2.extras = given ? 3 : 2;
+    wa.nw0 = p1.MT * p1.NT * W.ksplit;
+    wa.nw = wa.nw0 + p2.MT * p2.NT * W.ksplit;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
+    if (int rc = nplda_launch_status()) return rc;
+    // K-C
+    ReduceArgs ra = {};
+    ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
+    ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = L.D0; ra.D1 = L.D1; ra.D2 = L.D2; ra.out = grad_flat;
+    const size_t ngrad = (size_t)L.D1 * L.D0 + L.D1 + (size_t)L.D2 * L.D1 + 3 * (size_t)L.D2;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ngrad + 255) / 256)), dim3(256), 0, st, ra);
+    if (int rc = nplda_launch_status()) return rc;
+    if (dx0) {  // dL/dx = du . W1 (the E2E head's input gradient, utils/models.py:251-268)
+        return input_grad_from_du(wsf + W.du, K, ldz, packed, L, wsf + W.frag, dx0, dx1, nsplit, lddx, st);
+    }
+    return NPLDA_OK;
 }
 
 }  // namespace
@@ -544,7 +636,12 @@ size_t nplda_grad_floats(int D0, int D1, int D2) {
 
 size_t nplda_backward_workspace_bytes(int64_t B, int D0, int D1, int D2) {
     if (B < 0 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
-    return ws_layout(B, nplda_layout(D0, D1, D2)).total * sizeof(float);
+    return ws_layout(2 * B, nplda_layout(D0, D1, D2), false).total * sizeof(float);
+}
+
+size_t nplda_backward_ex_workspace_bytes(int64_t rows, int D0, int D1, int D2, int want_dx) {
+    if (rows < 0 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return ws_layout(rows, nplda_layout(D0, D1, D2), want_dx != 0).total * sizeof(float);
 }
 
 int nplda_forward_train_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0,
@@ -563,12 +660,28 @@ int nplda_forward_train_f32(const float* x1, const float* x2, int64_t B, int64_t
     return launch_fwd<MODE_TRAIN>(a, L, (hipStream_t)stream);
 }
 
-int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
-                       int D2, const float* g, const float* y, const float* z, const float* rn, int64_t ldz,
-                       const float* P_sqrt, void* ws, size_t ws_bytes, float* grad_flat, nplda_stream_t stream) {
+int nplda_embed_train_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2, float* z,
+                          float* y, float* rn, int64_t ldz, nplda_stream_t stream) {
+    if (N < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (N == 0) return NPLDA_OK;
+    if (!packed || !rn || !nplda_aligned16(packed) || !rows_ok(x, ldx, D0)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!rows_ok(y, ldz, 16 * L.NB) || !rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
+    FwdArgs a = {};
+    a.xa = x; a.xb = x; a.n = N; a.ldx = ldx; a.packed = (const float*)packed;
+    a.out_z = z; a.ldz = ldz; a.out_y = y; a.out_rn = rn;
+    return launch_fwd<MODE_EMBED>(a, L, (hipStream_t)stream);
+}
+
+int nplda_backward_ex_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                          int D2, const float* g, const float* y, const float* z, const float* rn, int64_t ldz,
+                          const float* P_sqrt, void* ws, size_t ws_bytes, float* grad_flat, float* dx1, float* dx2,
+                          int64_t lddx, nplda_stream_t stream) {
     if (B < 0) return NPLDA_EINVAL;
     if (int rc = check_model(D0, D1, D2)) return rc;
     if (!grad_flat) return NPLDA_EINVAL;
+    if ((dx1 == nullptr) != (dx2 == nullptr)) return NPLDA_EINVAL;
     hipStream_t st = (hipStream_t)stream;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
@@ -579,56 +692,83 @@ int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
     if (!packed || !g || !rn || !P_sqrt || !ws || !nplda_aligned16(packed) || !nplda_aligned16(ws)) return NPLDA_EINVAL;
     if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
     if (!rows_ok(y, ldz, 16 * L.NB) || !rows_ok(z, ldz, 16 * L.NB) || ldz != 16 * L.NB) return NPLDA_EINVAL;
-    const WsLayout W = ws_layout(B, L);
+    if (dx1 && (!rows_ok(dx1, lddx, D0) || !rows_ok(dx2, lddx, D0))) return NPLDA_EINVAL;
+    const WsLayout W = ws_layout(2 * B, L, dx1 != nullptr);
+    if (ws_bytes < W.total * sizeof(float)) return NPLDA_ENOSPC;
+    return backward_launch(false, x1, x2, 2 * B, B, ldx, (const float*)packed, L, g, y, z, rn, ldz, P_sqrt, (float*)ws, W,
+                           grad_flat, dx1, dx2, lddx, st);
+}
+
+int nplda_backward_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                       int D2, const float* g, const float* y, const float* z, const float* rn, int64_t ldz,
+                       const float* P_sqrt, void* ws, size_t ws_bytes, float* grad_flat, nplda_stream_t stream) {
+    return nplda_backward_ex_f32(x1, x2, B, ldx, packed, D0, D1, D2, g, y, z, rn, ldz, P_sqrt, ws, ws_bytes, grad_flat,
+                                 nullptr, nullptr, 0, stream);
+}
+
+int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
+                             const float* gz, int64_t ldgz, const float* y, const float* rn, int64_t ldz, void* ws,
+                             size_t ws_bytes, float* grad_flat, float* dx, int64_t lddx, nplda_stream_t stream) {
+    if (N < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (!grad_flat) return NPLDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    const size_t ngrad = nplda_grad_floats(D0, D1, D2);
+    if (N == 0) {
+        hipError_t e = hipMemsetAsync(grad_flat, 0, ngrad * sizeof(float), st);
+        return e == hipSuccess ? NPLDA_OK : (int)e;
+    }
+    if (!packed || !gz || !rn || !ws || ldgz < D2 || !nplda_aligned16(packed) || !nplda_aligned16(ws)) return NPLDA_EINVAL;
+    if (!rows_ok(x, ldx, D0) || !rows_ok(y, ldz, 16 * L.NB) || ldz != 16 * L.NB) return NPLDA_EINVAL;
+    if (dx && !rows_ok(dx, lddx, D0)) return NPLDA_EINVAL;
+    const WsLayout W = ws_layout(N, L, dx != nullptr);
     if (ws_bytes < W.total * sizeof(float)) return NPLDA_ENOSPC;
     float* wsf = (float*)ws;
+    if (int rc = pad_rows(gz, ldgz, N, D2, wsf + W.dz, ldz, st)) return rc;
+    return backward_launch(true, x, x, N, N, ldx, (const float*)packed, L, nullptr, y, nullptr, rn, ldz, nullptr, wsf, W,
+                           grad_flat, dx, dx, lddx, st);
+}
 
-    // K-A
-    BwdArgs b = {};
-    b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = (const float*)packed; b.n = B; b.ldz = ldz;
-    b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
-    b.dz = wsf + W.dz; b.du = wsf + W.du;
-    const long long ntb = (B + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
-    if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
-    b.ntb = (int)ntb;
-    {
-        // small batches: 4 waves share a 16-pair tile (feature split), so a 4096-pair minibatch fills 256 CUs
-        const bool small = B <= 16 * 1024;
-        dim3 grid(small ? (unsigned)((B + 15) / 16) : (unsigned)(ntb < 2048 ? ntb : 2048)), block(256);
-#define NPLDA_LAUNCH(NBV)                                                                 \
-    if (small) hipLaunchKernelGGL((bwd_data_small_kernel<NBV>), grid, block, 0, st, b);    \
-    else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves>), grid, block, 0, st, b)
-        switch (L.NB) {
-            case 2: NPLDA_LAUNCH(2); break;
-            case 4: NPLDA_LAUNCH(4); break;
-            case 8: NPLDA_LAUNCH(8); break;
-            case 10: NPLDA_LAUNCH(10); break;
-            case 11: NPLDA_LAUNCH(11); break;
-            case 12: NPLDA_LAUNCH(12); break;
-            default: return NPLDA_EUNSUPPORTED;
-        }
-#undef NPLDA_LAUNCH
-        if (int rc = nplda_launch_status()) return rc;
+size_t nplda_lda_wgrad_workspace_bytes(int64_t B, int D0, int D1) {
+    if (B < 0 || check_model(D0, D1, D1) != NPLDA_OK) return 0;
+    const WsLayout W = ws_layout(2 * B, nplda_layout(D0, D1, D1), false);
+    return ((size_t)W.ksplit * W.Mp * W.Np1 + (size_t)W.ksplit * 4 * W.Mp) * sizeof(float);
+}
+
+int nplda_lda_wgrad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* du, int64_t ldz, int D0,
+                        int D1, void* ws, size_t ws_bytes, float* out, nplda_stream_t stream) {
+    if (B < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D1)) return rc;
+    if (!out) return NPLDA_EINVAL;
+    hipStream_t st = (hipStream_t)stream;
+    const size_t nout = (size_t)D1 * D0 + D1;
+    if (B == 0) {
+        hipError_t e = hipMemsetAsync(out, 0, nout * sizeof(float), st);
+        return e == hipSuccess ? NPLDA_OK : (int)e;
     }
-    // K-B
+    const NpldaLayout L = nplda_layout(D0, D1, D1);
+    const WsLayout W = ws_layout(2 * B, L, false);
+    if (!ws || !nplda_aligned16(ws) || !rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0) || !rows_ok(du, ldz, W.Mp))
+        return NPLDA_EINVAL;
+    if (ws_bytes < nplda_lda_wgrad_workspace_bytes(B, D0, D1)) return NPLDA_ENOSPC;
+    float* slab = (float*)ws;
+    float* ext = slab + (size_t)W.ksplit * W.Mp * W.Np1;
     WgradArgs wa = {};
-    wa.n = B; wa.ksplit = W.ksplit; wa.rows_per_split = W.rows_per_split;
-    wa.z = z; wa.g = g; wa.ldz = ldz; wa.ext = wsf + W.ext; wa.Mp = W.Mp;
-    WgradProblem& p1 = wa.p[0];  // dW1 = du^T [x1; x2]
-    p1.A = wsf + W.du; p1.lda = ldz; p1.B0 = x1; p1.B1 = x2; p1.ldb = ldx; p1.M = W.Mp; p1.N = D0;
-    p1.MT = (W.Mp + 63) / 64; p1.NT = (D0 + 63) / 64; p1.slab = wsf + W.slab1; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
-    WgradProblem& p2 = wa.p[1];  // dW2 = dz^T [y1; y2]
-    p2.A = wsf + W.dz; p2.lda = ldz; p2.B0 = y; p2.B1 = y + (size_t)B * ldz; p2.ldb = ldz; p2.M = W.Mp; p2.N = W.Mp;
-    p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp; p2.extras = 2;
+    wa.K = 2 * B; wa.nsplit = B; wa.ksplit = W.ksplit; wa.rows_per_split = W.rows_per_split;
+    wa.ldz = ldz; wa.ext = ext; wa.Mp = W.Mp;
+    WgradProblem& p1 = wa.p[0];
+    p1.A = du; p1.lda = ldz; p1.B0 = x1; p1.B1 = x2; p1.ldb = ldx; p1.M = W.Mp; p1.N = D0;
+    p1.MT = (W.Mp + 63) / 64; p1.NT = (D0 + 63) / 64; p1.slab = slab; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
+    wa.p[1] = p1;  // never scheduled (nw == nw0)
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
-    wa.nw = wa.nw0 + p2.MT * p2.NT * W.ksplit;
+    wa.nw = wa.nw0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
-    // K-C
     ReduceArgs ra = {};
-    ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
-    ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = D0; ra.D1 = D1; ra.D2 = D2; ra.out = grad_flat;
-    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ngrad + 255) / 256)), dim3(256), 0, st, ra);
+    ra.slab1 = slab; ra.slab2 = slab; ra.ext = ext; ra.P_sqrt = nullptr;
+    ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = D0; ra.D1 = D1; ra.D2 = 0; ra.out = out;
+    hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((nout + 255) / 256)), dim3(256), 0, st, ra);
     return nplda_launch_status();
 }
 

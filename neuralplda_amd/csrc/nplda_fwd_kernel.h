@@ -242,6 +242,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 4 ? 2 : 2)) void nplda_fwd_ke
         }
     }
 
+    if (MODE == MODE_GB && a.out_rn != nullptr && g == 0 && okA) {  // DPlda / GB rows for an LDA backward
+        a.out_rn[rowA] = invA;
+        a.out_rn[a.n + rowB] = invB;
+    }
     if (MODE == MODE_GB) {
         // ---- GaussianBackend.forward (utils/models.py:584-593) on x = [y1; y2] --------------------
         // S = -(x-mu_t)^T L_t (x-mu_t) + (x-mu_n)^T L_n (x-mu_n) = x^T M x + x^T v + c with

@@ -144,6 +144,24 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         a.out_rn[rowA] = invA;
         a.out_rn[a.n + rowB] = invB;
     }
+    if (MODE == MODE_GB && a.out_rn != nullptr && wave == 0 && g == 0 && okA) {  // DPlda / GB rows for an LDA backward
+        a.out_rn[rowA] = invA;
+        a.out_rn[a.n + rowB] = invB;
+    }
+    if (MODE == MODE_EMBED && a.out_y != nullptr) {  // embedding rows saved for nplda_embed_backward_f32
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            if (nb < NB) {
+                if (okA) *reinterpret_cast<f32x4*>(a.out_y + rowA * a.ldz + 16 * nb + 4 * g) = accA[i];
+                if (okB) *reinterpret_cast<f32x4*>(a.out_y + rowB * a.ldz + 16 * nb + 4 * g) = accB[i];
+            }
+        }
+        if (wave == 0 && g == 0) {
+            if (okA) a.out_rn[rowA] = invA;
+            if (okB) a.out_rn[rowB] = invB;
+        }
+    }
 
     if (MODE == MODE_GB) {
         // ---- quadratic form on x = [y1; y2] (GaussianBackend.forward / DPlda.forward; image: nplda_gb.hip) --------

@@ -184,6 +184,17 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
             a.out_rn[a.n + rowB] = invB;
         }
     }
+    if (MODE == MODE_EMBED && a.out_y != nullptr) {  // embedding rows saved for nplda_embed_backward_f32
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (okA) *reinterpret_cast<f32x4*>(a.out_y + rowA * a.ldz + 16 * nb + 4 * g) = accA[nb];
+            if (okB) *reinterpret_cast<f32x4*>(a.out_y + rowB * a.ldz + 16 * nb + 4 * g) = accB[nb];
+        }
+        if (g == 0) {
+            if (okA) a.out_rn[rowA] = invA;
+            if (okB) a.out_rn[rowB] = invB;
+        }
+    }
 
     // ---- layer 2 -----------------------------------------------------------------------------------------
     f32x4 zA[NB], zB[NB];

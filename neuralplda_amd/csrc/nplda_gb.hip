@@ -243,20 +243,25 @@ int gb_pack_dplda_f32(const float* W1, const float* b1, const float* wlr, const 
 }
 
 static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
-                         float* s, float* paired, int no_norm, nplda_stream_t stream);
+                         float* s, float* paired, float* rn, int no_norm, nplda_stream_t stream);
 
 int gb_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
                        float* s, float* paired, nplda_stream_t stream) {
-    return gb_score_impl(x1, x2, B, ldx, packed, D0, D1, s, paired, 0, stream);
+    return gb_score_impl(x1, x2, B, ldx, packed, D0, D1, s, paired, nullptr, 0, stream);
+}
+
+int gb_score_pairs_ex_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
+                          float* s, float* paired, float* rn, nplda_stream_t stream) {
+    return gb_score_impl(x1, x2, B, ldx, packed, D0, D1, s, paired, rn, 0, stream);
 }
 
 int gb_score_rows_f32(const float* y1, const float* y2, int64_t B, int64_t ldy, const void* packed, int D0, int D1,
                       float* s, nplda_stream_t stream) {
-    return gb_score_impl(y1, y2, B, ldy, packed, D0, D1, s, nullptr, 1, stream);
+    return gb_score_impl(y1, y2, B, ldy, packed, D0, D1, s, nullptr, nullptr, 1, stream);
 }
 
 static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ldx, const void* packed, int D0, int D1,
-                         float* s, float* paired, int no_norm, nplda_stream_t stream) {
+                         float* s, float* paired, float* rn, int no_norm, nplda_stream_t stream) {
     if (B < 0) return NPLDA_EINVAL;
     if (int rc = gb_check(D0, D1)) return rc;
     if (B == 0) return NPLDA_OK;
@@ -267,7 +272,7 @@ static int gb_score_impl(const float* x1, const float* x2, int64_t B, int64_t ld
     a.xa = x1; a.xb = x2; a.n = B; a.ldx = ldx; a.packed = (const float*)packed;
     a.D0 = D0; a.KS1 = L.KS1;
     a.oW2 = L.oG; a.ob1 = L.ob1; a.ob2 = L.ov; a.oQ = L.oc; a.oP = L.oc; a.total = L.total;
-    a.out_s = s; a.out_z = paired; a.ldz = 2 * (long long)D1;
+    a.out_s = s; a.out_z = paired; a.ldz = 2 * (long long)D1; a.out_rn = rn;
     a.no_norm = no_norm;
     if (B <= 256 * 64) return launch_gb_small(a, L, (hipStream_t)stream);
     return launch_gb<8, false>(a, L, (hipStream_t)stream);

@@ -110,12 +110,14 @@ def shard_batch(tensors, group=None):
 
 
 def make_data_parallel(model, group=None):
-    """Turn a NeuralPlda into its data-parallel form: each rank feeds its shard of the global minibatch
+    """Turn a NeuralPlda (or DPlda) into its data-parallel form: each rank feeds its shard of the global minibatch
     to model(x1, x2) / model.loss(...) / loss.backward() exactly as on one GPU; the loss value and every
     parameter gradient then equal the single-process result on the whole minibatch.  Parameters must be
     identical on all ranks at entry (same seed or a broadcast)."""
     model._reduce_sums = lambda sums: allreduce_sum_(sums, group)
     model._reduce_flat = lambda flat: allreduce_sum_(flat, group)
+    # DPlda: the folded fp64 gradient of the linear unit (and of the LDA when it trains) is summed before it is rounded
+    model.__dict__["_reduce_sums64"] = lambda v: allreduce_sum_(v, group)
     return model
 
 

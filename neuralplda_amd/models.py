@@ -59,28 +59,60 @@ def _loss_kind(name):
 # autograd bridges
 # ---------------------------------------------------------------------------------------------------
 
+def _bump(*tensors):
+    """Mark tensors that a raw kernel (or a `.data` write) has just modified in place as changed, so that the
+    packed-image cache below and autograd's saved-tensor checks both notice."""
+    for t in tensors:
+        torch.autograd.graph.increment_version(t)
+
+
+def _packed_for(cache, prm, precision):
+    """The MFMA-fragment image of `prm` (six device tensors), rebuilt only when a parameter changed: keyed on each
+    tensor's storage address and autograd version counter (optimizer steps, load_state_dict and every in-place op bump
+    it; the fused steps and the Kaldi loaders, which write through raw kernels / `.data`, bump it explicitly).  A
+    `forward()` on a 10 240-pair scoring chunk otherwise spends as long re-packing the 0.5 MB image as scoring."""
+    if cache is None:
+        return ops.pack_params(*prm, precision=precision)
+    key = (precision,) + tuple((t.data_ptr(), t._version, t.device) for t in prm)
+    hit = cache.get("key")
+    if hit != key:
+        cache["packed"] = ops.pack_params(*prm, precision=precision)
+        cache["key"] = key
+    return cache["packed"]
+
+
+def _back(t, like):
+    """Gradient `t` on the device / dtype of the tensor it belongs to."""
+    if t is None:
+        return None
+    if t.dtype != like.dtype:
+        t = t.to(like.dtype)
+    return t if t.device == like.device else t.to(like.device)
+
+
 class _PairScoreFn(torch.autograd.Function):
-    """s = NeuralPlda.forward(x1, x2) with the hand-derived backward."""
+    """s = NeuralPlda.forward(x1, x2) with the hand-derived backward: parameter gradients from
+    nplda_backward, and — when the x-vectors themselves carry a graph (an extractor trained jointly with the head, the
+    reference's Etdnn_Xvec_NeuralPlda, utils/models.py:251-268) — dL/dx1, dL/dx2 = du . W1 from the same launch set."""
 
     @staticmethod
     def forward(ctx, x1, x2, opts, W1, b1, W2, b2, P_sqrt, Q):
-        reduce_flat, precision = opts
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[1]:
-            raise NotImplementedError("gradients w.r.t. the x-vectors are outside the NPLDA hot path")
+        reduce_flat, precision, cache = opts
         dev = _compute_device(x1, W1)
-        prm = [_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)]
-        need = any(ctx.needs_input_grad[3:])  # Function.forward runs with grad mode off: ask the ctx
+        params = (W1, b1, W2, b2, P_sqrt, Q)
+        on_dev = all(t.device == dev and t.dtype == torch.float32 for t in params)
+        prm = [_to_dev(t, dev) for t in params]
+        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        need = need_x or any(ctx.needs_input_grad[3:])  # Function.forward runs with grad mode off: ask the ctx
         # training always runs the exact-fp32 kernels; `precision` only selects the inference kernel
-        packed = ops.pack_params(*prm, precision="fp32" if need else precision)
+        packed = _packed_for(cache if on_dev else None, prm, "fp32" if need else precision)
         X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
-        ctx.need = need
+        ctx.need, ctx.need_x = need, need_x
         ctx.reduce_flat = reduce_flat
         if need:
-            s, saved = ops.forward_train(X1, X2, packed)
-            ctx.saved = saved
-            ctx.packed = packed
-            ctx.ps = prm[4]
-            ctx.pdev = [t.device for t in (W1, b1, W2, b2, P_sqrt, Q)]
+            s, (X1, X2, ld, y, z, rn) = ops.forward_train(X1, X2, packed)
+            ctx.save_for_backward(X1, X2, y, z, rn, packed.buf, prm[4], x1, x2, *params)
+            ctx.ld, ctx.dims = ld, (packed.D0, packed.D1, packed.D2, packed.ldz)
         else:
             s = ops.score_pairs(X1, X2, packed)
         return s if s.device == x1.device else s.to(x1.device)
@@ -89,77 +121,149 @@ class _PairScoreFn(torch.autograd.Function):
     def backward(ctx, gs):
         if not ctx.need:
             return (None,) * 9
-        dev = ctx.packed.device
-        flat = ops.backward(ctx.saved, _to_dev(gs, dev), ctx.packed, ctx.ps)
+        X1, X2, y, z, rn, buf, ps, x1, x2 = ctx.saved_tensors[:9]
+        params = ctx.saved_tensors[9:]
+        D0, D1, D2, ldz = ctx.dims
+        packed = ops.PackedParams(buf, D0, D1, D2, ldz)
+        out = ops.backward((X1, X2, ctx.ld, y, z, rn), _to_dev(gs, buf.device), packed, ps, want_dx=ctx.need_x)
+        flat, dx1, dx2 = out if ctx.need_x else (out, None, None)
         if ctx.reduce_flat is not None:  # data parallel: ONE sum-all-reduce of the flat gradient
             flat = ctx.reduce_flat(flat)
-        grads = ops.split_flat_grad(flat, ctx.packed.D0, ctx.packed.D1, ctx.packed.D2)
-        grads = [g if g.device == d else g.to(d) for g, d in zip(grads, ctx.pdev)]
-        ctx.saved = None
-        return (None, None, None) + tuple(grads)
+        grads = [_back(g, t) if need else None
+                 for g, t, need in zip(ops.split_flat_grad(flat, D0, D1, D2), params, ctx.needs_input_grad[3:])]
+        return (_back(dx1, x1) if ctx.needs_input_grad[0] else None,
+                _back(dx2, x2) if ctx.needs_input_grad[1] else None, None) + tuple(grads)
 
 
 class _EmbedFn(torch.autograd.Function):
+    """z = extract_plda_embeddings(x) (utils/models.py:366-370), differentiable like the reference's: gradients of
+    W1, b1, W2, b2 and of x from nplda_embed_backward."""
+
     @staticmethod
-    def forward(ctx, x, W1, b1, W2, b2, P_sqrt, Q):
+    def forward(ctx, x, opts, W1, b1, W2, b2, P_sqrt, Q):
+        reduce_flat, cache = opts
         dev = _compute_device(x, W1)
-        packed = ops.pack_params(*[_to_dev(t, dev) for t in (W1, b1, W2, b2, P_sqrt, Q)])
-        z, _ = ops.embed(_to_dev(x, dev), packed, want_q=False)
+        params = (W1, b1, W2, b2, P_sqrt, Q)
+        on_dev = all(t.device == dev and t.dtype == torch.float32 for t in params)
+        packed = _packed_for(cache if on_dev else None, [_to_dev(t, dev) for t in params], "fp32")
+        need = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:6])
+        ctx.need, ctx.reduce_flat = need, reduce_flat
+        X = _to_dev(x, dev)
+        if need:
+            z, (X, ld, y, rn) = ops.embed_train(X, packed)
+            ctx.save_for_backward(X, y, rn, packed.buf, x, W1, b1, W2, b2)
+            ctx.ld, ctx.dims = ld, (packed.D0, packed.D1, packed.D2, packed.ldz)
+        else:
+            z, _ = ops.embed(X, packed, want_q=False)
         z = z[:, :packed.D2]
         return z if z.device == x.device else z.to(x.device)
 
     @staticmethod
     def backward(ctx, gz):
-        raise NotImplementedError(
-            "backward through extract_plda_embeddings alone is not part of the hot path; "
-            "train through NeuralPlda.forward(x1, x2)")
+        if not ctx.need:
+            return (None,) * 8
+        X, y, rn, buf, x = ctx.saved_tensors[:5]
+        params = ctx.saved_tensors[5:]
+        D0, D1, D2, ldz = ctx.dims
+        packed = ops.PackedParams(buf, D0, D1, D2, ldz)
+        flat, dx = ops.embed_backward((X, ctx.ld, y, rn), _to_dev(gz, buf.device), packed,
+                                      want_dx=ctx.needs_input_grad[0])
+        if ctx.reduce_flat is not None:
+            flat = ctx.reduce_flat(flat)
+        grads = [_back(g, t) if need else None
+                 for g, t, need in zip(ops.split_flat_grad(flat, D0, D1, D2)[:4], params, ctx.needs_input_grad[2:6])]
+        return (_back(dx, x) if ctx.needs_input_grad[0] else None, None) + tuple(grads) + (None, None)
 
 
 class _EmbScoreFn(torch.autograd.Function):
+    """s = forward_from_plda_embeddings(z1, z2) (utils/models.py:372-376) with its backward (dz1, dz2, dP_sqrt, dQ)."""
+
     @staticmethod
-    def forward(ctx, z1, z2, P_sqrt, Q):
+    def forward(ctx, z1, z2, reduce_flat, P_sqrt, Q):
         dev = _compute_device(z1, Q)
-        s = ops.score_embeddings(_to_dev(z1, dev), _to_dev(z2, dev), _to_dev(P_sqrt, dev), _to_dev(Q, dev))
+        Z1, Z2, ps, q = _to_dev(z1, dev), _to_dev(z2, dev), _to_dev(P_sqrt, dev), _to_dev(Q, dev)
+        s = ops.score_embeddings(Z1, Z2, ps, q)
+        ctx.need = any(ctx.needs_input_grad)
+        ctx.reduce_flat = reduce_flat
+        if ctx.need:
+            ctx.save_for_backward(Z1, Z2, ps, q, z1, z2, P_sqrt, Q)
         return s if s.device == z1.device else s.to(z1.device)
 
     @staticmethod
     def backward(ctx, gs):
-        raise NotImplementedError(
-            "backward through forward_from_plda_embeddings alone is not part of the hot path; "
-            "train through NeuralPlda.forward(x1, x2)")
+        if not ctx.need:
+            return (None,) * 5
+        Z1, Z2, ps, q, z1, z2, P_sqrt, Q = ctx.saved_tensors
+        need = ctx.needs_input_grad
+        dz1, dz2, dP, dQ = ops.score_embeddings_bwd(Z1, Z2, ps, q, _to_dev(gs, Z1.device), need[0], need[1])
+        if ctx.reduce_flat is not None and (need[3] or need[4]):
+            both = ctx.reduce_flat(torch.cat([dP, dQ]))
+            dP, dQ = both[:dP.numel()], both[dP.numel():]
+        return (_back(dz1, z1) if need[0] else None, _back(dz2, z2) if need[1] else None, None,
+                _back(dP, P_sqrt) if need[3] else None, _back(dQ, Q) if need[4] else None)
 
 
 class _DPldaScoreFn(torch.autograd.Function):
-    """DPlda.forward with a gradient for the linear unit only (the recipe freezes the LDA,
-    xvector_DPlda_pytorch.py:140-147): forward = fused LDA + normalise + quadratic form, saving the paired rows
-    [y1, y2]; backward = one weighted-moments pass (sum_k g_k x x^T) folded into d wlr, d bias."""
+    """DPlda.forward (utils/models.py:492-495): fused LDA + normalise + quadratic form, saving the paired rows [y1, y2].
+    Backward: the linear unit's gradient is one weighted-moments pass (sum_k g_k x x^T) folded into d wlr, d bias — what
+    the recipe trains (xvector_DPlda_pytorch.py:140-147 freezes the LDA).  When the LDA or the x-vectors DO carry a graph
+    (a joint fine-tune), dL/d[y1; y2] = g ((M + M^T) x + v) is one resident-matrix GEMM on the paired rows, followed by
+    the F.normalize backward and the LDA wgrad / dgrad GEMMs (csrc/nplda_matmul.hip)."""
 
     @staticmethod
-    def forward(ctx, x1, x2, W1, b1, wlr, blr):
+    def forward(ctx, x1, x2, opts, W1, b1, wlr, blr):
+        reduce_sums64, = opts
         dev = _compute_device(x1, W1)
         D1 = W1.shape[0]
         W1d, b1d = _to_dev(W1, dev), _to_dev(b1, dev)
         packed = ops.dplda_pack(W1d, b1d, _to_dev(wlr, dev), _to_dev(blr, dev))
-        need = any(ctx.needs_input_grad[2:])
-        ctx.lda_needs = ctx.needs_input_grad[2] or ctx.needs_input_grad[3]
-        s, paired = ops._gb_call(_to_dev(x1, dev), _to_dev(x2, dev), packed, True, need)
-        ctx.need, ctx.D1 = need, D1
-        ctx.devs = (wlr.device, blr.device)
-        if need:
-            ctx.save_for_backward(paired)
+        need_unit = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
+        need_lda = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+        X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
+        ctx.need_unit, ctx.need_lda, ctx.D1 = need_unit, need_lda, D1
+        ctx.reduce = reduce_sums64
+        if need_lda:
+            if D1 % 2:
+                raise ValueError("a backward through DPlda's LDA needs an even layer1_LDA_dim (16-byte paired rows)")
+            s, paired, rn = ops._gb_call(X1, X2, packed, True, True, want_rn=True)
+            ctx.save_for_backward(paired, rn, X1, X2, W1d, _to_dev(wlr, dev), x1, x2, W1, b1, wlr, blr)
+        elif need_unit:
+            s, paired = ops._gb_call(X1, X2, packed, True, True)
+            ctx.save_for_backward(paired, wlr, blr)
+        else:
+            s, _ = ops._gb_call(X1, X2, packed, True, False)
         return s if s.device == x1.device else s.to(x1.device)
 
     @staticmethod
     def backward(ctx, gs):
-        if not ctx.need:
-            return (None,) * 6
-        if ctx.lda_needs:
-            raise NotImplementedError("DPlda trains with centering_and_LDA frozen (xvector_DPlda_pytorch.py:140-147): "
-                                      "set requires_grad = False on its weight and bias")
-        (paired,) = ctx.saved_tensors
+        if not (ctx.need_unit or ctx.need_lda):
+            return (None,) * 7
+        saved = ctx.saved_tensors
+        paired = saved[0]
         g = gs.to(paired.device, torch.float32).contiguous()
-        dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), ctx.D1)
-        return None, None, None, None, dw.to(ctx.devs[0]), db.to(ctx.devs[1])
+        D1 = ctx.D1
+        dw = db = dW1 = db1 = dx1 = dx2 = None
+        if ctx.need_lda:
+            _, rn, X1, X2, W1d, wlrd, x1, x2, W1, b1, wlr, blr = saved
+        else:
+            _, wlr, blr = saved
+        if ctx.need_unit:
+            dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), D1, reduce=ctx.reduce)
+            dw, db = _back(dw, wlr), _back(db, blr)
+        if ctx.need_lda:
+            M, v, _ = ops.dplda_quadform(wlrd, None, D1)
+            dpaired = ops.rows_matmul(paired, ops.pack_matrix(M, mode=2), bias=v, rowscale=g)
+            need = ctx.needs_input_grad
+            dW1, db1, dx1, dx2 = ops.lda_backward(X1, X2, paired, rn, dpaired, W1d, want_w=need[3] or need[4],
+                                                  want_dx=need[0] or need[1])
+            if ctx.reduce is not None and dW1 is not None:
+                both = ctx.reduce(torch.cat([dW1.reshape(-1), db1]))
+                dW1, db1 = both[:dW1.numel()].view_as(dW1), both[dW1.numel():]
+            dW1 = _back(dW1, W1) if need[3] else None
+            db1 = _back(db1, b1) if need[4] else None
+            dx1 = _back(dx1, x1) if need[0] else None
+            dx2 = _back(dx2, x2) if need[1] else None
+        return dx1, dx2, None, dW1, db1, dw, db
 
 
 class _LossFn(torch.autograd.Function):
@@ -179,24 +283,19 @@ class _LossFn(torch.autograd.Function):
         ctx.need = need
         ctx.nth = len(thetas)
         if need:
-            ctx.g, ctx.dth = g, dth
-            ctx.odev = output.device
-            ctx.tdev = [th.device for th in thetas]
+            ctx.save_for_backward(g, dth, output, *thetas)
         return loss if loss.device == output.device else loss.to(output.device)
 
     @staticmethod
     def backward(ctx, gl):
         if not ctx.need:
             return (None,) * (6 + ctx.nth)
-        dev = ctx.g.device
-        gl = gl.to(dev)
-        g = ctx.g * gl
-        dths = []
-        for k, d in enumerate(ctx.tdev):
-            v = (ctx.dth[k:k + 1] * gl)
-            dths.append(v if v.device == d else v.to(d))
-        g = g if g.device == ctx.odev else g.to(ctx.odev)
-        return (g, None, None, None, None, None) + tuple(dths)
+        g, dth, output = ctx.saved_tensors[:3]
+        thetas = ctx.saved_tensors[3:]
+        gl = gl.to(g.device)
+        dths = [_back(dth[k:k + 1] * gl, th) if need else None
+                for k, (th, need) in enumerate(zip(thetas, ctx.needs_input_grad[6:]))]
+        return (_back(g * gl, output) if ctx.needs_input_grad[0] else None, None, None, None, None, None) + tuple(dths)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -225,6 +324,7 @@ class NeuralPlda(nn.Module):
         self.lossfn = nc.loss
         self._reduce_sums = None  # both set by neuralplda_amd.dist.make_data_parallel()
         self._reduce_flat = None
+        self._pack_cache = {}  # packed parameter image, rebuilt when a parameter's version changes (_packed_for)
         # inference kernel: "fp32" (exact fp32 MFMA, default) or "bf16x3" (split-bf16, fp32-class accuracy, ~1.5x faster)
         self.scoring_precision = "fp32"
 
@@ -233,12 +333,16 @@ class NeuralPlda(nn.Module):
         super(NeuralPlda, self).__setstate__(state)
         self.__dict__.setdefault("_reduce_sums", None)
         self.__dict__.setdefault("_reduce_flat", None)
+        self.__dict__["_pack_cache"] = {}
         self.__dict__.setdefault("scoring_precision", "fp32")
 
     def __getstate__(self):
-        state = self.__dict__.copy()
+        base = getattr(super(NeuralPlda, self), "__getstate__", None)
+        state = dict(base()) if base is not None else self.__dict__.copy()
         state["_reduce_sums"] = None  # process-group closures do not pickle
         state["_reduce_flat"] = None
+        state["_pack_cache"] = {}     # device buffers of a cache do not belong in a model file
+        state.pop("_reduce_sums64", None)
         return state
 
     def _params(self):
@@ -248,11 +352,11 @@ class NeuralPlda(nn.Module):
     def extract_plda_embeddings(self, x):
         """utils/models.py:366-370 -> (B, D2)."""
         x = x.reshape(-1, self.centering_and_LDA.in_features) if x.dim() != 2 else x
-        return _EmbedFn.apply(x, *self._params())
+        return _EmbedFn.apply(x, (self._reduce_flat, self.__dict__.get("_pack_cache")), *self._params())
 
     def forward_from_plda_embeddings(self, x1, x2):
         """utils/models.py:372-376."""
-        return _EmbScoreFn.apply(x1, x2, self.P_sqrt, self.Q)
+        return _EmbScoreFn.apply(x1, x2, self._reduce_flat, self.P_sqrt, self.Q)
 
     def forward(self, x1, x2):
         """utils/models.py:378-382: (B, D0), (B, D0) -> (B,).  B == 0 returns an empty tensor (the
@@ -260,8 +364,8 @@ class NeuralPlda(nn.Module):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32")),
-                                  *self._params())
+        return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32"),
+                                           self.__dict__.get("_pack_cache")), *self._params())
 
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):
@@ -303,23 +407,13 @@ class NeuralPlda(nn.Module):
         if update_thresholds:
             for beta in self.beta:
                 self.state_dict()["Th{}".format(int(beta))].data.copy_(minc_threshold[beta])
+                _bump(self.threshold[beta])
         return minc_avg, minc_threshold
 
     # -- initialisation / persistence ---------------------------------------------------------------
     def LoadPldaParamsFromKaldi(self, mean_vec_file, transform_mat_file, PldaFile):
         """utils/models.py:441-457, reading the Kaldi files natively (no Kaldi binaries needed)."""
-        plda = kaldi_format.read_plda(PldaFile)
-        transform_mat = kaldi_format.read_matrix(transform_mat_file)
-        mean_vec = kaldi_format.read_vector(mean_vec_file)
-        mdsd = self.state_dict()
-        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
-        mdsd['centering_and_LDA.bias'].data.copy_(
-            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
-        mdsd['centering_and_wccn_plda.weight'].data.copy_(torch.from_numpy(plda['diagonalizing_transform']).float())
-        mdsd['centering_and_wccn_plda.bias'].data.copy_(
-            torch.from_numpy(-plda['diagonalizing_transform'].dot(plda['plda_mean'])).float())
-        mdsd['P_sqrt'].data.copy_(torch.from_numpy(np.sqrt(plda['diagP'])).float())
-        mdsd['Q'].data.copy_(torch.from_numpy(plda['diagQ']).float())
+        kaldi_format.fold_init(self, mean_vec_file, transform_mat_file, PldaFile)
 
     def SaveModel(self, filename):
         """utils/models.py:459-461: pickle of the whole module."""
@@ -391,8 +485,8 @@ class DPlda(NeuralPlda):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        return _DPldaScoreFn.apply(x1, x2, self.centering_and_LDA.weight, self.centering_and_LDA.bias,
-                                   self.logistic_regres.weight, self.logistic_regres.bias)
+        return _DPldaScoreFn.apply(x1, x2, (self.__dict__.get("_reduce_sums64"),), self.centering_and_LDA.weight,
+                                   self.centering_and_LDA.bias, self.logistic_regres.weight, self.logistic_regres.bias)
 
     def crossentropy(self, output, target):
         """utils/models.py:503-506: BCE(sigmoid(output), target) — no threshold."""
@@ -401,12 +495,7 @@ class DPlda(NeuralPlda):
 
     def LoadParamsFromKaldi(self, mean_vec_file, transform_mat_file):
         """utils/models.py:551-564."""
-        transform_mat = kaldi_format.read_matrix(transform_mat_file)
-        mean_vec = kaldi_format.read_vector(mean_vec_file)
-        mdsd = self.state_dict()
-        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
-        mdsd['centering_and_LDA.bias'].data.copy_(
-            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
+        kaldi_format.fold_init(self, mean_vec_file, transform_mat_file)
 
     def LoadPldaParamsFromKaldi(self, *a, **k):
         raise AttributeError("DPlda has no PLDA layer; use LoadParamsFromKaldi(mean_vec_file, transform_mat_file)")
@@ -508,12 +597,7 @@ class GaussianBackend(nn.Module):
 
     def LoadPldaParamsFromKaldi(self, mean_vec_file, transform_mat_file):
         """utils/models.py:653-658."""
-        transform_mat = kaldi_format.read_matrix(transform_mat_file)
-        mean_vec = kaldi_format.read_vector(mean_vec_file)
-        mdsd = self.state_dict()
-        mdsd['centering_and_LDA.weight'].data.copy_(torch.from_numpy(transform_mat[:, :-1]).float())
-        mdsd['centering_and_LDA.bias'].data.copy_(
-            torch.from_numpy(transform_mat[:, -1] - transform_mat[:, :-1].dot(mean_vec)).float())
+        kaldi_format.fold_init(self, mean_vec_file, transform_mat_file)
 
     def SaveModel(self, filename):
         with open(filename, 'wb') as f:

@@ -151,8 +151,9 @@ def forward_train(x1, x2, packed):
     return s, (x1, x2, ld1, y, z, rn)
 
 
-def backward(saved, g, packed, P_sqrt):
-    """nplda_backward_f32: flat gradient [dW1 | db1 | dW2 | db2 | dP_sqrt | dQ] for dL/ds = g."""
+def backward(saved, g, packed, P_sqrt, want_dx=False):
+    """nplda_backward_ex_f32: flat gradient [dW1 | db1 | dW2 | db2 | dP_sqrt | dQ] for dL/ds = g; with want_dx also
+    the input gradients -> (flat, dx1, dx2), dx (B, D0) = du . W1."""
     lib = _lib.load()
     x1, x2, ld, y, z, rn = saved
     B = x1.shape[0]
@@ -161,15 +162,166 @@ def backward(saved, g, packed, P_sqrt):
     g = g.contiguous()
     n = lib.nplda_grad_floats(packed.D0, packed.D1, packed.D2)
     flat = torch.empty(n, dtype=torch.float32, device=dev)
-    wsb = lib.nplda_backward_workspace_bytes(B, packed.D0, packed.D1, packed.D2)
+    wsb = lib.nplda_backward_ex_workspace_bytes(2 * B, packed.D0, packed.D1, packed.D2, 1 if want_dx else 0)
     ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
     ps = P_sqrt.detach().contiguous()
+    dx1 = torch.empty((B, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
+    dx2 = torch.empty((B, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
     with torch.cuda.device(dev):
-        code = lib.nplda_backward_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld, _lib.ptr(packed.buf), packed.D0, packed.D1,
-                                      packed.D2, _lib.ptr(g), _lib.ptr(y), _lib.ptr(z), _lib.ptr(rn), packed.ldz,
-                                      _lib.ptr(ps), _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.current_stream())
-    _lib.check(code, "nplda_backward_f32")
-    return flat
+        code = lib.nplda_backward_ex_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld, _lib.ptr(packed.buf), packed.D0, packed.D1,
+                                         packed.D2, _lib.ptr(g), _lib.ptr(y), _lib.ptr(z), _lib.ptr(rn), packed.ldz,
+                                         _lib.ptr(ps), _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.ptr(dx1), _lib.ptr(dx2),
+                                         packed.D0, _lib.current_stream())
+    _lib.check(code, "nplda_backward_ex_f32")
+    return (flat, dx1, dx2) if want_dx else flat
+
+
+def embed_train(x, packed):
+    """nplda_embed_train_f32: (N, D0) -> z (N, ldz) plus the saved rows (x, ld, y (N, ldz), rn (N)) of its backward."""
+    lib = _lib.load()
+    _need_fp32(packed, "embed_train")
+    x, ld = _rows(x, "x", packed.D0)
+    N = x.shape[0]
+    dev = x.device
+    z = torch.empty((N, packed.ldz), dtype=torch.float32, device=dev)
+    y = torch.empty((N, packed.ldz), dtype=torch.float32, device=dev)
+    rn = torch.empty(N, dtype=torch.float32, device=dev)
+    if N > 0:
+        with torch.cuda.device(dev):
+            code = lib.nplda_embed_train_f32(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
+                                             _lib.ptr(z), _lib.ptr(y), _lib.ptr(rn), packed.ldz, _lib.current_stream())
+        _lib.check(code, "nplda_embed_train_f32")
+    return z, (x, ld, y, rn)
+
+
+def embed_backward(saved, gz, packed, want_dx=False):
+    """nplda_embed_backward_f32: gz = dL/dz (N, D2) -> (flat gradient with dP_sqrt = dQ = 0, dx (N, D0) or None)."""
+    lib = _lib.load()
+    x, ld, y, rn = saved
+    N = x.shape[0]
+    dev = x.device
+    _require_dev_f32(gz, "gz")
+    if gz.dim() != 2 or gz.shape != (N, packed.D2):
+        raise ValueError(f"gz must be ({N}, {packed.D2})")
+    if gz.stride(1) != 1 or (N > 1 and gz.stride(0) < packed.D2):
+        gz = gz.contiguous()
+    n = lib.nplda_grad_floats(packed.D0, packed.D1, packed.D2)
+    flat = torch.empty(n, dtype=torch.float32, device=dev)
+    wsb = lib.nplda_backward_ex_workspace_bytes(N, packed.D0, packed.D1, packed.D2, 1 if want_dx else 0)
+    ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
+    dx = torch.empty((N, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
+    with torch.cuda.device(dev):
+        code = lib.nplda_embed_backward_f32(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
+                                            _lib.ptr(gz), gz.stride(0) if N > 1 else packed.D2, _lib.ptr(y),
+                                            _lib.ptr(rn), packed.ldz, _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.ptr(dx),
+                                            packed.D0, _lib.current_stream())
+    _lib.check(code, "nplda_embed_backward_f32")
+    return flat, dx
+
+
+def score_embeddings_bwd(z1, z2, P_sqrt, Q, g, want_dz1=True, want_dz2=True):
+    """nplda_score_embeddings_bwd_f32 -> (dz1 or None, dz2 or None, dP_sqrt (D2), dQ (D2))."""
+    lib = _lib.load()
+    for n, t in (("z1", z1), ("z2", z2), ("P_sqrt", P_sqrt), ("Q", Q), ("g", g)):
+        _require_dev_f32(t, n)
+    D2 = Q.numel()
+    if z1.stride(1) != 1:
+        z1 = z1.contiguous()
+    if z2.stride(1) != 1:
+        z2 = z2.contiguous()
+    B = z1.shape[0]
+    dev = z1.device
+    dz1 = torch.empty((B, D2), dtype=torch.float32, device=dev) if want_dz1 else None
+    dz2 = torch.empty((B, D2), dtype=torch.float32, device=dev) if want_dz2 else None
+    dP = torch.empty(D2, dtype=torch.float32, device=dev)
+    dQ = torch.empty(D2, dtype=torch.float32, device=dev)
+    wsb = lib.nplda_score_embeddings_bwd_workspace_bytes(B, D2)
+    if wsb == 0:
+        raise _lib.NpldaHipError(f"embedding dimension {D2} is outside the compiled kernel set")
+    ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    ld1 = z1.stride(0) if B > 1 else D2
+    ld2 = z2.stride(0) if B > 1 else D2
+    with torch.cuda.device(dev):
+        code = lib.nplda_score_embeddings_bwd_f32(_lib.ptr(z1), ld1, _lib.ptr(z2), ld2, B, D2,
+                                                  _lib.ptr(P_sqrt.contiguous()), _lib.ptr(Q.contiguous()),
+                                                  _lib.ptr(g.contiguous()), _lib.ptr(dz1), D2, _lib.ptr(dz2), D2,
+                                                  _lib.ptr(dP), _lib.ptr(dQ), _lib.ptr(ws), wsb, _lib.current_stream())
+    _lib.check(code, "nplda_score_embeddings_bwd_f32")
+    return dz1, dz2, dP, dQ
+
+
+def pack_matrix(src, mode=0):
+    """nplda_pack_matrix_f32: fragment image of Wm = src (mode 0), src^T (1) or src + src^T (2) -> (frag, K, N)."""
+    lib = _lib.load()
+    _require_dev_f32(src, "src")
+    if src.dim() != 2 or src.stride(1) != 1:
+        raise ValueError("src must be a 2-D tensor with unit inner stride")
+    K, N = (src.shape[1], src.shape[0]) if mode == 1 else (src.shape[0], src.shape[1])
+    nbytes = lib.nplda_matrix_frag_bytes(K, N)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"a {K} x {N} matrix is outside the resident-matrix GEMM (K <= 512, N % 4 == 0)")
+    frag = torch.empty(nbytes // 4, dtype=torch.float32, device=src.device)
+    with torch.cuda.device(src.device):
+        code = lib.nplda_pack_matrix_f32(_lib.ptr(src), src.stride(0), K, N, mode, _lib.ptr(frag), nbytes,
+                                         _lib.current_stream())
+    _lib.check(code, "nplda_pack_matrix_f32")
+    return frag, K, N
+
+
+def rows_matmul(rows, packed_matrix, bias=None, rowscale=None):
+    """nplda_rows_matmul_f32: out[r] = rowscale[r] * (rows[r, :K] . Wm + bias) -> (R, N)."""
+    lib = _lib.load()
+    frag, K, N = packed_matrix
+    rows, ld = _rows(rows, "rows", K)
+    R = rows.shape[0]
+    out = torch.empty((R, N), dtype=torch.float32, device=rows.device)
+    if R == 0:
+        return out
+    with torch.cuda.device(rows.device):
+        code = lib.nplda_rows_matmul_f32(_lib.ptr(rows), ld, R, K, _lib.ptr(frag), N,
+                                         _lib.ptr(bias.contiguous()) if bias is not None else None,
+                                         _lib.ptr(rowscale.contiguous()) if rowscale is not None else None,
+                                         _lib.ptr(out), N, _lib.current_stream())
+    _lib.check(code, "nplda_rows_matmul_f32")
+    return out
+
+
+def lda_backward(x1, x2, paired, rn, dpaired, W1, want_w=True, want_dx=True):
+    """Backward through y = normalize(LDA x) of a paired-row head (DPlda): dpaired = dL/d[y1 | y2] (B, 2 D1) ->
+    (dW1 (D1, D0), db1 (D1), dx1, dx2): F.normalize backward on the paired rows, then the wgrad / dgrad GEMMs."""
+    lib = _lib.load()
+    D1, D0 = W1.shape
+    x1, ld1 = _rows(x1, "x1", D0)
+    x2, ld2 = _rows(x2, "x2", D0)
+    if ld1 != ld2:
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ld1 = D0
+    B = x1.shape[0]
+    dev = x1.device
+    Mp = lib.nplda_padded_dim(D1, D1)
+    du = torch.empty((2 * B, Mp), dtype=torch.float32, device=dev)
+    dW1 = db1 = dx1 = dx2 = None
+    st = _lib.current_stream()
+    with torch.cuda.device(dev):
+        _lib.check(lib.nplda_normalize_bwd_paired_f32(_lib.ptr(dpaired), dpaired.stride(0), _lib.ptr(paired),
+                                                      paired.stride(0), _lib.ptr(rn), B, D1, _lib.ptr(du), Mp, st),
+                   "nplda_normalize_bwd_paired_f32")
+        if want_w:
+            wsb = lib.nplda_lda_wgrad_workspace_bytes(B, D0, D1)
+            ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
+            out = torch.empty(D1 * D0 + D1, dtype=torch.float32, device=dev)
+            _lib.check(lib.nplda_lda_wgrad_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(du), Mp, D0, D1,
+                                               _lib.ptr(ws), wsb, _lib.ptr(out), st), "nplda_lda_wgrad_f32")
+            dW1, db1 = out[:D1 * D0].view(D1, D0), out[D1 * D0:]
+        if want_dx:
+            wsb = lib.nplda_lda_dgrad_workspace_bytes(D0, D1)
+            ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
+            dx1 = torch.empty((B, D0), dtype=torch.float32, device=dev)
+            dx2 = torch.empty((B, D0), dtype=torch.float32, device=dev)
+            _lib.check(lib.nplda_lda_dgrad_f32(_lib.ptr(du), Mp, B, _lib.ptr(W1.detach().contiguous()), D0, D1,
+                                               _lib.ptr(ws), wsb, _lib.ptr(dx1), _lib.ptr(dx2), D0, st),
+                       "nplda_lda_dgrad_f32")
+    return dW1, db1, dx1, dx2
 
 
 def split_flat_grad(flat, D0, D1, D2):
@@ -440,7 +592,7 @@ def gb_pack(W1, b1, mu_t, Lam_t, mu_n, Lam_n):
     return buf, D0, D1
 
 
-def _gb_call(x1, x2, packed, want_s, want_paired):
+def _gb_call(x1, x2, packed, want_s, want_paired, want_rn=False):
     lib = _lib.load()
     buf, D0, D1 = packed
     x1, ld1 = _rows(x1, "x1", D0)
@@ -453,12 +605,13 @@ def _gb_call(x1, x2, packed, want_s, want_paired):
     B = x1.shape[0]
     s = torch.empty(B, dtype=torch.float32, device=x1.device) if want_s else None
     paired = torch.empty((B, 2 * D1), dtype=torch.float32, device=x1.device) if want_paired else None
+    rn = torch.empty(2 * B, dtype=torch.float32, device=x1.device) if want_rn else None
     if B > 0:
         with torch.cuda.device(x1.device):
-            code = lib.gb_score_pairs_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
-                                          _lib.ptr(paired), _lib.current_stream())
-        _lib.check(code, "gb_score_pairs_f32")
-    return s, paired
+            code = lib.gb_score_pairs_ex_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
+                                             _lib.ptr(paired), _lib.ptr(rn), _lib.current_stream())
+        _lib.check(code, "gb_score_pairs_ex_f32")
+    return (s, paired, rn) if want_rn else (s, paired)
 
 
 def gb_score_pairs(x1, x2, W1, b1, mu_t, Lam_t, mu_n, Lam_n):
@@ -553,7 +706,7 @@ def dplda_quadform(wlr, blr, D1):
         raise ValueError("logistic_regres.weight must have 2 D1^2 + D1 inputs")
     Wb, Ww, ws = w[:n].reshape(D1, D1), w[n:2 * n].reshape(D1, D1), w[2 * n:]
     M = torch.cat([torch.cat([Ww, Wb], 1), torch.cat([Wb, Ww], 1)], 0).contiguous()
-    return M, torch.cat([ws, ws]).contiguous(), float(blr.detach().reshape(-1)[0])
+    return M, torch.cat([ws, ws]).contiguous(), (float(blr.detach().reshape(-1)[0]) if blr is not None else 0.0)
 
 
 def weighted_moments(x, w0, w1=None, out=None):
@@ -597,13 +750,17 @@ def weighted_moments(x, w0, w1=None, out=None):
     return cnt, sm, sq
 
 
-def dplda_fold_grad(cnt, sm, sq, D1):
+def dplda_fold_grad(cnt, sm, sq, D1, reduce=None):
     """(cnt, sum, sq) of paired rows weighted by g = dL/ds -> gradient of DPlda's linear unit (utils/models.py:484-490):
-    d wlr = [G12 + G21 | G11 + G22 | s1 + s2] (row-major blocks of G = sum g x x^T), d bias = sum g."""
+    d wlr = [G12 + G21 | G11 + G22 | s1 + s2] (row-major blocks of G = sum g x x^T), d bias = sum g.
+    `reduce` (data parallel): sum-all-reduce of the folded fp64 vector [d wlr | d bias] before it is rounded to fp32,
+    so that N ranks give the single-process gradient to fp64 rounding."""
     G = sq[0]
     G11, G12, G21, G22 = G[:D1, :D1], G[:D1, D1:], G[D1:, :D1], G[D1:, D1:]
-    dw = torch.cat([(G12 + G21).reshape(-1), (G11 + G22).reshape(-1), sm[0, :D1] + sm[0, D1:]])
-    return dw.float().reshape(1, -1), cnt[:1].float()
+    dw = torch.cat([(G12 + G21).reshape(-1), (G11 + G22).reshape(-1), sm[0, :D1] + sm[0, D1:], cnt[:1]])
+    if reduce is not None:
+        dw = reduce(dw)
+    return dw[:-1].float().reshape(1, -1), dw[-1:].float()
 
 
 def detcost_sweep(scores, target, betas, exact=False, want_eer=False):

@@ -175,7 +175,12 @@ def get_trials_loaders_dict(trials_key_files_list, id_to_num_dict, subsample_fac
 # ---------------------------------------------------------------------------------------------------
 
 class XvectorTable:
-    """Row-major (N_utt, D) float32 matrix of a mega dict, with id -> row maps, host and device copies."""
+    """Row-major (N_utt, D) float32 matrix of x-vectors with id -> row maps, host and device copies.
+
+    Built from a mega dict {utt_id: float32[D]} (the pickle dataprep_sre.py:152-167 writes) or — without ever
+    materialising that dict — straight from the Kaldi archives it was made from (`from_ark`, `from_scp`: the vectors go
+    archive -> one pinned host matrix -> device).  The table is accepted wherever the loaders / score generators /
+    train() take `mega_dict`: it iterates, indexes and reports its length like the dict of the reference."""
 
     def __init__(self, mega_dict):
         self.ids = list(mega_dict.keys())
@@ -185,6 +190,81 @@ class XvectorTable:
         self._dev = {}
         self._num_maps = {}
         self._idblob = None
+        self._pinned = None
+
+    @classmethod
+    def from_matrix(cls, ids, mat, pinned=None):
+        """ids (N) + an (N, D) float32 matrix (numpy; `pinned`: the CPU torch tensor that owns its memory)."""
+        self = cls.__new__(cls)
+        self.ids = list(ids)
+        if mat.shape[0] != len(self.ids):
+            raise ValueError("one id per row")
+        self.row_of = {u: i for i, u in enumerate(self.ids)}
+        if len(self.row_of) != len(self.ids):  # a repeated key: the last occurrence wins, as dict.update does
+            keep = sorted(self.row_of.values())
+            self.ids = [self.ids[i] for i in keep]
+            mat = np.ascontiguousarray(mat[keep])
+            self.row_of = {u: i for i, u in enumerate(self.ids)}
+            pinned = None
+        self.host = mat
+        self._dev, self._num_maps, self._idblob, self._pinned = {}, {}, None, pinned
+        return self
+
+    @staticmethod
+    def _pinned_buffer(n, dim):
+        t = torch.empty((n, dim), dtype=torch.float32)
+        if torch.cuda.is_available():
+            try:
+                t = t.pin_memory()
+            except RuntimeError:
+                pass
+        return t
+
+    @classmethod
+    def from_ark(cls, *ark_paths):
+        """Binary Kaldi vector archives -> table (rows in archive order; dataprep_sre.py:152-167 without kaldi_io, the
+        per-utterance arrays, the dict and the pickle)."""
+        from . import kaldi_format
+        parts = [kaldi_format.load_vector_ark(p) for p in ark_paths]
+        return cls._from_parts(parts)
+
+    @classmethod
+    def from_scp(cls, *scp_paths):
+        """Kaldi scp files ('utt ark:offset' lines) -> table, every referenced archive memory-mapped once."""
+        from . import kaldi_format
+        parts = [kaldi_format.load_vector_scp(p) for p in scp_paths]
+        return cls._from_parts(parts)
+
+    @classmethod
+    def _from_parts(cls, parts):
+        parts = [(k, m) for k, m in parts if len(k)]
+        if not parts:
+            return cls.from_matrix([], np.zeros((0, 0), np.float32))
+        n, dim = sum(len(k) for k, _ in parts), parts[0][1].shape[1]
+        buf = cls._pinned_buffer(n, dim)
+        host = buf.numpy()
+        ids, lo = [], 0
+        for k, m in parts:
+            host[lo:lo + len(k)] = m
+            ids += k
+            lo += len(k)
+        return cls.from_matrix(ids, host, pinned=buf)
+
+    # -- the dict protocol the reference's scripts use on mega_xvec_dict (iteration order = row order)
+    def __len__(self):
+        return len(self.ids)
+
+    def __iter__(self):
+        return iter(self.ids)
+
+    def keys(self):
+        return self.ids
+
+    def __contains__(self, u):
+        return u in self.row_of
+
+    def __getitem__(self, u):
+        return self.host[self.row_of[u]]
 
     @property
     def idblob(self):
@@ -203,7 +283,8 @@ class XvectorTable:
         key = (device.type, device.index if device.index is not None else (torch.cuda.current_device()
                                                                            if device.type == "cuda" else -1))
         if key not in self._dev:
-            self._dev[key] = torch.from_numpy(self.host).to(device)
+            src = self._pinned if self._pinned is not None else torch.from_numpy(self.host)
+            self._dev[key] = src.to(device, non_blocking=self._pinned is not None)
         return self._dev[key]
 
     def rows_from_nums(self, num_to_id_dict):
@@ -240,7 +321,10 @@ _TABLES = {}
 
 
 def xvector_table(mega_dict):
-    """The (cached) XvectorTable of a mega dict; rebuilt if the dict object or its size changed."""
+    """The (cached) XvectorTable of a mega dict; rebuilt if the dict object or its size changed.  An XvectorTable
+    (e.g. XvectorTable.from_scp) passes through."""
+    if isinstance(mega_dict, XvectorTable):
+        return mega_dict
     k = id(mega_dict)
     hit = _TABLES.get(k)
     if hit is None or hit[0] != len(mega_dict):
@@ -261,7 +345,15 @@ def load_xvec_trials_from_numbatch(mega_dict, num_to_id_dict, data1, data2, devi
         if key not in devmaps:
             devmaps[key] = torch.from_numpy(m).to(data1.device)
         mm = devmaps[key]
-        return tab.gather(mm[data1.reshape(-1).long()], device), tab.gather(mm[data2.reshape(-1).long()], device)
+        i1, i2 = data1.reshape(-1).long(), data2.reshape(-1).long()
+        # the reference's dict look-up raises KeyError for an unknown number; the gather kernel would write NaN rows
+        if i1.numel() and (int(torch.minimum(i1.min(), i2.min())) < 0
+                           or int(torch.maximum(i1.max(), i2.max())) >= mm.numel()):
+            raise KeyError("trial index is outside num_to_id_dict")
+        r1, r2 = mm[i1], mm[i2]
+        if r1.numel() and int(torch.minimum(r1.min(), r2.min())) < 0:
+            raise KeyError("trial index refers to an utterance that is not in mega_dict")
+        return tab.gather(r1, device), tab.gather(r2, device)
     d1 = data1.cpu().numpy() if isinstance(data1, torch.Tensor) else np.asarray(data1)
     d2 = data2.cpu().numpy() if isinstance(data2, torch.Tensor) else np.asarray(data2)
     r1, r2 = m[d1.reshape(-1).astype(np.int64)], m[d2.reshape(-1).astype(np.int64)]

@@ -201,7 +201,10 @@ class FusedTrainStep:
     pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat gradient) -> one-launch Adam
     (nplda_adam_step_f32, same update rule as torch.optim.Adam(lr, weight_decay) of the reference,
     xvector_NeuralPlda_pytorch.py:139) — seven launches up to 4096 pairs (the loss is one launch there; ten beyond), optionally replayed from a HIP graph.
-    With `reduce_sums` / `reduce_flat` callables (neuralplda_amd.dist) it is the data-parallel step (eager only)."""
+    With the `reduce_sums` / `reduce_flat` hooks of a data-parallel model (neuralplda_amd.dist.make_data_parallel) it is
+    the data-parallel step: each rank feeds its shard of the global minibatch, the fp64 loss sums and the flat gradient
+    are all-reduced (SUM) between the launches, and both collectives are captured INSIDE the HIP graph (RCCL collectives
+    are stream operations), so the replayed step stays one graph launch per rank."""
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
         from . import _lib, ops
@@ -236,8 +239,6 @@ class FusedTrainStep:
         self.i1 = self.i2 = None
         self.reduce_sums = getattr(model, "_reduce_sums", None)
         self.reduce_flat = getattr(model, "_reduce_flat", None)
-        if self.use_graph and (self.reduce_sums is not None or self.reduce_flat is not None):
-            raise ValueError("graph replay and data-parallel reductions cannot be combined; pass graph=False")
         if self.use_graph:
             self.x1 = torch.zeros(batch_size, D0, device=self.dev)
             self.x2 = torch.zeros(batch_size, D0, device=self.dev)
@@ -264,6 +265,12 @@ class FusedTrainStep:
             grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
             self._adam(prm + ths, grads)
         return loss
+
+    def _touched(self):
+        """The raw Adam kernel has rewritten the parameters: bump their version counters (autograd's saved-tensor
+        checks, the model's packed-image cache)."""
+        for q in self.params + self.thetas:
+            torch.autograd.graph.increment_version(q)
 
     def _adam(self, tensors, grads):
         """One nplda_adam_step_f32 launch over `tensors` (moments in self.m / self.v, segment by segment)."""
@@ -300,7 +307,10 @@ class FusedTrainStep:
             self.v.copy_(v0)
             self.step_count.copy_(s0)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        # with collectives in the step the RCCL watchdog thread polls events while we capture: only this thread's calls
+        # may be checked against the capture
+        dp = self.reduce_sums is not None or self.reduce_flat is not None
+        with torch.cuda.graph(graph, **({"capture_error_mode": "thread_local"} if dp else {})):
             loss = fn()
         return graph, loss
 
@@ -314,13 +324,16 @@ class FusedTrainStep:
         ops = self._ops
         B = rows1.shape[0]
         if not self.use_graph or B != self.batch_size:
-            return self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
+            loss = self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
+            self._touched()
+            return loss
         if self._graph_rows is None or self._graph_table != (table.data_ptr(), table.shape, table.stride(0)):
             self._capture_rows(table)
         self.i1.copy_(rows1, non_blocking=True)
         self.i2.copy_(rows2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self._graph_rows.replay()
+        self._touched()
         return self._loss_rows
 
     def _eager_rows(self, table):
@@ -338,13 +351,16 @@ class FusedTrainStep:
 
     def __call__(self, x1, x2, target):
         if not self.use_graph or x1.shape[0] != self.batch_size:
-            return self._eager(x1, x2, target)
+            loss = self._eager(x1, x2, target)
+            self._touched()
+            return loss
         if self._graph is None:
             self._capture()
         self.x1.copy_(x1, non_blocking=True)
         self.x2.copy_(x2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self._graph.replay()
+        self._touched()
         return self._loss
 
 
@@ -368,8 +384,9 @@ class FusedDPldaStep(FusedTrainStep):
         self.model, self.dev = model, p.device
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.kind = _loss_kind(model.lossfn)
-        self.thetas = ([model.threshold[b] for b in model.beta] if self.kind == ops.LOSS_SOFTCDET
-                       else [model.threshold_Xent])
+        # DPlda's BCE has no threshold (utils/models.py:503-506): the loss kernels get a constant zero, nothing to train
+        self.thetas = [model.threshold[b] for b in model.beta] if self.kind == ops.LOSS_SOFTCDET else []
+        self._zero = torch.zeros(1, device=p.device)
         self.betas_loss = [float(b) for b in model.beta] if self.kind == ops.LOSS_SOFTCDET else []
         self.alpha = float(model.alpha) if self.kind == ops.LOSS_SOFTCDET else 0.0
         self.params = [model.logistic_regres.weight, model.logistic_regres.bias]
@@ -382,7 +399,9 @@ class FusedDPldaStep(FusedTrainStep):
         self.use_graph = bool(graph) and batch_size is not None
         self._graph = self._loss = self._graph_rows = self._loss_rows = self._graph_table = None
         self.i1 = self.i2 = None
-        self.reduce_sums = self.reduce_flat = None
+        # data parallel (neuralplda_amd.dist.make_data_parallel): the fp64 loss sums, then the folded fp64 gradient
+        self.reduce_sums = getattr(model, "_reduce_sums", None)
+        self.reduce_flat = model.__dict__.get("_reduce_sums64")
         if self.use_graph:
             self.x1 = torch.zeros(batch_size, D0, device=self.dev)
             self.x2 = torch.zeros(batch_size, D0, device=self.dev)
@@ -396,8 +415,13 @@ class FusedDPldaStep(FusedTrainStep):
             packed = ops.dplda_pack(mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach(), wlr, blr)
             s, paired = ops._gb_call(x1, x2, packed, True, True)
             ths = [th.detach() for th in self.thetas]
-            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
-            dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1)
+            lths = ths if self.kind == ops.LOSS_SOFTCDET else [self._zero]
+            if self.reduce_sums is None:
+                loss, g, dth, _ = ops.loss_fwd_bwd(s, t, lths, self.betas_loss, self.alpha, self.kind)
+            else:
+                sums = self.reduce_sums(ops.loss_sums(s, t, lths, self.alpha, self.kind))
+                loss, g, dth = ops.loss_finish(s, t, lths, self.betas_loss, self.alpha, self.kind, sums)
+            dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1, reduce=self.reduce_flat)
             self._adam([wlr, blr] + ths, [dw.contiguous(), db.contiguous()] + [dth[k:k + 1] for k in range(len(ths))])
         return loss
 
@@ -472,7 +496,13 @@ def main_kaldiplda(configfile='conf/voices_config.cfg', use_graph=True):
     print("Initializing the thresholds... Training and validation loss printed now is not meaningful.")
     validate(nc, model, device, mega_xvec_dict, num_to_id_dict, valid_loaders[nc.heldout_set_for_th_init],
              update_thresholds=True)
+    # epoch-0 validation of every set; the held-out minC opens the LR-decay history (xvector_NeuralPlda_pytorch.py:146-153)
     all_losses = []
+    val_losses = {}
+    for val_set, loader in valid_loaders.items():
+        print("Validating on {}".format(val_set))
+        val_losses[val_set], _ = validate(nc, model, device, mega_xvec_dict, num_to_id_dict, loader)
+    all_losses.append(float(val_losses[nc.heldout_set_for_lr_decay]))
     for epoch in range(1, nc.n_epochs + 1):
         train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, valid_loaders,
               step_fn=step_fn)
@@ -538,6 +568,10 @@ def main_dplda(configfile='conf/voices_config.cfg', use_graph=True):
     validate(nc, model, device, mega_xvec_dict, num_to_id_dict, valid_loaders[nc.heldout_set_for_th_init],
              update_thresholds=True)
     all_losses = []
+    val_losses = {}
+    for val_set, loader in valid_loaders.items():  # epoch 0, as xvector_DPlda_pytorch.py:153-160
+        val_losses[val_set], _ = validate(nc, model, device, mega_xvec_dict, num_to_id_dict, loader)
+    all_losses.append(float(val_losses[nc.heldout_set_for_lr_decay]))
     for epoch in range(1, nc.n_epochs + 1):
         train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optimizer, epoch, step_fn=step_fn)
         val_losses = {}

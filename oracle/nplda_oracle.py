@@ -168,19 +168,50 @@ def backward(x1, x2, g, p, dtype=np.float64):
     dW2 = dz1.T @ y1 + dz2.T @ y2
     db2 = (dz1 + dz2).sum(axis=0)
 
-    def norm_bwd(dz, y, nrm):
-        dy = dz @ p.W2
-        den = np.maximum(nrm, EPS_NORMALIZE)[:, None]
-        du = (dy - y * (y * dy).sum(axis=1, keepdims=True)) / den
-        # clamp branch of F.normalize: where ||u|| < eps the denominator is the constant eps
-        small = (nrm < EPS_NORMALIZE)[:, None]
-        return np.where(small, dy / den, du)
-
-    du1, du2 = norm_bwd(dz1, y1, n1), norm_bwd(dz2, y2, n2)
+    du1, du2 = _normalize_bwd(dz1 @ p.W2, y1, n1), _normalize_bwd(dz2 @ p.W2, y2, n2)
     x1d, x2d = _as(x1, dtype), _as(x2, dtype)
     dW1 = du1.T @ x1d + du2.T @ x2d
     db1 = (du1 + du2).sum(axis=0)
     return dict(W1=dW1, b1=db1, W2=dW2, b2=db2, P_sqrt=dPs, Q=dQ)
+
+
+def _normalize_bwd(dy, y, nrm):
+    """Backward of F.normalize (utils/models.py:368): du = (dy - y (y . dy)) / max(||u||, eps); where ||u|| < eps the
+    denominator is the constant eps."""
+    den = np.maximum(nrm, EPS_NORMALIZE)[:, None]
+    du = (dy - y * (y * dy).sum(axis=1, keepdims=True)) / den
+    return np.where((nrm < EPS_NORMALIZE)[:, None], dy / den, du)
+
+
+def embed_backward(x, gz, p, dtype=np.float64):
+    """Backward of z = extract_plda_embeddings(x) (utils/models.py:366-370) for an upstream gradient gz = dL/dz:
+    dict(W1, b1, W2, b2, x) — what the reference's autograd returns for these three lines (pinned by golden G11)."""
+    p = p.astype(dtype)
+    gz = _as(gz, dtype)
+    _, (u, y, nrm) = extract_plda_embeddings(x, p, dtype, True)
+    du = _normalize_bwd(gz @ p.W2, y, nrm)
+    xd = _as(x, dtype)
+    return dict(W1=du.T @ xd, b1=du.sum(axis=0), W2=gz.T @ y, b2=gz.sum(axis=0), x=du @ p.W1)
+
+
+def embscore_backward(z1, z2, g, p, dtype=np.float64):
+    """Backward of s = forward_from_plda_embeddings(z1, z2) (utils/models.py:372-376) for g = dL/ds:
+    dict(z1, z2, P_sqrt, Q)."""
+    z1, z2, g = _as(z1, dtype), _as(z2, dtype), _as(g, dtype)[:, None]
+    ps, Q = _as(p.P_sqrt, dtype), _as(p.Q, dtype)
+    P = ps * ps
+    return dict(z1=2 * g * (Q * z1 + P * z2), z2=2 * g * (Q * z2 + P * z1),
+                P_sqrt=4 * ps * (g * z1 * z2).sum(axis=0), Q=(g * (z1 * z1 + z2 * z2)).sum(axis=0))
+
+
+def input_grads(x1, x2, g, p, dtype=np.float64):
+    """dL/dx1, dL/dx2 of sum_i g_i s_i, s = forward(x1, x2) (utils/models.py:378-382): the chain of the two functions
+    above — the gradient the E2E model (utils/models.py:251-268) passes to its x-vector extractor."""
+    p = p.astype(dtype)
+    z1 = extract_plda_embeddings(x1, p, dtype)
+    z2 = extract_plda_embeddings(x2, p, dtype)
+    d = embscore_backward(z1, z2, g, p, dtype)
+    return embed_backward(x1, d["z1"], p, dtype)["x"], embed_backward(x2, d["z2"], p, dtype)["x"]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -344,6 +375,24 @@ def dplda_backward(y1, y2, g, dtype=np.float64):
     within = (y1[:, :, None] * y1[:, None, :] + y2[:, :, None] * y2[:, None, :]).reshape(B, -1)
     feats = np.concatenate([between, within, y1 + y2], axis=1)
     return (g @ feats).reshape(1, -1), np.asarray([g.sum()], dtype=dtype)
+
+
+def dplda_lda_backward(x1, x2, g, W1, b1, wlr, dtype=np.float64):
+    """Gradient of sum_i g_i s_i, s = DPlda.forward(x1, x2) (utils/models.py:492-495), w.r.t. the LDA layer and the
+    inputs: dict(W1, b1, x1, x2).  With x = [y1; y2] the score is x^T M x + x^T v + c, M = [[Ww, Wb], [Wb, Ww]],
+    v = [ws; ws] (the linear unit's weight split [Wb | Ww | ws] as :484-490 concatenates the features), hence
+    dL/dx = g ((M + M^T) x + v), then the F.normalize backward and the LDA's own two GEMMs."""
+    W1, b1, g = _as(W1, dtype), _as(b1, dtype), _as(g, dtype)[:, None]
+    D1 = W1.shape[0]
+    w = _as(wlr, dtype).reshape(-1)
+    Wb, Ww, ws = w[:D1 * D1].reshape(D1, D1), w[D1 * D1:2 * D1 * D1].reshape(D1, D1), w[2 * D1 * D1:]
+    x1d, x2d = _as(x1, dtype), _as(x2, dtype)
+    y1, n1 = normalize(x1d @ W1.T + b1, dtype)
+    y2, n2 = normalize(x2d @ W1.T + b1, dtype)
+    dy1 = g * (y1 @ (Ww + Ww.T) + y2 @ (Wb + Wb.T) + ws)
+    dy2 = g * (y2 @ (Ww + Ww.T) + y1 @ (Wb + Wb.T) + ws)
+    du1, du2 = _normalize_bwd(dy1, y1, n1), _normalize_bwd(dy2, y2, n2)
+    return dict(W1=du1.T @ x1d + du2.T @ x2d, b1=(du1 + du2).sum(axis=0), x1=du1 @ W1, x2=du2 @ W1)
 
 
 def weighted_moments(x, w, dtype=np.float64):

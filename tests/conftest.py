@@ -33,6 +33,10 @@ def pytest_collection_modifyitems(config, items):
 def hip_lib():
     """Build (if stale) and load libnplda_hip.so; fails loudly when it cannot."""
     from neuralplda_amd import _lib, build
-    if not os.path.exists(_lib.LIB_PATH):
+    # build.build() is incremental: it recompiles only the csrc/ units newer than their objects and relinks only when
+    # something changed, so a library that is stale relative to csrc/ (e.g. a snapshot pushed to the GPU box with an old
+    # .so) is rebuilt here, not just a missing one.  Without hipcc an existing library is used as it is.
+    import shutil
+    if shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc") or not os.path.exists(_lib.LIB_PATH):
         build.build()
     return _lib.load()

@@ -29,6 +29,11 @@ def _check(line, steps, warmup, with_cpu):
     if with_cpu:
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+        # torch CPU ops at all physical cores and one core, D = 150 and 170, gather-inclusive figure
+        for k in ("d150_all_cores", "d150_one_core", "d170_all_cores", "d170_one_core", "gather_inclusive_all_cores"):
+            assert c["detail"][k]["pairs_per_s"] > 0 and c["detail"][k]["reps"] >= 3, k
+        assert c["detail"]["d150_all_cores"]["threads"] == c["cores"] and c["detail"]["d150_one_core"]["threads"] == 1
+        assert c["detail"]["gather_inclusive_all_cores"]["pairs_per_s"] < c["value"] and c["cpu_model"]
     return d
 
 
@@ -40,6 +45,10 @@ def test_bench_single_process_contract(hip_lib):
     assert len(lines) == 1  # exactly one JSON line
     d = _check(lines[0], 4, 1, True)
     assert "alt_bf16x3" in d and d["alt_bf16x3"]["max_abs_diff_vs_fp32_scores"] < 2e-5
+    a = d["alt_d170"]  # the reference's shipped shape rides on the same line
+    assert a["bound"] == "mfma" and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-9 and 0.3 < a["frac"] < 1.0
+    assert a["flop_per_pair_algorithmic"] == 465120 and a["checksum_finite"]
+    assert d["config"]["ranks_in_group"] == 1
 
 
 def test_bench_torchrun_one_rank(hip_lib):
@@ -52,3 +61,59 @@ def test_bench_torchrun_one_rank(hip_lib):
     lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     _check(lines[0], 3, 1, False)
+
+
+def _run(argv, env=None, timeout=900):
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + argv, capture_output=True, text=True,
+                         timeout=timeout, cwd=ROOT, env=dict(os.environ, **(env or {})))
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    return out, lines
+
+
+def test_bench_gpus_flag_launches_the_ranks_itself(hip_lib):
+    """`python bench.py --gpus N` (no torchrun) must start N ranks or fail: with RCCL and one visible GPU, N = 2 is an
+    error exit, never a silent one-rank number; under the gloo dry-run backend the two ranks really form a group."""
+    import torch
+    if torch.cuda.device_count() < 2:
+        out, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1"])
+        assert out.returncode != 0 and not lines
+    for scaling in ("weak", "strong"):
+        out, lines = _run(["--gpus", "2", "--steps", "2", "--warmup", "1", "--pairs", "65536", "--scaling", scaling,
+                           "--no-cpu-baseline", "--no-alt", "--no-clock-probe"], env={"NPLDA_BENCH_BACKEND": "gloo"})
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert len(lines) == 1
+        d = json.loads(lines[0])
+        assert d["n_gpus"] == 2 and d["config"]["ranks_in_group"] == 2 and d["scaling"] == scaling
+        assert d["config"]["parallelism"] == "trial-list shard x2" and d["config"]["backend"] == "gloo"
+        per_gpu = d["config"]["pairs_per_gpu_per_step"]
+        assert per_gpu == (65536 if scaling == "weak" else 32768)
+        total = 2 * per_gpu if scaling == "weak" else 65536
+        assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+
+
+def test_bench_cfg3_single_and_two_rank_dry_run(hip_lib):
+    """--workload cfg3: embed -> row-sharded cohort statistics -> ONE all-gather of (R, 4) -> trial-sharded apply."""
+    small = ["--workload", "cfg3", "--steps", "2", "--warmup", "1", "--cohort", "2000", "--enroll", "300", "--test",
+             "1700", "--trials", "100000"]
+    out, lines = _run(small)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d1 = json.loads(lines[0])
+    assert d1["n_gpus"] == 1 and d1["unit"] == "trials/s" and d1["config"]["rows_per_gpu"] == 2000
+    assert d1["roofline"]["bound"] == "mfma" and d1["roofline"]["kernel_ms"] > 0
+    assert abs(d1["value"] - 100000 / (d1["ms_per_step"] * 1e-3)) <= 1e-6 * d1["value"]
+    assert d1["config"]["stats_ms"] + d1["config"]["allgather_ms"] + d1["config"]["apply_ms"] <= d1["ms_per_step"] * 1.5
+    out, lines = _run(["--gpus", "2"] + small, env={"NPLDA_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["ranks_in_group"] == 2 and d2["config"]["rows_per_gpu"] == 1000
+    assert d2["config"]["trials_per_gpu"] == 50000 and d2["config"]["allgather_bytes"] == 2 * 1000 * 32
+    assert d2["config"]["parallelism"] == "row shard + trial shard x2"
+
+
+def test_bench_cfg3_full_size_line(hip_lib):
+    """BASELINE configs[3] at full size on one GPU: the line the driver would get from `--workload cfg3`."""
+    out, lines = _run(["--workload", "cfg3", "--steps", "3", "--warmup", "1"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(lines[0])
+    assert d["config"]["cohort"] == 10000 and d["config"]["rows"] == 22000 and d["config"]["trials"] == 2000000
+    assert d["ms_per_step"] < 20.0 and d["config"]["cohort_scores_per_s"] > 1e10

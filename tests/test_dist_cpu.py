@@ -123,6 +123,34 @@ def _worker(rank, world, port, tmp):
         assert m._reduce_sums(v).tolist() == [sum(1.0 + r for r in range(world)), 2.0 * world]
         f = torch.ones(5)
         assert m._reduce_flat(f).tolist() == [float(world)] * 5
+        # ---- 5. data-parallel DPlda step: global loss sums, then the folded fp64 gradient of the linear unit summed
+        #         through the hook make_data_parallel installs (what train.FusedDPldaStep / _DPldaScoreFn call) ----------
+        from neuralplda_amd import ops
+        D1 = 8
+        Wl = rng.uniform(-0.2, 0.2, (D1, 64)).astype(np.float32)
+        bl = rng.uniform(-0.1, 0.1, D1).astype(np.float32)
+        wlr = (0.1 * rng.standard_normal((1, 2 * D1 * D1 + D1))).astype(np.float32)
+        blr = np.asarray([0.05], np.float32)
+        sd_full = orc.dplda_forward(x1, x2, Wl, bl, wlr, blr, np.float64)
+        gd_full, _ = orc.softcdet_grad(sd_full, t, theta, beta, alpha)
+
+        def paired(a, b):
+            y1, _ = orc.normalize(a.astype(np.float64) @ Wl.T.astype(np.float64) + bl, np.float64)
+            y2, _ = orc.normalize(b.astype(np.float64) @ Wl.T.astype(np.float64) + bl, np.float64)
+            return y1, y2
+
+        dw_full, db_full = orc.dplda_backward(*paired(x1, x2), gd_full)
+        sd_loc = orc.dplda_forward(sx1, sx2, Wl, bl, wlr, blr, np.float64)
+        dsums = torch.from_numpy(_softcdet_sums(sd_loc, st, theta, alpha))
+        dsums = m._reduce_sums(dsums).numpy()
+        gd_loc, _ = orc.softcdet_grad(sd_loc, st, theta, beta, alpha, nt=dsums[0], nn=dsums[1])
+        y1l, y2l = paired(sx1, sx2)
+        xp = np.concatenate([y1l, y2l], axis=1)
+        cnt, sm, sq = orc.weighted_moments(xp, gd_loc)
+        dw, db = ops.dplda_fold_grad(torch.tensor([cnt]), torch.from_numpy(sm)[None], torch.from_numpy(sq)[None], D1,
+                                     reduce=m.__dict__["_reduce_sums64"])
+        np.testing.assert_allclose(dw.numpy(), dw_full.astype(np.float32), rtol=2e-6, atol=1e-9)
+        np.testing.assert_allclose(db.numpy(), db_full.astype(np.float32), rtol=2e-6, atol=1e-9)
         open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
     finally:
         torch.distributed.destroy_process_group()

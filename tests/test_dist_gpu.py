@@ -75,3 +75,56 @@ def test_rccl_single_rank_paths(hip_lib, one_rank_group):
             assert torch.equal(p1.grad, p2.grad), k
     step = train.FusedTrainStep(m2, 1e-4, batch_size=5000, graph=False)
     assert np.isfinite(step(xs1, xs2, ts).item())
+
+
+def test_data_parallel_fused_steps_replay_from_a_graph(hip_lib, one_rank_group):
+    """The data-parallel fused steps carry their two collectives INSIDE the captured HIP graph (RCCL collectives are
+    stream operations): with a one-rank RCCL group the graph-replayed DP step must follow the plain fused step bit for
+    bit — NeuralPlda (loss sums + flat gradient) and DPlda (loss sums + folded fp64 unit gradient)."""
+    ndist = one_rank_group
+    from neuralplda_amd import models, train
+    gen = torch.Generator(device="cuda").manual_seed(3)
+    B = 2048
+    batches = [(torch.randn(B, 512, device="cuda", generator=gen), torch.randn(B, 512, device="cuda", generator=gen),
+                (torch.rand(B, device="cuda", generator=gen) < 0.2).float()) for _ in range(4)]
+    torch.manual_seed(0)
+    m_plain = models.NeuralPlda(NC()).cuda()
+    m_dp = models.NeuralPlda(NC()).cuda()
+    m_dp.load_state_dict(m_plain.state_dict())
+    ndist.make_data_parallel(m_dp)
+    s_plain = train.FusedTrainStep(m_plain, 1e-3, batch_size=B, graph=True)
+    s_dp = train.FusedTrainStep(m_dp, 1e-3, batch_size=B, graph=True)
+    assert s_dp.reduce_sums is not None and s_dp.reduce_flat is not None and s_dp.use_graph
+    for x1, x2, t in batches:
+        a, b = s_plain(x1, x2, t), s_dp(x1, x2, t)
+        assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
+    assert s_dp._graph is not None
+    for (k, p1), (_, p2) in zip(m_plain.state_dict().items(), m_dp.state_dict().items()):
+        assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-8), k
+
+    class NCD:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 170, 170
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
+
+    torch.manual_seed(1)
+    d_plain = models.DPlda(NCD()).cuda()
+    d_dp = models.DPlda(NCD()).cuda()
+    d_dp.load_state_dict(d_plain.state_dict())
+    for d in (d_plain, d_dp):
+        d.centering_and_LDA.weight.requires_grad = False
+        d.centering_and_LDA.bias.requires_grad = False
+    ndist.make_data_parallel(d_dp)
+    f_plain = train.FusedDPldaStep(d_plain, 1e-3, batch_size=B, graph=True)
+    f_dp = train.FusedDPldaStep(d_dp, 1e-3, batch_size=B, graph=True)
+    assert f_dp.reduce_sums is not None and f_dp.reduce_flat is not None
+    for x1, x2, t in batches:
+        a, b = f_plain(x1, x2, t), f_dp(x1, x2, t)
+        assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a))
+    for (k, p1), (_, p2) in zip(d_plain.state_dict().items(), d_dp.state_dict().items()):
+        assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-8), k
+    # autograd path of the DP DPlda model: same gradients as the plain one
+    x1, x2, t = batches[0]
+    for d in (d_plain, d_dp):
+        d.zero_grad()
+        d.loss(d(x1, x2), t).backward()
+    assert torch.allclose(d_plain.logistic_regres.weight.grad, d_dp.logistic_regres.weight.grad, rtol=1e-6, atol=1e-9)

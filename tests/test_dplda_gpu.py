@@ -141,14 +141,17 @@ def test_dplda_gradients_golden(hip_lib):
         assert m.centering_and_LDA.weight.grad is None
 
 
-def test_dplda_unfrozen_lda_fails_loudly(hip_lib):
+def test_dplda_unfrozen_lda_trains(hip_lib):
+    """With the LDA left trainable (not the reference's recipe, but what its autograd allows) the backward reaches
+    centering_and_LDA too; golden check in tests/test_input_grads_gpu.py::test_dplda_input_and_lda_grads_golden."""
     g = np.load(os.path.join(G, "g10_dplda_small.npz"), allow_pickle=True)
     m = make(64, 24, g["W1"], g["b1"], g["wlr"], g["blr"])
     m(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())  # scoring needs no freeze
     with torch.enable_grad():
         s = m(torch.from_numpy(g["x1"]).cuda(), torch.from_numpy(g["x2"]).cuda())
-        with pytest.raises(NotImplementedError):
-            s.sum().backward()
+        s.sum().backward()
+    assert m.centering_and_LDA.weight.grad is not None and torch.isfinite(m.centering_and_LDA.weight.grad).all()
+    assert m.logistic_regres.weight.grad is not None
 
 
 def test_dplda_adam_steps_match_torch_recipe(hip_lib):
