@@ -102,7 +102,7 @@ def cpu_baseline(dims, D0, headline_dim, budget_s=12.0, chunk=10240):
     x1 = torch.from_numpy(rng.standard_normal((nbuf, D0), dtype=np.float32))
     x2 = torch.from_numpy(rng.standard_normal((nbuf, D0), dtype=np.float32))
     prev_threads = torch.get_num_threads()
-    share = budget_s / (2 * len(dims) + 1)
+    share = budget_s / (6 * len(dims) + 1)
     detail = {}
 
     def measure(p, chunks_per_rep, min_reps=10):
@@ -120,16 +120,29 @@ def cpu_baseline(dims, D0, headline_dim, budget_s=12.0, chunk=10240):
             times.append(time.perf_counter() - t0)
         return chunks_per_rep * chunk / float(np.median(times)), len(times)
 
+    # thread widths: all physical cores and one core plus a calibration over narrower pools — on a
+    # many-core host these 10240 x 512 x 150 GEMMs run FASTER on 16-32 threads than on all cores, and the fair baseline
+    # is the best the host can do
+    widths = sorted({w for w in (8, 16, 32, 64) if w < ncores} | {ncores})
     for D in dims:
         prm, _ = make_params(D, "cpu")
         p = ot.TorchParams(*[t.numpy() for t in prm])
-        for nt, tag in ((ncores, "all_cores"), (1, "one_core")):
+        best = None
+        for nt in widths:
             torch.set_num_threads(nt)
-            rate, reps = measure(p, 4 if nt > 1 else 1)
-            detail[f"d{D}_{tag}"] = {"pairs_per_s": rate, "threads": nt, "reps": reps}
+            rate, reps = measure(p, 4, min_reps=10 if nt == ncores else 5)
+            if nt == ncores:
+                detail[f"d{D}_all_cores"] = {"pairs_per_s": rate, "threads": nt, "reps": reps}
+            if best is None or rate > best["pairs_per_s"]:
+                best = {"pairs_per_s": rate, "threads": nt, "reps": reps}
+        detail[f"d{D}_best_width"] = best
+        torch.set_num_threads(1)
+        rate, reps = measure(p, 1)
+        detail[f"d{D}_one_core"] = {"pairs_per_s": rate, "threads": 1, "reps": reps}
     # gather-inclusive (utils/sv_trials_loaders.py:418-426 + forward), all cores, headline dim: what the reference's
     # scoring / training loops actually sustain per batch
-    torch.set_num_threads(ncores)
+    best_nt = detail[f"d{headline_dim}_best_width"]["threads"]
+    torch.set_num_threads(best_nt)
     prm, _ = make_params(headline_dim, "cpu")
     p = ot.TorchParams(*[t.numpy() for t in prm])
     nutt = 20000
@@ -144,14 +157,15 @@ def cpu_baseline(dims, D0, headline_dim, budget_s=12.0, chunk=10240):
         with torch.no_grad():
             ot.forward(a, b, p)
         times.append(time.perf_counter() - t0)
-    detail["gather_inclusive_all_cores"] = {"pairs_per_s": chunk / float(np.median(times)), "threads": ncores, "reps": 3}
+    detail["gather_inclusive"] = {"pairs_per_s": chunk / float(np.median(times)), "threads": best_nt, "reps": 3}
     torch.set_num_threads(prev_threads)
-    head = detail[f"d{headline_dim}_all_cores"]
-    return {"value": head["pairs_per_s"], "unit": "pairs/s", "cores": int(ncores), "kind": "port",
+    head = detail[f"d{headline_dim}_best_width"]
+    return {"value": head["pairs_per_s"], "unit": "pairs/s", "cores": int(head["threads"]), "kind": "port",
             "sample": f"median of {head['reps']} sweeps of {4 * chunk} pairs in chunks of {chunk} (the reference driver's "
                       f"5*2048), the reference's forward restated as torch CPU ops (oracle/nplda_oracle_torch.py), "
-                      f"torch.set_num_threads({ncores}) = physical cores; 512->{headline_dim}->{headline_dim}",
-            "cpu_model": _cpu_model(), "logical_cpus": os.cpu_count(), "detail": detail}
+                      f"torch.set_num_threads({head['threads']}) = the fastest of {widths} ({ncores} physical cores: see "
+                      f"detail.d{headline_dim}_all_cores / _one_core); 512->{headline_dim}->{headline_dim}",
+            "cpu_model": _cpu_model(), "physical_cores": int(ncores), "logical_cpus": os.cpu_count(), "detail": detail}
 
 
 # ---------------------------------------------------------------------------------------------------------------------

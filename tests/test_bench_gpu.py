@@ -30,10 +30,12 @@ def _check(line, steps, warmup, with_cpu):
         c = d["cpu_baseline"]
         assert c["kind"] == "port" and c["unit"] == "pairs/s" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
         # torch CPU ops at all physical cores and one core, D = 150 and 170, gather-inclusive figure
-        for k in ("d150_all_cores", "d150_one_core", "d170_all_cores", "d170_one_core", "gather_inclusive_all_cores"):
+        for k in ("d150_all_cores", "d150_one_core", "d150_best_width", "d170_all_cores", "d170_one_core",
+                  "d170_best_width", "gather_inclusive"):
             assert c["detail"][k]["pairs_per_s"] > 0 and c["detail"][k]["reps"] >= 3, k
-        assert c["detail"]["d150_all_cores"]["threads"] == c["cores"] and c["detail"]["d150_one_core"]["threads"] == 1
-        assert c["detail"]["gather_inclusive_all_cores"]["pairs_per_s"] < c["value"] and c["cpu_model"]
+        assert c["detail"]["d150_all_cores"]["threads"] == c["physical_cores"] and c["detail"]["d150_one_core"]["threads"] == 1
+        assert c["value"] == c["detail"]["d150_best_width"]["pairs_per_s"] >= c["detail"]["d150_all_cores"]["pairs_per_s"]
+        assert c["cores"] == c["detail"]["d150_best_width"]["threads"] and c["cpu_model"]
     return d
 
 
