@@ -209,10 +209,16 @@ int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int6
 
 /* ---- adaptive score normalisation (utils/adaptive_score_normalization.py:27-73) ------------------ */
 
-/* Bytes of workspace: a 256-byte control block (tile counters of the score GEMM) followed by the spilled
- * cohort score matrix (whole matrix up to 4 GiB, else row chunks).  Any ws_bytes >= 256 + one padded score
- * row (4 * ceil(M / 4) * 4 bytes) is accepted by nplda_cohort_stats_f32; less gives NPLDA_ENOSPC. */
+/* Recommended bytes of workspace: enough for the spilled cohort score matrix (whole matrix up to 4 GiB, else row
+ * chunks, behind a 256-byte control block) and for the fused path's per-row candidate lists.  Any ws_bytes >= 256 + one
+ * padded score row (4 * ceil(M / 4) * 4 bytes) is accepted by nplda_cohort_stats_f32; less gives NPLDA_ENOSPC. */
 size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M);
+
+/* Smallest workspace with which nplda_cohort_stats_f32 takes its FUSED path for this shape (statistics formed in the
+ * score GEMM's epilogue, no score matrix: csrc/nplda_cohort_fused.hip) — 0 when the shape is not eligible (M < 4096,
+ * a top-N too large for the candidate lists).  With less workspace the spilling path is used; both are exact, they differ
+ * in the last bits of the fp64 means (different summation orders). */
+size_t nplda_cohort_fused_min_workspace_bytes(int64_t M, int topn, int D1, int D2);
 
 /* Cohort score matrix + per-row statistics.  z_rows (R, ldz) / q_rows (R) and z_coh (M, ldz) / q_coh (M)
  * come from nplda_embed_f32.  For every row r: stats[4r..4r+3] = (mean, std, mean_top, std_top) of the M

@@ -627,6 +627,31 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
 
 }  // namespace
 
+namespace nplda {
+
+// Gram matrix of a row table for nplda_cohort_fused.hip: slab[ks][i][j] = sum over the rows of k-group ks of
+// Z[k][i] Z[k][j] (i, j < Mp = the padded row width, a multiple of 16) and ext[ks][3][i] = the column sums, with the
+// split-K "A^T B" kernel above (A = B = Z).  The caller sums the ksplit slabs in a fixed order.
+int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int ksplit, float* slab, float* ext,
+                      hipStream_t st) {
+    if (rows <= 0 || ksplit < 1 || (Mp % 16) != 0) return NPLDA_EINVAL;
+    long long rps = (rows + ksplit - 1) / ksplit;
+    rps = (rps + 16 * kPF - 1) / (16 * kPF) * (16 * kPF);
+    WgradArgs wa = {};
+    wa.K = rows; wa.nsplit = rows; wa.ksplit = ksplit; wa.rows_per_split = rps;
+    wa.ldz = ldz; wa.ext = ext; wa.Mp = Mp;
+    WgradProblem& p1 = wa.p[0];
+    p1.A = Z; p1.lda = ldz; p1.B0 = Z; p1.B1 = Z; p1.ldb = ldz; p1.M = Mp; p1.N = Mp;
+    p1.MT = (Mp + 63) / 64; p1.NT = (Mp + 63) / 64; p1.slab = slab; p1.Mp = Mp; p1.Np = Mp; p1.extras = 1;
+    wa.p[1] = p1;
+    wa.nw0 = p1.MT * p1.NT * ksplit;
+    wa.nw = wa.nw0;
+    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
+    return nplda_launch_status();
+}
+
+}  // namespace nplda
+
 extern "C" {
 
 size_t nplda_grad_floats(int D0, int D1, int D2) {

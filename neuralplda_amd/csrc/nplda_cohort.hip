@@ -25,6 +25,8 @@
 //  K9  asnorm_apply_kernel  per trial: z-norm, t-norm, s-norm, as-norm1 from the two rows' statistics
 //                           (adaptive_score_normalization.py:65-73), fp64, ~100 B/trial: HBM-bound.
 #include "nplda_common.h"
+#include "nplda_cohort_common.h"
+#include "nplda_cohort_fused.h"
 
 namespace {
 
@@ -257,65 +259,6 @@ constexpr int kListCap = 512;       // candidate keys of the quantile shortcut
 constexpr unsigned kUnwritten = 0xffffffffu;  // a rank slot nobody wrote (as a float: one particular NaN)
 constexpr int kMaxRowLds = 38000;  // floats of one row kept in LDS (with the shortcut's lists: < 160 KiB)
 
-__device__ __forceinline__ unsigned f2key(float f) {
-    const unsigned u = __float_as_uint(f);
-    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending float order == ascending unsigned order
-}
-__device__ __forceinline__ float key2f(unsigned k) {
-    const unsigned u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
-    return __uint_as_float(u);
-}
-
-// Wave64 reductions on the DPP path: xor 1 and xor 2 by quad_perm, then rotations by 4 and 8 inside each row of 16
-// lanes (every lane of a row then holds the row's result), and the four row results meet through v_readlane.  __shfl_xor
-// compiles to ds_bpermute_b32 — a round trip through the LDS crossbar per step and per 32-bit half, 126 of them in the
-// first version of this kernel, a fifth of its time.
-template <int CTRL>
-__device__ __forceinline__ unsigned dpp_u32(unsigned v) {
-    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
-}
-template <int CTRL>
-__device__ __forceinline__ double dpp_f64(double v) {
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
-    return __hiloint2double(hi, lo);
-}
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E, kDppRor4 = 0x124, kDppRor8 = 0x128;
-
-__device__ __forceinline__ unsigned wave_sum_u32(unsigned v) {
-    v += dpp_u32<kDppXor1>(v);
-    v += dpp_u32<kDppXor2>(v);
-    v += dpp_u32<kDppRor4>(v);
-    v += dpp_u32<kDppRor8>(v);
-    return (unsigned)__builtin_amdgcn_readlane((int)v, 0) + (unsigned)__builtin_amdgcn_readlane((int)v, 16) +
-           (unsigned)__builtin_amdgcn_readlane((int)v, 32) + (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-}
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v) {
-    unsigned t;
-    t = dpp_u32<kDppXor1>(v); v = t < v ? t : v;
-    t = dpp_u32<kDppXor2>(v); v = t < v ? t : v;
-    t = dpp_u32<kDppRor4>(v); v = t < v ? t : v;
-    t = dpp_u32<kDppRor8>(v); v = t < v ? t : v;
-    const unsigned a = (unsigned)__builtin_amdgcn_readlane((int)v, 0), b = (unsigned)__builtin_amdgcn_readlane((int)v, 16),
-                   c = (unsigned)__builtin_amdgcn_readlane((int)v, 32), d = (unsigned)__builtin_amdgcn_readlane((int)v, 48);
-    const unsigned ab = a < b ? a : b, cd = c < d ? c : d;
-    return ab < cd ? ab : cd;
-}
-__device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~wave_min_u32(~v); }
-// fixed association ((r0 + r1) + r2) + r3 over the four rows of 16 lanes: deterministic
-__device__ __forceinline__ double wave_sum_f64(double v) {
-    v += dpp_f64<kDppXor1>(v);
-    v += dpp_f64<kDppXor2>(v);
-    v += dpp_f64<kDppRor4>(v);
-    v += dpp_f64<kDppRor8>(v);
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    double r[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-        r[q] = __hiloint2double(__builtin_amdgcn_readlane(hi, 16 * q), __builtin_amdgcn_readlane(lo, 16 * q));
-    return ((r[0] + r[1]) + r[2]) + r[3];
-}
-
 __device__ __forceinline__ double block_sum_d(double v, double* red) {
     v = wave_sum_f64(v);
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -381,20 +324,17 @@ __device__ __forceinline__ void for_row_keys(int use_lds, const u32x4* keys4, co
     }
 }
 
-__global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __restrict__ S, long long lds_stride,
-                                                                long long M, int topn, int lowest, int use_lds,
-                                                                double* __restrict__ stats) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+// Statistics of ONE score row (block-wide; every thread of the block calls it, the call is uniform): out4 = (mean, std,
+// mean_top, std_top).  Srow: 16-byte aligned, padded to a multiple of 4 floats.
+__device__ __forceinline__ void row_stats_row(const float* __restrict__ Srow, long long M, int topn, int lowest,
+                                              int use_lds, double* __restrict__ out4, unsigned char* smem_raw) {
     unsigned* keys = reinterpret_cast<unsigned*>(smem_raw);                  // [M] when use_lds
     u32x4* keys4 = reinterpret_cast<u32x4*>(smem_raw);
     unsigned* cnt = keys + (use_lds ? ((M + 3) / 4) * 4 : 0);                  // [2][8][4] count partials
     double* red = reinterpret_cast<double*>(cnt + 64);                         // [2][2][8]
     constexpr int NWV = kRowThreads / 64;
 
-    // newest rows first: in the cohort pipeline the GEMM has just written the matrix row tile by row tile, so the last rows
-    // are the ones still held by the memory-side cache
-    const long long row = (long long)gridDim.x - 1 - blockIdx.x;
-    const f32x4* src4 = reinterpret_cast<const f32x4*>(S + row * lds_stride);
+    const f32x4* src4 = reinterpret_cast<const f32x4*>(Srow);
     const long long nvec = (M + 3) / 4;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
 
@@ -697,7 +637,7 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
             const double mt = t1 / nn;
             double vt = t2 / nn - mt * mt;
             if (vt < 0.0) vt = 0.0;
-            double* o = stats + row * 4;
+            double* o = out4;
             o[0] = mean;
             o[1] = sqrt(var);
             o[2] = mt;
@@ -792,11 +732,66 @@ __global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __r
         const double mt = t1 / nn;
         double vt = t2 / nn - mt * mt;
         if (vt < 0.0) vt = 0.0;
-        double* o = stats + row * 4;
+        double* o = out4;
         o[0] = mean;
         o[1] = sqrt(var);
         o[2] = mt;
         o[3] = sqrt(vt);
+    }
+}
+
+__global__ __launch_bounds__(kRowThreads) void row_stats_kernel(const float* __restrict__ S, long long lds_stride,
+                                                                long long M, int topn, int lowest, int use_lds,
+                                                                double* __restrict__ stats) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    // newest rows first: in the cohort pipeline the GEMM has just written the matrix row tile by row tile, so the last rows
+    // are the ones still held by the memory-side cache
+    const long long row = (long long)gridDim.x - 1 - blockIdx.x;
+    row_stats_row(S + row * lds_stride, M, topn, lowest, use_lds, stats + row * 4, smem_raw);
+}
+
+// Rows the fused path (nplda_cohort_fused.hip) could not finish — the threshold proposed from the row's analytic mean /
+// std did not bracket the N-th smallest score (a far-from-normal row) — listed on the device.  Each block walks the
+// list: it forms the row's M scores into a scratch row with the same operation order as the MFMA tiles
+// (acc = fma chain over k ascending on (z_m, 2 P z_r), then + (q_m + q_r)) and runs the exact row statistics on it.
+struct FallbackArgs {
+    const float* zr; const float* qr; const float* zc; const float* qc; const float* P;
+    long long M, ldz, lds;
+    int kp;                      // padded embedding width (16 * ksteps)
+    int topn, lowest, use_lds;
+    const unsigned* fail_rows;   // row indices (relative to zr / stats)
+    const unsigned* nfail;
+    float* scratch;              // [gridDim.x][lds]
+    double* stats;
+};
+
+__global__ __launch_bounds__(kRowThreads) void cohort_fallback_kernel(const FallbackArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    __shared__ float arow[NPLDA_MAX_DIM];
+    const unsigned n = *a.nfail;
+    float* srow = a.scratch + (size_t)blockIdx.x * a.lds;
+    for (unsigned i = blockIdx.x; i < n; i += gridDim.x) {
+        const long long r = a.fail_rows[i];
+        __syncthreads();
+        for (int d = threadIdx.x; d < a.kp; d += kRowThreads) arow[d] = a.zr[r * a.ldz + d] * (2.0f * a.P[d]);
+        __syncthreads();
+        const float qrv = a.qr[r];
+        for (long long m = threadIdx.x; m < a.lds; m += kRowThreads) {
+            float s = 0.f;
+            if (m < a.M) {
+                const f32x4* zm = reinterpret_cast<const f32x4*>(a.zc + m * a.ldz);
+                float acc = 0.f;
+                for (int d4 = 0; d4 < a.kp / 4; ++d4) {
+                    const f32x4 v = zm[d4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc = fmaf(v[e], arow[4 * d4 + e], acc);
+                }
+                s = acc + (a.qc[m] + qrv);
+            }
+            srow[m] = s;
+        }
+        __syncthreads();  // the scratch row is complete (block-scope visibility of the global writes)
+        row_stats_row(srow, a.M, a.topn, a.lowest, a.use_lds, a.stats + r * 4, smem_raw);
     }
 }
 
@@ -834,8 +829,9 @@ extern "C" {
 // the workspace starts with the tile counters of the GEMM (one per XCD), the spilled score rows follow
 static constexpr size_t kCohortCtlBytes = 256;
 
-size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
-    if (R <= 0 || M <= 0) return 0;
+static constexpr int kFallbackBlocks = 64;
+
+static size_t spill_workspace_bytes(int64_t R, int64_t M) {
     // whole matrix if it is below 4 GiB, else row chunks of at least 128 rows
     const unsigned long long row = ((unsigned long long)M + 3) / 4 * 4 * sizeof(float);
     unsigned long long rows = (unsigned long long)R;
@@ -846,6 +842,34 @@ size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
         rows = rows / 128 * 128;
     }
     return (size_t)(rows * row) + kCohortCtlBytes;
+}
+
+// workspace of the fused path for `rows` rows (a multiple of 128): fixed part + per-row arrays + the fallback's scratch rows
+static size_t fused_workspace_bytes(const nplda::FusedPlan& p, long long rows, long long M) {
+    const size_t lds = (size_t)((M + 3) / 4 * 4);
+    return p.fixed_bytes + (size_t)rows * p.row_bytes + (size_t)kFallbackBlocks * lds * sizeof(float) + 256;
+}
+
+size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
+    if (R <= 0 || M <= 0) return 0;
+    size_t need = spill_workspace_bytes(R, M);
+    // the fused path (no score matrix) for the default top-N: its workspace is a few KB per row
+    const nplda::FusedPlan p = nplda::cohort_fused_plan(M, 500, NPLDA_MAX_DIM);
+    if (p.eligible) {
+        long long rows = (R + 127) / 128 * 128;
+        if (rows > p.max_rows) rows = p.max_rows;
+        const long long cap_rows = (long long)(((4ull << 30) - fused_workspace_bytes(p, 0, M)) / p.row_bytes) / 128 * 128;
+        if (rows > cap_rows) rows = cap_rows;  // like the spilled matrix: at most 4 GiB, the table is then chunked
+        const size_t f = fused_workspace_bytes(p, rows, M);
+        if (f > need) need = f;
+    }
+    return need;
+}
+
+size_t nplda_cohort_fused_min_workspace_bytes(int64_t M, int topn, int D1, int D2) {
+    if (M <= 0 || nplda_kernel_nb(D1, D2) == 0) return 0;
+    const nplda::FusedPlan p = nplda::cohort_fused_plan(M, topn, 16 * nplda_kernel_nb(D1, D2));
+    return p.eligible ? fused_workspace_bytes(p, 128, M) : 0;
 }
 
 int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
@@ -865,8 +889,6 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     const long long lds = (M + 3) / 4 * 4;
     const size_t row_bytes = (size_t)lds * sizeof(float);
     if (ws_bytes < kCohortCtlBytes + row_bytes) return NPLDA_ENOSPC;
-    long long rows_per = (long long)((ws_bytes - kCohortCtlBytes) / row_bytes);
-    if (rows_per > R) rows_per = R;
     hipStream_t st = (hipStream_t)stream;
     const int use_lds = M <= kMaxRowLds ? 1 : 0;
     const size_t shmem = (use_lds ? (size_t)((M + 3) / 4 * 4) * 4 : 0) + 64 * 4 + (kRowThreads / 64) * 32 + (2 * kListCap + 4 + 8 + kListCap / 2) * 4 + 16;
@@ -874,7 +896,44 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
         hipError_t e = hipFuncSetAttribute((const void*)row_stats_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                            (int)shmem);
         if (e != hipSuccess) return (int)e;
+        e = hipFuncSetAttribute((const void*)cohort_fallback_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);
+        if (e != hipSuccess) return (int)e;
     }
+
+    // ---- fused path: statistics in the GEMM's epilogue, no score matrix (nplda_cohort_fused.hip) -----------------------
+    // Chosen by the shape (M, top-N) alone, and every row is computed independently of its neighbours, so the result of
+    // a row does not depend on R, on the row's position or on how the workspace chunks the table.
+    const nplda::FusedPlan plan = nplda::cohort_fused_plan(M, topn, 16 * L.NB);
+    if (plan.eligible && ws_bytes >= fused_workspace_bytes(plan, 128, M)) {
+        const size_t scratch_bytes = (size_t)kFallbackBlocks * lds * sizeof(float);
+        long long rows_cap = (long long)((ws_bytes - plan.fixed_bytes - scratch_bytes - 256) / plan.row_bytes) / 128 * 128;
+        if (rows_cap > plan.max_rows) rows_cap = plan.max_rows;
+        if (rows_cap > (R + 127) / 128 * 128) rows_cap = (R + 127) / 128 * 128;
+        float* scratch = (float*)((char*)ws + (ws_bytes - scratch_bytes) / 256 * 256);
+        const long long resident = nplda::cohort_fused_resident_blocks();
+        if (resident <= 0) return NPLDA_EINVAL;
+        for (long long r0 = 0; r0 < R; r0 += rows_cap) {
+            const long long rc = (R - r0 < rows_cap) ? R - r0 : rows_cap;
+            unsigned* fail_rows = nullptr;
+            unsigned* nfail = nullptr;
+            if (int rc2 = nplda::cohort_fused_run(plan, z_rows + r0 * ldz, q_rows + r0, rc, z_coh, q_coh, M, ldz,
+                                                  (const float*)packed + L.oP, L.NB, topn, select_lowest ? 1 : 0,
+                                                  stats + 4 * r0, (unsigned char*)ws, rows_cap, r0 == 0, &fail_rows,
+                                                  &nfail, resident, st))
+                return rc2;
+            FallbackArgs fb;
+            fb.zr = z_rows + r0 * ldz; fb.qr = q_rows + r0; fb.zc = z_coh; fb.qc = q_coh; fb.P = (const float*)packed + L.oP;
+            fb.M = M; fb.ldz = ldz; fb.lds = lds; fb.kp = 16 * L.NB; fb.topn = topn; fb.lowest = select_lowest ? 1 : 0;
+            fb.use_lds = use_lds; fb.fail_rows = fail_rows; fb.nfail = nfail; fb.scratch = scratch; fb.stats = stats + 4 * r0;
+            hipLaunchKernelGGL(cohort_fallback_kernel, dim3(kFallbackBlocks), dim3(kRowThreads), shmem, st, fb);
+            if (int rc2 = nplda_launch_status()) return rc2;
+        }
+        return NPLDA_OK;
+    }
+
+    // ---- spill path: score matrix in the workspace, then one block per row -----------------------------------------------
+    long long rows_per = (long long)((ws_bytes - kCohortCtlBytes) / row_bytes);
+    if (rows_per > R) rows_per = R;
     // persistent tile walkers: as many blocks as are resident at once, a multiple of 8 so that a block keeps its XCD
     long long resident = 0;
     {

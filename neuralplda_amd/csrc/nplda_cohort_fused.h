@@ -1,0 +1,23 @@
+// nplda_cohort_fused.h — host interface of the fused cohort-statistics path (nplda_cohort_fused.hip) for the dispatch
+// in nplda_cohort.hip.
+#pragma once
+#include "nplda_common.h"
+
+namespace nplda {
+
+struct FusedPlan {
+    bool eligible;
+    int nxp, nx, nsb, nsub;
+    float zhi;                        // normal quantile of the candidate fraction
+    size_t fixed_bytes, row_bytes;    // workspace: fixed part and per row (rows are planned in multiples of 128)
+    long long max_rows;               // rows one launch may cover (32-bit list offsets)
+};
+
+FusedPlan cohort_fused_plan(long long M, int topn, int Mp);
+long long cohort_fused_resident_blocks();
+int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
+                     const float* q_coh, long long M, long long ldz, const float* P, int ksteps, int topn, int lowest,
+                     double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
+                     unsigned** nfail_out, long long resident, hipStream_t st);
+
+}  // namespace nplda

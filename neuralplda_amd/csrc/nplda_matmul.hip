@@ -295,6 +295,16 @@ int input_grad_from_du(const float* du, long long rows, long long ldz, const flo
     return launch_rows_matmul(a, st);
 }
 
+// out (R, ldout) = in[:, :K] . Wm for a fragment image built by frag_pack_kernel's layout (nplda_cohort_fused.hip)
+int rows_matmul_launch(const float* in, long long ldin, long long R, int K, const float* frag, int N, float* out,
+                       long long ldout, hipStream_t st) {
+    MatmulArgs a = {};
+    a.in = in; a.ldin = ldin; a.R = R; a.K = K; a.KB = (K + 15) / 16; a.XB = (N + 15) / 16; a.N = N;
+    a.frag = reinterpret_cast<const f32x4*>(frag);
+    a.out0 = out; a.out1 = out; a.nsplit = R; a.ldout = ldout;
+    return launch_rows_matmul(a, st);
+}
+
 int pad_rows(const float* in, long long ldin, long long N, int D, float* out, long long ldo, hipStream_t st) {
     if (N <= 0) return NPLDA_OK;
     const long long total = N * ldo;

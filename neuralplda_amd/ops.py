@@ -502,8 +502,9 @@ def gather_rows(table, idx, out=None):
 
 # ---- adaptive score normalisation -----------------------------------------------------------------
 
-def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None):
-    """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top)."""
+def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None, force_spill=False):
+    """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top).  force_spill (tests / A-B timing):
+    hand the call a workspace just below the fused path's minimum, so that it materialises the score matrix."""
     lib = _lib.load()
     _need_fp32(packed, "cohort_stats")
     for n, t in (("z_rows", z_rows), ("q_rows", q_rows), ("z_coh", z_coh), ("q_coh", q_coh)):
@@ -519,7 +520,16 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
         return stats
     wsb = lib.nplda_cohort_workspace_bytes(R, M)
     if max_ws_bytes is not None:
-        wsb = max(min(wsb, int(max_ws_bytes)), 256 + ((M + 3) // 4 * 4) * 4)  # control block + one score row
+        # never below one score row, nor below what keeps the call on the path its shape selects (fused / spilling)
+        floor = max(256 + ((M + 3) // 4 * 4) * 4,
+                    lib.nplda_cohort_fused_min_workspace_bytes(M, int(topn), packed.D1, packed.D2))
+        wsb = max(min(wsb, int(max_ws_bytes)), floor)
+    if force_spill:
+        fmin = lib.nplda_cohort_fused_min_workspace_bytes(M, int(topn), packed.D1, packed.D2)
+        if fmin:
+            wsb = min(wsb, fmin - 256)
+            if wsb < 256 + ((M + 3) // 4 * 4) * 4:
+                raise ValueError("no workspace size selects the spilling path for this shape")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
     with torch.cuda.device(dev):
         code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),

@@ -1,0 +1,92 @@
+"""The fused cohort-statistics path (csrc/nplda_cohort_fused.hip: statistics in the score GEMM's epilogue, no score
+matrix) against the fp64 oracle (NeuralPlda.forward on the expanded pair list, then sort-then-slice:
+adaptive_score_normalization.py:32-36) and against the spilling path it replaces.  Tolerance 2e-5 like
+tests/test_asnorm_gpu.py; run-to-run and row-order bit-reproducibility."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import nplda_oracle as orc
+from tests.test_train_gpu import rand_params
+
+pytestmark = pytest.mark.gpu
+
+
+def setup(D, R, M, seed, coh_fn=None):
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(seed)
+    p = rand_params(rng, 512, D, D)
+    xr = rng.standard_normal((R, 512)).astype(np.float32)
+    xc = rng.standard_normal((M, 512)).astype(np.float32)
+    if coh_fn is not None:
+        xc = coh_fn(rng, xc)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    zr, qr = ops.embed(torch.from_numpy(xr).cuda(), packed)
+    zc, qc = ops.embed(torch.from_numpy(xc).cuda(), packed)
+    C = orc.cohort_scores(orc.extract_plda_embeddings(xr, p, np.float64), orc.extract_plda_embeddings(xc, p, np.float64),
+                          p, np.float64)
+    return ops, packed, zr, qr, zc, qc, C
+
+
+@pytest.mark.parametrize("D,R,M,topn", [(150, 300, 10000, 500), (170, 129, 4096, 100), (24, 260, 24700, 100),
+                                        (16, 128, 5000, 37), (170, 1, 10000, 500), (150, 517, 9999, 1)])
+def test_fused_matches_oracle_and_the_spilling_path(hip_lib, D, R, M, topn):
+    ops, packed, zr, qr, zc, qc, C = setup(D, R, M, D + R + M)
+    lib = hip_lib
+    assert lib.nplda_cohort_fused_min_workspace_bytes(M, topn, D, D) > 0  # these shapes take the fused path
+    for select in ("lowest", "highest"):
+        got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select=select)
+        ref = orc.cohort_stats(C, topn, select)
+        np.testing.assert_allclose(got.cpu().numpy(), ref, atol=2e-5, rtol=2e-5, err_msg=select)
+        spill = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select=select, force_spill=True)
+        # same fp32 scores underneath: the two paths differ only by the summation order of their fp64 / centred sums
+        np.testing.assert_allclose(got.cpu().numpy(), spill.cpu().numpy(), rtol=2e-6, atol=2e-7, err_msg=select)
+        # top-N mean: both select exactly the same N scores
+        np.testing.assert_allclose(got[:, 2].cpu().numpy(), spill[:, 2].cpu().numpy(), rtol=1e-12, atol=1e-12)
+        assert torch.equal(got, ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select=select))  # bit-reproducible
+    # a row's statistics do not depend on its position, on its neighbours, or on the workspace chunking
+    got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn)
+    perm = torch.randperm(R, device="cuda")
+    assert torch.equal(ops.cohort_stats(zr[perm].contiguous(), qr[perm].contiguous(), zc, qc, packed, topn=topn), got[perm])
+    if R > 128:
+        fmin = lib.nplda_cohort_fused_min_workspace_bytes(M, topn, D, D)
+        assert torch.equal(ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, max_ws_bytes=fmin), got)  # 128-row chunks
+
+
+def _spiky(rng, xc):
+    xc[: int(0.6 * len(xc))] = xc[0]                      # 60 % identical cohort utterances: a spike of tied scores
+    return xc
+
+
+def _bimodal(rng, xc):
+    xc[::2] += 3.0 * rng.standard_normal(512).astype(np.float32)  # two clusters: rows are far from normal
+    return xc
+
+
+def _outliers(rng, xc):
+    xc[:40] *= 25.0                                        # a few huge-norm utterances (same direction after the
+    return xc                                              # length normalisation, but they move the moments)
+
+
+@pytest.mark.parametrize("coh_fn", [_spiky, _bimodal, _outliers])
+def test_rows_the_proposal_misses_take_the_general_path(hip_lib, coh_fn):
+    """Cohorts built so that the normal-model threshold cannot bracket the N-th smallest score for (some) rows — ties
+    far beyond the candidate capacity, bimodal rows: those rows are recomputed by the exact general path, results as
+    the oracle's."""
+    D, R, M, topn = 150, 200, 6000, 400
+    ops, packed, zr, qr, zc, qc, C = setup(D, R, M, 5, coh_fn)
+    for select in ("lowest", "highest"):
+        got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select=select).cpu().numpy()
+        ref = orc.cohort_stats(C, topn, select)
+        scale = np.maximum(np.abs(ref).max(axis=1, keepdims=True), 1.0)
+        assert np.all(np.abs(got - ref) <= 2e-5 * scale), (coh_fn.__name__, select, np.abs(got - ref).max())
+        assert np.array_equal(got, ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, select=select).cpu().numpy())
+
+
+def test_ineligible_shapes_keep_the_spilling_path(hip_lib):
+    assert hip_lib.nplda_cohort_fused_min_workspace_bytes(1000, 100, 150, 150) == 0        # small cohort
+    assert hip_lib.nplda_cohort_fused_min_workspace_bytes(10000, 4000, 150, 150) == 0      # top-N too large for the lists
+    assert hip_lib.nplda_cohort_fused_min_workspace_bytes(10000, 500, 150, 150) > 0
+    ops, packed, zr, qr, zc, qc, C = setup(150, 64, 8000, 9)
+    got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=3000).cpu().numpy()                # 3000 of 8000: spilling path
+    np.testing.assert_allclose(got, orc.cohort_stats(C, 3000), atol=2e-5, rtol=2e-5)
