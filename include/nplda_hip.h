@@ -219,6 +219,9 @@ size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M);
  * a top-N too large for the candidate lists).  With less workspace the spilling path is used; both are exact, they differ
  * in the last bits of the fp64 means (different summation orders). */
 size_t nplda_cohort_fused_min_workspace_bytes(int64_t M, int topn, int D1, int D2);
+/* Workspace for THIS call's parameters: the fused path's lists when the shape is eligible (a few KB per row), else the
+ * spilled matrix as nplda_cohort_workspace_bytes. */
+size_t nplda_cohort_workspace_bytes_ex(int64_t R, int64_t M, int topn, int D1, int D2);
 
 /* Cohort score matrix + per-row statistics.  z_rows (R, ldz) / q_rows (R) and z_coh (M, ldz) / q_coh (M)
  * come from nplda_embed_f32.  For every row r: stats[4r..4r+3] = (mean, std, mean_top, std_top) of the M

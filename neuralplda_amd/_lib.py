@@ -46,6 +46,7 @@ SIGNATURES = {
     "nplda_gather_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_int, _c_f32p, _c_i64, _c_vp]),
     "nplda_cohort_workspace_bytes": (_c_sz, [_c_i64, _c_i64]),
     "nplda_cohort_fused_min_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
+    "nplda_cohort_workspace_bytes_ex": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int, _c_int]),
     "nplda_cohort_stats_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int,
                                         _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
     "nplda_row_stats_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),

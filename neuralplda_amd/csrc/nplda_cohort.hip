@@ -286,19 +286,6 @@ __device__ __forceinline__ void block_sum_d2(double& a, double& b, double* red) 
 
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-// Inverse normal CDF for the quantile bracket, |error| < 4.5e-4 (Abramowitz & Stegun 26.2.23) in ~25 fp32 instructions.
-// The bracket is +-0.06 sigma wide and only SELECTS candidates (the counts decide), so this accuracy is plenty; the fp64
-// normcdfinv it replaces was a quarter of the kernel's VALU instructions (every wave evaluates it).
-__device__ __forceinline__ float fast_normcdfinv(float p) {
-    const bool lower = p < 0.5f;
-    const float pp = lower ? p : 1.0f - p;
-    const float t = sqrtf(-2.0f * __logf(fmaxf(pp, 1e-30f)));
-    const float num = 2.515517f + t * (0.802853f + t * 0.010328f);
-    const float den = 1.0f + t * (1.432788f + t * (0.189269f + t * 0.001308f));
-    const float z = t - num / den;
-    return lower ? -z : z;
-}
-
 // The row is handled in 16-byte groups (S rows are 16-byte aligned and padded to a multiple of 4 floats): the keys of
 // group g are keys4[g]; elements past M carry the key 0xffffffff, which no pivot reaches (pivots are capped at
 // 0xfffffffe; only a NaN with the payload 0x7fffffff maps there, and a row holding one has NaN statistics anyway).
@@ -779,12 +766,18 @@ __global__ __launch_bounds__(kRowThreads) void cohort_fallback_kernel(const Fall
         for (long long m = threadIdx.x; m < a.lds; m += kRowThreads) {
             float s = 0.f;
             if (m < a.M) {
-                const f32x4* zm = reinterpret_cast<const f32x4*>(a.zc + m * a.ldz);
+                // the order in which the MFMA tiles meet the features: k16-stage by stage, instruction kk of a stage
+                // multiplies the features 16 ks + 4 g + kk, g = 0..3
+                const float* zm = a.zc + m * a.ldz;
                 float acc = 0.f;
-                for (int d4 = 0; d4 < a.kp / 4; ++d4) {
-                    const f32x4 v = zm[d4];
+                for (int ks = 0; ks < a.kp / 16; ++ks) {
+                    f32x4 v[4];
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) acc = fmaf(v[e], arow[4 * d4 + e], acc);
+                    for (int g = 0; g < 4; ++g) v[g] = *reinterpret_cast<const f32x4*>(zm + 16 * ks + 4 * g);
+#pragma unroll
+                    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) acc = fmaf(v[g][kk], arow[16 * ks + 4 * g + kk], acc);
                 }
                 s = acc + (a.qc[m] + qrv);
             }
@@ -862,6 +855,20 @@ size_t nplda_cohort_workspace_bytes(int64_t R, int64_t M) {
         if (rows > cap_rows) rows = cap_rows;  // like the spilled matrix: at most 4 GiB, the table is then chunked
         const size_t f = fused_workspace_bytes(p, rows, M);
         if (f > need) need = f;
+    }
+    return need;
+}
+
+size_t nplda_cohort_workspace_bytes_ex(int64_t R, int64_t M, int topn, int D1, int D2) {
+    if (R <= 0 || M <= 0 || nplda_kernel_nb(D1, D2) == 0) return 0;
+    size_t need = spill_workspace_bytes(R, M);
+    const nplda::FusedPlan p = nplda::cohort_fused_plan(M, topn, 16 * nplda_kernel_nb(D1, D2));
+    if (p.eligible) {
+        long long rows = (R + 127) / 128 * 128;
+        if (rows > p.max_rows) rows = p.max_rows;
+        const long long cap_rows = (long long)(((4ull << 30) - fused_workspace_bytes(p, 0, M)) / p.row_bytes) / 128 * 128;
+        if (rows > cap_rows) rows = cap_rows;
+        need = fused_workspace_bytes(p, rows, M);  // the fused path never needs the score matrix
     }
     return need;
 }

@@ -22,6 +22,8 @@
 // Pre-pass (five small launches): Gram matrix of the cohort table by the split-K wgrad kernel (nplda_backward.hip) +
 // sums of q, q^2, q z; centred covariance folded with 2 P into a fragment image; (z_rows . C'') by the resident-matrix
 // GEMM (nplda_matmul.hip); one wave per row forms c_r and t_r.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "nplda_cohort_common.h"
@@ -37,7 +39,7 @@ int rows_matmul_launch(const float* in, long long ldin, long long R, int K, cons
 namespace {
 
 #ifndef NPLDA_FUSED_MINBLOCKS
-#define NPLDA_FUSED_MINBLOCKS 2   // 3 (<= 168 VGPRs) spills 50 registers in the epilogue
+#define NPLDA_FUSED_MINBLOCKS 3   // 167 VGPRs with the per-row state in LDS (52 KB per block: three blocks per CU)
 #endif
 constexpr int kSub = 64;          // slots per candidate sub-list (47 usable + slack for one tile's 16 appends)
 constexpr int kSubFull = 47;      // a sub-list that reaches this count is treated as overflowed
@@ -57,15 +59,27 @@ __global__ __launch_bounds__(256) void cohort_qz_kernel(const float* __restrict_
     const long long per = (M + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
     float acc[3] = {0.f, 0.f, 0.f}, sq = 0.f, sqq = 0.f;
-    for (long long m = lo + wy; m < hi; m += 4) {
-        const float q = qc[m];
+    // four rows in flight per wave (independent loads), accumulated in row order
+    for (long long m0 = lo + wy; m0 < hi; m0 += 16) {
+        float q[4], z[4][3];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) {
-            const int f = lane + 64 * c;
-            if (f < Mp) acc[c] = fmaf(q, zc[m * ldz + f], acc[c]);
+        for (int u = 0; u < 4; ++u) {
+            const long long m = m0 + 4 * u;
+            const long long mc = m < hi ? m : hi - 1;
+            q[u] = m < hi ? qc[mc] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const int f = lane + 64 * c;
+                z[u][c] = f < Mp ? zc[mc * ldz + f] : 0.f;
+            }
         }
-        sq += q;
-        sqq = fmaf(q, q, sqq);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+#pragma unroll
+            for (int c = 0; c < 3; ++c) acc[c] = fmaf(q[u], z[u][c], acc[c]);
+            sq += q[u];
+            sqq = fmaf(q[u], q[u], sqq);
+        }
     }
 #pragma unroll
     for (int c = 0; c < 3; ++c)
@@ -88,19 +102,27 @@ struct PrepArgs {
 };
 
 __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
+    __shared__ double zbar[NPLDA_MAX_DIM];
     const int Mp = a.Mp, KB = Mp / 16;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double n = (double)a.M;
-    auto zsum = [&](int i) {
+    if ((int)threadIdx.x < Mp) {  // every block forms the cohort mean for itself (ksplit x Mp L2-resident floats)
         double s = 0.0;
-        for (int k = 0; k < a.ksplit; ++k) s += (double)a.ext[((size_t)k * 4 + 3) * Mp + i];
-        return s;
-    };
-    auto qsum = [&](int i) {
-        double s = 0.0;
-        for (int b = 0; b < kQzBlocks; ++b) s += (double)a.qz[(size_t)b * (Mp + 2) + i];
-        return s;
-    };
+        for (int k = 0; k < a.ksplit; ++k) s += (double)a.ext[((size_t)k * 4 + 3) * Mp + threadIdx.x];
+        zbar[threadIdx.x] = s / n;
+    }
+    __syncthreads();
+    __shared__ double qsh[NPLDA_MAX_DIM + 2];
+    if (blockIdx.x == 0) {  // sums of q z, q, q^2 over the qz kernel's blocks, fixed order (only block 0 needs them)
+        for (int i = threadIdx.x; i < Mp + 2; i += 256) {
+            double sacc = 0.0;
+#pragma unroll 16
+            for (int b = 0; b < kQzBlocks; ++b) sacc += (double)a.qz[(size_t)b * (Mp + 2) + i];
+            qsh[i] = sacc;
+        }
+        __syncthreads();
+    }
+    auto qsum = [&](int i) { return qsh[i]; };
     if (idx < (size_t)KB * KB * 256) {
         const int e = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
         const size_t blk = idx >> 8;
@@ -108,12 +130,12 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
         const int i = 16 * kb + 4 * (lane >> 4) + e, j = 16 * xb + (lane & 15);
         double g = 0.0;
         for (int k = 0; k < a.ksplit; ++k) g += (double)a.slab[((size_t)k * Mp + i) * Mp + j];
-        const double cov = g / n - (zsum(i) / n) * (zsum(j) / n);
+        const double cov = g / n - zbar[i] * zbar[j];
         a.frag[idx] = (float)(4.0 * (double)a.P[i] * (double)a.P[j] * cov);
     }
     if (idx < (size_t)Mp) {
         const int i = (int)idx;
-        const double zm = zsum(i) / n, qm = qsum(Mp) / n;
+        const double zm = zbar[i], qm = qsum(Mp) / n;
         a.vec[i] = (float)(2.0 * (double)a.P[i] * zm);
         a.vec[Mp + i] = (float)(4.0 * (double)a.P[i] * (qsum(i) / n - qm * zm));
         if (i == 0) {
@@ -124,7 +146,8 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
     }
 }
 
-// one wave per row: c_r (centre) and t_r (candidate threshold), both in "ordered" values w = sgn * s
+// one wave per row: c_r = the row's analytic mean and t_r = the candidate threshold, c_r + sgn * zhi * sd (zhi < 0: below the
+// mean for the N smallest, sgn = +1; above it for the N largest, sgn = -1)
 __global__ __launch_bounds__(256) void cohort_threshold_kernel(const float* __restrict__ zr, const float* __restrict__ qr,
                                                                const float* __restrict__ tmp, long long R,
                                                                long long ldz, int Mp, const float* __restrict__ vec,
@@ -150,9 +173,8 @@ __global__ __launch_bounds__(256) void cohort_threshold_kernel(const float* __re
         const float mean = qr[r] + vec[2 * Mp] + mu;
         const float var = vec[2 * Mp + 1] + lin + quad;
         const float sd = sqrtf(fmaxf(var, 0.f));
-        const float c = sgn * mean;
-        crow[r] = c;
-        trow[r] = c + zhi * sd;
+        crow[r] = mean;
+        trow[r] = mean + sgn * zhi * sd;
     }
 }
 
@@ -167,18 +189,23 @@ struct FusedArgs {
     unsigned* ctr;          // 8 work-item counters (one per XCD), zero at launch
     const float* crow;      // (R)
     const float* trow;      // (R)
-    float* lists;           // [R][nsub][kSub]
+    float* lists;           // [R][kSub][nsub]: slot e of sub-list s of row r at (r kSub + e) nsub + s (slot-major: the
+                            // select kernel reads whole slot rows, a row's appended lines stay dense)
     unsigned* counts;       // [R][nsub]
     double* part;           // [R][nsub / 4][2]
     int nsub;               // 8 (bands per super-band) * nsb * 2 (wave columns) * 4 (lane groups)
 };
 
-template <bool LOWEST>
-__global__ __launch_bounds__(256, NPLDA_FUSED_MINBLOCKS) void cohort_fused_kernel(const FusedArgs a) {
-    __shared__ f32x4 smem[2 * 2 * 512 + 48 + 128 + 1];
+template <bool LOWEST, int MINBLOCKS>
+__global__ __launch_bounds__(256, MINBLOCKS) void cohort_fused_kernel(const FusedArgs a) {
+    // ONE __shared__ object (see cohort_gemm_kernel): stages | 2 P fragments | self terms | next-slot word | per-lane row
+    // state (centre, threshold, running sums of the lane's four rows: 16 floats per thread kept OUT of the register file,
+    // which is what lets three blocks share a CU)
+    __shared__ f32x4 smem[2 * 2 * 512 + 48 + 128 + 8 + 1024];
     f32x4 (*tile)[2][512] = reinterpret_cast<f32x4 (*)[2][512]>(smem);
     f32x4* p2s = smem + 2048;
     float* qs = reinterpret_cast<float*>(smem + 2096);
+    float* lst = reinterpret_cast<float*>(smem + 2232) + threadIdx.x;  // lst[256 k]: k = 0..3 centre, 4..7 threshold, 8..11 s1, 12..15 s2
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
@@ -249,20 +276,20 @@ __global__ __launch_bounds__(256, NPLDA_FUSED_MINBLOCKS) void cohort_fused_kerne
 
     // per-lane state of the work item: the lane's four rows (ca), their centre / threshold, the write cursor of the
     // lane's private candidate sub-list of each row, and the running fp64 sums
-    float cen[4], thr[4];
+    // cur: BYTE offset of the lane's next free slot in each row's private sub-list.  The centred sums of ONE work item
+    // (~10 tiles x 16 values per lane and row) are kept in fp32: ample.
     unsigned cur[4];
-    float s1[4], s2[4];  // centred sums of ONE work item (~10 tiles x 16 values per lane and row): fp32 is ample
     auto item_begin = [&](long long rb_, int band_) {
 #pragma unroll
         for (int ca = 0; ca < 4; ++ca) {
             const long long row = rb_ + (wave >> 1) * 64 + 16 * ca + i16;
             const bool ok = row < a.R;
             const long long rc = ok ? row : a.R - 1;
-            cen[ca] = a.crow[rc];
-            thr[ca] = ok ? a.trow[rc] : -__builtin_inff();   // rows past the table never append
-            cur[ca] = (unsigned)((rc * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4) * kSub);
-            s1[ca] = 0.f;
-            s2[ca] = 0.f;
+            lst[256 * ca] = a.crow[rc];
+            lst[256 * (4 + ca)] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
+            lst[256 * (8 + ca)] = 0.f;
+            lst[256 * (12 + ca)] = 0.f;
+            cur[ca] = 4u * (unsigned)(rc * kSub * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4);
         }
     };
     auto item_end = [&](long long rb_, int band_) {
@@ -270,14 +297,14 @@ __global__ __launch_bounds__(256, NPLDA_FUSED_MINBLOCKS) void cohort_fused_kerne
         for (int ca = 0; ca < 4; ++ca) {
             const long long row = rb_ + (wave >> 1) * 64 + 16 * ca + i16;
             // the four lane groups of a row: fixed association ((g0 + g1) + (g2 + g3)) by two exchanges
-            double t1 = (double)s1[ca], t2 = (double)s2[ca];
+            double t1 = (double)lst[256 * (8 + ca)], t2 = (double)lst[256 * (12 + ca)];
             t1 += __hiloint2double(__shfl_xor(__double2hiint(t1), 16, 64), __shfl_xor(__double2loint(t1), 16, 64));
             t2 += __hiloint2double(__shfl_xor(__double2hiint(t2), 16, 64), __shfl_xor(__double2loint(t2), 16, 64));
             t1 += __hiloint2double(__shfl_xor(__double2hiint(t1), 32, 64), __shfl_xor(__double2loint(t1), 32, 64));
             t2 += __hiloint2double(__shfl_xor(__double2hiint(t2), 32, 64), __shfl_xor(__double2loint(t2), 32, 64));
             if (row < a.R) {
                 const size_t sub = (size_t)row * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4;
-                a.counts[sub] = cur[ca] & (kSub - 1);
+                a.counts[sub] = (cur[ca] / 4u - (unsigned)(row * kSub * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4)) / (unsigned)a.nsub;
                 if (g4 == 0) {
                     double* o = a.part + ((size_t)row * (a.nsub / 4) + band_ * 2 + (wave & 1)) * 2;
                     o[0] = t1;
@@ -357,38 +384,71 @@ __global__ __launch_bounds__(256, NPLDA_FUSED_MINBLOCKS) void cohort_fused_kerne
         f32x4 qmv[4];
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) qmv[cb] = *reinterpret_cast<const f32x4*>(qm_s + 16 * cb);
+        const unsigned stride_b = 4u * (unsigned)a.nsub;          // bytes between consecutive slots of a sub-list
+        const long long rlane = rb + (wave >> 1) * 64 + i16;       // this lane's row of ca = 0
+        const unsigned sidx = (unsigned)((band * 2 + (wave & 1)) * 4 + g4);
+        const float* lbase = a.lists;
         auto epilogue = [&](auto masked) {
             constexpr bool MASKED = decltype(masked)::value;
+            typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int ca = 0; ca < 4; ++ca) {
                 const float qrv = qr_s[16 * ca];
-                const float c = cen[ca], th = thr[ca];
-                float ps = s1[ca], pq = s2[ca];
+                const float c = lst[256 * ca], th = lst[256 * (4 + ca)];
+                // two-wide partial sums: the adds / fmas below are packed fp32 instructions (v_pk_add_f32, v_pk_fma_f32)
+                f32x2 ps2 = {lst[256 * (8 + ca)], 0.f}, pq2 = {lst[256 * (12 + ca)], 0.f};
                 unsigned o = cur[ca];
 #pragma unroll
                 for (int cb = 0; cb < 4; ++cb) {
-                    const f32x4 s4 = acc[ca][cb] + (qmv[cb] + qrv);   // the score, same bits as the spilling kernel
+                    f32x4 s4 = acc[ca][cb] + (qmv[cb] + qrv);   // the score, same bits as the spilling kernel
+                    f32x4 d4 = s4 - c;                             // centred on the row's analytic mean
+                    if (MASKED) {
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float s = s4[r];
-                        float w = LOWEST ? s : -s;
-                        float d = w - c;
-                        if (MASKED) {
+                        for (int r = 0; r < 4; ++r) {
                             const bool okc = m0 + 16 * cb + 4 * g4 + r < a.M;
-                            d = okc ? d : 0.f;
-                            w = okc ? w : __builtin_inff();
-                        }
-                        ps += d;
-                        pq = fmaf(d, d, pq);
-                        if (w <= th) {
-                            a.lists[o] = s;
-                            ++o;
+                            d4[r] = okc ? d4[r] : 0.f;
+                            s4[r] = okc ? s4[r] : (LOWEST ? __builtin_inff() : -__builtin_inff());
                         }
                     }
+                    const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
+                    ps2 += dl;
+                    ps2 += dh;
+                    pq2 = __builtin_elementwise_fma(dl, dl, pq2);
+                    pq2 = __builtin_elementwise_fma(dh, dh, pq2);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        // if (s <= th) { lists[o] = s; o += stride; } (>= for the N largest) as one exec-masked store: no
+                        // branch, no 64-bit address arithmetic (SGPR base + 32-bit byte offset), one VALU for the cursor
+                        unsigned long long sv;
+                        if (LOWEST)
+                            asm volatile(
+                                "v_cmp_le_f32 vcc, %[s], %[th]\n\t"
+                                "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                "global_store_dword %[o], %[s], %[base]\n\t"
+                                "v_add_u32 %[o], %[o], %[st]\n\t"
+                                "s_mov_b64 exec, %[sv]"
+                                : [o] "+v"(o), [sv] "=&s"(sv)
+                                : [th] "v"(th), [s] "v"(s4[r]), [base] "s"(lbase), [st] "s"(stride_b)
+                                : "vcc", "memory");
+                        else
+                            asm volatile(
+                                "v_cmp_ge_f32 vcc, %[s], %[th]\n\t"
+                                "s_and_saveexec_b64 %[sv], vcc\n\t"
+                                "global_store_dword %[o], %[s], %[base]\n\t"
+                                "v_add_u32 %[o], %[o], %[st]\n\t"
+                                "s_mov_b64 exec, %[sv]"
+                                : [o] "+v"(o), [sv] "=&s"(sv)
+                                : [th] "v"(th), [s] "v"(s4[r]), [base] "s"(lbase), [st] "s"(stride_b)
+                                : "vcc", "memory");
+                    }
                 }
-                s1[ca] = ps;
-                s2[ca] = pq;
-                const unsigned lim = (o & ~(unsigned)(kSub - 1)) + kSubFull;  // o stays inside its kSub-slot sub-list
+                lst[256 * (8 + ca)] = ps2[0] + ps2[1];
+                lst[256 * (12 + ca)] = pq2[0] + pq2[1];
+                // at most kSubFull entries stay: slot kSubFull absorbs what a full sub-list still receives (the select
+                // kernel treats a count of kSubFull as an overflow)
+                long long rc = rlane + 16 * ca;
+                if (rc >= a.R) rc = a.R - 1;
+                const unsigned lim = 4u * ((unsigned)((rc * kSub + kSubFull) * a.nsub) + sidx);
                 cur[ca] = o < lim ? o : lim;
             }
         };
@@ -414,7 +474,9 @@ __global__ __launch_bounds__(256, NPLDA_FUSED_MINBLOCKS) void cohort_fused_kerne
 struct FinishArgs {
     const float* lists; const unsigned* counts; const double* part; const float* crow;
     long long R, M;
-    int nsub, topn, lowest;
+    const float* trow;
+    float zhi, fhi;                       // the proposal: t_r = c_r + sgn zhi sd_r, fhi = Phi(zhi) = proposed fraction
+    int nsub, nsub_valid, topn, lowest;   // sub-lists [nsub_valid, nsub) belong to bands past the last column tile: never written
     unsigned* nfail; unsigned* fail_rows;
     double* stats;
 };
@@ -432,7 +494,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int s = 64 * j + lane;
-        creg[j] = s < a.nsub ? cnt[s] : 0u;
+        creg[j] = s < a.nsub_valid ? cnt[s] : 0u;
         ovf |= creg[j] >= (unsigned)kSubFull ? 1u : 0u;
         unsigned inc = creg[j];  // inclusive scan over the 64 lanes
 #pragma unroll
@@ -451,18 +513,26 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
         if (lane == 0) a.fail_rows[atomicAdd(a.nfail, 1u)] = (unsigned)row;
         return;
     }
-    // gather the sub-lists, in their fixed order, into this wave's LDS run as order-preserving keys
-    const float* lrow = a.lists + (size_t)row * a.nsub * kSub;
+    // gather the sub-lists (lane = sub-list, slot rows are contiguous) into this wave's LDS run as order-preserving
+    // keys: element e of sub-list s lands at pre[s] + e — a fixed order
+    const float* lrow = a.lists + (size_t)row * kSub * a.nsub;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        if (64 * j >= a.nsub) break;
-#pragma unroll 8
-        for (int sl = 0; sl < 64; ++sl) {
-            const unsigned c = (unsigned)__builtin_amdgcn_readlane((int)creg[j], sl);   // wave-uniform
-            const unsigned b = (unsigned)__builtin_amdgcn_readlane((int)pre[j], sl);
-            if ((unsigned)lane < c) {
-                const float v = lrow[(size_t)(64 * j + sl) * kSub + lane];
-                kl[b + lane] = f2key(a.lowest ? v : -v);
+        if (64 * j >= a.nsub_valid) break;
+        const unsigned maxc = wave_max_u32(creg[j]);
+        for (unsigned e0 = 0; e0 < maxc; e0 += 16) {
+            float v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                // unconditional (slot index clamped into the row's list region): a load under a lane predicate is a
+                // branch with its own wait, and the 30-odd slot rows of a row then come in one memory round trip each
+                const unsigned e = e0 + u < (unsigned)kSub ? e0 + u : (unsigned)kSub - 1;
+                v[u] = lrow[(size_t)e * a.nsub + 64 * j + lane];
+            }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                const unsigned e = e0 + u;
+                if (e < creg[j]) kl[pre[j] + e] = f2key(a.lowest ? v[u] : -v[u]);
             }
         }
     }
@@ -480,15 +550,68 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     }
     unsigned lo = wave_min_u32(kmin), hi = wave_max_u32(kmax);
     const int J = (int)((total + 63) / 64);  // wave-uniform: only the occupied register slots are compared
-    while (lo < hi) {
-        const unsigned mid = lo + (hi - lo) / 2;
+    // wave-wide count of keys <= p on the scalar unit: one v_cmp per register, popcount of its lane mask
+    auto count_le = [&](unsigned p) {
         unsigned c = 0;
 #pragma unroll
         for (int j = 0; j < kCandMax / 64; ++j)
-            if (j < J) c += k[j] <= mid;
-        c = wave_sum_u32(c);
-        if (c >= (unsigned)N) hi = mid;
-        else lo = mid + 1;
+            if (j < J) c += (unsigned)__builtin_popcountll(__ballot(k[j] <= p));
+        return c;
+    };
+    // Shortcut.  A bisection over the candidates' key range takes ~23 counts of ~17 registers each (the scalar unit
+    // bounds it: 95 of this kernel's 156 us).  Instead: the list's own size calibrates the normal model of the row's
+    // tail (the model predicted fhi M candidates below t_r, `total` came), that gives the value expected at rank N and
+    // the local density; two counts check a bracket of ~+-96 ranks around it, its <= 256 keys are compacted (in their
+    // fixed order) and the bisection runs on four registers per lane.  The counts decide; a miss takes the full search.
+    unsigned rank = (unsigned)N;
+    {
+        const float c = a.crow[row], t = a.trow[row];
+        const float sgn = a.lowest ? 1.f : -1.f;
+        const float sd = (t - c) / (sgn * a.zhi);
+        const float q = a.fhi * (float)N / (float)total;
+        const float z0 = fast_normcdfinv(q);
+        const float rho = (float)total / a.fhi * 0.3989423f * __expf(-0.5f * z0 * z0) / sd;  // candidates per unit score
+        const float T0 = sgn * c + z0 * sd, delta = 96.f / rho;
+        unsigned p1 = f2key(T0 - delta), p2 = f2key(T0 + delta);
+        if (sd > 0.f && rho > 0.f && p1 < p2 && p2 < 0xffffffffu) {
+            const unsigned c1 = count_le(p1), c2 = count_le(p2);
+            if (c1 < (unsigned)N && (unsigned)N <= c2 && c2 - c1 <= 256u) {
+                unsigned base = 0;
+#pragma unroll
+                for (int j = 0; j < kCandMax / 64; ++j) {
+                    if (j < J) {
+                        const bool in = k[j] > p1 && k[j] <= p2;
+                        const unsigned long long m = __ballot(in);
+                        const unsigned pos = base + __builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+                        if (in) kl[pos] = k[j];
+                        base += (unsigned)__builtin_popcountll(m);
+                    }
+                }
+                __builtin_amdgcn_s_waitcnt(0xC07F);
+                unsigned kk[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) kk[j] = (unsigned)(lane + 64 * j) < base ? kl[lane + 64 * j] : 0xffffffffu;
+                rank = (unsigned)N - c1;
+                lo = p1 + 1;
+                hi = p2;
+                while (lo < hi) {
+                    const unsigned mid = lo + (hi - lo) / 2;
+                    unsigned cc = 0;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) cc += (unsigned)__builtin_popcountll(__ballot(kk[j] <= mid));
+                    if (cc >= rank) hi = mid;
+                    else lo = mid + 1;
+                }
+                rank = 0;  // done
+            }
+        }
+    }
+    if (rank != 0) {
+        while (lo < hi) {
+            const unsigned mid = lo + (hi - lo) / 2;
+            if (count_le(mid) >= (unsigned)N) hi = mid;
+            else lo = mid + 1;
+        }
     }
     const unsigned tkey = lo;  // key of the N-th smallest score
     double t1 = 0.0, t2 = 0.0;
@@ -509,7 +632,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     // whole-row sums: the (band, wave column) partials in their fixed order
     double d1 = 0.0, d2 = 0.0;
     const double* pr = a.part + (size_t)row * (a.nsub / 4) * 2;
-    for (int i = lane; i < a.nsub / 4; i += 64) {
+    for (int i = lane; i < a.nsub_valid / 4; i += 64) {
         d1 += pr[2 * i];
         d2 += pr[2 * i + 1];
     }
@@ -520,7 +643,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
         const double mw = d1 / n;
         double var = d2 / n - mw * mw;
         if (var < 0.0) var = 0.0;
-        const double mean_w = (double)a.crow[row] + mw;
+        const double mean_s = (double)a.crow[row] + mw;
         double tv = (double)key2f(tkey);           // the threshold in ordered space -> raw score
         if (!a.lowest) tv = -tv;
         const double ties = nn - (double)nless;
@@ -530,7 +653,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
         double vt = t2 / nn - mt * mt;
         if (vt < 0.0) vt = 0.0;
         double* o = a.stats + row * 4;
-        o[0] = a.lowest ? mean_w : -mean_w;
+        o[0] = mean_s;
         o[1] = sqrt(var);
         o[2] = mt;
         o[3] = sqrt(vt);
@@ -558,12 +681,18 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     FusedPlan p = {};
     p.eligible = false;
     if (M < 4096 || topn < 1 || Mp < 16 || Mp > NPLDA_MAX_DIM) return p;
-    const double want = 2.0 * topn + 16.0;           // candidates proposed per row
+    // candidates proposed per row: about twice the wanted count, and relatively more when N is small — the proposal
+    // sits far out in the tail there, where a row's distribution agrees least with the normal model
+    const double want = 2.0 * topn + 16.0 + 300.0 * exp(-(double)topn / 300.0);
     const double f = want / (double)M;
     if (f > 0.25 || want > 0.8 * kCandMax) return p;
     const long long nx = (M + 127) / 128;
     p.nx = (int)nx;
     p.nxp = (int)((nx + 7) / 8 < 24 ? (nx + 7) / 8 : 24);
+    if (const char* e = getenv("NPLDA_FUSED_NXP")) {  // tuning knob: column tiles per work item
+        const int v = atoi(e);
+        if (v >= 1 && v <= 24) p.nxp = v;
+    }
     p.nsb = (int)((nx + 8LL * p.nxp - 1) / (8LL * p.nxp));
     p.nsub = 8 * p.nsb * 8;
     if (p.nsub > 256) return p;                       // the select kernel holds the sub-list counts in 4 registers
@@ -571,6 +700,7 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     const double lam = f * (double)p.nxp * 128.0 / 8.0;
     if (lam + 6.0 * sqrt(lam) + 4.0 > (double)kSubFull) return p;
     p.zhi = host_normcdfinv(f);
+    p.fhi = (float)f;
     const size_t kb = (size_t)Mp / 16;
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256(kb * kb * 256 * 4) +
@@ -634,11 +764,13 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     fa.nsub = p.nsub;
     long long grid = 8LL * fa.ny * p.nsb;  // at most one block per work item of the busiest XCD
     if (grid > resident) grid = resident;
-    if (lowest) hipLaunchKernelGGL(cohort_fused_kernel<true>, dim3((unsigned)grid), dim3(256), 0, st, fa);
-    else hipLaunchKernelGGL(cohort_fused_kernel<false>, dim3((unsigned)grid), dim3(256), 0, st, fa);
+    if (lowest) hipLaunchKernelGGL((cohort_fused_kernel<true, NPLDA_FUSED_MINBLOCKS>), dim3((unsigned)grid), dim3(256), 0, st, fa);
+    else hipLaunchKernelGGL((cohort_fused_kernel<false, NPLDA_FUSED_MINBLOCKS>), dim3((unsigned)grid), dim3(256), 0, st, fa);
     if (int rc = nplda_launch_status()) return rc;
 
-    FinishArgs fi = {lists, counts, part, crow, R, M, p.nsub, topn, lowest, ctl + 8, fail_rows, stats};
+    const int nbands = (p.nx + p.nxp - 1) / p.nxp;  // bands that hold column tiles
+    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, nbands * 8, topn, lowest, ctl + 8,
+                     fail_rows, stats};
     hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, fi);
     return nplda_launch_status();
 }
@@ -647,7 +779,7 @@ long long cohort_fused_resident_blocks() {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused_kernel<true>, 256, 0) != hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused_kernel<true, NPLDA_FUSED_MINBLOCKS>, 256, 0) != hipSuccess)
         return 0;
     long long r = (long long)cus * per_cu / 8 * 8;
     return r < 8 ? 8 : r;

@@ -157,7 +157,9 @@ int launch_rows_matmul(MatmulArgs a, hipStream_t st) {
     if (nt > 0x7fffffffLL) return NPLDA_EINVAL;
     a.ntiles = (int)nt;
     // column blocks per LDS-resident slice: 8 while KB * 8 KiB fits comfortably (dx: KB <= 12 -> <= 96 KiB), else 4
-    const int NS = a.KB * 8 <= 96 ? 8 : 4;
+    // ... and 4 as well when 8-wide slices would leave the last slice mostly empty (N = 176: 8 + 3 blocks -> 4 + 4 + 3,
+    // and 44 KiB of LDS instead of 88: three resident blocks per CU)
+    const int NS = (a.KB * 8 <= 96 && (a.XB % 8 == 0 || a.XB >= 24)) ? 8 : 4;
     const size_t lds = (size_t)a.KB * NS * 1024;
     if (lds > 160 * 1024) return NPLDA_EUNSUPPORTED;
     const int slices = (a.XB + NS - 1) / NS;

@@ -502,9 +502,12 @@ def gather_rows(table, idx, out=None):
 
 # ---- adaptive score normalisation -----------------------------------------------------------------
 
-def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None, force_spill=False):
+def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None, force_spill=False,
+                 return_fallback_rows=False):
     """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top).  force_spill (tests / A-B timing):
-    hand the call a workspace just below the fused path's minimum, so that it materialises the score matrix."""
+    hand the call a workspace just below the fused path's minimum, so that it materialises the score matrix.
+    return_fallback_rows (diagnostics): also return how many rows of the (last chunk of the) fused path were handed to the
+    general path because the proposed threshold did not bracket their N-th smallest score (reads the workspace: a sync)."""
     lib = _lib.load()
     _need_fp32(packed, "cohort_stats")
     for n, t in (("z_rows", z_rows), ("q_rows", q_rows), ("z_coh", z_coh), ("q_coh", q_coh)):
@@ -518,7 +521,9 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
     stats = torch.empty((R, 4), dtype=torch.float64, device=dev)
     if R == 0:
         return stats
-    wsb = lib.nplda_cohort_workspace_bytes(R, M)
+    wsb = lib.nplda_cohort_workspace_bytes_ex(R, M, int(topn), packed.D1, packed.D2)
+    if force_spill:
+        wsb = lib.nplda_cohort_workspace_bytes(R, M)
     if max_ws_bytes is not None:
         # never below one score row, nor below what keeps the call on the path its shape selects (fused / spilling)
         floor = max(256 + ((M + 3) // 4 * 4) * 4,
@@ -537,6 +542,9 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
                                           packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0,
                                           _lib.ptr(stats), _lib.ptr(ws), wsb, _lib.current_stream())
     _lib.check(code, "nplda_cohort_stats_f32")
+    if return_fallback_rows:
+        fused = lib.nplda_cohort_fused_min_workspace_bytes(M, int(topn), packed.D1, packed.D2)
+        return stats, (int(ws.view(torch.int32)[8].item()) if fused and wsb >= fused else None)
     return stats
 
 
