@@ -7,7 +7,7 @@ namespace nplda {
 
 struct FusedPlan {
     bool eligible;
-    int nxp, nx, nsb, nsub;
+    int nbands, nx, nsub;             // column bands (a multiple of 8), column tiles, candidate sub-lists per row
     float zhi, fhi;                   // proposed candidate fraction fhi and its normal quantile zhi = Phi^-1(fhi)
     size_t fixed_bytes, row_bytes;    // workspace: fixed part and per row (rows are planned in multiples of 128)
     long long max_rows;               // rows one launch may cover (32-bit list offsets)

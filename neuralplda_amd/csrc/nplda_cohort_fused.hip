@@ -22,7 +22,6 @@
 // Pre-pass (five small launches): Gram matrix of the cohort table by the split-K wgrad kernel (nplda_backward.hip) +
 // sums of q, q^2, q z; centred covariance folded with 2 P into a fragment image; (z_rows . C'') by the resident-matrix
 // GEMM (nplda_matmul.hip); one wave per row forms c_r and t_r.
-#include <stdlib.h>
 
 #include <type_traits>
 
@@ -38,11 +37,8 @@ int rows_matmul_launch(const float* in, long long ldin, long long R, int K, cons
 
 namespace {
 
-#ifndef NPLDA_FUSED_MINBLOCKS
-#define NPLDA_FUSED_MINBLOCKS 3   // 167 VGPRs with the per-row state in LDS (52 KB per block: three blocks per CU)
-#endif
-constexpr int kSub = 64;          // slots per candidate sub-list (47 usable + slack for one tile's 16 appends)
-constexpr int kSubFull = 47;      // a sub-list that reaches this count is treated as overflowed
+constexpr int kSub = 128;         // slots per candidate sub-list (111 usable + slack for one tile's 16 appends)
+constexpr int kSubFull = 111;     // a sub-list that reaches this count is treated as overflowed
 constexpr int kCandMax = 2048;    // candidates one row may bring to the select kernel (32 keys per lane)
 constexpr int kGramSplit = 16;    // k-groups of the cohort Gram matrix
 constexpr int kQzBlocks = 64;
@@ -179,233 +175,215 @@ __global__ __launch_bounds__(256) void cohort_threshold_kernel(const float* __re
 }
 
 // ------------------------------------------------------------------------------------------------------------------
-// the fused GEMM (tile pipeline of cohort_gemm_kernel, nplda_cohort.hip — see the comments there — with the statistics
-// epilogue instead of the stores)
+// the fused GEMM: rows in registers, only the cohort goes through LDS, statistics epilogue instead of stores
 // ------------------------------------------------------------------------------------------------------------------
 struct FusedArgs {
     const float* zr; const float* qr; const float* zc; const float* qc; const float* P;
     long long R, M, ldz;
-    int ksteps, nxp, ny, nx, nsb;
+    int ksteps, nbands, ny, nx;   // nbands: a multiple of 8; band b -> XCD b % 8, column tiles [b nx / nbands, (b + 1) nx / nbands)
     unsigned* ctr;          // 8 work-item counters (one per XCD), zero at launch
     const float* crow;      // (R)
     const float* trow;      // (R)
-    float* lists;           // [R][kSub][nsub]: slot e of sub-list s of row r at (r kSub + e) nsub + s (slot-major: the
-                            // select kernel reads whole slot rows, a row's appended lines stay dense)
+    float* lists;           // [R][nbands][kSub][4]: slot e of sub-list (band, g) of row r at ((r nbands + band) kSub + e) 4 + g.
+                            // The 128-byte lines of a (row, band) region are written by ONE wave, while its block works
+                            // through the band: they fill up in that XCD's L2 and go to memory once.  (A slot-major
+                            // [R][kSub][nsub] layout — every line shared by all bands, i.e. by blocks on all XCDs at
+                            // different times — turned each 4-byte append into its own partial-line write-back: 575 MB
+                            // of HBM writes for 88 MB of candidates, profiles/r02n.)
     unsigned* counts;       // [R][nsub]
     double* part;           // [R][nsub / 4][2]
-    int nsub;               // 8 (bands per super-band) * nsb * 2 (wave columns) * 4 (lane groups)
+    int nsub;               // nbands * 4 (lane groups)
 };
 
-template <bool LOWEST, int MINBLOCKS>
-__global__ __launch_bounds__(256, MINBLOCKS) void cohort_fused_kernel(const FusedArgs a) {
-    // ONE __shared__ object (see cohort_gemm_kernel): stages | 2 P fragments | self terms | next-slot word | per-lane row
-    // state (centre, threshold, running sums of the lane's four rows: 16 floats per thread kept OUT of the register file,
-    // which is what lets three blocks share a CU)
-    __shared__ f32x4 smem[2 * 2 * 512 + 48 + 128 + 8 + 1024];
-    f32x4 (*tile)[2][512] = reinterpret_cast<f32x4 (*)[2][512]>(smem);
-    f32x4* p2s = smem + 2048;
-    float* qs = reinterpret_cast<float*>(smem + 2096);
-    float* lst = reinterpret_cast<float*>(smem + 2232) + threadIdx.x;  // lst[256 k]: k = 0..3 centre, 4..7 threshold, 8..11 s1, 12..15 s2
+// The first form of this kernel kept the tile pipeline of the spilling GEMM (cohort_gemm_kernel): both operands staged
+// through LDS one k16 stage at a time, a barrier per stage — 830-880 us at cfg3, 0.62 of the fp32-MFMA peak, the same as
+// the GEMM it replaced.  But here a block OWNS its rows for a whole band of column tiles, which is the situation of the
+// forward kernel (nplda_fwd_v3.h): the per-row operand can live in REGISTERS for the
+// whole work item (a wave's 32 rows x K <= 192: 2 x NB float4 per lane, pre-multiplied by 2 P) and only the cohort
+// streams — as whole 64-column tiles in MFMA-fragment order (the LDS-DMA takes a per-lane source address, so one wave
+// instruction drops a finished 1 KiB A-fragment into LDS), double buffered, ONE barrier per tile instead of eleven,
+// a quarter of the L2 -> LDS traffic per MFMA (a tile serves 256 rows, and no row operand is staged at all), and the
+// epilogue works on 32 accumulator registers at a time.
+template <bool LOWEST, int NB>
+__global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a) {
+    constexpr int NF = 4 * NB;  // 1 KiB fragments of a 64-column tile: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..
+    __shared__ f32x4 smem[2 * NF * 64 + 2 * 16 + NB * 4 + 2];
+    f32x4* tbuf = smem;
+    float* qms = reinterpret_cast<float*>(smem + 2 * NF * 64);                 // q_m of the two buffered tiles
+    f32x4* p2s = smem + 2 * NF * 64 + 32;                                      // 2 P as fragment-shaped float4
+    unsigned* nxt_s = reinterpret_cast<unsigned*>(smem + 2 * NF * 64 + 32 + NB * 4);
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
     const int xcd = blockIdx.x & 7;
-    // work item `slot` of this XCD: super-band by super-band, row tile by row tile -> (row tile, band, its column tiles)
-    auto decode = [&](int slot, long long& rb, int& band, int& tx0, int& tx1) {
-        for (int sb = 0; sb < a.nsb; ++sb) {
-            const int t0 = (sb * 8 + xcd) * a.nxp;
-            int w = a.nx - t0;
-            if (w > a.nxp) w = a.nxp;
-            if (w <= 0) break;
-            if (slot < a.ny) {
-                rb = (long long)slot * 128;
-                band = sb * 8 + xcd;
-                tx0 = t0;
-                tx1 = t0 + w;
-                return true;
-            }
-            slot -= a.ny;
-        }
-        return false;
+    const int nt64 = (int)((a.M + 63) / 64);
+    auto decode = [&](int slot, long long& rb, int& band, int& t0, int& t1) {
+        const int kb = slot / a.ny;
+        band = kb * 8 + xcd;
+        if (band >= a.nbands) return false;
+        rb = (long long)(slot - kb * a.ny) * 256;
+        t0 = 2 * (int)((long long)band * a.nx / a.nbands);
+        t1 = 2 * (int)((long long)(band + 1) * a.nx / a.nbands);
+        if (t1 > nt64) t1 = nt64;
+        return true;
     };
-
-    const int srow = lane >> 2, sq = (lane & 3) ^ ((lane >> 4) & 2);
-    const float* ga[2];
-    const float* gb[2];
-    auto set_ptrs = [&](long long rb, long long mb) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            const int row = 16 * (2 * wave + i) + srow;
-            long long r = rb + row, m = mb + row;
-            if (r >= a.R) r = a.R - 1;
+    // LDS-DMA of the 64-column tile `t` into buffer `buf`: wave w fills fragments w, w + 8, ...
+    auto tile_in = [&](int t, int buf) {
+        for (int f = wave; f < NF; f += 8) {
+            const int ks = f >> 2, c = f & 3;
+            long long m = (long long)t * 64 + 16 * c + i16;
             if (m >= a.M) m = a.M - 1;
-            ga[i] = a.zr + r * a.ldz + 4 * sq;
-            gb[i] = a.zc + m * a.ldz + 4 * sq;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.zc + m * a.ldz + 16 * ks + 4 * g4),
+                                             (__attribute__((address_space(3))) void*)&tbuf[(buf * NF + f) * 64], 16, 0, 0);
         }
-    };
-    auto stage_in = [&](int ks, int buf) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(ga[i] + 16 * ks),
-                                             (__attribute__((address_space(3))) void*)&tile[buf][0][64 * (2 * wave + i)],
-                                             16, 0, 0);
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gb[i] + 16 * ks),
-                                             (__attribute__((address_space(3))) void*)&tile[buf][1][64 * (2 * wave + i)],
-                                             16, 0, 0);
+        if (wave == 0) {
+            long long m = (long long)t * 64 + lane;
+            if (m >= a.M) m = a.M - 1;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.qc + m),
+                                             (__attribute__((address_space(3))) void*)&qms[buf * 64], 4, 0, 0);
         }
-    };
-    auto q_in = [&](long long rb, long long mb, int par) {
-        const bool isr = wave < 2;
-        long long j = (isr ? rb : mb) + 64 * (wave & 1) + lane;
-        const long long lim = isr ? a.R : a.M;
-        if (j >= lim) j = lim - 1;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((isr ? a.qr : a.qc) + j),
-                                         (__attribute__((address_space(3))) void*)&qs[par * 256 + 64 * wave], 4, 0, 0);
     };
 
     long long rb = 0, nrb = 0;
-    int band = 0, tx = 0, tx1 = 0, nband = 0, ntx0 = 0, ntx1 = 0;
-    unsigned* nxt_s = reinterpret_cast<unsigned*>(smem + 2224);
-    if (tid == 0) *nxt_s = atomicAdd(a.ctr + xcd, 1u);
+    int band = 0, t = 0, t1 = 0, nband = 0, nt0 = 0, nt1 = 0;
+    if (tid == 0) nxt_s[0] = atomicAdd(a.ctr + xcd, 1u);
+    if (tid < 4 * NB) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
     __syncthreads();
-    if (!decode(__builtin_amdgcn_readfirstlane((int)*nxt_s), rb, band, tx, tx1)) return;
-    if (tid < 4 * a.ksteps) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
-    const int fo = i16 * 4 + (g4 ^ ((i16 >> 2) & 2));
-    const f32x4* fra = &tile[0][0][(wave >> 1) * 256 + fo];
-    const f32x4* frb = &tile[0][1][(wave & 1) * 256 + fo];
+    if (!decode(__builtin_amdgcn_readfirstlane((int)nxt_s[0]), rb, band, t, t1)) return;
+    if (tid == 0) nxt_s[1] = atomicAdd(a.ctr + xcd, 1u);  // the item after this one, asked for a whole item ahead
+    int npar = 1;                                          // which word holds the next item's slot
 
-    // per-lane state of the work item: the lane's four rows (ca), their centre / threshold, the write cursor of the
-    // lane's private candidate sub-list of each row, and the running fp64 sums
-    // cur: BYTE offset of the lane's next free slot in each row's private sub-list.  The centred sums of ONE work item
-    // (~10 tiles x 16 values per lane and row) are kept in fp32: ample.
-    unsigned cur[4];
-    auto item_begin = [&](long long rb_, int band_) {
+    // per-lane state of a work item: the lane's two rows (wave's row group A / B, row i16), their operand fragments
+    f32x4 brow[2][NB];
+    float cen[2], thr[2], qrv[2], s1[2], s2[2];
+    unsigned cur[2];
+    auto item_rows = [&](long long rb_) {
 #pragma unroll
-        for (int ca = 0; ca < 4; ++ca) {
-            const long long row = rb_ + (wave >> 1) * 64 + 16 * ca + i16;
+        for (int g = 0; g < 2; ++g) {
+            long long row = rb_ + wave * 32 + 16 * g + i16;
+            if (row >= a.R) row = a.R - 1;
+            const f32x4* zp = reinterpret_cast<const f32x4*>(a.zr + row * a.ldz + 4 * g4);
+#pragma unroll
+            for (int ks = 0; ks < NB; ++ks) brow[g][ks] = zp[4 * ks] * p2s[4 * ks + g4];
+        }
+    };
+    auto item_state = [&](long long rb_, int band_) {
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const long long row = rb_ + wave * 32 + 16 * g + i16;
             const bool ok = row < a.R;
             const long long rc = ok ? row : a.R - 1;
-            lst[256 * ca] = a.crow[rc];
-            lst[256 * (4 + ca)] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
-            lst[256 * (8 + ca)] = 0.f;
-            lst[256 * (12 + ca)] = 0.f;
-            cur[ca] = 4u * (unsigned)(rc * kSub * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4);
+            cen[g] = a.crow[rc];
+            thr[g] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
+            qrv[g] = a.qr[rc];
+            s1[g] = 0.f;
+            s2[g] = 0.f;
+            cur[g] = 4u * (unsigned)(((rc * a.nbands + band_) * kSub) * 4 + g4);
         }
     };
     auto item_end = [&](long long rb_, int band_) {
 #pragma unroll
-        for (int ca = 0; ca < 4; ++ca) {
-            const long long row = rb_ + (wave >> 1) * 64 + 16 * ca + i16;
+        for (int g = 0; g < 2; ++g) {
+            const long long row = rb_ + wave * 32 + 16 * g + i16;
             // the four lane groups of a row: fixed association ((g0 + g1) + (g2 + g3)) by two exchanges
-            double t1 = (double)lst[256 * (8 + ca)], t2 = (double)lst[256 * (12 + ca)];
-            t1 += __hiloint2double(__shfl_xor(__double2hiint(t1), 16, 64), __shfl_xor(__double2loint(t1), 16, 64));
-            t2 += __hiloint2double(__shfl_xor(__double2hiint(t2), 16, 64), __shfl_xor(__double2loint(t2), 16, 64));
-            t1 += __hiloint2double(__shfl_xor(__double2hiint(t1), 32, 64), __shfl_xor(__double2loint(t1), 32, 64));
-            t2 += __hiloint2double(__shfl_xor(__double2hiint(t2), 32, 64), __shfl_xor(__double2loint(t2), 32, 64));
+            double u1 = (double)s1[g], u2 = (double)s2[g];
+            u1 += __hiloint2double(__shfl_xor(__double2hiint(u1), 16, 64), __shfl_xor(__double2loint(u1), 16, 64));
+            u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 16, 64), __shfl_xor(__double2loint(u2), 16, 64));
+            u1 += __hiloint2double(__shfl_xor(__double2hiint(u1), 32, 64), __shfl_xor(__double2loint(u1), 32, 64));
+            u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 32, 64), __shfl_xor(__double2loint(u2), 32, 64));
             if (row < a.R) {
-                const size_t sub = (size_t)row * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4;
-                a.counts[sub] = (cur[ca] / 4u - (unsigned)(row * kSub * a.nsub + (band_ * 2 + (wave & 1)) * 4 + g4)) / (unsigned)a.nsub;
+                const unsigned sidx = (unsigned)(band_ * 4 + g4);
+                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(((row * a.nbands + band_) * kSub) * 4 + g4)) / 4u;
                 if (g4 == 0) {
-                    double* o = a.part + ((size_t)row * (a.nsub / 4) + band_ * 2 + (wave & 1)) * 2;
-                    o[0] = t1;
-                    o[1] = t2;
+                    double* o = a.part + ((size_t)row * (a.nsub / 4) + band_) * 2;
+                    o[0] = u1;
+                    o[1] = u2;
                 }
             }
         }
     };
 
-    set_ptrs(rb, (long long)tx * 128);
-    stage_in(0, 0);
-    q_in(rb, (long long)tx * 128, 0);
-    item_begin(rb, band);
-    __syncthreads();
-    int gpar = 0, qpar = 0;
+    item_rows(rb);
+    item_state(rb, band);
+    tile_in(t, 0);
+    __syncthreads();  // (drains the DMA: it is a pending LDS write)
+    int buf = 0;
+    const unsigned stride_b = 16u;  // bytes between consecutive slots of a sub-list
+    const float* lbase = a.lists;
 
     for (;;) {
-        const bool last_tile = tx + 1 == tx1;   // of this work item
-        unsigned pend = 0;
-        if (last_tile && tid == 0) pend = atomicAdd(a.ctr + xcd, 1u);
-        if (last_tile && a.ksteps == 1) {
-            if (tid == 0) *nxt_s = pend;
-            __syncthreads();
-        }
+        const bool last_tile = t + 1 == t1;
         bool have_next = true;
-        f32x4 acc[4][4];
-#pragma unroll
-        for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-            for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
-
-        for (int ks = 0; ks < a.ksteps; ++ks) {
-            const int cb_ = gpar;
-            if (ks + 1 < a.ksteps) {
-                stage_in(ks + 1, cb_ ^ 1);
-            } else if (!last_tile) {  // next tile of the same work item
-                set_ptrs(rb, (long long)(tx + 1) * 128);
-                stage_in(0, cb_ ^ 1);
-                q_in(rb, (long long)(tx + 1) * 128, qpar ^ 1);
-            } else {                  // first tile of the next work item
-                const int nslot = __builtin_amdgcn_readfirstlane((int)*nxt_s);
-                have_next = decode(nslot, nrb, nband, ntx0, ntx1);
-                if (have_next) {
-                    set_ptrs(nrb, (long long)ntx0 * 128);
-                    stage_in(0, cb_ ^ 1);
-                    q_in(nrb, (long long)ntx0 * 128, qpar ^ 1);
-                }
-            }
-            f32x4 fa[4], fb[4];
-            const f32x4 pf = p2s[4 * ks + g4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                fa[c] = fra[cb_ * 1024 + c * 64] * pf;
-                fb[c] = frb[cb_ * 1024 + c * 64];
-            }
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int ca = 0; ca < 4; ++ca)
-#pragma unroll
-                    for (int cb = 0; cb < 4; ++cb)
-                        acc[ca][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(fb[cb][kk], fa[ca][kk], acc[ca][cb], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            __builtin_amdgcn_s_waitcnt(0x0F70);
-            if (last_tile && ks == 0 && a.ksteps > 1) {
-                if (tid == 0) *nxt_s = pend;
-                __builtin_amdgcn_s_waitcnt(0xC07F);
-            }
-            __builtin_amdgcn_s_barrier();
-            gpar ^= 1;
+        // next tile into the other buffer: of this item, or the first of the next one
+        if (!last_tile) {
+            tile_in(t + 1, buf ^ 1);
+        } else {
+            have_next = decode(__builtin_amdgcn_readfirstlane((int)nxt_s[npar]), nrb, nband, nt0, nt1);
+            if (have_next) tile_in(nt0, buf ^ 1);
         }
-
-        // ---- statistics epilogue: lane (i16, g4) of block (ca, cb) holds row 16 ca + i16, columns 16 cb + 4 g4 + r ----
-        const long long m0 = (long long)tx * 128 + (wave & 1) * 64;
-        const float* qr_s = qs + qpar * 256 + (wave >> 1) * 64 + i16;
-        const float* qm_s = qs + qpar * 256 + 128 + (wave & 1) * 64 + 4 * g4;
-        f32x4 qmv[4];
+        f32x4 acc[2][4];
 #pragma unroll
-        for (int cb = 0; cb < 4; ++cb) qmv[cb] = *reinterpret_cast<const f32x4*>(qm_s + 16 * cb);
-        const unsigned stride_b = 4u * (unsigned)a.nsub;          // bytes between consecutive slots of a sub-list
-        const long long rlane = rb + (wave >> 1) * 64 + i16;       // this lane's row of ca = 0
-        const unsigned sidx = (unsigned)((band * 2 + (wave & 1)) * 4 + g4);
-        const float* lbase = a.lists;
+        for (int g = 0; g < 2; ++g)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const f32x4* tb = tbuf + buf * NF * 64 + lane;
+        // The A fragments of the next k16-step are read in the MIDDLE of this step's MFMAs (two register sets, the reads
+        // pinned by scheduling barriers: hipcc otherwise sinks them to just before their use, and it waits lgkmcnt(0)
+        // there).  The two waves of a SIMD run this loop in step, so an LDS round trip that is not covered by 16 MFMAs
+        // stalls the matrix pipe for both at once (measured: the loop alone ran at 0.77 of the pipe's rate).
+        f32x4 af[2][4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) af[0][c] = tb[c * 64];
+#pragma unroll
+        for (int ks = 0; ks < NB; ++ks) {
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[0][ks][kk], acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[1][ks][kk], acc[1][c], 0, 0, 0);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+            if (ks + 1 < NB) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c) af[(ks + 1) & 1][c] = tb[((ks + 1) * 4 + c) * 64];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 2; kk < 4; ++kk)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[0][ks][kk], acc[0][c], 0, 0, 0);
+                    acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[1][ks][kk], acc[1][c], 0, 0, 0);
+                }
+        }
+        // (No barrier here.  Cycle stamps show the two waves of a SIMD falling into alternation — one in its MFMA loop while
+        // the other works through its epilogue, whose VALU instructions then find issue slots only between the other
+        // wave's MFMAs: ~13 cycles each, 29.6 k cycles per tile against 23.4 k for the MFMA loops alone.  Forcing the
+        // phases together with a barrier at this point gives the same tile time (24.6 k + 4.6 k) and a kernel 2 % slower.)
+        // the operand rows of the NEXT item are fetched here, under the epilogue of this item's last tile
+        if (last_tile && have_next) item_rows(nrb);
+
+        // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
+        const long long m0 = (long long)t * 64;
+        const float* qm_s = qms + buf * 64 + 4 * g4;
         auto epilogue = [&](auto masked) {
             constexpr bool MASKED = decltype(masked)::value;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int ca = 0; ca < 4; ++ca) {
-                const float qrv = qr_s[16 * ca];
-                const float c = lst[256 * ca], th = lst[256 * (4 + ca)];
-                // two-wide partial sums: the adds / fmas below are packed fp32 instructions (v_pk_add_f32, v_pk_fma_f32)
-                f32x2 ps2 = {lst[256 * (8 + ca)], 0.f}, pq2 = {lst[256 * (12 + ca)], 0.f};
-                unsigned o = cur[ca];
+            for (int g = 0; g < 2; ++g) {
+                const float c0 = cen[g], th = thr[g], qr_ = qrv[g];
+                f32x2 ps2 = {s1[g], 0.f}, pq2 = {s2[g], 0.f};
+                unsigned o = cur[g];
 #pragma unroll
-                for (int cb = 0; cb < 4; ++cb) {
-                    f32x4 s4 = acc[ca][cb] + (qmv[cb] + qrv);   // the score, same bits as the spilling kernel
-                    f32x4 d4 = s4 - c;                             // centred on the row's analytic mean
+                for (int c = 0; c < 4; ++c) {
+                    const f32x4 qmv = *reinterpret_cast<const f32x4*>(qm_s + 16 * c);
+                    f32x4 s4 = acc[g][c] + (qmv + qr_);   // the score, same bits as the spilling kernel
+                    f32x4 d4 = s4 - c0;                     // centred on the row's analytic mean
                     if (MASKED) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
-                            const bool okc = m0 + 16 * cb + 4 * g4 + r < a.M;
+                            const bool okc = m0 + 16 * c + 4 * g4 + r < a.M;
                             d4[r] = okc ? d4[r] : 0.f;
                             s4[r] = okc ? s4[r] : (LOWEST ? __builtin_inff() : -__builtin_inff());
                         }
@@ -418,7 +396,10 @@ __global__ __launch_bounds__(256, MINBLOCKS) void cohort_fused_kernel(const Fuse
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
                         // if (s <= th) { lists[o] = s; o += stride; } (>= for the N largest) as one exec-masked store: no
-                        // branch, no 64-bit address arithmetic (SGPR base + 32-bit byte offset), one VALU for the cursor
+                        // branch, no 64-bit address arithmetic (SGPR base + 32-bit byte offset), one VALU for the cursor.
+                        // (Appending whole float4 groups with one v_cmpx-masked 16-byte store per group was tried: the
+                        // epilogue got 2 k cycles per tile shorter, but the lists tripled, the kernel as a whole did not
+                        // get faster and the select kernel had to re-filter: 1.10 ms against 1.04 ms for the pipeline.)
                         unsigned long long sv;
                         if (LOWEST)
                             asm volatile(
@@ -442,29 +423,33 @@ __global__ __launch_bounds__(256, MINBLOCKS) void cohort_fused_kernel(const Fuse
                                 : "vcc", "memory");
                     }
                 }
-                lst[256 * (8 + ca)] = ps2[0] + ps2[1];
-                lst[256 * (12 + ca)] = pq2[0] + pq2[1];
-                // at most kSubFull entries stay: slot kSubFull absorbs what a full sub-list still receives (the select
-                // kernel treats a count of kSubFull as an overflow)
-                long long rc = rlane + 16 * ca;
+                s1[g] = ps2[0] + ps2[1];
+                s2[g] = pq2[0] + pq2[1];
+                // at most kSubFull entries stay (the select kernel treats that count as an overflow)
+                long long rc = rb + wave * 32 + 16 * g + i16;
                 if (rc >= a.R) rc = a.R - 1;
-                const unsigned lim = 4u * ((unsigned)((rc * kSub + kSubFull) * a.nsub) + sidx);
-                cur[ca] = o < lim ? o : lim;
+                const unsigned lim = 4u * (unsigned)(((rc * a.nbands + band) * kSub + kSubFull) * 4 + g4);
+                cur[g] = o < lim ? o : lim;
             }
         };
-        if (m0 - (wave & 1) * 64 + 128 > a.M) epilogue(std::true_type{});
+        if (m0 + 64 > a.M) epilogue(std::true_type{});
         else epilogue(std::false_type{});
 
         if (last_tile) {
             item_end(rb, band);
             if (!have_next) break;
-            rb = nrb; band = nband; tx = ntx0; tx1 = ntx1;
-            item_begin(rb, band);
+            rb = nrb; band = nband; t = nt0; t1 = nt1;
+            item_state(rb, band);
+            npar ^= 1;
+            if (tid == 0) nxt_s[npar] = atomicAdd(a.ctr + xcd, 1u);  // visible after the barrier below; read >= 1 tile later
         } else {
-            ++tx;
+            ++t;
         }
-        if (a.ksteps == 1) __syncthreads();
-        qpar ^= 1;
+        // end of tile: this wave's part of the next tile has landed (and its appends are out), then everybody's; nobody
+        // still reads the buffer the tile after next will overwrite
+        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
+        __builtin_amdgcn_s_barrier();
+        buf ^= 1;
     }
 }
 
@@ -513,21 +498,23 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
         if (lane == 0) a.fail_rows[atomicAdd(a.nfail, 1u)] = (unsigned)row;
         return;
     }
-    // gather the sub-lists (lane = sub-list, slot rows are contiguous) into this wave's LDS run as order-preserving
-    // keys: element e of sub-list s lands at pre[s] + e — a fixed order
-    const float* lrow = a.lists + (size_t)row * kSub * a.nsub;
+    // gather the sub-lists (lane = sub-list) into this wave's LDS run as order-preserving keys: element e of sub-list s
+    // lands at pre[s] + e — a fixed order
+    const float* lrow = a.lists + (size_t)row * a.nsub * kSub;  // [band][slot][g]: sub-list s = band 4 + g
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         if (64 * j >= a.nsub_valid) break;
         const unsigned maxc = wave_max_u32(creg[j]);
+        const unsigned sl = 64 * j + lane < (unsigned)a.nsub ? 64 * j + lane : (unsigned)a.nsub - 1;  // stay in the row's region
+        const float* lsub = lrow + (size_t)(sl >> 2) * kSub * 4 + (sl & 3);
         for (unsigned e0 = 0; e0 < maxc; e0 += 16) {
             float v[16];
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
-                // unconditional (slot index clamped into the row's list region): a load under a lane predicate is a
-                // branch with its own wait, and the 30-odd slot rows of a row then come in one memory round trip each
+                // unconditional (slot index clamped into the sub-list): a load under a lane predicate is a branch with its
+                // own wait, and the slot rows of a row would then come in one memory round trip each
                 const unsigned e = e0 + u < (unsigned)kSub ? e0 + u : (unsigned)kSub - 1;
-                v[u] = lrow[(size_t)e * a.nsub + 64 * j + lane];
+                v[u] = lsub[(size_t)e * 4];
             }
 #pragma unroll
             for (int u = 0; u < 16; ++u) {
@@ -688,16 +675,22 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     if (f > 0.25 || want > 0.8 * kCandMax) return p;
     const long long nx = (M + 127) / 128;
     p.nx = (int)nx;
-    p.nxp = (int)((nx + 7) / 8 < 24 ? (nx + 7) / 8 : 24);
-    if (const char* e = getenv("NPLDA_FUSED_NXP")) {  // tuning knob: column tiles per work item
-        const int v = atoi(e);
-        if (v >= 1 && v <= 24) p.nxp = v;
+    // Column bands: a multiple of 8 (band b belongs to XCD b % 8), widths equal to within one tile; a work item is (tile of
+    // 256 rows, band) and ONE block walks it.  Eight bands unless a band's slice of the cohort table would not stay in an
+    // XCD's 4 MB L2 next to the row fragments (> 2 MB), or its sub-lists would overflow.  Finer items do not pay: every
+    // item switch re-fetches 256 rows of operands, and the measured kernel time (cfg3) is 772 / 800 / 800 us for
+    // 8 / 16 / 32 bands although the CUs' shares of the items even out.
+    if (nx < 8) return p;
+    int bpx = 1;  // bands per XCD
+    for (;; ++bpx) {
+        const double cols = (double)((nx + 8 * bpx - 1) / (8 * bpx)) * 128.0;
+        const double lam_ = f * cols / 4.0;
+        if ((cols * Mp * 4.0 <= 2097152.0 && lam_ + 6.0 * sqrt(lam_) + 4.0 <= (double)kSubFull) || bpx == 8 || 8LL * (bpx + 1) > nx) break;
     }
-    p.nsb = (int)((nx + 8LL * p.nxp - 1) / (8LL * p.nxp));
-    p.nsub = 8 * p.nsb * 8;
-    if (p.nsub > 256) return p;                       // the select kernel holds the sub-list counts in 4 registers
-    // expected candidates of one sub-list (a band's columns seen by one lane group of one wave column)
-    const double lam = f * (double)p.nxp * 128.0 / 8.0;
+    p.nbands = 8 * bpx;
+    p.nsub = p.nbands * 4;
+    // expected candidates of one sub-list (a band's columns seen by one lane group)
+    const double lam = f * (double)((nx + p.nbands - 1) / p.nbands) * 128.0 / 4.0;
     if (lam + 6.0 * sqrt(lam) + 4.0 > (double)kSubFull) return p;
     p.zhi = host_normcdfinv(f);
     p.fhi = (float)f;
@@ -705,7 +698,7 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256(kb * kb * 256 * 4) +
                     align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
-    p.max_rows = ((1LL << 30) / ((long long)p.nsub * kSub)) / 128 * 128;
+    p.max_rows = ((1LL << 30) / ((long long)p.nsub * kSub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
     p.row_bytes = (size_t)Mp * 4 + 8 + (size_t)p.nsub * kSub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 16 + 4;
     p.eligible = true;
     return p;
@@ -759,17 +752,26 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
 
     FusedArgs fa = {};
     fa.zr = z_rows; fa.qr = q_rows; fa.zc = z_coh; fa.qc = q_coh; fa.P = P;
-    fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nxp = p.nxp; fa.ny = (int)((R + 127) / 128); fa.nx = p.nx;
-    fa.nsb = p.nsb; fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
+    fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + 255) / 256); fa.nx = p.nx;
+    fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
     fa.nsub = p.nsub;
-    long long grid = 8LL * fa.ny * p.nsb;  // at most one block per work item of the busiest XCD
+    long long grid = (long long)fa.ny * p.nbands;  // at most one block per work item
     if (grid > resident) grid = resident;
-    if (lowest) hipLaunchKernelGGL((cohort_fused_kernel<true, NPLDA_FUSED_MINBLOCKS>), dim3((unsigned)grid), dim3(256), 0, st, fa);
-    else hipLaunchKernelGGL((cohort_fused_kernel<false, NPLDA_FUSED_MINBLOCKS>), dim3((unsigned)grid), dim3(256), 0, st, fa);
+#define NPLDA_LAUNCH(NBV)                                                                                          \
+    if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa);  \
+    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+    switch (ksteps) {
+        case 2: NPLDA_LAUNCH(2); break;
+        case 4: NPLDA_LAUNCH(4); break;
+        case 8: NPLDA_LAUNCH(8); break;
+        case 10: NPLDA_LAUNCH(10); break;
+        case 11: NPLDA_LAUNCH(11); break;
+        case 12: NPLDA_LAUNCH(12); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+#undef NPLDA_LAUNCH
     if (int rc = nplda_launch_status()) return rc;
-
-    const int nbands = (p.nx + p.nxp - 1) / p.nxp;  // bands that hold column tiles
-    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, nbands * 8, topn, lowest, ctl + 8,
+    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, ctl + 8,
                      fail_rows, stats};
     hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, fi);
     return nplda_launch_status();
@@ -779,7 +781,7 @@ long long cohort_fused_resident_blocks() {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused_kernel<true, NPLDA_FUSED_MINBLOCKS>, 256, 0) != hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused2_kernel<true, 12>, 512, 0) != hipSuccess)
         return 0;
     long long r = (long long)cus * per_cu / 8 * 8;
     return r < 8 ? 8 : r;
