@@ -225,16 +225,22 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True):
     return elapsed, kern_ms, out
 
 
-def kernel_ms_of(fn, reps=10):
-    fn()
+def kernel_ms_of(fn, reps=10, batches=3, warm=3):
+    """Per-launch time of fn's kernel: median over `batches` event-bracketed runs of `reps` launches, after `warm` untimed
+    launches (the first launches after a different kernel run 3-4 % slow while the clock settles: tools/d170_clock.py)."""
+    for _ in range(warm):
+        fn()
     torch.cuda.synchronize()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(reps):
-        out = fn()
-    e1.record()
-    torch.cuda.synchronize()
-    return e0.elapsed_time(e1) / reps, out
+    ms = []
+    for _ in range(batches):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            out = fn()
+        e1.record()
+        torch.cuda.synchronize()
+        ms.append(e0.elapsed_time(e1) / reps)
+    return sorted(ms)[len(ms) // 2], out
 
 
 def run_cfg1(args, ctx):
@@ -302,7 +308,8 @@ def run_cfg1(args, ctx):
             f170 = algorithmic_flops_per_pair(D0, 170, 170)
             ach = B * f170 / (ms170 * 1e-3) / 1e12
             alt170 = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None, "kernel_ms": ms170,
+                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                      "kernel": "nplda_fwd_v5_kernel<11, 8 waves, 2 k16-steps/barrier, groups of 4> (persistent)", "kernel_ms": ms170,
                       "pairs_per_s_1gpu": B / (ms170 * 1e-3), "flop_per_pair_algorithmic": f170,
                       "workload": f"{B} trial pairs, 512->170->170 (conf/voices_config.cfg:14-16), scoring only",
                       "checksum_finite": bool(torch.isfinite(s170).all().item())}

@@ -4,6 +4,7 @@
 #include "nplda_fwd_small.h"
 #include "nplda_fwd_v2.h"
 #include "nplda_fwd_v3.h"
+#include "nplda_fwd_v5.h"
 
 namespace nplda {
 
@@ -12,9 +13,12 @@ namespace nplda {
 //  * large batches, pair scoring, NB <= 10: the persistent continuous-stream schedule (nplda_fwd_v3.h),
 //    8 waves/block, one block per CU, 2 k16-steps of weights per barrier, LDS fragments read 4 feature blocks at a
 //    time: 0.82 of the fp32 MFMA peak at D = 150;
-//  * large batches otherwise (NB >= 11, embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
+//  * large batches, pair scoring, NB = 11 / 12 (D = 170, the reference's shipped size): the same persistent schedule with
+//    LDS-DMA weight chunks and a group-major layer 2 (nplda_fwd_v5.h), 171 registers and no spill where v3 spills:
+//    0.86 at D = 170 against 0.84 for v2 in the same process (profiles/r02d_*); at NB = 10 it is 1-3 % behind v3;
+//  * large batches otherwise (embedding, training mode): the v2 schedule (nplda_fwd_v2.h), 8 waves/block, 2 k16-steps
 //    per barrier, x prefetched a whole chunk ahead, plain (cached) x loads: 0.81 at D = 150, 0.84 at D = 170
-//    (v3 spills at NB = 11; v1 with non-temporal loads was 0.72 / 0.75);
+//    (v1 with non-temporal loads was 0.72 / 0.75);
 //  * batches of <= 16 384 pairs: the feature-split small-batch schedule (nplda_fwd_small.h): 4 waves share one
 //    16-pair tile, so a 4096-pair training minibatch runs on all 1024 SIMDs (forward 105 us -> see DESIGN.md).
 template <int MODE>
@@ -66,6 +70,25 @@ static inline int launch_fwd_v3(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     return nplda_launch_status();
 }
 
+// pair scoring at NB = 11 / 12: persistent grid, weight chunks by LDS-DMA, layer 2 by output groups (nplda_fwd_v5.h)
+static inline int launch_fwd_v5(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    constexpr int WAVES = 8;
+    const long long ntiles = (a.n + 16 * WAVES - 1) / (16 * WAVES);
+    if (ntiles > 0x7fffffffLL) return NPLDA_EINVAL;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long blocks = ntiles < cus ? ntiles : cus;
+    dim3 grid((unsigned)blocks), block(WAVES * 64);
+    switch (L.NB) {
+        case 11: hipLaunchKernelGGL((nplda_fwd_v5_kernel<11, WAVES, 2, 4, 1>), grid, block, 0, st, a, (int)ntiles); break;
+        case 12: hipLaunchKernelGGL((nplda_fwd_v5_kernel<12, WAVES, 4, 4, 1>), grid, block, 0, st, a, (int)ntiles); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+    return nplda_launch_status();
+}
+
 template <int MODE>
 static inline int launch_fwd_small(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long per_block = (MODE == MODE_EMBED ? 32 : 16);
@@ -95,6 +118,7 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     // (1.2 M rows: 0.72 of the peak either way; the mode is paced by its 0.77 GB of output)
     if constexpr (MODE == MODE_PAIR) {
         if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
+        return launch_fwd_v5(a, L, st);
     }
     return launch_fwd_v2<MODE>(a, L, st);
 }

@@ -5,10 +5,9 @@
 #include <cstdlib>
 #include <vector>
 #include <cmath>
-#include "exp/nplda_fwd_persist.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v3.h"
-#include "exp/nplda_fwd_v4.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_v5.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_bf16x3.h"
 
 using namespace nplda;
@@ -92,23 +91,13 @@ void launch_3(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((nplda_fwd_v3_kernel<NB, MODE_PAIR, WAVES, NT, KPB, G>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
 }
 
-static SplitOff g_so;
-template <int NBF, int LO, int WAVES, int KPB, int G = 4>
-void launch_4(const FwdArgs& a, long long B, hipStream_t st) {
+template <int NB, int WAVES, int KPB, int G = 4, int H = 2>
+void launch_5(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
     const int ntiles = (int)((B + per_block - 1) / per_block);
     int grid = 256;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((nplda_fwd_v4_kernel<NBF, LO, WAVES, KPB, G>), dim3(grid), dim3(WAVES * 64), 0, st, a, g_so, ntiles);
-}
-
-template <int NB, int WAVES, bool NT, int KPB>
-void launch_p(const FwdArgs& a, long long B, hipStream_t st) {
-    const long long per_block = 16 * WAVES;
-    const int ntiles = (int)((B + per_block - 1) / per_block);
-    int grid = 256 * (WAVES == 8 ? 1 : 2);
-    if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((nplda_fwd_persist_kernel<NB, MODE_PAIR, WAVES, NT, KPB>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
+    hipLaunchKernelGGL((nplda_fwd_v5_kernel<NB, WAVES, KPB, G, H>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
 }
 
 int main(int argc, char** argv) {
@@ -120,8 +109,7 @@ int main(int argc, char** argv) {
     const NpldaLayout L = nplda_layout(D0, D, D);
     float *x1, *x2, *s, *packed, *W1, *b1, *W2, *b2, *Ps, *Q;
     CK(hipMalloc(&x1, B * D0 * 4)); CK(hipMalloc(&x2, B * D0 * 4)); CK(hipMalloc(&s, B * 4));
-    const NpldaSplit S = nplda_split(L);
-    CK(hipMalloc(&packed, S.total * 4));
+    CK(hipMalloc(&packed, L.total * 4));
     CK(hipMalloc(&W1, D * D0 * 4)); CK(hipMalloc(&b1, D * 4)); CK(hipMalloc(&W2, D * D * 4));
     CK(hipMalloc(&b2, D * 4)); CK(hipMalloc(&Ps, D * 4)); CK(hipMalloc(&Q, D * 4));
     fill_rand<<<4096, 256>>>(x1, (size_t)B * D0, 1); fill_rand<<<4096, 256>>>(x2, (size_t)B * D0, 2);
@@ -129,8 +117,6 @@ int main(int argc, char** argv) {
     fill_rand<<<64, 256>>>(W2, (size_t)D * D, 5); fill_rand<<<1, 256>>>(b2, D, 6);
     fill_rand<<<1, 256>>>(Ps, D, 7); fill_rand<<<1, 256>>>(Q, D, 8);
     nplda_pack_kernel<<<(unsigned)((L.total + 255) / 256), 256>>>(W1, b1, W2, b2, Ps, Q, L, packed);
-    if (S.LO) nplda_pack_split_kernel<<<(unsigned)((S.total - S.oA + 255) / 256), 256>>>(W1, b1, W2, b2, Ps, Q, L, S, packed);
-    g_so = SplitOff{S.oA, S.oB, S.oT1, S.oT3, S.oT2};
     CK(hipDeviceSynchronize());
 
     FwdArgs a = {};
@@ -150,18 +136,17 @@ int main(int argc, char** argv) {
     g_b3.oW2 = L3.oW2; g_b3.ob1 = L3.ob1; g_b3.ob2 = L3.ob2; g_b3.oQ = L3.oQ; g_b3.oP = L3.oP;
     std::vector<float> sref(1 << 16);
     std::vector<Variant> vs;
-    if (L.NB == 10 && S.LO == 6) {
-        vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v2 w8 kpb2", launch_2<10, 8, false, 2>},
-               {"v3 w4 kpb2 x2", launch_3<10, 4, false, 2, 2>}, {"v3 w4 kpb4 x2", launch_3<10, 4, false, 4, 2>},
-               {"v3 w8 kpb2 g2", launch_3<10, 8, false, 2, 1, 2>}, {"v3 w8 kpb2 g5", launch_3<10, 8, false, 2, 1, 5>} };
-    } else if (L.NB == 11 && S.LO == 10) {
-        vs = { {"v2 w8 kpb2", launch_2<11, 8, false, 2>}, {"v3 w8 kpb2", launch_3<11, 8, false, 2, 1>},
-               {"v4 10+10 w8 kpb2 (exp)", launch_4<10, 10, 8, 2>} };
+    if (L.NB == 10) {
+        vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v5 w8 kpb2", launch_5<10, 8, 2>},
+               {"v2 w8 kpb2", launch_2<10, 8, false, 2>}, {"v5 w8 kpb4 h1", launch_5<10, 8, 4, 4, 1>}, {"v5 w8 kpb2 h1", launch_5<10, 8, 2, 4, 1>} };
+    } else if (L.NB == 11) {
+        vs = { {"v2 w8 kpb2", launch_2<11, 8, false, 2>}, {"v5 w8 kpb2", launch_5<11, 8, 2>},
+               {"v5 w8 kpb4 h1", launch_5<11, 8, 4, 4, 1>}, {"v5 w8 kpb2 h1", launch_5<11, 8, 2, 4, 1>} };
     } else if (L.NB == 8) {
-        vs = { {"v3 w8 kpb2 nb8", launch_3<8, 8, false, 2, 1>}, {"v2 w8 kpb2 nb8", launch_2<8, 8, false, 2>} };
+        vs = { {"v3 w8 kpb2 nb8", launch_3<8, 8, false, 2, 1>}, {"v5 w8 kpb2 nb8", launch_5<8, 8, 2>} };
     } else {
-        vs = { {"v1 w8 nt kpb1", launch_v<12, 8, true, 1>}, {"v1 w8 pl kpb2", launch_v<12, 8, false, 2>},
-               {"v2 w8 kpb2", launch_2<12, 8, false, 2>}, {"v1 w4 pl kpb2", launch_v<12, 4, false, 2>} };
+        vs = { {"v2 w8 kpb2", launch_2<12, 8, false, 2>}, {"v5 w8 kpb2", launch_5<12, 8, 2>},
+               {"v5 w8 kpb4 h1", launch_5<12, 8, 4, 4, 1>}, {"v5 w8 kpb2 h1", launch_5<12, 8, 2, 4, 1>} };
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
