@@ -380,6 +380,27 @@ int nplda_adam_step_f32(float* const* params, const float* const* grads, float* 
                         float* const* exp_avg_sq, const int64_t* numel, int nseg, float* step, float lr,
                         float beta1, float beta2, float eps, float weight_decay, nplda_stream_t stream);
 
+/* One whole optimisation step on B <= 16384 pairs in FOUR launches: forward (training mode) -> data gradients with the
+ * loss folded in (dL/ds of a pair needs its own score / target and the batch counts only) -> weight-gradient slabs ->
+ * slab sums + Adam + refreshed fragment image + loss / dL/dtheta / threshold update.  What the reference spends
+ * `loss.backward(); optimizer.step()` on (xvector_NeuralPlda_pytorch.py:66-75: ~250 ATen launches).  Same arithmetic as
+ * nplda_pack_params_f32 -> nplda_forward_train_f32 -> nplda_loss_fwd_bwd_f32 -> nplda_backward_f32 ->
+ * nplda_adam_step_f32; the loss sums are formed per block of 16 pairs (fp64, fixed order).
+ *   params:  HOST array of the 6 DEVICE tensors W1 (D1, D0), b1, W2 (D2, D1), b2, P_sqrt, Q — updated in place;
+ *   thetas:  HOST array of K device scalars (the thresholds; kind 1 = BCE uses thetas[0]), updated in place;
+ *   betas:   HOST array of K floats (kind 0 = SoftCdet);  exp_avg / exp_avg_sq: nplda_grad_floats + K floats each, in
+ *            flat-gradient order followed by the thresholds;  step: as nplda_adam_step_f32;
+ *   packed:  IN the image of the current parameters (nplda_pack_params_f32), OUT the image of the updated ones — the
+ *            caller re-packs only when the parameters were changed by something else;
+ *   loss:    device scalar;  grad_out: optional nplda_grad_floats + K floats (the gradient that was applied).
+ * NPLDA_EUNSUPPORTED for B > 16384 or the hard cost (kind 2): use the separate entry points. */
+size_t nplda_train_step_workspace_bytes(int64_t B, int D0, int D1, int D2);
+int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+                         float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
+                         float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
+                         float* grad_out, nplda_stream_t stream);
+
 /* ---- split-bf16 scoring (opt-in) --------------------------------------------------------------------------- */
 
 /* Same functions as nplda_pack_params_f32 / nplda_score_pairs_f32 / nplda_embed_f32 computed on the bf16 matrix

@@ -18,6 +18,8 @@
 //         [dW1 | db1 | dW2 | db2 | dP_sqrt (= 4 P_sqrt dP) | dQ]  — deterministic, and the single
 //         buffer a data-parallel all-reduce needs.
 #include "nplda_fwd_dispatch.h"
+#include "nplda_adam_math.h"
+#include "nplda_loss_math.h"
 
 namespace nplda {  // nplda_matmul.hip
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
@@ -35,6 +37,22 @@ using namespace nplda;
 // Row bookkeeping: a tile holds 16 "A" rows t0 + j (< nA) and 16 "B" rows offB + t0 + j (t0 + j < nB).  Pair scoring:
 // nA = nB = offB = B (x1 side, x2 side).  Embedding rows (GIVEN): N rows split into two halves, nA = ceil(N / 2),
 // nB = N - nA, offB = nA — the same kernels, the pairing is then just a way to fill both MFMA row groups.
+// Loss folded into the data-gradient kernel (the fused training step, nplda_train_step_f32): dL/ds of a pair depends on
+// the pair's own score and target and on the batch counts N_t, N_n only (utils/models.py:384-399), so the kernel that
+// needs g forms it itself and leaves the batch sums of the loss as one fp64 partial per block.
+constexpr int kLossNS = 2 + 4 * nplda_loss::kMaxK;
+struct BwdLoss {
+    const float* s;       // (B) scores of this step's forward
+    const float* t;       // (B) targets, 16-byte aligned
+    nplda_loss::ThetaPtrs th;
+    nplda_loss::BetaVals beta;
+    int K, kind;          // kind 0 = SoftCdet, 1 = BCE
+    float alpha;
+    long long B;
+    float* g_out;         // (B) dL/ds, for the weight-gradient kernel's dQ / dP sums
+    double* partial;      // [blocks][kLossNS] loss sums of the block's 16 pairs
+};
+
 struct BwdArgs {
     const float* g;       // (nA) dL/ds per pair                       [unused when GIVEN]
     const float* z;       // (rows, ldz)                               [unused when GIVEN]
@@ -46,6 +64,7 @@ struct BwdArgs {
     float* dz;            // (rows, ldz): written, or READ when GIVEN (upstream dL/dz, zero-padded columns)
     float* du;            // (rows, ldz)
     int ntb;              // tile-blocks = ceil(nA / (16 * WAVES))
+    BwdLoss ls;           // [LOSS kernels only]
 };
 
 template <int NB, int WAVES, bool GIVEN>
@@ -160,8 +179,25 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 // accumulator layout (= the B operand of the chained MFMA), computes ITS dy blocks from all of dz with W2^T
 // fragments read straight from the L2-resident image through a register ring, and the y.dy dot product of the
 // normalize backward is reduced across the waves through LDS.
-template <int NB, bool GIVEN>
+template <int K>
+__device__ __forceinline__ float loss_pair_softcdet(const BwdLoss& L, double Nt, double Nn, float si, float ti,
+                                                    double (&acc)[kLossNS]) {
+    float theta[K], cn[K], ct;
+#pragma unroll
+    for (int k = 0; k < K; ++k) theta[k] = L.th.p[k][0];
+    nplda_loss::softcdet_consts<K>(Nt, Nn, L.beta, L.alpha, cn, ct);
+    double a2[2 + 4 * K];
+#pragma unroll
+    for (int i = 0; i < 2 + 4 * K; ++i) a2[i] = 0.0;
+    nplda_loss::softcdet_accumulate<K, false>(si, ti, theta, L.alpha, a2);
+#pragma unroll
+    for (int i = 0; i < 2 + 4 * K; ++i) acc[i] = a2[i];
+    return nplda_loss::softcdet_gi<K>(si, ti, theta, cn, ct, L.alpha);
+}
+
+template <int NB, bool GIVEN, bool LOSS = false>
 __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a) {
+    static_assert(!(GIVEN && LOSS), "the loss is formed from pair scores");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;
     constexpr int PF = 4;
@@ -190,7 +226,51 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch(s, s);
 
-    const float tg = (!GIVEN && okA) ? 2.0f * a.g[rA] : 0.f;
+    float tg = 0.f;
+    __shared__ double lacc[LOSS ? 16 : 1][kLossNS];
+    if constexpr (LOSS) {
+        const BwdLoss& L = a.ls;
+        // N_t: every block sums the targets itself (<= 16 float4 per thread, L2 hits): no launch, no grid-wide hand-over
+        __shared__ float cnt_s[NW];
+        float cnt = 0.f;
+        const int nv = (int)(L.B / 4);
+        const f32x4* t4 = reinterpret_cast<const f32x4*>(L.t);
+        for (int i = tid; i < nv; i += 256) {
+            const f32x4 v = t4[i];
+            cnt += (v[0] + v[1]) + (v[2] + v[3]);
+        }
+        for (long long i = 4LL * nv + tid; i < L.B; i += 256) cnt += L.t[i];
+#pragma unroll
+        for (int msk = 1; msk < 64; msk <<= 1) cnt = wave_xor_add(cnt, msk);
+        if (lane == 0) cnt_s[wave] = cnt;
+        __syncthreads();
+        const double Nt = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // exact: a count below 2^24
+        const double Nn = (double)L.B - Nt;
+        const float si = L.s[rA], ti = L.t[rA];
+        double acc[kLossNS];
+#pragma unroll
+        for (int i = 0; i < kLossNS; ++i) acc[i] = 0.0;
+        float gi;
+        if (L.kind == 1) {
+            double a4[4] = {0.0, 0.0, 0.0, 0.0};
+            const float theta = L.th.p[0][0];
+            nplda_loss::bce_accumulate(si, ti, theta, a4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) acc[i] = a4[i];
+            gi = nplda_loss::bce_gi(si, ti, theta, (float)(1.0 / (Nt + Nn)));
+        } else if (L.K == 1) gi = loss_pair_softcdet<1>(L, Nt, Nn, si, ti, acc);
+        else if (L.K == 2) gi = loss_pair_softcdet<2>(L, Nt, Nn, si, ti, acc);
+        else if (L.K == 3) gi = loss_pair_softcdet<3>(L, Nt, Nn, si, ti, acc);
+        else gi = loss_pair_softcdet<4>(L, Nt, Nn, si, ti, acc);
+        tg = okA ? 2.0f * gi : 0.f;
+        if (wave == 0 && g4 == 0) {
+            if (okA) L.g_out[rA] = gi;
+#pragma unroll
+            for (int i = 0; i < kLossNS; ++i) lacc[j][i] = okA ? acc[i] : 0.0;
+        }
+    } else {
+        tg = (!GIVEN && okA) ? 2.0f * a.g[rA] : 0.f;
+    }
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
         const int nb = wave + NW * i;
@@ -214,6 +294,14 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
         }
     }
     __syncthreads();
+    if constexpr (LOSS) {  // the block's 16 pairs, summed in pair order
+        if (tid < kLossNS) {
+            double v = 0.0;
+#pragma unroll
+            for (int p = 0; p < 16; ++p) v += lacc[p][tid];
+            a.ls.partial[(size_t)blockIdx.x * kLossNS + tid] = v;
+        }
+    }
 
     f32x4 dyA[NBW], dyB[NBW];
 #pragma unroll
@@ -518,6 +606,156 @@ __global__ __launch_bounds__(256) void reduce_kernel(const ReduceArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// K-D : the tail of the fused training step in one launch — K-C's slab sums, torch.optim.Adam's update of the six
+// parameter tensors (xvector_NeuralPlda_pytorch.py:139), the refreshed fragment image of the updated parameters (what
+// nplda_pack_params_f32 would rebuild at the start of the next step), and in the last block the loss, dL/dtheta and
+// the thresholds' own Adam update from the per-block loss partials K-A left.
+// ------------------------------------------------------------------------------------------------
+struct UpdateArgs {
+    ReduceArgs r;             // r.out: optional copy of the flat gradient (+ dtheta), may be null
+    float* prm[6];            // W1, b1, W2, b2, P_sqrt, Q
+    float* m;                 // exp_avg    [ngrad + K], flat-gradient order then the thresholds
+    float* v;                 // exp_avg_sq
+    float* step;              // [steps taken, arrival ticket]  (as nplda_adam_step_f32)
+    float lr, beta1, beta2, eps, wd;
+    NpldaLayout L;
+    float* packed;
+    const double* partial;    // [nblk][kLossNS]
+    int nblk, K, kind;
+    nplda_loss::BetaVals beta;
+    float alpha;
+    float* theta[nplda_loss::kMaxK];
+    float* loss;
+    unsigned ngrad_blocks;
+};
+
+// position of W[f][k] in a fragment image [k / 16][f / 16][lane = 16 ((k % 16) / 4) + f % 16][k % 4]
+__device__ __forceinline__ size_t frag_pos(int f, int k, int NB) {
+    return ((((size_t)(k >> 4) * NB + (f >> 4)) * 64 + (((k & 15) >> 2) << 4) + (f & 15)) << 2) + (k & 3);
+}
+
+__global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
+    const float t = a.step[0] + 1.0f;
+    const nplda_adam::Consts c = nplda_adam::consts_for(t, a.lr, a.beta1, a.beta2, a.eps, a.wd);
+    const int D0 = a.r.D0, D1 = a.r.D1, D2 = a.r.D2;
+    const size_t nW1 = (size_t)D1 * D0, nW2 = (size_t)D2 * D1;
+    const size_t ngrad = nW1 + D1 + nW2 + 3 * (size_t)D2;
+    if (blockIdx.x < a.ngrad_blocks) {
+        const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+        if (idx < ngrad) {
+            const float* src;
+            size_t stride;
+            float* pp;
+            size_t pk0, pk1 = (size_t)-1;
+            int which = 0;  // 1: P_sqrt
+            if (idx < nW1) {
+                const int f = (int)(idx / D0), k = (int)(idx % D0);
+                src = a.r.slab1 + (size_t)f * a.r.Np1 + k;
+                stride = (size_t)a.r.Mp * a.r.Np1;
+                pp = a.prm[0] + idx;
+                pk0 = a.L.oW1 + frag_pos(f, k, a.L.NB);
+            } else if (idx < nW1 + D1) {
+                const int f = (int)(idx - nW1);
+                src = a.r.ext + 3 * a.r.Mp + f;
+                stride = 4 * (size_t)a.r.Mp;
+                pp = a.prm[1] + f;
+                pk0 = a.L.ob1 + f;
+            } else if (idx < nW1 + D1 + nW2) {
+                const size_t rr = idx - nW1 - D1;
+                const int f = (int)(rr / D1), k = (int)(rr % D1);
+                src = a.r.slab2 + (size_t)f * a.r.Mp + k;
+                stride = (size_t)a.r.Mp * a.r.Mp;
+                pp = a.prm[2] + rr;
+                pk0 = a.L.oW2 + frag_pos(f, k, a.L.NB);
+                pk1 = a.L.oW2T + frag_pos(k, f, a.L.NB);  // W2^T image: rows and columns change places
+            } else {
+                const size_t rr = idx - nW1 - D1 - nW2;
+                const int sel = (int)(rr / D2), f = (int)(rr % D2);
+                // sel: 0 = b2 (ext row 2), 1 = P_sqrt (ext row 1, times 4 P_sqrt), 2 = Q (ext row 0)
+                const int row = sel == 0 ? 2 : (sel == 1 ? 1 : 0);
+                src = a.r.ext + row * a.r.Mp + f;
+                stride = 4 * (size_t)a.r.Mp;
+                pp = a.prm[3 + sel] + f;
+                pk0 = (sel == 0 ? a.L.ob2 : (sel == 1 ? a.L.oP : a.L.oQ)) + f;
+                which = sel == 1;
+            }
+            // at most 16 slabs (ws_layout): all 16 loads in flight at once, summed in slab order like K-C
+            float part[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) part[k] = src[(k < a.r.ksplit ? k : 0) * stride];
+            float sum = 0.f;
+#pragma unroll
+            for (int k = 0; k < 16; ++k) sum += k < a.r.ksplit ? part[k] : 0.f;
+            const float p = *pp;
+            // the product is rounded on its own, as K-C stores it: left to the compiler it is contracted into Adam's g + wd p
+            float g = which ? sum * (4.0f * p) : sum;
+            asm volatile("" : "+v"(g));
+            if (a.r.out) a.r.out[idx] = g;
+            float m = a.m[idx], v = a.v[idx];
+            const float pn = nplda_adam::update(p, g, m, v, c);
+            a.m[idx] = m;
+            a.v[idx] = v;
+            *pp = pn;
+            a.packed[pk0] = which ? pn * pn : pn;  // P = P_sqrt^2 (utils/models.py:373)
+            if (pk1 != (size_t)-1) a.packed[pk1] = pn;
+        }
+    } else {
+        // ---- loss block: partials -> sums (fixed order: 8 interleaved chains per sum, then the chains in order) ----
+        __shared__ double tile[256][kLossNS + 1];
+        __shared__ double chain[kLossNS][8];
+        __shared__ double sums[kLossNS];
+        __shared__ float dth[nplda_loss::kMaxK];
+        const int ns = nplda_loss::nsums(a.K, a.kind);
+        const int i = threadIdx.x >> 3, cc = threadIdx.x & 7;
+        double vv = 0.0;
+        for (int base = 0; base < a.nblk; base += 256) {  // 256 partial rows at a time through LDS
+            const int b = base + threadIdx.x;
+#pragma unroll
+            for (int q = 0; q < kLossNS; ++q) tile[threadIdx.x][q] = b < a.nblk ? a.partial[(size_t)b * kLossNS + q] : 0.0;
+            __syncthreads();
+            if (i < ns)
+                for (int r = cc; r < 256; r += 8) vv += tile[r][i];
+            __syncthreads();
+        }
+        if (i < ns) chain[i][cc] = vv;
+        __syncthreads();
+        if (threadIdx.x < ns) {
+            double w = 0.0;
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) w += chain[threadIdx.x][c8];
+            sums[threadIdx.x] = w;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            if (a.kind == 1) nplda_loss::bce_scalars(sums, a.loss, dth);
+            else if (a.K == 1) nplda_loss::softcdet_scalars<1>(sums, a.beta, a.alpha, a.loss, dth);
+            else if (a.K == 2) nplda_loss::softcdet_scalars<2>(sums, a.beta, a.alpha, a.loss, dth);
+            else if (a.K == 3) nplda_loss::softcdet_scalars<3>(sums, a.beta, a.alpha, a.loss, dth);
+            else nplda_loss::softcdet_scalars<4>(sums, a.beta, a.alpha, a.loss, dth);
+        }
+        __syncthreads();
+        const int nth = a.kind == 1 ? 1 : a.K;
+        if (threadIdx.x < nth) {
+            const int k = threadIdx.x;
+            const float g = dth[k];
+            if (a.r.out) a.r.out[ngrad + k] = g;
+            float m = a.m[ngrad + k], v = a.v[ngrad + k];
+            a.theta[k][0] = nplda_adam::update(a.theta[k][0], g, m, v, c);
+            a.m[ngrad + k] = m;
+            a.v[ngrad + k] = v;
+        }
+    }
+    __syncthreads();  // the whole block has read step[0]
+    if (threadIdx.x == 0) {
+        unsigned* ticket = reinterpret_cast<unsigned*>(a.step + 1);
+        if (atomicAdd(ticket, 1u) == gridDim.x - 1) {
+            a.step[0] = t;
+            *ticket = 0u;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 constexpr int kBwdWaves = 4;
 
 struct WsLayout {
@@ -563,8 +801,13 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
 int backward_launch(bool given, const float* xa, const float* xb, long long K, long long nsplit, long long ldx,
                     const float* packed, const NpldaLayout& L, const float* g, const float* y, const float* z,
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
-                    float* dx0, float* dx1, long long lddx, hipStream_t st) {
+                    float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
+                    ReduceArgs* defer_reduce = nullptr) {
     BwdArgs b = {};
+    if (ls) {
+        if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
+        b.ls = *ls;
+    }
     b.g = g; b.z = z; b.y = y; b.rn = rn; b.packed = packed; b.ldz = ldz;
     if (given) {
         b.nA = (K + 1) / 2; b.nB = K - b.nA; b.offB = b.nB > 0 ? b.nA : 0;
@@ -583,7 +826,9 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
 #define NPLDA_LAUNCH2(NBV, GV)                                                                  \
     if (small) hipLaunchKernelGGL((bwd_data_small_kernel<NBV, GV>), grid, block, 0, st, b);      \
     else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves, GV>), grid, block, 0, st, b)
-#define NPLDA_LAUNCH(NBV) if (given) { NPLDA_LAUNCH2(NBV, true); } else { NPLDA_LAUNCH2(NBV, false); }
+#define NPLDA_LAUNCH(NBV)                                                                        \
+    if (ls) hipLaunchKernelGGL((bwd_data_small_kernel<NBV, false, true>), grid, block, 0, st, b); \
+    else if (given) { NPLDA_LAUNCH2(NBV, true); } else { NPLDA_LAUNCH2(NBV, false); }
         switch (L.NB) {
             case 2: NPLDA_LAUNCH(2); break;
             case 4: NPLDA_LAUNCH(4); break;
@@ -600,7 +845,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     // K-B
     WgradArgs wa = {};
     wa.K = K; wa.nsplit = nsplit; wa.ksplit = W.ksplit; wa.rows_per_split = W.rows_per_split;
-    wa.z = z; wa.g = g; wa.ldz = ldz; wa.ext = wsf + W.ext; wa.Mp = W.Mp;
+    wa.z = z; wa.g = ls ? ls->g_out : g; wa.ldz = ldz; wa.ext = wsf + W.ext; wa.Mp = W.Mp;
     WgradProblem& p1 = wa.p[0];  // dW1 = du^T [x1; x2]
     p1.A = wsf + W.du; p1.lda = ldz; p1.B0 = xa; p1.B1 = xb; p1.ldb = ldx; p1.M = W.Mp; p1.N = L.D0;
     p1.MT = (W.Mp + 63) / 64; p1.NT = (L.D0 + 63) / 64; p1.slab = wsf + W.slab1; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
@@ -617,6 +862,10 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
     ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = L.D0; ra.D1 = L.D1; ra.D2 = L.D2; ra.out = grad_flat;
     const size_t ngrad = (size_t)L.D1 * L.D0 + L.D1 + (size_t)L.D2 * L.D1 + 3 * (size_t)L.D2;
+    if (defer_reduce) {  // the caller's update kernel sums the slabs itself
+        *defer_reduce = ra;
+        return NPLDA_OK;
+    }
     hipLaunchKernelGGL(reduce_kernel, dim3((unsigned)((ngrad + 255) / 256)), dim3(256), 0, st, ra);
     if (int rc = nplda_launch_status()) return rc;
     if (dx0) {  // dL/dx = du . W1 (the E2E head's input gradient, utils/models.py:251-268)
@@ -753,6 +1002,85 @@ int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void*
     if (int rc = pad_rows(gz, ldgz, N, D2, wsf + W.dz, ldz, st)) return rc;
     return backward_launch(true, x, x, N, N, ldx, (const float*)packed, L, nullptr, y, nullptr, rn, ldz, nullptr, wsf, W,
                            grad_flat, dx, dx, lddx, st);
+}
+
+// ---- the fused training step --------------------------------------------------------------------------------
+namespace {
+struct StepWs { size_t y, z, rn, s, g, partial, bwd, total; long long ldz; int nblk; };  // float offsets
+StepWs step_ws(long long B, const NpldaLayout& L) {
+    StepWs w;
+    w.ldz = 16 * L.NB;
+    w.nblk = (int)((B + 15) / 16);
+    auto al = [](size_t v) { return (v + 63) / 64 * 64; };
+    w.y = 0;
+    w.z = al(w.y + (size_t)2 * B * w.ldz);
+    w.rn = al(w.z + (size_t)2 * B * w.ldz);
+    w.s = al(w.rn + (size_t)2 * B);
+    w.g = al(w.s + (size_t)B);
+    w.partial = al(w.g + (size_t)B);
+    w.bwd = al(w.partial + (size_t)w.nblk * kLossNS * 2);
+    w.total = w.bwd + ws_layout(2 * B, L, false).total;
+    return w;
+}
+}  // namespace
+
+size_t nplda_train_step_workspace_bytes(int64_t B, int D0, int D1, int D2) {
+    if (B < 1 || B > 16 * 1024 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return step_ws(B, nplda_layout(D0, D1, D2)).total * sizeof(float);
+}
+
+int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+                         float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
+                         float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
+                         float* grad_out, nplda_stream_t stream) {
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (B < 1) return NPLDA_EINVAL;
+    if (B > 16 * 1024) return NPLDA_EUNSUPPORTED;  // larger batches: the separate launches (two-pass loss)
+    if (kind != 0 && kind != 1) return kind == 2 ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
+    const int nth = kind == 1 ? 1 : K;
+    if (nth < 1 || nth > nplda_loss::kMaxK || !thetas || !params || (kind == 0 && !betas)) return NPLDA_EINVAL;
+    if (!target || !exp_avg || !exp_avg_sq || !step || !packed || !ws || !loss) return NPLDA_EINVAL;
+    if (!nplda_aligned16(packed) || !nplda_aligned16(ws) || !nplda_aligned16(target)) return NPLDA_EINVAL;
+    if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
+    for (int i = 0; i < 6; ++i)
+        if (!params[i]) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    const StepWs S = step_ws(B, L);
+    if (ws_bytes < S.total * sizeof(float)) return NPLDA_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    float* wsf = (float*)ws;
+
+    FwdArgs fa = {};
+    fa.xa = x1; fa.xb = x2; fa.n = B; fa.ldx = ldx; fa.packed = (const float*)packed;
+    fa.out_s = wsf + S.s; fa.out_z = wsf + S.z; fa.ldz = S.ldz; fa.out_y = wsf + S.y; fa.out_rn = wsf + S.rn;
+    if (int rc = launch_fwd<MODE_TRAIN>(fa, L, st)) return rc;
+
+    BwdLoss ls = {};
+    ls.s = wsf + S.s; ls.t = target; ls.K = nth; ls.kind = kind; ls.alpha = alpha; ls.B = B;
+    ls.g_out = wsf + S.g; ls.partial = reinterpret_cast<double*>(wsf + S.partial);
+    UpdateArgs ua = {};
+    for (int k = 0; k < nth; ++k) {
+        if (!thetas[k]) return NPLDA_EINVAL;
+        ls.th.p[k] = thetas[k];
+        ua.theta[k] = thetas[k];
+        if (kind == 0) ls.beta.b[k] = betas[k];
+    }
+    const WsLayout W = ws_layout(2 * B, L, false);
+    if (int rc = backward_launch(false, x1, x2, 2 * B, B, ldx, (const float*)packed, L, nullptr, wsf + S.y, wsf + S.z,
+                                 wsf + S.rn, S.ldz, params[4], wsf + S.bwd, W, grad_out, nullptr, nullptr, 0, st, &ls,
+                                 &ua.r))
+        return rc;
+    for (int i = 0; i < 6; ++i) ua.prm[i] = params[i];
+    ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;
+    ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
+    ua.L = L; ua.packed = (float*)packed;
+    ua.partial = ls.partial; ua.nblk = S.nblk; ua.K = nth; ua.kind = kind; ua.beta = ls.beta; ua.alpha = alpha;
+    ua.loss = loss;
+    const size_t ngrad = nplda_grad_floats(D0, D1, D2);
+    ua.ngrad_blocks = (unsigned)((ngrad + 255) / 256);
+    hipLaunchKernelGGL(train_update_kernel, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
+    return nplda_launch_status();
 }
 
 size_t nplda_lda_wgrad_workspace_bytes(int64_t B, int D0, int D1) {

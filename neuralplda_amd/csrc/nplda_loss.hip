@@ -12,17 +12,12 @@
 //   2. nplda_loss_finish_f32 : loss, dL/dtheta_k and g_i = dL/ds_i from the (global) sums.
 // sigma'(v) is evaluated as e/(1+e)^2, e = exp(-|v|) (no 1 - sigma cancellation: the reference's
 // fp32 autograd loses ~1e-3 relative accuracy there, see tests/test_oracle_golden.py).
-#include "nplda_common.h"
+#include "nplda_loss_math.h"
 
 namespace {
 
-constexpr int kMaxK = 4;
+using namespace nplda_loss;
 constexpr int kThreads = 256;
-
-struct ThetaPtrs { const float* p[kMaxK]; };
-struct BetaVals { float b[kMaxK]; };
-
-__device__ __forceinline__ float sigmoidf_(float v) { return 1.0f / (1.0f + __expf(-v)); }
 
 __device__ __forceinline__ double wave_sum_d(double v) {
 #pragma unroll
@@ -91,33 +86,7 @@ __global__ __launch_bounds__(kThreads) void loss_sums_softcdet(const float* __re
     float theta[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
-    auto accumulate = [&](float si, float ti) {
-        const float ni = 1.0f - ti;
-        acc[0] += ti;
-        acc[1] += ni;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            float sm, sf, d;
-            if (HARD) {
-                sm = si < theta[k] ? 1.0f : 0.0f;
-                sf = si > theta[k] ? 1.0f : 0.0f;
-                d = 0.0f;
-            } else {
-                const float v = alpha * (theta[k] - si);
-                const float e = __expf(-fabsf(v));
-                const float inv = 1.0f / (1.0f + e);
-                const float sg_pos = inv;        // sigma(|v|)
-                const float sg_neg = e * inv;    // sigma(-|v|)
-                sm = v >= 0.f ? sg_pos : sg_neg;  // sigma(alpha (theta - s))   (miss)
-                sf = v >= 0.f ? sg_neg : sg_pos;  // sigma(alpha (s - theta))   (false alarm)
-                d = e * inv * inv;                // sigma'(v)
-            }
-            acc[2 + 4 * k + 0] += sm * ti;
-            acc[2 + 4 * k + 1] += sf * ni;
-            acc[2 + 4 * k + 2] += d * ti;
-            acc[2 + 4 * k + 3] += d * ni;
-        }
-    };
+    auto accumulate = [&](float si, float ti) { softcdet_accumulate<K, HARD>(si, ti, theta, alpha, acc); };
     if (single) {
         sums_single_block(s, t, B, accumulate);
     } else {
@@ -131,16 +100,7 @@ __global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restric
                                                           long long B, ThetaPtrs th, double* sums, int single) {
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const float theta = th.p[0][0];
-    auto accumulate = [&](float si, float ti) {
-        // F.binary_cross_entropy(sigmoid(s - theta), t): log terms clamped at -100 (utils/models.py:390-393)
-        const float p = 1.0f / (1.0f + expf(-(si - theta)));
-        const float lp = fmaxf(logf(p), -100.0f);
-        const float lq = fmaxf(logf(1.0f - p), -100.0f);
-        acc[0] += ti;
-        acc[1] += 1.0f - ti;
-        acc[2] += -(ti * lp + (1.0f - ti) * lq);
-        acc[3] += p - ti;
-    };
+    auto accumulate = [&](float si, float ti) { bce_accumulate(si, ti, theta, acc); };
     if (single) {
         sums_single_block(s, t, B, accumulate);
     } else {
@@ -148,39 +108,6 @@ __global__ __launch_bounds__(kThreads) void loss_sums_bce(const float* __restric
         for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) accumulate(s[i], t[i]);
     }
     block_reduce_add<4>(acc, sums, single);
-}
-
-// dL/ds_i of SoftCdet given the batch constants (shared by the two-pass finish kernel and the fused small-batch kernel)
-template <int K>
-__device__ __forceinline__ float softcdet_gi(float si, float ti, const float (&theta)[K], const float (&cn)[K], float ct,
-                                             float alpha) {
-    const float ni = 1.0f - ti;
-    float gi = 0.f;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        const float v = alpha * (theta[k] - si);
-        const float e = __expf(-fabsf(v));
-        const float inv = 1.0f / (1.0f + e);
-        const float d = e * inv * inv;
-        gi = fmaf(d, fmaf(ct, ti, cn[k] * ni), gi);  // explicit contraction: the same bits wherever this is inlined
-    }
-    return gi;
-}
-
-// loss and dL/dtheta from the sums (one thread)
-template <int K>
-__device__ __forceinline__ void softcdet_scalars(const double* sums, const BetaVals& beta, float alpha, float* loss,
-                                                 float* dtheta) {
-    const double Nt = sums[0], Nn = sums[1];
-    double L = 0.0;
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-        L += sums[2 + 4 * k] / Nt + (double)beta.b[k] * sums[2 + 4 * k + 1] / Nn;
-        if (dtheta)
-            dtheta[k] = (float)(((double)alpha * sums[2 + 4 * k + 2] / Nt -
-                                 (double)beta.b[k] * alpha * sums[2 + 4 * k + 3] / Nn) / K);
-    }
-    if (loss) loss[0] = (float)(L / K);
 }
 
 template <int K>
@@ -192,13 +119,10 @@ __global__ __launch_bounds__(kThreads) void loss_finish_softcdet(const float* __
     const double Nt = sums[0], Nn = sums[1];
     if (blockIdx.x == 0 && threadIdx.x == 0) softcdet_scalars<K>(sums, beta, alpha, loss, dtheta);
     if (g == nullptr) return;
-    float theta[K], cn[K];
+    float theta[K], cn[K], ct;
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-        theta[k] = th.p[k][0];
-        cn[k] = (float)((double)beta.b[k] * alpha / (Nn * K));
-    }
-    const float ct = (float)(-(double)alpha / (Nt * K));
+    for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
+    softcdet_consts<K>(Nt, Nn, beta, alpha, cn, ct);
     const long long stride = (long long)gridDim.x * kThreads;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
         g[i] = softcdet_gi<K>(s[i], t[i], theta, cn, ct, alpha);
@@ -210,17 +134,13 @@ __global__ __launch_bounds__(kThreads) void loss_finish_bce(const float* __restr
                                                             const double* __restrict__ sums, float* loss,
                                                             float* __restrict__ g, float* dtheta) {
     const double N = sums[0] + sums[1];
-    if (blockIdx.x == 0 && threadIdx.x == 0) {
-        if (loss) loss[0] = (float)(sums[2] / N);
-        if (dtheta) dtheta[0] = (float)(-sums[3] / N);
-    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) bce_scalars(sums, loss, dtheta);
     if (g == nullptr) return;
     const float theta = th.p[0][0];
     const float invN = (float)(1.0 / N);
     const long long stride = (long long)gridDim.x * kThreads;
     for (long long i = (long long)blockIdx.x * kThreads + threadIdx.x; i < B; i += stride) {
-        const float p = 1.0f / (1.0f + expf(-(s[i] - theta)));
-        g[i] = (p - t[i]) * invN;
+        g[i] = bce_gi(s[i], t[i], theta, invN);
     }
 }
 
@@ -289,31 +209,12 @@ __global__ __launch_bounds__(kThreads) void loss_fused_softcdet(const float* __r
     float theta[K];
 #pragma unroll
     for (int k = 0; k < K; ++k) theta[k] = th.p[k][0];
-    sums_single_block(s, t, B, [&](float si, float ti) {
-        const float ni = 1.0f - ti;
-        acc[0] += ti;
-        acc[1] += ni;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-            const float v = alpha * (theta[k] - si);
-            const float e = __expf(-fabsf(v));
-            const float inv = 1.0f / (1.0f + e);
-            const float sm = v >= 0.f ? inv : e * inv;
-            const float sf = v >= 0.f ? e * inv : inv;
-            const float d = e * inv * inv;
-            acc[2 + 4 * k + 0] += sm * ti;
-            acc[2 + 4 * k + 1] += sf * ni;
-            acc[2 + 4 * k + 2] += d * ti;
-            acc[2 + 4 * k + 3] += d * ni;
-        }
-    });
+    sums_single_block(s, t, B, [&](float si, float ti) { softcdet_accumulate<K, false>(si, ti, theta, alpha, acc); });
     block_totals<NS>(acc, tot, sums);
     if (threadIdx.x == 0) softcdet_scalars<K>(tot, beta, alpha, loss, dtheta);
     const double Nt = tot[0], Nn = tot[1];
-    float cn[K];
-#pragma unroll
-    for (int k = 0; k < K; ++k) cn[k] = (float)((double)beta.b[k] * alpha / (Nn * K));
-    const float ct = (float)(-(double)alpha / (Nt * K));
+    float cn[K], ct;
+    softcdet_consts<K>(Nt, Nn, beta, alpha, cn, ct);
     grad_single_block(s, t, g, B, [&](float si, float ti) { return softcdet_gi<K>(si, ti, theta, cn, ct, alpha); });
 }
 
@@ -323,26 +224,12 @@ __global__ __launch_bounds__(kThreads) void loss_fused_bce(const float* __restri
     __shared__ double tot[4];
     double acc[4] = {0.0, 0.0, 0.0, 0.0};
     const float theta = th.p[0][0];
-    sums_single_block(s, t, B, [&](float si, float ti) {
-        const float p = 1.0f / (1.0f + expf(-(si - theta)));
-        const float lp = fmaxf(logf(p), -100.0f);
-        const float lq = fmaxf(logf(1.0f - p), -100.0f);
-        acc[0] += ti;
-        acc[1] += 1.0f - ti;
-        acc[2] += -(ti * lp + (1.0f - ti) * lq);
-        acc[3] += p - ti;
-    });
+    sums_single_block(s, t, B, [&](float si, float ti) { bce_accumulate(si, ti, theta, acc); });
     block_totals<4>(acc, tot, sums);
     const double N = tot[0] + tot[1];
-    if (threadIdx.x == 0) {
-        if (loss) loss[0] = (float)(tot[2] / N);
-        if (dtheta) dtheta[0] = (float)(-tot[3] / N);
-    }
+    if (threadIdx.x == 0) bce_scalars(tot, loss, dtheta);
     const float invN = (float)(1.0 / N);
-    grad_single_block(s, t, g, B, [&](float si, float ti) {
-        const float p = 1.0f / (1.0f + expf(-(si - theta)));
-        return (p - ti) * invN;
-    });
+    grad_single_block(s, t, g, B, [&](float si, float ti) { return bce_gi(si, ti, theta, invN); });
 }
 
 unsigned grid_for(long long B) {
@@ -359,7 +246,7 @@ extern "C" {
 int nplda_loss_nsums(int K, int kind) {
     if (kind == 1) return 4;
     if ((kind != 0 && kind != 2) || K < 1 || K > kMaxK) return 0;
-    return 2 + 4 * K;
+    return nsums(K, kind);
 }
 
 int nplda_loss_sums_f32(const float* s, const float* t, int64_t B, const float* const* theta, int K, float alpha,

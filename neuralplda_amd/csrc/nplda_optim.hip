@@ -7,7 +7,7 @@
 // square root, no amsgrad) to up to 12 (param, grad, m, v) segments in ONE launch, reading the gradients where
 // nplda_backward_f32 / nplda_loss_finish_f32 left them.  The step counter lives on the device so that the
 // whole optimisation step can be replayed from a HIP graph.
-#include "nplda_common.h"
+#include "nplda_adam_math.h"
 
 namespace {
 
@@ -28,10 +28,7 @@ struct AdamArgs {
 // own (it was a 1-thread kernel: 4.5 us of a 109 us training step) and the pair stays graph-replay safe.
 __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
     const float t = a.step[0] + 1.0f;
-    const float bc1 = 1.0f - powf(a.beta1, t);
-    const float bc2 = 1.0f - powf(a.beta2, t);
-    const float step_size = a.lr / bc1;
-    const float inv_sqrt_bc2 = 1.0f / sqrtf(bc2);
+    const nplda_adam::Consts c = nplda_adam::consts_for(t, a.lr, a.beta1, a.beta2, a.eps, a.wd);
     const long long stride = (long long)gridDim.x * 256;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < a.total; i += stride) {
         long long r = i;
@@ -39,14 +36,10 @@ __global__ __launch_bounds__(256) void adam_kernel(const AdamArgs a) {
 #pragma unroll 1
         for (; s < a.nseg - 1 && r >= a.seg[s].n; ++s) r -= a.seg[s].n;
         const AdamSeg& sg = a.seg[s];
-        const float p = sg.p[r];
-        const float g = sg.g[r] + a.wd * p;
-        const float m = a.beta1 * sg.m[r] + (1.0f - a.beta1) * g;
-        const float v = a.beta2 * sg.v[r] + (1.0f - a.beta2) * g * g;
+        float m = sg.m[r], v = sg.v[r];
+        sg.p[r] = nplda_adam::update(sg.p[r], sg.g[r], m, v, c);
         sg.m[r] = m;
         sg.v[r] = v;
-        const float denom = sqrtf(v) * inv_sqrt_bc2 + a.eps;
-        sg.p[r] = p - step_size * (m / denom);
     }
     __syncthreads();  // the whole block has read step[0]
     if (threadIdx.x == 0) {

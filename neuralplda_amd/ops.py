@@ -413,6 +413,64 @@ def loss_fwd_bwd(s, t, thetas, betas, alpha, kind):
     return loss, g, dth, sums
 
 
+def pack_params_into(packed, W1, b1, W2, b2, P_sqrt, Q):
+    """nplda_pack_params_f32 into an EXISTING PackedParams buffer (its address is baked into captured graphs)."""
+    lib = _lib.load()
+    _need_fp32(packed, "pack_params_into")
+    ts = [t.detach().contiguous() for t in (W1, b1, W2, b2, P_sqrt, Q)]
+    for n, t in zip(("W1", "b1", "W2", "b2", "P_sqrt", "Q"), ts):
+        _require_dev_f32(t, n)
+    with torch.cuda.device(packed.buf.device):
+        code = lib.nplda_pack_params_f32(*[_lib.ptr(t) for t in ts], packed.D0, packed.D1, packed.D2, _lib.ptr(packed.buf),
+                                         packed.buf.numel() * 4, _lib.current_stream())
+    _lib.check(code, "nplda_pack_params_f32")
+    return packed
+
+
+def train_step_workspace(B, packed):
+    """Workspace tensor for train_step at batch size B (None when the fused step does not cover this size)."""
+    n = _lib.load().nplda_train_step_workspace_bytes(B, packed.D0, packed.D1, packed.D2)
+    if n == 0:
+        return None
+    return torch.empty(n // 4, dtype=torch.float32, device=packed.buf.device)
+
+
+def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
+               weight_decay, packed, ws, loss, grad_out=None):
+    """nplda_train_step_f32: forward -> loss -> backward -> Adam on `params` (the six parameter tensors, updated IN
+    PLACE) and `thetas`, `packed` refreshed to the updated parameters, `loss` (0-d device tensor) written.  Four launches."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step")
+    x1, ld1 = _rows(x1, "x1", packed.D0)
+    x2, ld2 = _rows(x2, "x2", packed.D0)
+    if x1.shape[0] != x2.shape[0] or target.shape[0] != x1.shape[0]:
+        raise ValueError("x1, x2 and target must have the same number of rows")
+    if ld1 != ld2:
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ld1 = ld2 = packed.D0
+    _require_dev_f32(target, "target")
+    target = target.contiguous()
+    if target.data_ptr() % 16:
+        target = target.clone()
+    for q in list(params) + list(thetas):
+        _require_dev_f32(q, "parameter")
+        if not q.is_contiguous():
+            raise ValueError("train_step updates the parameter tensors in place: they must be contiguous")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(x1.device):
+        code = lib.nplda_train_step_f32(_lib.ptr(x1), _lib.ptr(x2), x1.shape[0], ld1, _lib.ptr(target), parr, packed.D0,
+                                        packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha), kind,
+                                        _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step), float(lr), float(beta1),
+                                        float(beta2), float(eps), float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(ws),
+                                        ws.numel() * 4, _lib.ptr(loss), _lib.ptr(grad_out) if grad_out is not None else None,
+                                        _lib.current_stream())
+    _lib.check(code, "nplda_train_step_f32")
+    return loss
+
+
 # ---- indexed scoring / gather -------------------------------------------------------------------
 
 def _idx(t, name, dev):

@@ -197,14 +197,19 @@ class GraphedTrainStep:
 
 
 class FusedTrainStep:
-    """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser:
-    pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat gradient) -> one-launch Adam
-    (nplda_adam_step_f32, same update rule as torch.optim.Adam(lr, weight_decay) of the reference,
-    xvector_NeuralPlda_pytorch.py:139) — seven launches up to 4096 pairs (the loss is one launch there; ten beyond), optionally replayed from a HIP graph.
+    """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser.  Up to 16384 pairs on
+    one rank it is ONE call, nplda_train_step_f32: forward(train) -> data gradients with the loss folded in -> weight
+    gradient slabs -> slab sums + Adam + refreshed parameter image + loss / dtheta (four launches; the update rule is
+    torch.optim.Adam(lr, weight_decay) of the reference, xvector_NeuralPlda_pytorch.py:139).  Larger batches and
+    data-parallel models take the separate calls: pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat
+    gradient) -> one-launch Adam (nplda_adam_step_f32).  Either form is optionally replayed from a HIP graph.
     With the `reduce_sums` / `reduce_flat` hooks of a data-parallel model (neuralplda_amd.dist.make_data_parallel) it is
     the data-parallel step: each rank feeds its shard of the global minibatch, the fp64 loss sums and the flat gradient
     are all-reduced (SUM) between the launches, and both collectives are captured INSIDE the HIP graph (RCCL collectives
     are stream operations), so the replayed step stays one graph launch per rank."""
+
+    _one_call = False  # subclasses with their own kernels (FusedDPldaStep) keep the separate calls
+    _packed = _packed_key = None
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
         from . import _lib, ops
@@ -239,15 +244,56 @@ class FusedTrainStep:
         self.i1 = self.i2 = None
         self.reduce_sums = getattr(model, "_reduce_sums", None)
         self.reduce_flat = getattr(model, "_reduce_flat", None)
+        # one-call step (nplda_train_step_f32): single rank, SoftCdet / BCE; its parameter image lives here and follows the
+        # parameters from step to step (re-packed only when something else has touched them: version counters)
+        self._one_call = (type(self) is FusedTrainStep and self.reduce_sums is None and self.reduce_flat is None
+                          and self.kind in (ops.LOSS_SOFTCDET, ops.LOSS_BCE))
+        self._packed = None
+        self._packed_key = None
+        self._ws = {}
+        self._loss_buf = torch.zeros((), device=self.dev)
         if self.use_graph:
             self.x1 = torch.zeros(batch_size, D0, device=self.dev)
             self.x2 = torch.zeros(batch_size, D0, device=self.dev)
             self.t = torch.zeros(batch_size, device=self.dev)
             self.t[::2] = 1
 
+    def _sync_packed(self):
+        """The step's parameter image, re-packed if anything but the step itself changed the parameters."""
+        key = tuple(q._version for q in self.params)
+        if self._packed is None:
+            self._packed = self._ops.pack_params(*[q.detach() for q in self.params])
+        elif key != self._packed_key:
+            self._ops.pack_params_into(self._packed, *[q.detach() for q in self.params])
+        self._packed_key = key
+
+    def _touched(self):
+        """The raw kernels have rewritten the parameters: bump their version counters (autograd's saved-tensor
+        checks, the model's packed-image cache); the step's own image was refreshed by the same launch."""
+        for q in self.params + self.thetas:
+            torch.autograd.graph.increment_version(q)
+        self._packed_key = tuple(q._version for q in self.params)
+
+    def _one_call_step(self, x1, x2, t):
+        ops = self._ops
+        B = x1.shape[0]
+        ws = self._ws.get(B)
+        if ws is None:
+            ws = self._ws[B] = ops.train_step_workspace(B, self._packed)
+        with torch.no_grad():
+            ops.train_step(x1, x2, t, [q.detach() for q in self.params], [th.detach() for th in self.thetas],
+                           self.betas_loss, self.alpha, self.kind, self.m, self.v, self.step_count, self.lr, self.betas[0],
+                           self.betas[1], self.eps, self.wd, self._packed, ws, self._loss_buf)
+        # the captured step hands out its static output; an eager step a tensor of its own (callers keep losses around)
+        return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
+
     def _eager(self, x1, x2, t):
         ops = self._ops
         D0, D1, D2 = self.dims
+        if self._one_call and 0 < x1.shape[0] <= 16384:
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            return self._one_call_step(x1, x2, t)
         with torch.no_grad():
             prm = [q.detach() for q in self.params]
             packed = ops.pack_params(*prm)
@@ -265,12 +311,6 @@ class FusedTrainStep:
             grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
             self._adam(prm + ths, grads)
         return loss
-
-    def _touched(self):
-        """The raw Adam kernel has rewritten the parameters: bump their version counters (autograd's saved-tensor
-        checks, the model's packed-image cache)."""
-        for q in self.params + self.thetas:
-            torch.autograd.graph.increment_version(q)
 
     def _adam(self, tensors, grads):
         """One nplda_adam_step_f32 launch over `tensors` (moments in self.m / self.v, segment by segment)."""
@@ -306,6 +346,8 @@ class FusedTrainStep:
             self.m.copy_(m0)
             self.v.copy_(v0)
             self.step_count.copy_(s0)
+        if self._one_call:
+            self._sync_packed()  # the warm-up moved the image along with the parameters: back to the restored values
         graph = torch.cuda.CUDAGraph()
         # with collectives in the step the RCCL watchdog thread polls events while we capture: only this thread's calls
         # may be checked against the capture
@@ -329,6 +371,8 @@ class FusedTrainStep:
             return loss
         if self._graph_rows is None or self._graph_table != (table.data_ptr(), table.shape, table.stride(0)):
             self._capture_rows(table)
+        if self._one_call:
+            self._sync_packed()
         self.i1.copy_(rows1, non_blocking=True)
         self.i2.copy_(rows2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
@@ -356,9 +400,16 @@ class FusedTrainStep:
             return loss
         if self._graph is None:
             self._capture()
-        self.x1.copy_(x1, non_blocking=True)
-        self.x2.copy_(x2, non_blocking=True)
-        self.t.copy_(target, non_blocking=True)
+        if self._one_call:
+            self._sync_packed()
+        # a caller that fills the step's own input buffers (step.x1 / .x2 / .t, e.g. gather_rows(..., out=step.x1)) skips
+        # the staging copies: at 4096 x 512 they are 2 x 8 MB, 16 us of a 70 us step
+        if x1 is not self.x1:
+            self.x1.copy_(x1, non_blocking=True)
+        if x2 is not self.x2:
+            self.x2.copy_(x2, non_blocking=True)
+        if target is not self.t:
+            self.t.copy_(target, non_blocking=True)
         self._graph.replay()
         self._touched()
         return self._loss

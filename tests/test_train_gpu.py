@@ -369,6 +369,69 @@ def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
     assert step.step_count[0].item() == 5 and step.step_count[1].item() == 0
 
 
+@pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("SoftCdet", 1003, 170), ("crossentropy", 250, 150),
+                                          ("SoftCdet", 16, 40)])
+def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
+    """nplda_train_step_f32 (loss folded into the data-gradient kernel, slab sums + Adam + re-pack in one launch) against
+    the same step as separate C-ABI calls: the SAME parameter bits after every step (dL/ds, the slabs and Adam's update
+    are the same arithmetic); the loss scalar may differ in its last bit (fp64 sums taken per block of 16 pairs)."""
+    from neuralplda_amd import ops, train
+    rng = np.random.default_rng(77)
+    p = rand_params(rng, 512, D, D)
+    xs = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(4)]
+    nc = NC(512, D, D, loss=lossname)
+    m_a = model_from(p, nc, thetas=[-0.5, -0.3], theta_xent=0.1)
+    m_b = model_from(p, nc, thetas=[-0.5, -0.3], theta_xent=0.1)
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    assert sa._one_call
+    sb._one_call = False
+    for i, (x1, x2, t) in enumerate(xs):
+        la, lb = sa(x1, x2, t), sb(x1, x2, t)
+        assert abs(la.item() - lb.item()) <= 2e-7 * abs(lb.item())
+        for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            assert torch.equal(a, b), (i, k, (a - b).abs().max().item())
+        assert torch.equal(sa.m, sb.m) and torch.equal(sa.v, sb.v)
+        # the image the step carries along is the image of the updated parameters
+        fresh = ops.pack_params(*[q.detach() for q in sa.params])
+        assert torch.equal(sa._packed.buf, fresh.buf), i
+        if i == 1:  # somebody else rewrites a parameter between steps: the step notices and re-packs
+            with torch.no_grad():
+                for mm in (m_a, m_b):
+                    list(mm._params())[1].mul_(0.5)
+    assert sa.step_count[0].item() == 4 and sa.step_count[1].item() == 0
+
+
+def test_one_call_step_reports_the_applied_gradient(hip_lib):
+    """grad_out of nplda_train_step_f32 = flat gradient of the separate backward + dtheta of the separate loss."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(78)
+    D, B = 150, 777
+    rp = rand_params(rng, 512, D, D)
+    prm = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in (rp.W1, rp.b1, rp.W2, rp.b2, rp.P_sqrt, rp.Q)]
+    x1 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(B) < 0.3).astype(np.float32)).cuda()
+    ths = [torch.tensor([-0.4], device="cuda"), torch.tensor([-0.2], device="cuda")]
+    betas, alpha = [99.0, 199.0], 15.0
+    packed = ops.pack_params(*prm)
+    s, saved = ops.forward_train(x1, x2, packed)
+    loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, betas, alpha, ops.LOSS_SOFTCDET)
+    flat = ops.backward(saved, g, packed, prm[4])
+    n = flat.numel()
+    m, v, step = torch.zeros(n + 2, device="cuda"), torch.zeros(n + 2, device="cuda"), torch.zeros(2, device="cuda")
+    out, lbuf = torch.zeros(n + 2, device="cuda"), torch.zeros((), device="cuda")
+    ws = ops.train_step_workspace(B, packed)
+    ops.train_step(x1, x2, t, prm, ths, betas, alpha, ops.LOSS_SOFTCDET, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-5, packed,
+                   ws, lbuf, grad_out=out)
+    assert torch.equal(out[:n], flat)
+    np.testing.assert_allclose(out[n:].cpu().numpy(), dth.cpu().numpy(), rtol=1e-6)
+    assert abs(lbuf.item() - loss.item()) <= 2e-7 * abs(loss.item())
+    assert ops.train_step_workspace(16385, packed) is None
+
+
 def test_cfg2_full_size_minibatch_from_a_voxceleb_scale_table(hip_lib):
     """BASELINE cfg2 at full size: 4096-pair minibatches gathered from a 1.2 M-utterance resident table (2.4 GB),
     512 -> 150 -> 150, SoftCdet, three fused optimiser steps.  Properties: the device gather equals plain indexing bit

@@ -1,5 +1,12 @@
 #!/usr/bin/env python3
-"""FusedTrainStep replays at B = 4096 (BASELINE cfg2) for rocprofv3 --kernel-trace: what the graph's launches cost."""
+"""FusedTrainStep replays at B = 4096 (BASELINE cfg2) for rocprofv3 --kernel-trace: what the graph's launches cost.
+
+Three ways of feeding the step, each timed over 200 replays:
+  inplace : the minibatch is written into the step's own input buffers (step.x1 / .x2 / .t) — no staging copies;
+  copy    : foreign tensors -> three device copies (2 x 8 MB + 16 KB) in front of every replay;
+  rows    : step_rows(table, rows1, rows2, t) — the training loop's form: index copies + in-graph gathers from the
+            resident x-vector table.
+usage: fused_step_profile.py [D=150] [graph|eager] [modes=inplace,copy,rows]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -13,19 +20,35 @@ class NC:
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 graph = (sys.argv[2] != "eager") if len(sys.argv) > 2 else True
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["inplace", "copy", "rows"]
 NC.layer1_LDA_dim = NC.layer2_PLDA_spkfactor_dim = D
 torch.manual_seed(0)
 m = models.NeuralPlda(NC()).cuda()
 B = 4096
 x1 = torch.randn(B, 512, device="cuda"); x2 = torch.randn(B, 512, device="cuda")
 t = (torch.rand(B, device="cuda") < 0.1).float()
+table = torch.randn(200000, 512, device="cuda")
+r1 = torch.randint(0, table.shape[0], (B,), device="cuda"); r2 = torch.randint(0, table.shape[0], (B,), device="cuda")
 step = train.FusedTrainStep(m, 1e-4, weight_decay=1e-5, batch_size=B, graph=graph)
-for _ in range(5):
-    step(x1, x2, t)
-torch.cuda.synchronize()
-n = 200
-t0 = time.perf_counter()
-for _ in range(n):
-    step(x1, x2, t)
-torch.cuda.synchronize()
-print(f"D={D} B={B} graph={graph}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms/step (wall)")
+
+
+def timed(fn, n=200):
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(n):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / n * 1e3
+
+
+for mode in modes:
+    if mode == "inplace" and graph:
+        step.x1.copy_(x1); step.x2.copy_(x2); step.t.copy_(t)
+        ms = timed(lambda: step(step.x1, step.x2, step.t))
+    elif mode == "rows":
+        ms = timed(lambda: step.step_rows(table, r1, r2, t))
+    else:
+        ms = timed(lambda: step(x1, x2, t))
+    print(f"D={D} B={B} graph={graph} feed={mode}: {ms:.4f} ms/step (wall)")

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Summarise rocprofv3 rocpd (.db) outputs: per-kernel time stats and per-kernel PMC means.
 
-usage: rocpd_summary.py <results.db> [...]   (prints a text table; redirect into profiles/)
+usage: rocpd_summary.py [--by-grid] <results.db> [...]   (prints a text table; redirect into profiles/)
+--by-grid: kernel-trace rows grouped by (kernel, grid size) — one kernel launched at several problem sizes.
 """
 import sqlite3
 import sys
@@ -13,9 +14,17 @@ def short(name, n=90):
 
 
 def main():
-    for path in sys.argv[1:]:
+    by_grid = "--by-grid" in sys.argv
+    for path in [a for a in sys.argv[1:] if a != "--by-grid"]:
         c = sqlite3.connect(path)
         print(f"== {path}")
+        if by_grid:
+            q = ("select name, grid_x, workgroup_x, count(*), avg(duration), min(duration) from kernels "
+                 "group by name, grid_x order by name, grid_x")
+            print(f"  {'kernel':70s} {'grid':>9s} {'wg':>5s} {'calls':>6s} {'avg_us':>10s} {'min_us':>10s}")
+            for name, gx, wx, n, avg, mn in c.execute(q):
+                print(f"  {short(name, 70):70s} {gx:9d} {wx:5d} {n:6d} {avg / 1e3:10.2f} {mn / 1e3:10.2f}")
+            continue
         try:
             rows = list(c.execute("select name, total_calls, total_duration, average, percentage from top_kernels"))
         except sqlite3.Error as e:
