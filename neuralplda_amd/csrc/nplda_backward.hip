@@ -64,6 +64,7 @@ struct BwdArgs {
     float* dz;            // (rows, ldz): written, or READ when GIVEN (upstream dL/dz, zero-padded columns)
     float* du;            // (rows, ldz)
     int ntb;              // tile-blocks = ceil(nA / (16 * WAVES))
+    float* pq;            // small kernel, pair scoring: [blocks][2][ldz] per-block sums of g (z1^2 + z2^2) and g z1 z2
     BwdLoss ls;           // [LOSS kernels only]
 };
 
@@ -290,6 +291,24 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
                     *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g4) = dA;
                     *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g4) = dB;
                 }
+                // dQ_f = sum_pairs g (z1_f^2 + z2_f^2), dP_f = sum_pairs g z1_f z2_f: this block's 16 pairs, from the z
+                // rows and g already in registers (in the weight-gradient kernel they were three more un-prefetched loads
+                // per k4-step, and its 45 blocks that carried them set the kernel's time)
+                const float gh = 0.5f * tg;
+                f32x4 eq = gh * (zA * zA + zB * zB), ep = gh * (zA * zB);
+#pragma unroll
+                for (int msk = 1; msk < 16; msk <<= 1) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        eq[r] += __shfl_xor(eq[r], msk, 64);
+                        ep[r] += __shfl_xor(ep[r], msk, 64);
+                    }
+                }
+                if (j == 0) {
+                    float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * nb + 4 * g4;
+                    *reinterpret_cast<f32x4*>(o) = eq;
+                    *reinterpret_cast<f32x4*>(o + a.ldz) = ep;
+                }
             }
         }
     }
@@ -376,7 +395,8 @@ struct WgradProblem {
     int MT, NT;           // 64-wide tiles
     float* slab;          // [ksplit][Mp][Np]
     int Mp, Np;
-    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}, 3 = {db2 from A; dQ = dP = 0}
+    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}, 3 = {db2 from A; dQ = dP = 0},
+                          // 4 = {db2 from A; the dQ / dP rows are summed by the pair-sum blocks from K-A's per-block sums}
 };
 
 struct WgradArgs {
@@ -392,6 +412,9 @@ struct WgradArgs {
     int Mp;
     int nw0;              // work items of problem 0 = MT0*NT0*ksplit
     int nw;               // total work items
+    const float* pq;      // [nblk][2][ldz] per-block dQ / dP sums of K-A (small-batch pair scoring), else null
+    int nblk;
+    int nw_mm;            // work items of the two GEMMs; items [nw_mm, nw) = one pair-sum block per k-group
 };
 
 constexpr int kPF = 4;  // k4-steps of operand prefetch per wave (8 needed 330 registers: one block per CU; at 4 two are resident)
@@ -433,23 +456,21 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProble
         for (int cb = 0; cb < 4; ++cb) acc[ca][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0, e2 = e0;  // column-sum accumulators (per lane: 4 m-values)
 
-    // branch-free operand loads (clamped address + select): a predicated load would force s_waitcnt vmcnt(0)
-    // at every use and defeat the kPF-deep prefetch ring
+    // Branch-free operand loads: the address is clamped into the table and the ring holds the RAW loaded values; rows
+    // past the wave's range are zeroed when the slot is CONSUMED, kPF steps later.  (A select right after the load
+    // makes the loaded value live at once: hipcc then waits for every load of a round before the loop's back-edge, and
+    // the ring prefetches nothing — 0.9 us per k4-step instead of 0.45.)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
     const int mcol = mval ? m0 + 4 * i16 : 0;
     const int ncol = nval ? n0 + 4 * i16 : 0;
     auto loadA = [&](long long row) -> f32x4 {
-        const bool ok = row < k1 && mval;
         const long long rc = row < K ? row : K - 1;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(PA + rc * lda + mcol);
-        return ok ? v : zero4;
+        return *reinterpret_cast<const f32x4*>(PA + rc * lda + mcol);
     };
     auto loadB = [&](long long row) -> f32x4 {
-        const bool ok = row < k1 && nval;
         const long long rc = row < K ? row : K - 1;
         const float* base = rc < npairs ? PB0 + rc * ldb : PB1 + (rc - npairs) * ldb;
-        const f32x4 v = *reinterpret_cast<const f32x4*>(base + ncol);
-        return ok ? v : zero4;
+        return *reinterpret_cast<const f32x4*>(base + ncol);
     };
 
     f32x4 fa[kPF], fb[kPF];
@@ -461,15 +482,19 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProble
     for (long long kk = k0; kk < k1; kk += 4 * kPF) {
 #pragma unroll
         for (int s = 0; s < kPF; ++s) {
-            const f32x4 av = fa[s], bv = fb[s];
             const long long row = kk + 4 * s + g4;
-            // prefetch the same slot one round ahead
+            const bool live = row < k1;
+            const f32x4 av = (live && mval) ? fa[s] : zero4;
+            const f32x4 bv = (live && nval) ? fb[s] : zero4;
+            // prefetch the same slot one round ahead — pinned here: the scheduler otherwise sinks the loads to the end of the
+            // round (shorter live ranges) and the next round starts by waiting for all of them
             fa[s] = loadA(row + 4 * kPF);
             fb[s] = loadB(row + 4 * kPF);
+            __builtin_amdgcn_sched_barrier(0);
             if (ext) {
                 e0 += av;  // db1 (extras 1) or db2 (extras 2)
                 if (ext == 2) {  // all loads unconditional (clamped), contributions masked by select
-                    const bool ok = row < k1 && mval;
+                    const bool ok = live && mval;
                     const long long rc = row < K ? row : K - 1;
                     const long long pr = rc < npairs ? rc : rc - npairs;
                     const float gi = ok ? gptr[pr] : 0.f;
@@ -535,6 +560,8 @@ __device__ __forceinline__ void wgrad_body(const WgradArgs& a, const WgradProble
         float* eb = a.ext + (size_t)ks * 4 * a.Mp + m0 + 4 * i16;
         if (ext == 1) {
             *reinterpret_cast<f32x4*>(eb + 3 * a.Mp) = t0;
+        } else if (ext == 4) {
+            *reinterpret_cast<f32x4*>(eb + 2 * a.Mp) = t0;
         } else {
             *reinterpret_cast<f32x4*>(eb + 0 * a.Mp) = t1;
             *reinterpret_cast<f32x4*>(eb + 1 * a.Mp) = t2;
@@ -548,6 +575,18 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __shared__ f32x4 rede[4][3][16];    // column-sum partials
     int w = blockIdx.x;
     if (w >= a.nw) return;
+    if (w >= a.nw_mm) {  // pair-sum block of k-group ks: ext[ks][0 / 1][f] = sum of its share of K-A's per-block sums
+        const int ks = w - a.nw_mm;
+        const int per = (a.nblk + a.ksplit - 1) / a.ksplit;
+        const int b0 = ks * per, b1 = b0 + per < a.nblk ? b0 + per : a.nblk;
+        for (int i = threadIdx.x; i < 2 * a.Mp; i += 256) {
+            const int row = i / a.Mp, f = i - row * a.Mp;
+            float sum = 0.f;
+            for (int b = b0; b < b1; ++b) sum += a.pq[((size_t)b * 2 + row) * a.ldz + f];
+            a.ext[(size_t)ks * 4 * a.Mp + row * a.Mp + f] = sum;
+        }
+        return;
+    }
     const int pi = w >= a.nw0 ? 1 : 0;
     if (pi) w -= a.nw0;
     const WgradProblem P = pi ? a.p[1] : a.p[0];
@@ -556,7 +595,8 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     if (ext == 0) wgrad_body<0>(a, P, w, red, rede);
     else if (ext == 1) wgrad_body<1>(a, P, w, red, rede);
     else if (ext == 2) wgrad_body<2>(a, P, w, red, rede);
-    else wgrad_body<3>(a, P, w, red, rede);
+    else if (ext == 3) wgrad_body<3>(a, P, w, red, rede);
+    else wgrad_body<4>(a, P, w, red, rede);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -759,7 +799,7 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
 constexpr int kBwdWaves = 4;
 
 struct WsLayout {
-    size_t dz, du, slab1, slab2, ext, frag, total;  // float offsets
+    size_t dz, du, slab1, slab2, ext, pq, frag, total;  // float offsets
     int ksplit;
     long long rows_per_split;
     int Mp, Np1;
@@ -790,7 +830,8 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     w.slab1 = w.du + rows;
     w.slab2 = w.slab1 + (size_t)w.ksplit * w.Mp * w.Np1;
     w.ext = w.slab2 + (size_t)w.ksplit * w.Mp * w.Mp;
-    w.frag = w.ext + (size_t)w.ksplit * 4 * w.Mp;
+    w.pq = w.ext + (size_t)w.ksplit * 4 * w.Mp;
+    w.frag = w.pq + (size_t)((K / 2 + 15) / 16) * 2 * w.Mp;  // small-batch pair scoring: K / 2 pairs in blocks of 16
     w.total = w.frag + (want_dx ? (size_t)L.NB * L.KS1 * 256 : 0);
     return w;
 }
@@ -816,6 +857,8 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     }
     b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
     b.dz = wsf + W.dz; b.du = wsf + W.du;
+    const bool pair_sums = !given && b.nA <= 16 * 1024;  // K-A (small kernel) leaves the dQ / dP sums per block
+    b.pq = pair_sums ? wsf + W.pq : nullptr;
     const long long ntb = (b.nA + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
     if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
     b.ntb = (int)ntb;
@@ -852,9 +895,11 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     WgradProblem& p2 = wa.p[1];  // dW2 = dz^T [y1; y2]
     p2.A = wsf + W.dz; p2.lda = ldz; p2.B0 = y; p2.B1 = y + (size_t)nsplit * ldz; p2.ldb = ldz; p2.M = W.Mp; p2.N = W.Mp;
     p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp;
-    p2.extras = given ? 3 : 2;
+    p2.extras = given ? 3 : (pair_sums ? 4 : 2);
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
-    wa.nw = wa.nw0 + p2.MT * p2.NT * W.ksplit;
+    wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
+    wa.nw = wa.nw_mm + (pair_sums ? W.ksplit : 0);
+    wa.pq = b.pq; wa.nblk = (int)((b.nA + 15) / 16);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
     // K-C
@@ -894,7 +939,7 @@ int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int
     p1.MT = (Mp + 63) / 64; p1.NT = (Mp + 63) / 64; p1.slab = slab; p1.Mp = Mp; p1.Np = Mp; p1.extras = 1;
     wa.p[1] = p1;
     wa.nw0 = p1.MT * p1.NT * ksplit;
-    wa.nw = wa.nw0;
+    wa.nw = wa.nw_mm = wa.nw0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     return nplda_launch_status();
 }
@@ -1115,7 +1160,7 @@ int nplda_lda_wgrad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx
     p1.MT = (W.Mp + 63) / 64; p1.NT = (D0 + 63) / 64; p1.slab = slab; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
     wa.p[1] = p1;  // never scheduled (nw == nw0)
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
-    wa.nw = wa.nw0;
+    wa.nw = wa.nw_mm = wa.nw0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
     ReduceArgs ra = {};
