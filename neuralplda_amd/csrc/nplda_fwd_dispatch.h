@@ -94,16 +94,21 @@ static inline int launch_fwd_small(FwdArgs a, const NpldaLayout& L, hipStream_t 
     const long long per_block = (MODE == MODE_EMBED ? 32 : 16);
     const long long blocks = (a.n + per_block - 1) / per_block;
     dim3 grid((unsigned)blocks), block(256);
+    // 512-d x-vectors (KS1 = 32) at the recipe sizes: the fully unrolled K loop (see nplda_fwd_small.h)
 #define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE>), grid, block, 0, st, a)
+#define NPLDA_LAUNCH32(NBV)                                                                           \
+    if (L.KS1 == 32 && L.D0 == 512) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE, 32>), grid, block, 0, st, a); \
+    else NPLDA_LAUNCH(NBV)
     switch (L.NB) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
         case 8: NPLDA_LAUNCH(8); break;
-        case 10: NPLDA_LAUNCH(10); break;
-        case 11: NPLDA_LAUNCH(11); break;
+        case 10: NPLDA_LAUNCH32(10); break;
+        case 11: NPLDA_LAUNCH32(11); break;
         case 12: NPLDA_LAUNCH(12); break;
         default: return NPLDA_EUNSUPPORTED;
     }
+#undef NPLDA_LAUNCH32
 #undef NPLDA_LAUNCH
     return nplda_launch_status();
 }

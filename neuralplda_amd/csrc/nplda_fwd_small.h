@@ -18,8 +18,20 @@
 
 namespace nplda {
 
-template <int NB, int MODE>
+#ifdef NPLDA_SMALL_STAMPS  // tools/exp_fwd.hip only: 100 MHz time stamps of one wave at the phase boundaries
+__device__ unsigned long long g_small_stamps[16];
+#define NPLDA_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == 0) { g_small_stamps[i] = __builtin_amdgcn_s_memrealtime(); g_small_stamps[8 + i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define NPLDA_STAMP(i) do {} while (0)
+#endif
+
+// KS1C: layer 1's k16-step count when known at compile time (32 = the 512-d x-vectors of every reference recipe), 0 = read
+// it from the arguments.  With a constant count the K loop is fully unrolled: hipcc places an s_waitcnt vmcnt(0) at the
+// head of a loop whose loads are carried across the back-edge (it gives up merging the two predecessors' counters), which
+// drains the whole prefetch ring once per round — ~1 us of exposed latency every 4 k16-steps.
+template <int NB, int MODE, int KS1C = 0>
 __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a) {
+    NPLDA_STAMP(0);
     static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN || MODE == MODE_GB, "small kernel modes");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
@@ -56,7 +68,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
     const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
-    const int KS1 = a.KS1;
+    const int KS1 = KS1C ? KS1C : a.KS1;
     const int D0 = a.D0;
 
     // ---- layer 1 --------------------------------------------------------------------------------------------
@@ -67,41 +79,61 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         accB[i] = accA[i];
     }
-    f32x4 wf[PF][NBW], xa[PF], xb[PF];
+    // Register ring of PF + 1 k16-steps: during step ks the slot that step ks - 1 released is refilled with step ks + PF,
+    // one load after each quarter of the step's MFMAs.  With one wave per SIMD nothing else fills the matrix pipe while
+    // this wave computes addresses: a step's 5 loads and their ~25 scalar / vector address instructions issued in one
+    // block after its 24 MFMAs cost 0.45 us per step against 0.32 us of MFMA time; spread through the step they issue in
+    // the shadow of the MFMAs.  sched_barrier pins the pieces: left free, the scheduler sinks every load to its first use.
+    constexpr int PF1 = PF + 1;
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
     // every load is unconditional (indices clamped): predicated loads would make hipcc wait vmcnt(0) per step
-    auto fetch1 = [&](int slot, int ks) {
-        const bool in = ks < KS1;
-        const int ksc = in ? ks : KS1 - 1;
-#pragma unroll
-        for (int i = 0; i < NBW; ++i) {
-            const int nb = wave + NW * i;
-            wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
-        }
+    auto fetchw = [&](int slot, int ks, int i) {
+        const int ksc = ks < KS1 ? ks : KS1 - 1;
+        const int nb = wave + NW * i;
+        wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+    };
+    auto fetchx = [&](int slot, int ks) {
         xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
         xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
     };
 #pragma unroll
-    for (int s = 0; s < PF; ++s) fetch1(s, s);
-    for (int ks0 = 0; ks0 < KS1; ks0 += PF) {
+    for (int s = 0; s < PF; ++s) {
 #pragma unroll
-        for (int s = 0; s < PF; ++s) {
-            const int ks = ks0 + s;
-            if (ks < KS1) {
+        for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
+        fetchx(s, s);
+    }
+    auto step = [&](int ks, int slot, int rs) {
 #pragma unroll
-                for (int r = 0; r < 4; ++r) {
+        for (int r = 0; r < 4; ++r) {
 #pragma unroll
-                    for (int i = 0; i < NBW; ++i) {
-                        // no guard: a wave whose i-th block does not exist (nb >= NB) multiplies the clamped
-                        // fragment into an accumulator that is never read — cheaper than a branch per MFMA
-                        accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], xa[s][r], accA[i], 0, 0, 0);
-                        accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], xb[s][r], accB[i], 0, 0, 0);
-                    }
-                }
+            for (int i = 0; i < NBW; ++i) {
+                // no guard: a wave whose i-th block does not exist (nb >= NB) multiplies the clamped
+                // fragment into an accumulator that is never read — cheaper than a branch per MFMA
+                accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
+                accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
             }
-            fetch1(s, ks + PF);
+            if (r < NBW) fetchw(rs, ks + PF, r);
+            if (r == 3) fetchx(rs, ks + PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    static_assert(NBW <= 3, "one weight load per MFMA quarter, the x loads after the last");
+    NPLDA_STAMP(1);
+    if constexpr (KS1C > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ++ks) {
+            if (ks == 8) NPLDA_STAMP(2);
+            step(ks, ks % PF1, (ks + PF) % PF1);
+        }
+    } else {
+        for (int ks0 = 0; ks0 < KS1; ks0 += PF1) {
+#pragma unroll
+            for (int s = 0; s < PF1; ++s)
+                if (ks0 + s < KS1) step(ks0 + s, s, (s + PF) % PF1);
         }
     }
 
+    NPLDA_STAMP(3);
     // ---- F.normalize: partial sums of squares over this wave's features -> LDS -> all waves -----------------
     {
         float ssA = 0.f, ssB = 0.f;
@@ -217,6 +249,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
                         t[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yv[r], t[i], 0, 0, 0);
                 }
                 fetchg(s, q + PF);
+                __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
             for (int i = 0; i < NBW; ++i) {
@@ -253,7 +286,9 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch2(s, s);
+    NPLDA_STAMP(4);
     __syncthreads();  // ylds complete (also orders the `red` reuse below after every wave's norm reads)
+    NPLDA_STAMP(5);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
@@ -267,8 +302,10 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
             }
         }
         fetch2(s, kb + PF);
+        __builtin_amdgcn_sched_barrier(0);
     }
 
+    NPLDA_STAMP(6);
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     if (MODE == MODE_PAIR || MODE == MODE_TRAIN) {
         float part = 0.f;
@@ -296,6 +333,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         __syncthreads();
         if (wave == 0 && g == 0 && okA)
             a.out_s[t0A + j] = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+        NPLDA_STAMP(7);
     } else {
         float qa = 0.f, qb = 0.f;
 #pragma unroll

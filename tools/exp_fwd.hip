@@ -1,10 +1,12 @@
 // exp_fwd.hip — within-process interleaved A/B of forward-kernel variants (not product code).
 // build: hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/exp_fwd.hip -o tools/exp_fwd
 // run:   tools/exp_fwd [log2_pairs=20] [rounds=3]
+#define NPLDA_SMALL_STAMPS 1
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
 #include <cmath>
+#include "../neuralplda_amd/csrc/nplda_fwd_small.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v2.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v3.h"
 #include "../neuralplda_amd/csrc/nplda_fwd_v5.h"
@@ -147,6 +149,25 @@ int main(int argc, char** argv) {
     } else {
         vs = { {"v2 w8 kpb2", launch_2<12, 8, false, 2>}, {"v5 w8 kpb2", launch_5<12, 8, 2>},
                {"v5 w8 kpb4 h1", launch_5<12, 8, 4, 4, 1>}, {"v5 w8 kpb2 h1", launch_5<12, 8, 2, 4, 1>} };
+    }
+    if (argc > 4) {  // phase stamps of the small-batch kernel (training mode) at 2^lg pairs: tools/exp_fwd 12 1 150 stamps
+        float *y, *z, *rn;
+        CK(hipMalloc(&y, 2 * B * 16 * L.NB * 4)); CK(hipMalloc(&z, 2 * B * 16 * L.NB * 4)); CK(hipMalloc(&rn, 2 * B * 4));
+        FwdArgs t = a;
+        t.out_y = y; t.out_z = z; t.out_rn = rn; t.ldz = 16 * L.NB;
+        for (int rep = 0; rep < 4; ++rep) {
+            if (L.NB == 10) hipLaunchKernelGGL((nplda_fwd_small_kernel<10, MODE_TRAIN, 32>), dim3((unsigned)(B / 16)), dim3(256), 0, 0, t);
+            else hipLaunchKernelGGL((nplda_fwd_small_kernel<11, MODE_TRAIN, 32>), dim3((unsigned)(B / 16)), dim3(256), 0, 0, t);
+            CK(hipDeviceSynchronize());
+            unsigned long long st[16];
+            CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_small_stamps), sizeof(st)));
+            printf("small-kernel stamps (us since kernel entry): loads issued %.2f | first 8 steps %.2f | K loop end %.2f | y published %.2f | barrier %.2f | layer 2 end %.2f | end %.2f\n",
+                   (st[1] - st[0]) / 100.0, (st[2] - st[0]) / 100.0, (st[3] - st[0]) / 100.0, (st[4] - st[0]) / 100.0,
+                   (st[5] - st[0]) / 100.0, (st[6] - st[0]) / 100.0, (st[7] - st[0]) / 100.0);
+            printf("   shader clock over steps 8..KS1: %.0f MHz (%llu cycles / %.2f us)\n", (double)(st[11] - st[10]) / ((st[3] - st[2]) / 100.0),
+                   st[11] - st[10], (st[3] - st[2]) / 100.0);
+        }
+        return 0;
     }
     const double flop_alg = 2.0 * (2.0 * D0 * D + 2.0 * D * D) + 8.0 * D;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
