@@ -55,6 +55,18 @@ def main():
             "indexed_algorithmic_TBps": B * bytes_pair / ms_i / 1e9,
             "gather_rows_per_s": B / timeit(lambda: ops.gather_rows(X, i1)) * 1e3,
         }
+        # the same call on a table larger than the 256 MB memory-side cache: 1.2 M utterances (VoxCeleb scale), rows come
+        # from HBM in ldz * 4-byte pieces at random
+        Nb = 1_200_000
+        zb = torch.randn(Nb, z.shape[1], device=dev, generator=gen)
+        qb = torch.randn(Nb, device=dev, generator=gen)
+        j1 = torch.randint(0, Nb, (B,), device=dev, generator=gen)
+        j2 = torch.randint(0, Nb, (B,), device=dev, generator=gen)
+        ms_b = timeit(lambda: ops.score_indexed(zb, qb, j1, j2, packed))
+        out[f"D{D}"].update({"indexed_big_table_MB": zb.numel() * 4 / 1e6, "indexed_big_pairs_per_s": B / ms_b * 1e3,
+                             "indexed_big_algorithmic_TBps": B * bytes_pair / ms_b / 1e9,
+                             "indexed_big_row_bytes_TBps": B * 2 * z.shape[1] * 4 / ms_b / 1e9})
+        del zb, qb
         # training step, B = 4096 (BASELINE cfg2): forward + SoftCdet + backward + Adam
         Bt = 4096
         x1 = torch.randn(Bt, 512, device=dev, generator=gen)
