@@ -37,8 +37,8 @@ int rows_matmul_launch(const float* in, long long ldin, long long R, int K, cons
 
 namespace {
 
-constexpr int kSub = 128;         // slots per candidate sub-list (111 usable + slack for one tile's 16 appends)
-constexpr int kSubFull = 111;     // a sub-list that reaches this count is treated as overflowed
+constexpr int kSubSlack = 17;     // a sub-list of ksub slots counts as overflowed at ksub - 17 (one tile appends <= 16 to it)
+constexpr int kParts = 4;         // list bands per column band when the band is divisible (see cohort_fused_plan)
 constexpr int kCandMax = 2048;    // candidates one row may bring to the select kernel (32 keys per lane)
 constexpr int kGramSplit = 16;    // k-groups of the cohort Gram matrix
 constexpr int kQzBlocks = 64;
@@ -184,7 +184,7 @@ struct FusedArgs {
     unsigned* ctr;          // 8 work-item counters (one per XCD), zero at launch
     const float* crow;      // (R)
     const float* trow;      // (R)
-    float* lists;           // [R][nbands][kSub][4]: slot e of sub-list (band, g) of row r at ((r nbands + band) kSub + e) 4 + g.
+    float* lists;           // [R][nlb][ksub][4], nlb = nbands q list bands: slot e of sub-list (lb, g) of row r at ((r nlb + lb) ksub + e) 4 + g.
                             // The 128-byte lines of a (row, band) region are written by ONE wave, while its block works
                             // through the band: they fill up in that XCD's L2 and go to memory once.  (A slot-major
                             // [R][kSub][nsub] layout — every line shared by all bands, i.e. by blocks on all XCDs at
@@ -192,7 +192,9 @@ struct FusedArgs {
                             // of HBM writes for 88 MB of candidates, profiles/r02n.)
     unsigned* counts;       // [R][nsub]
     double* part;           // [R][nsub / 4][2]
-    int nsub;               // nbands * 4 (lane groups)
+    int nsub;               // nlb * 4 (lane groups)
+    int q, ksub, nfull;     // list bands per band, slots per sub-list; row tiles [0, nfull) are handed out as whole bands,
+                            // the rest one list band at a time (the tail of the work queue in quarters)
 };
 
 // The first form of this kernel kept the tile pipeline of the spilling GEMM (cohort_gemm_kernel): both operands staged
@@ -217,14 +219,28 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     const int i16 = lane & 15, g4 = lane >> 4;
     const int xcd = blockIdx.x & 7;
     const int nt64 = (int)((a.M + 63) / 64);
-    auto decode = [&](int slot, long long& rb, int& band, int& t0, int& t1) {
-        const int kb = slot / a.ny;
-        band = kb * 8 + xcd;
+    // Work items of XCD x, in queue order: for each of its column bands (band = kb * 8 + x) first the row tiles [0, nfull)
+    // with the WHOLE band (q list bands walked back to back, the row operands fetched once), then the remaining row
+    // tiles one list band at a time.  A block takes ~ny * nbands / grid items; with whole bands only, 86 row tiles on the
+    // 32 CUs of an XCD are 2.69 items per CU and the kernel lasts 3 — the last round in quarters ends after 2.75.
+    const int nlb = a.nbands * a.q;
+    const int per_kb = a.nfull + (a.ny - a.nfull) * a.q;
+    auto lb_tile = [&](int lb) { return (int)((long long)lb * nt64 / nlb); };  // list bands in whole 64-column tiles
+    auto decode = [&](int slot, long long& rb, int& lb0, int& lbn) {
+        const int kb = slot / per_kb;
+        const int band = kb * 8 + xcd;
         if (band >= a.nbands) return false;
-        rb = (long long)(slot - kb * a.ny) * 256;
-        t0 = 2 * (int)((long long)band * a.nx / a.nbands);
-        t1 = 2 * (int)((long long)(band + 1) * a.nx / a.nbands);
-        if (t1 > nt64) t1 = nt64;
+        const int r = slot - kb * per_kb;
+        if (r < a.nfull) {
+            rb = (long long)r * 256;
+            lb0 = band * a.q;
+            lbn = lb0 + a.q;
+        } else {
+            const int r2 = r - a.nfull;
+            rb = (long long)(a.nfull + r2 / a.q) * 256;
+            lb0 = band * a.q + r2 % a.q;
+            lbn = lb0 + 1;
+        }
         return true;
     };
     // LDS-DMA of the 64-column tile `t` into buffer `buf`: wave w fills fragments w, w + 8, ...
@@ -245,11 +261,13 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     };
 
     long long rb = 0, nrb = 0;
-    int band = 0, t = 0, t1 = 0, nband = 0, nt0 = 0, nt1 = 0;
+    int band = 0, lbn = 0, t = 0, t1 = 0, nlb0 = 0, nlbn = 0;  // `band`: the list band being filled; the item ends at lbn
     if (tid == 0) nxt_s[0] = atomicAdd(a.ctr + xcd, 1u);
     if (tid < 4 * NB) p2s[tid] = 2.0f * *reinterpret_cast<const f32x4*>(a.P + 4 * tid);
     __syncthreads();
-    if (!decode(__builtin_amdgcn_readfirstlane((int)nxt_s[0]), rb, band, t, t1)) return;
+    if (!decode(__builtin_amdgcn_readfirstlane((int)nxt_s[0]), rb, band, lbn)) return;
+    t = lb_tile(band);
+    t1 = lb_tile(band + 1);
     if (tid == 0) nxt_s[1] = atomicAdd(a.ctr + xcd, 1u);  // the item after this one, asked for a whole item ahead
     int npar = 1;                                          // which word holds the next item's slot
 
@@ -278,7 +296,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             qrv[g] = a.qr[rc];
             s1[g] = 0.f;
             s2[g] = 0.f;
-            cur[g] = 4u * (unsigned)(((rc * a.nbands + band_) * kSub) * 4 + g4);
+            cur[g] = 4u * (unsigned)(((rc * nlb + band_) * a.ksub) * 4 + g4);
         }
     };
     auto item_end = [&](long long rb_, int band_) {
@@ -293,7 +311,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 32, 64), __shfl_xor(__double2loint(u2), 32, 64));
             if (row < a.R) {
                 const unsigned sidx = (unsigned)(band_ * 4 + g4);
-                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(((row * a.nbands + band_) * kSub) * 4 + g4)) / 4u;
+                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(((row * nlb + band_) * a.ksub) * 4 + g4)) / 4u;
                 if (g4 == 0) {
                     double* o = a.part + ((size_t)row * (a.nsub / 4) + band_) * 2;
                     o[0] = u1;
@@ -312,14 +330,15 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     const float* lbase = a.lists;
 
     for (;;) {
-        const bool last_tile = t + 1 == t1;
+        const bool last_tile = t + 1 == t1;                       // of the list band
+        const bool last_of_item = last_tile && band + 1 == lbn;
         bool have_next = true;
-        // next tile into the other buffer: of this item, or the first of the next one
-        if (!last_tile) {
+        // next tile into the other buffer: of this item (its list bands are contiguous), or the first of the next one
+        if (!last_of_item) {
             tile_in(t + 1, buf ^ 1);
         } else {
-            have_next = decode(__builtin_amdgcn_readfirstlane((int)nxt_s[npar]), nrb, nband, nt0, nt1);
-            if (have_next) tile_in(nt0, buf ^ 1);
+            have_next = decode(__builtin_amdgcn_readfirstlane((int)nxt_s[npar]), nrb, nlb0, nlbn);
+            if (have_next) tile_in(lb_tile(nlb0), buf ^ 1);
         }
         f32x4 acc[2][4];
 #pragma unroll
@@ -362,7 +381,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         // wave's MFMAs: ~13 cycles each, 29.6 k cycles per tile against 23.4 k for the MFMA loops alone.  Forcing the
         // phases together with a barrier at this point gives the same tile time (24.6 k + 4.6 k) and a kernel 2 % slower.)
         // the operand rows of the NEXT item are fetched here, under the epilogue of this item's last tile
-        if (last_tile && have_next) item_rows(nrb);
+        if (last_of_item && have_next) item_rows(nrb);
 
         // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
         const long long m0 = (long long)t * 64;
@@ -425,10 +444,10 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                 }
                 s1[g] = ps2[0] + ps2[1];
                 s2[g] = pq2[0] + pq2[1];
-                // at most kSubFull entries stay (the select kernel treats that count as an overflow)
+                // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
                 long long rc = rb + wave * 32 + 16 * g + i16;
                 if (rc >= a.R) rc = a.R - 1;
-                const unsigned lim = 4u * (unsigned)(((rc * a.nbands + band) * kSub + kSubFull) * 4 + g4);
+                const unsigned lim = 4u * (unsigned)(((rc * nlb + band) * a.ksub + (a.ksub - kSubSlack)) * 4 + g4);
                 cur[g] = o < lim ? o : lim;
             }
         };
@@ -437,11 +456,18 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
 
         if (last_tile) {
             item_end(rb, band);
-            if (!have_next) break;
-            rb = nrb; band = nband; t = nt0; t1 = nt1;
-            item_state(rb, band);
-            npar ^= 1;
-            if (tid == 0) nxt_s[npar] = atomicAdd(a.ctr + xcd, 1u);  // visible after the barrier below; read >= 1 tile later
+            if (!last_of_item) {  // next list band of the same item: same rows, the tiles go on
+                ++band;
+                ++t;
+                t1 = lb_tile(band + 1);
+                item_state(rb, band);
+            } else {
+                if (!have_next) break;
+                rb = nrb; band = nlb0; lbn = nlbn; t = lb_tile(band); t1 = lb_tile(band + 1);
+                item_state(rb, band);
+                npar ^= 1;
+                if (tid == 0) nxt_s[npar] = atomicAdd(a.ctr + xcd, 1u);  // visible after the barrier below; read >= 1 tile later
+            }
         } else {
             ++t;
         }
@@ -462,6 +488,7 @@ struct FinishArgs {
     const float* trow;
     float zhi, fhi;                       // the proposal: t_r = c_r + sgn zhi sd_r, fhi = Phi(zhi) = proposed fraction
     int nsub, nsub_valid, topn, lowest;   // sub-lists [nsub_valid, nsub) belong to bands past the last column tile: never written
+    int ksub;
     unsigned* nfail; unsigned* fail_rows;
     double* stats;
 };
@@ -480,7 +507,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     for (int j = 0; j < 4; ++j) {
         const int s = 64 * j + lane;
         creg[j] = s < a.nsub_valid ? cnt[s] : 0u;
-        ovf |= creg[j] >= (unsigned)kSubFull ? 1u : 0u;
+        ovf |= creg[j] >= (unsigned)(a.ksub - kSubSlack) ? 1u : 0u;
         unsigned inc = creg[j];  // inclusive scan over the 64 lanes
 #pragma unroll
         for (int d = 1; d < 64; d <<= 1) {
@@ -500,29 +527,41 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     }
     // gather the sub-lists (lane = sub-list) into this wave's LDS run as order-preserving keys: element e of sub-list s
     // lands at pre[s] + e — a fixed order
-    const float* lrow = a.lists + (size_t)row * a.nsub * kSub;  // [band][slot][g]: sub-list s = band 4 + g
+    const float* lrow = a.lists + (size_t)row * a.nsub * a.ksub;  // [list band][slot][g]: sub-list s = lb 4 + g
+    // Two groups of 64 sub-lists are fetched together (8 slots of each per batch): with 128 short sub-lists per row
+    // (list bands) the gather is a chain of memory round trips, and one batch per group doubled their number.
+    auto gather2 = [&](int j0) {
+        unsigned maxc = creg[j0] > creg[j0 + 1] ? creg[j0] : creg[j0 + 1];
+        maxc = wave_max_u32(maxc);
+        const float* lsub[2];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        if (64 * j >= a.nsub_valid) break;
-        const unsigned maxc = wave_max_u32(creg[j]);
-        const unsigned sl = 64 * j + lane < (unsigned)a.nsub ? 64 * j + lane : (unsigned)a.nsub - 1;  // stay in the row's region
-        const float* lsub = lrow + (size_t)(sl >> 2) * kSub * 4 + (sl & 3);
-        for (unsigned e0 = 0; e0 < maxc; e0 += 16) {
-            float v[16];
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                // unconditional (slot index clamped into the sub-list): a load under a lane predicate is a branch with its
-                // own wait, and the slot rows of a row would then come in one memory round trip each
-                const unsigned e = e0 + u < (unsigned)kSub ? e0 + u : (unsigned)kSub - 1;
-                v[u] = lsub[(size_t)e * 4];
-            }
-#pragma unroll
-            for (int u = 0; u < 16; ++u) {
-                const unsigned e = e0 + u;
-                if (e < creg[j]) kl[pre[j] + e] = f2key(a.lowest ? v[u] : -v[u]);
-            }
+        for (int h = 0; h < 2; ++h) {
+            const unsigned s_ = 64 * (j0 + h) + lane;
+            const unsigned sl = s_ < (unsigned)a.nsub ? s_ : (unsigned)a.nsub - 1;  // stay in the row's region
+            lsub[h] = lrow + (size_t)(sl >> 2) * a.ksub * 4 + (sl & 3);
         }
-    }
+        for (unsigned e0 = 0; e0 < maxc; e0 += 8) {
+            float v[2][8];
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    // unconditional (slot index clamped into the sub-list): a load under a lane predicate is a branch with
+                    // its own wait, and the slot rows of a row would then come in one memory round trip each
+                    const unsigned e = e0 + u < (unsigned)a.ksub ? e0 + u : (unsigned)a.ksub - 1;
+                    v[h][u] = lsub[h][(size_t)e * 4];
+                }
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const unsigned e = e0 + u;
+                    if (e < creg[j0 + h]) kl[pre[j0 + h] + e] = f2key(a.lowest ? v[h][u] : -v[h][u]);
+                }
+        }
+    };
+    gather2(0);
+    if (a.nsub_valid > 128) gather2(2);
     __builtin_amdgcn_s_waitcnt(0xC07F);  // this wave's LDS writes have landed (no other wave touches kl)
     unsigned k[kCandMax / 64];
     unsigned kmin = 0xffffffffu, kmax = 0u;
@@ -685,21 +724,33 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     for (;; ++bpx) {
         const double cols = (double)((nx + 8 * bpx - 1) / (8 * bpx)) * 128.0;
         const double lam_ = f * cols / 4.0;
-        if ((cols * Mp * 4.0 <= 2097152.0 && lam_ + 6.0 * sqrt(lam_) + 4.0 <= (double)kSubFull) || bpx == 8 || 8LL * (bpx + 1) > nx) break;
+        if ((cols * Mp * 4.0 <= 2097152.0 && lam_ + 6.0 * sqrt(lam_) + 4.0 <= (double)(128 - kSubSlack)) || bpx == 8 || 8LL * (bpx + 1) > nx) break;
     }
     p.nbands = 8 * bpx;
-    p.nsub = p.nbands * 4;
-    // expected candidates of one sub-list (a band's columns seen by one lane group)
-    const double lam = f * (double)((nx + p.nbands - 1) / p.nbands) * 128.0 / 4.0;
-    if (lam + 6.0 * sqrt(lam) + 4.0 > (double)kSubFull) return p;
+    // List bands: a band's columns in kParts pieces with sub-lists of their own, so that the row tiles at the END of the
+    // work queue can be handed out a piece at a time (cohort_fused2_kernel::decode) — when the pieces are at least one
+    // 128-column unit wide and the sub-list count fits the select kernel's 4 counts per lane.
+    p.q = (nx >= (long long)p.nbands * kParts && p.nbands * kParts * 4 <= 256) ? kParts : 1;
+    p.ksub = p.q > 1 ? 64 : 128;
+    const int nlb = p.nbands * p.q;
+    p.nsub = nlb * 4;
+    // expected candidates of one sub-list (a list band's columns seen by one lane group)
+    const long long nt64 = (M + 63) / 64;
+    const double lam = f * (double)((nt64 + nlb - 1) / nlb) * 64.0 / 4.0;
+    if (lam + 6.0 * sqrt(lam) + 4.0 > (double)(p.ksub - kSubSlack)) {
+        if (p.q == 1) return p;
+        p.q = 1; p.ksub = 128; p.nsub = p.nbands * 4;
+        const double lam1 = f * (double)((nt64 + p.nbands - 1) / p.nbands) * 64.0 / 4.0;
+        if (lam1 + 6.0 * sqrt(lam1) + 4.0 > (double)(p.ksub - kSubSlack)) return p;
+    }
     p.zhi = host_normcdfinv(f);
     p.fhi = (float)f;
     const size_t kb = (size_t)Mp / 16;
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256(kb * kb * 256 * 4) +
                     align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
-    p.max_rows = ((1LL << 30) / ((long long)p.nsub * kSub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
-    p.row_bytes = (size_t)Mp * 4 + 8 + (size_t)p.nsub * kSub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 16 + 4;
+    p.max_rows = ((1LL << 30) / ((long long)p.nsub * p.ksub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
+    p.row_bytes = (size_t)Mp * 4 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 16 + 4;
     p.eligible = true;
     return p;
 }
@@ -720,7 +771,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     float* vec = reinterpret_cast<float*>(q); q += align256((size_t)(2 * Mp + 2) * 4);
     // per-row arrays, sized for rows_cap rows
     double* part = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * (p.nsub / 4) * 16);
-    float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * p.nsub * kSub * 4);
+    float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * p.nsub * p.ksub * 4);
     unsigned* counts = reinterpret_cast<unsigned*>(q); q += align256((size_t)rows_cap * p.nsub * 4);
     float* tmp = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * Mp * 4);
     float* crow = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * 4);
@@ -754,9 +805,13 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     fa.zr = z_rows; fa.qr = q_rows; fa.zc = z_coh; fa.qc = q_coh; fa.P = P;
     fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + 255) / 256); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
-    fa.nsub = p.nsub;
-    long long grid = (long long)fa.ny * p.nbands;  // at most one block per work item
+    fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub;
+    long long grid = (long long)fa.ny * p.nbands * p.q;  // at most one block per work item
     if (grid > resident) grid = resident;
+    {   // whole-band items for as many row tiles as fill complete rounds of an XCD's blocks, the rest in list bands
+        const long long per_xcd = grid / 8 > 0 ? grid / 8 : 1;
+        fa.nfull = p.q > 1 ? (int)(fa.ny / per_xcd * per_xcd) : fa.ny;
+    }
 #define NPLDA_LAUNCH(NBV)                                                                                          \
     if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa);  \
     else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa)
@@ -771,7 +826,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
 #undef NPLDA_LAUNCH
     if (int rc = nplda_launch_status()) return rc;
-    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, ctl + 8,
+    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, ctl + 8,
                      fail_rows, stats};
     hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, fi);
     return nplda_launch_status();
