@@ -48,9 +48,14 @@ constexpr int kQzBlocks = 64;
 // ------------------------------------------------------------------------------------------------------------------
 
 // partial sums over a block's share of the cohort rows: part[b][0..Mp) = sum q_m z_m, part[b][Mp] = sum q, [Mp+1] = sum q^2
+// (fp32: they only feed the threshold proposal) and part64[b][0..Mp) = sum z_m, part64[b][Mp] = sum q in fp64 — the row
+// means the call RETURNS are formed analytically from these (mean_r = q_r + mean q + 2 (P z_r) . mean z)
 __global__ __launch_bounds__(256) void cohort_qz_kernel(const float* __restrict__ zc, const float* __restrict__ qc,
-                                                        long long M, long long ldz, int Mp, float* __restrict__ part) {
+                                                        long long M, long long ldz, int Mp, float* __restrict__ part,
+                                                        double* __restrict__ part64) {
     __shared__ float red[4][NPLDA_MAX_DIM + 2];
+    __shared__ double red64[4][NPLDA_MAX_DIM + 1];
+    double sz[3] = {0.0, 0.0, 0.0}, sq64 = 0.0;
     const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
     const long long per = (M + gridDim.x - 1) / gridDim.x;
     const long long lo = (long long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
@@ -66,14 +71,18 @@ __global__ __launch_bounds__(256) void cohort_qz_kernel(const float* __restrict_
 #pragma unroll
             for (int c = 0; c < 3; ++c) {
                 const int f = lane + 64 * c;
-                z[u][c] = f < Mp ? zc[mc * ldz + f] : 0.f;
+                z[u][c] = (f < Mp && m < hi) ? zc[mc * ldz + f] : 0.f;
             }
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
 #pragma unroll
-            for (int c = 0; c < 3; ++c) acc[c] = fmaf(q[u], z[u][c], acc[c]);
+            for (int c = 0; c < 3; ++c) {
+                acc[c] = fmaf(q[u], z[u][c], acc[c]);
+                sz[c] += (double)z[u][c];
+            }
             sq += q[u];
+            sq64 += (double)q[u];
             sqq = fmaf(q[u], q[u], sqq);
         }
     }
@@ -82,19 +91,28 @@ __global__ __launch_bounds__(256) void cohort_qz_kernel(const float* __restrict_
         if (lane + 64 * c < Mp) red[wy][lane + 64 * c] = acc[c];
     if (lane == 0) { red[wy][Mp] = sq; red[wy][Mp + 1] = sqq; }
     __syncthreads();
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+        if (lane + 64 * c < Mp) red64[wy][lane + 64 * c] = sz[c];
+    if (lane == 0) red64[wy][Mp] = sq64;  // (every lane of a wave holds the same q sums)
+    __syncthreads();
     for (int i = threadIdx.x; i < Mp + 2; i += 256)
         part[(size_t)blockIdx.x * (Mp + 2) + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
+    for (int i = threadIdx.x; i < Mp + 1; i += 256)
+        part64[(size_t)blockIdx.x * (Mp + 1) + i] = ((red64[0][i] + red64[1][i]) + red64[2][i]) + red64[3][i];
 }
 
 struct PrepArgs {
     const float* slab;   // [ksplit][Mp][Mp]
     const float* ext;    // [ksplit][4][Mp]  (row 3: column sums of z)
     const float* qz;     // [kQzBlocks][Mp + 2]
+    const double* qz64;  // [kQzBlocks][Mp + 1]: sum z, sum q in fp64
     const float* P;      // padded, zero beyond D2
     int ksplit, Mp;
     long long M;
     float* frag;         // [KB][KB][64][4]: C''[i][j] = 4 P_i P_j cov(z)_ij
     float* vec;          // [0, Mp): u = 2 P mean(z); [Mp, 2 Mp): v = 4 P cov(z, q); [2 Mp]: mean(q); [2 Mp + 1]: var(q)
+    double* vec64;       // [0, Mp): 2 P mean(z), [Mp]: mean(q) — fp64, for the row means the call returns
 };
 
 __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
@@ -102,9 +120,10 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
     const int Mp = a.Mp, KB = Mp / 16;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double n = (double)a.M;
-    if ((int)threadIdx.x < Mp) {  // every block forms the cohort mean for itself (ksplit x Mp L2-resident floats)
+    if ((int)threadIdx.x < Mp) {  // every block forms the cohort mean for itself (kQzBlocks x Mp L2-resident doubles)
         double s = 0.0;
-        for (int k = 0; k < a.ksplit; ++k) s += (double)a.ext[((size_t)k * 4 + 3) * Mp + threadIdx.x];
+#pragma unroll 16
+        for (int b = 0; b < kQzBlocks; ++b) s += a.qz64[(size_t)b * (Mp + 1) + threadIdx.x];
         zbar[threadIdx.x] = s / n;
     }
     __syncthreads();
@@ -133,8 +152,13 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
         const int i = (int)idx;
         const double zm = zbar[i], qm = qsum(Mp) / n;
         a.vec[i] = (float)(2.0 * (double)a.P[i] * zm);
+        a.vec64[i] = 2.0 * (double)a.P[i] * zm;
         a.vec[Mp + i] = (float)(4.0 * (double)a.P[i] * (qsum(i) / n - qm * zm));
         if (i == 0) {
+            double sq = 0.0;
+#pragma unroll 16
+            for (int b = 0; b < kQzBlocks; ++b) sq += a.qz64[(size_t)b * (Mp + 1) + Mp];
+            a.vec64[Mp] = sq / n;
             a.vec[2 * Mp] = (float)qm;
             double vq = qsum(Mp + 1) / n - qm * qm;
             a.vec[2 * Mp + 1] = (float)(vq > 0.0 ? vq : 0.0);
@@ -147,26 +171,30 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
 __global__ __launch_bounds__(256) void cohort_threshold_kernel(const float* __restrict__ zr, const float* __restrict__ qr,
                                                                const float* __restrict__ tmp, long long R,
                                                                long long ldz, int Mp, const float* __restrict__ vec,
-                                                               float zhi, float sgn, float* __restrict__ crow,
-                                                               float* __restrict__ trow) {
+                                                               const double* __restrict__ vec64, float zhi, float sgn,
+                                                               float* __restrict__ crow, float* __restrict__ trow,
+                                                               double* __restrict__ mean64) {
     const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     if (r >= R) return;
-    float quad = 0.f, lin = 0.f, mu = 0.f;
+    float quad = 0.f, lin = 0.f;
+    double mu = 0.0;  // the mean is an OUTPUT (stats[.][0]): fp64 on the fp64 cohort mean, exact to rounding of the inputs
     for (int f = lane; f < Mp; f += 64) {
         const float z = zr[r * ldz + f];
         quad = fmaf(z, tmp[r * Mp + f], quad);
         lin = fmaf(z, vec[Mp + f], lin);
-        mu = fmaf(z, vec[f], mu);
+        mu = fma((double)z, vec64[f], mu);
     }
+    mu = wave_sum_f64(mu);
 #pragma unroll
     for (int m = 32; m >= 1; m >>= 1) {
         quad += __shfl_xor(quad, m, 64);
         lin += __shfl_xor(lin, m, 64);
-        mu += __shfl_xor(mu, m, 64);
     }
     if (lane == 0) {
-        const float mean = qr[r] + vec[2 * Mp] + mu;
+        const double m64 = (double)qr[r] + vec64[Mp] + mu;
+        mean64[r] = m64;
+        const float mean = (float)m64;
         const float var = vec[2 * Mp + 1] + lin + quad;
         const float sd = sqrtf(fmaxf(var, 0.f));
         crow[r] = mean;
@@ -191,7 +219,7 @@ struct FusedArgs {
                             // different times — turned each 4-byte append into its own partial-line write-back: 575 MB
                             // of HBM writes for 88 MB of candidates, profiles/r02n.)
     unsigned* counts;       // [R][nsub]
-    double* part;           // [R][nsub / 4][2]
+    double* part;           // [R][nsub / 4]: sum over the list band's columns of (s - c_r)^2, c_r = the row's mean in fp32
     int nsub;               // nlb * 4 (lane groups)
     int q, ksub, nfull;     // list bands per band, slots per sub-list; row tiles [0, nfull) are handed out as whole bands,
                             // the rest one list band at a time (the tail of the work queue in quarters)
@@ -273,7 +301,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
 
     // per-lane state of a work item: the lane's two rows (wave's row group A / B, row i16), their operand fragments
     f32x4 brow[2][NB];
-    float cen[2], thr[2], qrv[2], s1[2], s2[2];
+    float cen[2], thr[2], qrv[2], s2[2];
     unsigned cur[2];
     auto item_rows = [&](long long rb_) {
 #pragma unroll
@@ -294,7 +322,6 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             cen[g] = a.crow[rc];
             thr[g] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
             qrv[g] = a.qr[rc];
-            s1[g] = 0.f;
             s2[g] = 0.f;
             cur[g] = 4u * (unsigned)(((rc * nlb + band_) * a.ksub) * 4 + g4);
         }
@@ -304,18 +331,14 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         for (int g = 0; g < 2; ++g) {
             const long long row = rb_ + wave * 32 + 16 * g + i16;
             // the four lane groups of a row: fixed association ((g0 + g1) + (g2 + g3)) by two exchanges
-            double u1 = (double)s1[g], u2 = (double)s2[g];
-            u1 += __hiloint2double(__shfl_xor(__double2hiint(u1), 16, 64), __shfl_xor(__double2loint(u1), 16, 64));
+            double u2 = (double)s2[g];
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 16, 64), __shfl_xor(__double2loint(u2), 16, 64));
-            u1 += __hiloint2double(__shfl_xor(__double2hiint(u1), 32, 64), __shfl_xor(__double2loint(u1), 32, 64));
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 32, 64), __shfl_xor(__double2loint(u2), 32, 64));
             if (row < a.R) {
                 const unsigned sidx = (unsigned)(band_ * 4 + g4);
                 a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(((row * nlb + band_) * a.ksub) * 4 + g4)) / 4u;
                 if (g4 == 0) {
-                    double* o = a.part + ((size_t)row * (a.nsub / 4) + band_) * 2;
-                    o[0] = u1;
-                    o[1] = u2;
+                    a.part[(size_t)row * (a.nsub / 4) + band_] = u2;
                 }
             }
         }
@@ -392,7 +415,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
 #pragma unroll
             for (int g = 0; g < 2; ++g) {
                 const float c0 = cen[g], th = thr[g], qr_ = qrv[g];
-                f32x2 ps2 = {s1[g], 0.f}, pq2 = {s2[g], 0.f};
+                f32x2 pq2 = {s2[g], 0.f};
                 unsigned o = cur[g];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
@@ -408,41 +431,34 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                         }
                     }
                     const f32x2 dl = {d4[0], d4[1]}, dh = {d4[2], d4[3]};
-                    ps2 += dl;
-                    ps2 += dh;
                     pq2 = __builtin_elementwise_fma(dl, dl, pq2);
                     pq2 = __builtin_elementwise_fma(dh, dh, pq2);
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        // if (s <= th) { lists[o] = s; o += stride; } (>= for the N largest) as one exec-masked store: no
-                        // branch, no 64-bit address arithmetic (SGPR base + 32-bit byte offset), one VALU for the cursor.
-                        // (Appending whole float4 groups with one v_cmpx-masked 16-byte store per group was tried: the
-                        // epilogue got 2 k cycles per tile shorter, but the lists tripled, the kernel as a whole did not
-                        // get faster and the select kernel had to re-filter: 1.10 ms against 1.04 ms for the pipeline.)
-                        unsigned long long sv;
-                        if (LOWEST)
-                            asm volatile(
-                                "v_cmp_le_f32 vcc, %[s], %[th]\n\t"
-                                "s_and_saveexec_b64 %[sv], vcc\n\t"
-                                "global_store_dword %[o], %[s], %[base]\n\t"
-                                "v_add_u32 %[o], %[o], %[st]\n\t"
-                                "s_mov_b64 exec, %[sv]"
-                                : [o] "+v"(o), [sv] "=&s"(sv)
-                                : [th] "v"(th), [s] "v"(s4[r]), [base] "s"(lbase), [st] "s"(stride_b)
-                                : "vcc", "memory");
-                        else
-                            asm volatile(
-                                "v_cmp_ge_f32 vcc, %[s], %[th]\n\t"
-                                "s_and_saveexec_b64 %[sv], vcc\n\t"
-                                "global_store_dword %[o], %[s], %[base]\n\t"
-                                "v_add_u32 %[o], %[o], %[st]\n\t"
-                                "s_mov_b64 exec, %[sv]"
-                                : [o] "+v"(o), [sv] "=&s"(sv)
-                                : [th] "v"(th), [s] "v"(s4[r]), [base] "s"(lbase), [st] "s"(stride_b)
-                                : "vcc", "memory");
-                    }
+                    // for r in 0..3: if (s[r] <= th) { lists[o] = s[r]; o += stride; }   (>= for the N largest)
+                    // as exec-masked stores: no branch, no 64-bit address arithmetic (SGPR base + 32-bit byte offset), one
+                    // VALU for the cursor.  The four compares are issued first, into four SGPR pairs: one compare ->
+                    // s_and_saveexec -> store chain per value made the epilogue a string of VALU -> SALU round trips
+                    // (~25 cycles each, 256 per tile and wave).
+                    // (Appending whole float4 groups with one v_cmpx-masked 16-byte store per group was tried: the
+                    // epilogue got 2 k cycles per tile shorter, but the lists tripled, the kernel as a whole did not
+                    // get faster and the select kernel had to re-filter: 1.10 ms against 1.04 ms for the pipeline.)
+                    unsigned long long sv, k0, k1, k2, k3;
+#define NPLDA_APPEND4(CMP)                                                                                         \
+    asm volatile(CMP " %[k0], %[s0], %[th]\n\t" CMP " %[k1], %[s1], %[th]\n\t" CMP " %[k2], %[s2], %[th]\n\t"       \
+                 CMP " %[k3], %[s3], %[th]\n\t"                                                                    \
+                 "s_mov_b64 %[sv], exec\n\t"                                                                       \
+                 "s_mov_b64 exec, %[k0]\n\tglobal_store_dword %[o], %[s0], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
+                 "s_mov_b64 exec, %[k1]\n\tglobal_store_dword %[o], %[s1], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
+                 "s_mov_b64 exec, %[k2]\n\tglobal_store_dword %[o], %[s2], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
+                 "s_mov_b64 exec, %[k3]\n\tglobal_store_dword %[o], %[s3], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
+                 "s_mov_b64 exec, %[sv]"                                                                            \
+                 : [o] "+v"(o), [sv] "=&s"(sv), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)       \
+                 : [th] "v"(th), [s0] "v"(s4[0]), [s1] "v"(s4[1]), [s2] "v"(s4[2]), [s3] "v"(s4[3]), [base] "s"(lbase), \
+                   [st] "s"(stride_b)                                                                               \
+                 : "memory")
+                    if (LOWEST) NPLDA_APPEND4("v_cmp_le_f32");
+                    else NPLDA_APPEND4("v_cmp_ge_f32");
+#undef NPLDA_APPEND4
                 }
-                s1[g] = ps2[0] + ps2[1];
                 s2[g] = pq2[0] + pq2[1];
                 // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
                 long long rc = rb + wave * 32 + 16 * g + i16;
@@ -483,7 +499,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
 // select: one wave per row
 // ------------------------------------------------------------------------------------------------------------------
 struct FinishArgs {
-    const float* lists; const unsigned* counts; const double* part; const float* crow;
+    const float* lists; const unsigned* counts; const double* part; const float* crow; const double* mean64;
     long long R, M;
     const float* trow;
     float zhi, fhi;                       // the proposal: t_r = c_r + sgn zhi sd_r, fhi = Phi(zhi) = proposed fraction
@@ -656,20 +672,17 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     t2 = wave_sum_f64(t2);
     nless = wave_sum_u32(nless);
     // whole-row sums: the (band, wave column) partials in their fixed order
-    double d1 = 0.0, d2 = 0.0;
-    const double* pr = a.part + (size_t)row * (a.nsub / 4) * 2;
-    for (int i = lane; i < a.nsub_valid / 4; i += 64) {
-        d1 += pr[2 * i];
-        d2 += pr[2 * i + 1];
-    }
-    d1 = wave_sum_f64(d1);
+    double d2 = 0.0;
+    const double* pr = a.part + (size_t)row * (a.nsub / 4);
+    for (int i = lane; i < a.nsub_valid / 4; i += 64) d2 += pr[i];
     d2 = wave_sum_f64(d2);
     if (lane == 0) {
         const double n = (double)a.M, nn = (double)N;
-        const double mw = d1 / n;
+        // mean: analytic, fp64 (cohort_threshold_kernel); the squares were centred on its fp32 rounding c_r
+        const double mean_s = a.mean64[row];
+        const double mw = mean_s - (double)a.crow[row];
         double var = d2 / n - mw * mw;
         if (var < 0.0) var = 0.0;
-        const double mean_s = (double)a.crow[row] + mw;
         double tv = (double)key2f(tkey);           // the threshold in ordered space -> raw score
         if (!a.lowest) tv = -tv;
         const double ties = nn - (double)nless;
@@ -747,10 +760,11 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     p.fhi = (float)f;
     const size_t kb = (size_t)Mp / 16;
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
-                    align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256(kb * kb * 256 * 4) +
-                    align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
+                    align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256((size_t)kQzBlocks * (Mp + 1) * 8) +
+                    align256((size_t)(Mp + 1) * 8) + align256(kb * kb * 256 * 4) +
+                    align256((size_t)(2 * Mp + 2) * 4) + 9 * 256;  // + the alignment slack of the per-row arrays
     p.max_rows = ((1LL << 30) / ((long long)p.nsub * p.ksub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
-    p.row_bytes = (size_t)Mp * 4 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 16 + 4;
+    p.row_bytes = (size_t)Mp * 4 + 8 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
     p.eligible = true;
     return p;
 }
@@ -767,10 +781,13 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     float* slab = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * Mp * Mp * 4);
     float* ext = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * 4 * Mp * 4);
     float* qz = reinterpret_cast<float*>(q); q += align256((size_t)kQzBlocks * (Mp + 2) * 4);
+    double* qz64 = reinterpret_cast<double*>(q); q += align256((size_t)kQzBlocks * (Mp + 1) * 8);
+    double* vec64 = reinterpret_cast<double*>(q); q += align256((size_t)(Mp + 1) * 8);
     float* frag = reinterpret_cast<float*>(q); q += align256((size_t)(Mp / 16) * (Mp / 16) * 256 * 4);
     float* vec = reinterpret_cast<float*>(q); q += align256((size_t)(2 * Mp + 2) * 4);
     // per-row arrays, sized for rows_cap rows
-    double* part = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * (p.nsub / 4) * 16);
+    double* part = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * (p.nsub / 4) * 8);
+    double* mean64 = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * 8);
     float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * p.nsub * p.ksub * 4);
     unsigned* counts = reinterpret_cast<unsigned*>(q); q += align256((size_t)rows_cap * p.nsub * 4);
     float* tmp = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * Mp * 4);
@@ -783,9 +800,9 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     if (hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NPLDA_EINVAL;
     if (prepass) {  // cohort moments: once per call, the cohort does not change between row chunks
         if (int rc = gram_slabs_launch(z_coh, ldz, M, Mp, kGramSplit, slab, ext, st)) return rc;
-        hipLaunchKernelGGL(cohort_qz_kernel, dim3(kQzBlocks), dim3(256), 0, st, z_coh, q_coh, M, ldz, Mp, qz);
+        hipLaunchKernelGGL(cohort_qz_kernel, dim3(kQzBlocks), dim3(256), 0, st, z_coh, q_coh, M, ldz, Mp, qz, qz64);
         if (int rc = nplda_launch_status()) return rc;
-        PrepArgs pa = {slab, ext, qz, P, kGramSplit, Mp, M, frag, vec};
+        PrepArgs pa = {slab, ext, qz, qz64, P, kGramSplit, Mp, M, frag, vec, vec64};
         // ksplit actually used by gram_slabs_launch: rows per split rounded up -> some trailing slabs may be unwritten
         {
             long long rps = (M + kGramSplit - 1) / kGramSplit;
@@ -798,7 +815,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
     if (int rc = rows_matmul_launch(z_rows, ldz, R, Mp, frag, Mp, tmp, Mp, st)) return rc;
     hipLaunchKernelGGL(cohort_threshold_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, z_rows, q_rows, tmp, R,
-                       ldz, Mp, vec, p.zhi, lowest ? 1.0f : -1.0f, crow, trow);
+                       ldz, Mp, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64);
     if (int rc = nplda_launch_status()) return rc;
 
     FusedArgs fa = {};
@@ -826,7 +843,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
 #undef NPLDA_LAUNCH
     if (int rc = nplda_launch_status()) return rc;
-    FinishArgs fi = {lists, counts, part, crow, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, ctl + 8,
+    FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, ctl + 8,
                      fail_rows, stats};
     hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, fi);
     return nplda_launch_status();
