@@ -20,6 +20,7 @@
 #include "nplda_fwd_dispatch.h"
 #include "nplda_adam_math.h"
 #include "nplda_loss_math.h"
+#include "nplda_cohort_qz.h"
 
 namespace nplda {  // nplda_matmul.hip
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
@@ -414,7 +415,9 @@ struct WgradArgs {
     int nw;               // total work items
     const float* pq;      // [nblk][2][ldz] per-block dQ / dP sums of K-A (small-batch pair scoring), else null
     int nblk;
-    int nw_mm;            // work items of the two GEMMs; items [nw_mm, nw) = one pair-sum block per k-group
+    int nw_mm;            // work items of the two GEMMs
+    int nw_ps;            // items [nw_mm, nw_ps) = one pair-sum block per k-group; items [nw_ps, nw) = cohort first-moment
+    nplda::QzArgs qz;     // blocks of the fused AS-norm pre-pass (nplda_cohort_qz.h), riding in the Gram matrix's launch
 };
 
 constexpr int kPF = 4;  // k4-steps of operand prefetch per wave (8 needed 330 registers: one block per CU; at 4 two are resident)
@@ -575,6 +578,10 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     __shared__ f32x4 rede[4][3][16];    // column-sum partials
     int w = blockIdx.x;
     if (w >= a.nw) return;
+    if (w >= a.nw_ps) {
+        nplda::cohort_qz_block(a.qz, w - a.nw_ps, red);
+        return;
+    }
     if (w >= a.nw_mm) {  // pair-sum block of k-group ks: ext[ks][0 / 1][f] = sum of its share of K-A's per-block sums
         const int ks = w - a.nw_mm;
         const int per = (a.nblk + a.ksplit - 1) / a.ksplit;
@@ -898,7 +905,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     p2.extras = given ? 3 : (pair_sums ? 4 : 2);
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
-    wa.nw = wa.nw_mm + (pair_sums ? W.ksplit : 0);
+    wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
     wa.pq = b.pq; wa.nblk = (int)((b.nA + 15) / 16);
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
@@ -927,7 +934,7 @@ namespace nplda {
 // Z[k][i] Z[k][j] (i, j < Mp = the padded row width, a multiple of 16) and ext[ks][3][i] = the column sums, with the
 // split-K "A^T B" kernel above (A = B = Z).  The caller sums the ksplit slabs in a fixed order.
 int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int ksplit, float* slab, float* ext,
-                      hipStream_t st) {
+                      const QzArgs* qz, hipStream_t st) {
     if (rows <= 0 || ksplit < 1 || (Mp % 16) != 0) return NPLDA_EINVAL;
     long long rps = (rows + ksplit - 1) / ksplit;
     rps = (rps + 16 * kPF - 1) / (16 * kPF) * (16 * kPF);
@@ -939,7 +946,11 @@ int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int
     p1.MT = (Mp + 63) / 64; p1.NT = (Mp + 63) / 64; p1.slab = slab; p1.Mp = Mp; p1.Np = Mp; p1.extras = 1;
     wa.p[1] = p1;
     wa.nw0 = p1.MT * p1.NT * ksplit;
-    wa.nw = wa.nw_mm = wa.nw0;
+    wa.nw = wa.nw_mm = wa.nw_ps = wa.nw0;
+    if (qz) {
+        wa.qz = *qz;
+        wa.nw += qz->nblocks;
+    }
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     return nplda_launch_status();
 }
@@ -1160,7 +1171,7 @@ int nplda_lda_wgrad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx
     p1.MT = (W.Mp + 63) / 64; p1.NT = (D0 + 63) / 64; p1.slab = slab; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
     wa.p[1] = p1;  // never scheduled (nw == nw0)
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
-    wa.nw = wa.nw_mm = wa.nw0;
+    wa.nw = wa.nw_mm = wa.nw_ps = wa.nw0;
     hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
     if (int rc = nplda_launch_status()) return rc;
     ReduceArgs ra = {};

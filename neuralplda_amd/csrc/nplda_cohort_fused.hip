@@ -27,10 +27,11 @@
 
 #include "nplda_cohort_common.h"
 #include "nplda_cohort_fused.h"
+#include "nplda_cohort_qz.h"
 
 namespace nplda {
 int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int ksplit, float* slab, float* ext,
-                      hipStream_t st);
+                      const QzArgs* qz, hipStream_t st);
 int rows_matmul_launch(const float* in, long long ldin, long long R, int K, const float* frag, int N, float* out,
                        long long ldout, hipStream_t st);
 }  // namespace nplda
@@ -47,61 +48,6 @@ constexpr int kQzBlocks = 64;
 // pre-pass
 // ------------------------------------------------------------------------------------------------------------------
 
-// partial sums over a block's share of the cohort rows: part[b][0..Mp) = sum q_m z_m, part[b][Mp] = sum q, [Mp+1] = sum q^2
-// (fp32: they only feed the threshold proposal) and part64[b][0..Mp) = sum z_m, part64[b][Mp] = sum q in fp64 — the row
-// means the call RETURNS are formed analytically from these (mean_r = q_r + mean q + 2 (P z_r) . mean z)
-__global__ __launch_bounds__(256) void cohort_qz_kernel(const float* __restrict__ zc, const float* __restrict__ qc,
-                                                        long long M, long long ldz, int Mp, float* __restrict__ part,
-                                                        double* __restrict__ part64) {
-    __shared__ float red[4][NPLDA_MAX_DIM + 2];
-    __shared__ double red64[4][NPLDA_MAX_DIM + 1];
-    double sz[3] = {0.0, 0.0, 0.0}, sq64 = 0.0;
-    const int lane = threadIdx.x & 63, wy = threadIdx.x >> 6;
-    const long long per = (M + gridDim.x - 1) / gridDim.x;
-    const long long lo = (long long)blockIdx.x * per, hi = lo + per < M ? lo + per : M;
-    float acc[3] = {0.f, 0.f, 0.f}, sq = 0.f, sqq = 0.f;
-    // four rows in flight per wave (independent loads), accumulated in row order
-    for (long long m0 = lo + wy; m0 < hi; m0 += 16) {
-        float q[4], z[4][3];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const long long m = m0 + 4 * u;
-            const long long mc = m < hi ? m : hi - 1;
-            q[u] = m < hi ? qc[mc] : 0.f;
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const int f = lane + 64 * c;
-                z[u][c] = (f < Mp && m < hi) ? zc[mc * ldz + f] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-#pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                acc[c] = fmaf(q[u], z[u][c], acc[c]);
-                sz[c] += (double)z[u][c];
-            }
-            sq += q[u];
-            sq64 += (double)q[u];
-            sqq = fmaf(q[u], q[u], sqq);
-        }
-    }
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        if (lane + 64 * c < Mp) red[wy][lane + 64 * c] = acc[c];
-    if (lane == 0) { red[wy][Mp] = sq; red[wy][Mp + 1] = sqq; }
-    __syncthreads();
-#pragma unroll
-    for (int c = 0; c < 3; ++c)
-        if (lane + 64 * c < Mp) red64[wy][lane + 64 * c] = sz[c];
-    if (lane == 0) red64[wy][Mp] = sq64;  // (every lane of a wave holds the same q sums)
-    __syncthreads();
-    for (int i = threadIdx.x; i < Mp + 2; i += 256)
-        part[(size_t)blockIdx.x * (Mp + 2) + i] = ((red[0][i] + red[1][i]) + red[2][i]) + red[3][i];
-    for (int i = threadIdx.x; i < Mp + 1; i += 256)
-        part64[(size_t)blockIdx.x * (Mp + 1) + i] = ((red64[0][i] + red64[1][i]) + red64[2][i]) + red64[3][i];
-}
-
 struct PrepArgs {
     const float* slab;   // [ksplit][Mp][Mp]
     const float* ext;    // [ksplit][4][Mp]  (row 3: column sums of z)
@@ -113,6 +59,7 @@ struct PrepArgs {
     float* frag;         // [KB][KB][64][4]: C''[i][j] = 4 P_i P_j cov(z)_ij
     float* vec;          // [0, Mp): u = 2 P mean(z); [Mp, 2 Mp): v = 4 P cov(z, q); [2 Mp]: mean(q); [2 Mp + 1]: var(q)
     double* vec64;       // [0, Mp): 2 P mean(z), [Mp]: mean(q) — fp64, for the row means the call returns
+    unsigned* ctl;       // the call's 64-word control block (work-item counters, fail count): zeroed here, one launch less
 };
 
 __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
@@ -120,6 +67,7 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
     const int Mp = a.Mp, KB = Mp / 16;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
     const double n = (double)a.M;
+    if (idx < 64) a.ctl[idx] = 0u;
     if ((int)threadIdx.x < Mp) {  // every block forms the cohort mean for itself (kQzBlocks x Mp L2-resident doubles)
         double s = 0.0;
 #pragma unroll 16
@@ -797,12 +745,12 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     *fail_rows_out = fail_rows;
     *nfail_out = ctl + 8;
 
-    if (hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NPLDA_EINVAL;
+    if (!prepass && hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NPLDA_EINVAL;  // (the pre-pass zeroes it itself)
     if (prepass) {  // cohort moments: once per call, the cohort does not change between row chunks
-        if (int rc = gram_slabs_launch(z_coh, ldz, M, Mp, kGramSplit, slab, ext, st)) return rc;
-        hipLaunchKernelGGL(cohort_qz_kernel, dim3(kQzBlocks), dim3(256), 0, st, z_coh, q_coh, M, ldz, Mp, qz, qz64);
-        if (int rc = nplda_launch_status()) return rc;
-        PrepArgs pa = {slab, ext, qz, qz64, P, kGramSplit, Mp, M, frag, vec, vec64};
+        // second and first moments of the cohort in ONE launch (the first-moment blocks ride along as extra work items)
+        const QzArgs qa = {z_coh, q_coh, M, ldz, Mp, kQzBlocks, qz, qz64};
+        if (int rc = gram_slabs_launch(z_coh, ldz, M, Mp, kGramSplit, slab, ext, &qa, st)) return rc;
+        PrepArgs pa = {slab, ext, qz, qz64, P, kGramSplit, Mp, M, frag, vec, vec64, ctl};
         // ksplit actually used by gram_slabs_launch: rows per split rounded up -> some trailing slabs may be unwritten
         {
             long long rps = (M + kGramSplit - 1) / kGramSplit;
