@@ -21,6 +21,8 @@
 #include "nplda_adam_math.h"
 #include "nplda_loss_math.h"
 #include "nplda_cohort_qz.h"
+#include "nplda_bwd_loss.h"
+#include "nplda_train_fb_small.h"
 
 namespace nplda {  // nplda_matmul.hip
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
@@ -38,22 +40,6 @@ using namespace nplda;
 // Row bookkeeping: a tile holds 16 "A" rows t0 + j (< nA) and 16 "B" rows offB + t0 + j (t0 + j < nB).  Pair scoring:
 // nA = nB = offB = B (x1 side, x2 side).  Embedding rows (GIVEN): N rows split into two halves, nA = ceil(N / 2),
 // nB = N - nA, offB = nA — the same kernels, the pairing is then just a way to fill both MFMA row groups.
-// Loss folded into the data-gradient kernel (the fused training step, nplda_train_step_f32): dL/ds of a pair depends on
-// the pair's own score and target and on the batch counts N_t, N_n only (utils/models.py:384-399), so the kernel that
-// needs g forms it itself and leaves the batch sums of the loss as one fp64 partial per block.
-constexpr int kLossNS = 2 + 4 * nplda_loss::kMaxK;
-struct BwdLoss {
-    const float* s;       // (B) scores of this step's forward
-    const float* t;       // (B) targets, 16-byte aligned
-    nplda_loss::ThetaPtrs th;
-    nplda_loss::BetaVals beta;
-    int K, kind;          // kind 0 = SoftCdet, 1 = BCE
-    float alpha;
-    long long B;
-    float* g_out;         // (B) dL/ds, for the weight-gradient kernel's dQ / dP sums
-    double* partial;      // [blocks][kLossNS] loss sums of the block's 16 pairs
-};
-
 struct BwdArgs {
     const float* g;       // (nA) dL/ds per pair                       [unused when GIVEN]
     const float* z;       // (rows, ldz)                               [unused when GIVEN]
@@ -181,22 +167,6 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
 // accumulator layout (= the B operand of the chained MFMA), computes ITS dy blocks from all of dz with W2^T
 // fragments read straight from the L2-resident image through a register ring, and the y.dy dot product of the
 // normalize backward is reduced across the waves through LDS.
-template <int K>
-__device__ __forceinline__ float loss_pair_softcdet(const BwdLoss& L, double Nt, double Nn, float si, float ti,
-                                                    double (&acc)[kLossNS]) {
-    float theta[K], cn[K], ct;
-#pragma unroll
-    for (int k = 0; k < K; ++k) theta[k] = L.th.p[k][0];
-    nplda_loss::softcdet_consts<K>(Nt, Nn, L.beta, L.alpha, cn, ct);
-    double a2[2 + 4 * K];
-#pragma unroll
-    for (int i = 0; i < 2 + 4 * K; ++i) a2[i] = 0.0;
-    nplda_loss::softcdet_accumulate<K, false>(si, ti, theta, L.alpha, a2);
-#pragma unroll
-    for (int i = 0; i < 2 + 4 * K; ++i) acc[i] = a2[i];
-    return nplda_loss::softcdet_gi<K>(si, ti, theta, cn, ct, L.alpha);
-}
-
 template <int NB, bool GIVEN, bool LOSS = false>
 __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a) {
     static_assert(!(GIVEN && LOSS), "the loss is formed from pair scores");
@@ -234,36 +204,10 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
         const BwdLoss& L = a.ls;
         // N_t: every block sums the targets itself (<= 16 float4 per thread, L2 hits): no launch, no grid-wide hand-over
         __shared__ float cnt_s[NW];
-        float cnt = 0.f;
-        const int nv = (int)(L.B / 4);
-        const f32x4* t4 = reinterpret_cast<const f32x4*>(L.t);
-        for (int i = tid; i < nv; i += 256) {
-            const f32x4 v = t4[i];
-            cnt += (v[0] + v[1]) + (v[2] + v[3]);
-        }
-        for (long long i = 4LL * nv + tid; i < L.B; i += 256) cnt += L.t[i];
-#pragma unroll
-        for (int msk = 1; msk < 64; msk <<= 1) cnt = wave_xor_add(cnt, msk);
-        if (lane == 0) cnt_s[wave] = cnt;
-        __syncthreads();
-        const double Nt = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // exact: a count below 2^24
+        const double Nt = block_target_count(L, cnt_s);
         const double Nn = (double)L.B - Nt;
-        const float si = L.s[rA], ti = L.t[rA];
         double acc[kLossNS];
-#pragma unroll
-        for (int i = 0; i < kLossNS; ++i) acc[i] = 0.0;
-        float gi;
-        if (L.kind == 1) {
-            double a4[4] = {0.0, 0.0, 0.0, 0.0};
-            const float theta = L.th.p[0][0];
-            nplda_loss::bce_accumulate(si, ti, theta, a4);
-#pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i] = a4[i];
-            gi = nplda_loss::bce_gi(si, ti, theta, (float)(1.0 / (Nt + Nn)));
-        } else if (L.K == 1) gi = loss_pair_softcdet<1>(L, Nt, Nn, si, ti, acc);
-        else if (L.K == 2) gi = loss_pair_softcdet<2>(L, Nt, Nn, si, ti, acc);
-        else if (L.K == 3) gi = loss_pair_softcdet<3>(L, Nt, Nn, si, ti, acc);
-        else gi = loss_pair_softcdet<4>(L, Nt, Nn, si, ti, acc);
+        const float gi = loss_pair(L, Nt, Nn, L.s[rA], L.t[rA], acc);
         tg = okA ? 2.0f * gi : 0.f;
         if (wave == 0 && g4 == 0) {
             if (okA) L.g_out[rA] = gi;
@@ -284,8 +228,8 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
                 const f32x4 zA = *reinterpret_cast<const f32x4*>(a.z + rA * a.ldz + 16 * nb + 4 * g4);
                 const f32x4 zB = *reinterpret_cast<const f32x4*>(a.z + rB * a.ldz + 16 * nb + 4 * g4);
                 const f32x4 q = Qp[4 * nb + g4], p = Pp[4 * nb + g4];
-                const f32x4 dA = tg * (q * zA + p * zB);
-                const f32x4 dB = tg * (q * zB + p * zA);
+                const f32x4 dA = dz_of(tg, q, p, zA, zB);
+                const f32x4 dB = dz_of(tg, q, p, zB, zA);
                 dzlds[0][nb][lane] = dA;
                 dzlds[1][nb][lane] = dB;
                 if (okA) {
@@ -296,7 +240,8 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
                 // rows and g already in registers (in the weight-gradient kernel they were three more un-prefetched loads
                 // per k4-step, and its 45 blocks that carried them set the kernel's time)
                 const float gh = 0.5f * tg;
-                f32x4 eq = gh * (zA * zA + zB * zB), ep = gh * (zA * zB);
+                f32x4 eq, ep;
+                pair_sum_terms(gh, zA, zB, eq, ep);
 #pragma unroll
                 for (int msk = 1; msk < 16; msk <<= 1) {
 #pragma unroll
@@ -377,8 +322,8 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     for (int i = 0; i < NBW; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
-            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[i] - yA[i] * dotA) * rnA;
-            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[i] - yB[i] * dotB) * rnB;
+            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = du_of(dyA[i], yA[i], dotA, rnA);
+            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = du_of(dyB[i], yB[i], dotB, rnB);
         }
     }
 }
@@ -850,7 +795,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
                     const float* packed, const NpldaLayout& L, const float* g, const float* y, const float* z,
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
                     float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
-                    ReduceArgs* defer_reduce = nullptr) {
+                    ReduceArgs* defer_reduce = nullptr, bool data_done = false) {
     BwdArgs b = {};
     if (ls) {
         if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
@@ -869,7 +814,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     const long long ntb = (b.nA + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
     if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
     b.ntb = (int)ntb;
-    {
+    if (!data_done) {  // (data_done: train_fb_small_kernel has already left dz, du, the pair sums and the loss partials)
         // small batches: 4 waves share a 16-pair tile (feature split), so a 4096-pair minibatch fills 256 CUs
         const bool small = b.nA <= 16 * 1024;
         dim3 grid(small ? (unsigned)((b.nA + 15) / 16) : (unsigned)(ntb < 2048 ? ntb : 2048)), block(256);
@@ -1107,11 +1052,6 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)ws;
 
-    FwdArgs fa = {};
-    fa.xa = x1; fa.xb = x2; fa.n = B; fa.ldx = ldx; fa.packed = (const float*)packed;
-    fa.out_s = wsf + S.s; fa.out_z = wsf + S.z; fa.ldz = S.ldz; fa.out_y = wsf + S.y; fa.out_rn = wsf + S.rn;
-    if (int rc = launch_fwd<MODE_TRAIN>(fa, L, st)) return rc;
-
     BwdLoss ls = {};
     ls.s = wsf + S.s; ls.t = target; ls.K = nth; ls.kind = kind; ls.alpha = alpha; ls.B = B;
     ls.g_out = wsf + S.g; ls.partial = reinterpret_cast<double*>(wsf + S.partial);
@@ -1123,9 +1063,33 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
         if (kind == 0) ls.beta.b[k] = betas[k];
     }
     const WsLayout W = ws_layout(2 * B, L, false);
+    float* bws = wsf + S.bwd;
+    {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h)
+        TrainFbArgs fb = {};
+        fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
+        fb.oW2 = L.oW2; fb.oW2T = L.oW2T; fb.ob1 = L.ob1; fb.ob2 = L.ob2; fb.oQ = L.oQ; fb.oP = L.oP;
+        fb.out_s = wsf + S.s; fb.out_y = wsf + S.y; fb.dz = bws + W.dz; fb.du = bws + W.du; fb.ldz = S.ldz;
+        fb.pq = bws + W.pq; fb.ls = ls;
+        const dim3 grid((unsigned)((B + 15) / 16)), block(256);
+        const bool k32 = L.KS1 == 32 && L.D0 == 512;
+#define NPLDA_LAUNCH(NBV)                                                                                   \
+    if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32>), grid, block, 0, st, fb);                    \
+    else hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0>), grid, block, 0, st, fb)
+        switch (L.NB) {
+            case 2: NPLDA_LAUNCH(2); break;
+            case 4: NPLDA_LAUNCH(4); break;
+            case 8: NPLDA_LAUNCH(8); break;
+            case 10: NPLDA_LAUNCH(10); break;
+            case 11: NPLDA_LAUNCH(11); break;
+            case 12: NPLDA_LAUNCH(12); break;
+            default: return NPLDA_EUNSUPPORTED;
+        }
+#undef NPLDA_LAUNCH
+        if (int rc = nplda_launch_status()) return rc;
+    }
     if (int rc = backward_launch(false, x1, x2, 2 * B, B, ldx, (const float*)packed, L, nullptr, wsf + S.y, wsf + S.z,
-                                 wsf + S.rn, S.ldz, params[4], wsf + S.bwd, W, grad_out, nullptr, nullptr, 0, st, &ls,
-                                 &ua.r))
+                                 wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0, st, &ls, &ua.r,
+                                 true))
         return rc;
     for (int i = 0; i < 6; ++i) ua.prm[i] = params[i];
     ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;

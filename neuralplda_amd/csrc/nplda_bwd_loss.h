@@ -1,0 +1,101 @@
+// nplda_bwd_loss.h — the loss as the data-gradient kernels see it (nplda_backward.hip, nplda_train_fb_small.h).
+#pragma once
+#include "nplda_loss_math.h"
+
+namespace nplda {
+
+// Loss folded into the data-gradient kernel (the fused training step, nplda_train_step_f32): dL/ds of a pair depends on
+// the pair's own score and target and on the batch counts N_t, N_n only (utils/models.py:384-399), so the kernel that
+// needs g forms it itself and leaves the batch sums of the loss as one fp64 partial per block.
+constexpr int kLossNS = 2 + 4 * nplda_loss::kMaxK;
+struct BwdLoss {
+    const float* s;       // (B) scores of this step's forward
+    const float* t;       // (B) targets, 16-byte aligned
+    nplda_loss::ThetaPtrs th;
+    nplda_loss::BetaVals beta;
+    int K, kind;          // kind 0 = SoftCdet, 1 = BCE
+    float alpha;
+    long long B;
+    float* g_out;         // (B) dL/ds, for the weight-gradient kernel's dQ / dP sums
+    double* partial;      // [blocks][kLossNS] loss sums of the block's 16 pairs
+};
+
+
+// g_i and the pair's contribution to the loss sums (SoftCdet with K thresholds)
+template <int K>
+__device__ __forceinline__ float loss_pair_softcdet(const BwdLoss& L, double Nt, double Nn, float si, float ti,
+                                                    double (&acc)[kLossNS]) {
+    float theta[K], cn[K], ct;
+#pragma unroll
+    for (int k = 0; k < K; ++k) theta[k] = L.th.p[k][0];
+    nplda_loss::softcdet_consts<K>(Nt, Nn, L.beta, L.alpha, cn, ct);
+    double a2[2 + 4 * K];
+#pragma unroll
+    for (int i = 0; i < 2 + 4 * K; ++i) a2[i] = 0.0;
+    nplda_loss::softcdet_accumulate<K, false>(si, ti, theta, L.alpha, a2);
+#pragma unroll
+    for (int i = 0; i < 2 + 4 * K; ++i) acc[i] = a2[i];
+    return nplda_loss::softcdet_gi<K>(si, ti, theta, cn, ct, L.alpha);
+}
+
+
+// The per-pair loss step shared by the kernels: returns g_i = dL/ds_i, fills acc with the pair's terms of the loss sums.
+__device__ __forceinline__ float loss_pair(const BwdLoss& L, double Nt, double Nn, float si, float ti, double (&acc)[kLossNS]) {
+#pragma unroll
+    for (int i = 0; i < kLossNS; ++i) acc[i] = 0.0;
+    if (L.kind == 1) {
+        double a4[4] = {0.0, 0.0, 0.0, 0.0};
+        const float theta = L.th.p[0][0];
+        nplda_loss::bce_accumulate(si, ti, theta, a4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[i] = a4[i];
+        return nplda_loss::bce_gi(si, ti, theta, (float)(1.0 / (Nt + Nn)));
+    }
+    if (L.K == 1) return loss_pair_softcdet<1>(L, Nt, Nn, si, ti, acc);
+    if (L.K == 2) return loss_pair_softcdet<2>(L, Nt, Nn, si, ti, acc);
+    if (L.K == 3) return loss_pair_softcdet<3>(L, Nt, Nn, si, ti, acc);
+    return loss_pair_softcdet<4>(L, Nt, Nn, si, ti, acc);
+}
+
+// The element formulas of the data gradients with every contraction spelled out, shared by the kernels that must agree
+// bit for bit (left to fp-contract=fast, `q z + p z'` fuses differently depending on where z comes from).
+__device__ __forceinline__ f32x4 dz_of(float tg, f32x4 q, f32x4 p, f32x4 z, f32x4 zo) {  // 2 g (Q z + P z')
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = tg * fmaf(q[c], z[c], p[c] * zo[c]);
+    return r;
+}
+__device__ __forceinline__ f32x4 du_of(f32x4 dy, f32x4 y, float dot, float rn) {  // (dy - y (y . dy)) / max(||u||, eps)
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = fmaf(-y[c], dot, dy[c]) * rn;
+    return r;
+}
+__device__ __forceinline__ void pair_sum_terms(float gh, f32x4 z1, f32x4 z2, f32x4& eq, f32x4& ep) {  // g (z1^2 + z2^2), g z1 z2
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        eq[c] = gh * fmaf(z1[c], z1[c], z2[c] * z2[c]);
+        ep[c] = gh * (z1[c] * z2[c]);
+    }
+}
+
+// N_t of the batch, summed by the whole 256-thread block (<= 16 float4 per thread out of L2); cnt_s: 4 floats of LDS.
+// Contains one __syncthreads().
+__device__ __forceinline__ double block_target_count(const BwdLoss& L, float* cnt_s) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    float cnt = 0.f;
+    const int nv = (int)(L.B / 4);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(L.t);
+    for (int i = tid; i < nv; i += 256) {
+        const f32x4 v = t4[i];
+        cnt += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (long long i = 4LL * nv + tid; i < L.B; i += 256) cnt += L.t[i];
+#pragma unroll
+    for (int msk = 1; msk < 64; msk <<= 1) cnt = wave_xor_add(cnt, msk);
+    if (lane == 0) cnt_s[wave] = cnt;
+    __syncthreads();
+    return (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // exact: a count below 2^24
+}
+
+}  // namespace nplda

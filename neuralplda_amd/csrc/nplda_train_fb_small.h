@@ -1,0 +1,327 @@
+// nplda_train_fb_small.h — forward AND data gradients of a training minibatch (<= 16 384 pairs) in one kernel.
+//
+// The fused training step (nplda_train_step_f32) ran nplda_fwd_small_kernel<MODE_TRAIN> and then
+// bwd_data_small_kernel<LOSS>: the same 16-pair tile on the same 4 waves with the same feature split, the second
+// launch re-reading what the first had just written (z, y, 1 / ||u||, s) after ~10 us of launch and first-load latency.
+// Here the block simply goes on: after the score it forms dL/ds of its pairs (the batch counts come from the targets,
+// summed by every block for itself), dz from the z blocks still in registers, dy = dz W2 as the chained MFMA with the
+// W2^T fragments, and the normalize backward from the y blocks still in registers.  Written for the weight-gradient
+// kernel: y, dz, du (+ the per-block dQ / dP sums and loss partials); z, 1 / ||u|| and g never leave the chip.
+// Same arithmetic, instruction for instruction, as the two kernels it replaces (tests compare the parameter bits).
+#pragma once
+#include "nplda_bwd_loss.h"
+#include "nplda_fwd_kernel.h"
+
+namespace nplda {
+
+struct TrainFbArgs {
+    const float* xa;      // (n, ldx) x1 rows
+    const float* xb;      // (n, ldx) x2 rows
+    long long n, ldx;
+    const float* packed;  // NpldaLayout image
+    int D0, KS1;
+    size_t oW2, oW2T, ob1, ob2, oQ, oP;
+    float* out_s;         // (n) scores (optional: diagnostics / callers that want them)
+    float* out_y;         // (2n, ldz) normalised layer-1 outputs, x1 rows then x2 rows
+    float* dz;            // (2n, ldz)
+    float* du;            // (2n, ldz)
+    long long ldz;
+    float* pq;            // [blocks][2][ldz] per-block sums of g (z1^2 + z2^2) and g z1 z2
+    BwdLoss ls;           // targets, thresholds, loss partials (ls.s and ls.g_out unused)
+};
+
+template <int NB, int KS1C>
+__global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArgs a) {
+    constexpr int NW = 4;
+    constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
+    constexpr int PF = 4, PF1 = PF + 1;
+    static_assert(NBW <= 3, "one weight load per MFMA quarter, the x loads after the last");
+    __shared__ f32x4 ylds[2][NB][64];        // y for layer 2 (accumulator layout), then dz for the dy chain
+    __shared__ float red[NW][2][16];
+    __shared__ float cnt_s[NW];
+    __shared__ double lacc[16][kLossNS];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;
+    const int g = lane >> 4;
+
+    const long long t0 = (long long)blockIdx.x * 16;
+    const bool ok = t0 + j < a.n;
+    const long long rA = ok ? t0 + j : a.n - 1;  // x1-side row of y / dz / du; the x2 side sits n rows further
+    const long long rB = a.n + rA;
+    const float* sa = a.xa + rA * a.ldx;
+    const float* sb = a.xb + rA * a.ldx;
+
+    const f32x4* W1p = reinterpret_cast<const f32x4*>(a.packed);
+    const f32x4* W2p = reinterpret_cast<const f32x4*>(a.packed + a.oW2);
+    const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
+    const f32x4* b1p = reinterpret_cast<const f32x4*>(a.packed + a.ob1);
+    const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    const int KS1 = KS1C ? KS1C : a.KS1;
+    const int D0 = a.D0;
+
+    // ---- layer 1 (nplda_fwd_small.h) -----------------------------------------------------------------------------
+    f32x4 accA[NBW], accB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        accB[i] = accA[i];
+    }
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
+    auto fetchw = [&](int slot, int ks, int i) {
+        const int ksc = ks < KS1 ? ks : KS1 - 1;
+        const int nb = wave + NW * i;
+        wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+    };
+    auto fetchx = [&](int slot, int ks) {
+        xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
+        xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) {
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
+        fetchx(s, s);
+    }
+    // the batch's target count, while the first fragments are on their way (one block-wide exchange)
+    const double Nt = block_target_count(a.ls, cnt_s);
+    const double Nn = (double)a.ls.B - Nt;
+    const float ti = a.ls.t[rA];
+
+    auto step = [&](int ks, int slot, int rs) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
+                accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
+            }
+            if (r < NBW) fetchw(rs, ks + PF, r);
+            if (r == 3) fetchx(rs, ks + PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    if constexpr (KS1C > 0) {
+#pragma unroll
+        for (int ks = 0; ks < KS1C; ++ks) step(ks, ks % PF1, (ks + PF) % PF1);
+    } else {
+        for (int ks0 = 0; ks0 < KS1; ks0 += PF1) {
+#pragma unroll
+            for (int s = 0; s < PF1; ++s)
+                if (ks0 + s < KS1) step(ks0 + s, s, (s + PF) % PF1);
+        }
+    }
+
+    // ---- F.normalize ------------------------------------------------------------------------------------------------
+    {
+        float ssA = 0.f, ssB = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            if (wave + NW * i < NB) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    ssA = fmaf(accA[i][r], accA[i][r], ssA);
+                    ssB = fmaf(accB[i][r], accB[i][r], ssB);
+                }
+            }
+        }
+        ssA = wave_xor_add(ssA, 16); ssA = wave_xor_add(ssA, 32);
+        ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
+        if (g == 0) {
+            red[wave][0][j] = ssA;
+            red[wave][1][j] = ssB;
+        }
+    }
+    __syncthreads();
+    const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
+    const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB) {
+            accA[i] *= invA;
+            accB[i] *= invB;
+            ylds[0][nb][lane] = accA[i];
+            ylds[1][nb][lane] = accB[i];
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.out_y + rA * a.ldz + 16 * nb + 4 * g) = accA[i];
+                *reinterpret_cast<f32x4*>(a.out_y + rB * a.ldz + 16 * nb + 4 * g) = accB[i];
+            }
+        }
+    }
+
+    // ---- layer 2 ------------------------------------------------------------------------------------------------------
+    f32x4 zA[NBW], zB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        zA[i] = nb < NB ? b2p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
+        zB[i] = zA[i];
+    }
+    f32x4 w2[PF][NBW];
+    auto fetch2 = [&](const f32x4* Wp, int slot, int kb) {
+        const int kbc = kb < NB ? kb : NB - 1;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            w2[slot][i] = Wp[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch2(W2p, s, s);
+    __syncthreads();  // ylds complete (also orders the `red` reuse below after every wave's norm reads)
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 yA = ylds[0][kb][lane], yB = ylds[1][kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                zA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], yA[r], zA[i], 0, 0, 0);
+                zB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], yB[r], zB[i], 0, 0, 0);
+            }
+        }
+        fetch2(W2p, s, kb + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- score ----------------------------------------------------------------------------------------------------------
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < NBW; ++i) {
+            const int nb = wave + NW * i;
+            if (nb < NB) {
+                const f32x4 q = Qp[4 * nb + g];
+                const f32x4 p = Pp[4 * nb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = zA[i][r], z2 = zB[i][r];
+                    part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
+                    part = fmaf(2.0f * p[r], z1 * z2, part);
+                }
+            }
+        }
+        part = wave_xor_add(part, 16);
+        part = wave_xor_add(part, 32);
+        if (g == 0) red[wave][0][j] = part;
+    }
+    // W2^T fragments of the dy chain: on their way during the exchanges below
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch2(W2T, s, s);
+    __syncthreads();  // scores of the tile; every wave is past layer 2: ylds is free for dz
+    const float si = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+    if (a.out_s != nullptr && wave == 0 && g == 0 && ok) a.out_s[t0 + j] = si;
+
+    // ---- loss: dL/ds of the tile's pairs, their terms of the loss sums (nplda_bwd_loss.h) ------------------------------
+    double lsum[kLossNS];
+    const float gi = loss_pair(a.ls, Nt, Nn, si, ti, lsum);
+    const float tg = ok ? 2.0f * gi : 0.f;
+    if (wave == 0 && g == 0) {
+#pragma unroll
+        for (int i = 0; i < kLossNS; ++i) lacc[j][i] = ok ? lsum[i] : 0.0;
+    }
+
+    // ---- dz = 2 g (Q z + P z'), the pair sums for dQ / dP (K-A of nplda_backward.hip) ------------------------------------
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB) {
+            const f32x4 q = Qp[4 * nb + g], p = Pp[4 * nb + g];
+            const f32x4 dA = dz_of(tg, q, p, zA[i], zB[i]);
+            const f32x4 dB = dz_of(tg, q, p, zB[i], zA[i]);
+            ylds[0][nb][lane] = dA;
+            ylds[1][nb][lane] = dB;
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * nb + 4 * g) = dA;
+                *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * nb + 4 * g) = dB;
+            }
+            const float gh = 0.5f * tg;
+            f32x4 eq, ep;
+            pair_sum_terms(gh, zA[i], zB[i], eq, ep);
+#pragma unroll
+            for (int msk = 1; msk < 16; msk <<= 1) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    eq[r] += __shfl_xor(eq[r], msk, 64);
+                    ep[r] += __shfl_xor(ep[r], msk, 64);
+                }
+            }
+            if (j == 0) {
+                float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * nb + 4 * g;
+                *reinterpret_cast<f32x4*>(o) = eq;
+                *reinterpret_cast<f32x4*>(o + a.ldz) = ep;
+            }
+        }
+    }
+    __syncthreads();  // dz of the tile in LDS, the loss terms of its pairs
+    if (tid < kLossNS) {
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < 16; ++p) v += lacc[p][tid];
+        a.ls.partial[(size_t)blockIdx.x * kLossNS + tid] = v;
+    }
+
+    // ---- dy = dz W2 (chained MFMA: A = W2^T fragments, B = dz from LDS) ---------------------------------------------------
+    f32x4 dyA[NBW], dyB[NBW];
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        dyA[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dyB[i] = dyA[i];
+    }
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 dA = ylds[0][kb][lane], dB = ylds[1][kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int i = 0; i < NBW; ++i) {
+                dyA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], dA[r], dyA[i], 0, 0, 0);
+                dyB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], dB[r], dyB[i], 0, 0, 0);
+            }
+        }
+        fetch2(W2T, s, kb + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+    // ---- F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); y is still in accA / accB ------------------------
+    float dotA = 0.f, dotB = 0.f;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        if (wave + NW * i < NB) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dotA = fmaf(accA[i][r], dyA[i][r], dotA);
+                dotB = fmaf(accB[i][r], dyB[i][r], dotB);
+            }
+        }
+    }
+    dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
+    dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
+    if (g == 0) {
+        red[wave][0][j] = dotA;
+        red[wave][1][j] = dotB;
+    }
+    __syncthreads();
+    dotA = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
+    dotB = ((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j];
+    if (invA >= 1e12f) dotA = 0.f;  // the clamp branch of F.normalize: u / eps, no projection term
+    if (invB >= 1e12f) dotB = 0.f;
+#pragma unroll
+    for (int i = 0; i < NBW; ++i) {
+        const int nb = wave + NW * i;
+        if (nb < NB && ok) {
+            *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g) = du_of(dyA[i], accA[i], dotA, invA);
+            *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g) = du_of(dyB[i], accB[i], dotB, invB);
+        }
+    }
+}
+
+}  // namespace nplda
