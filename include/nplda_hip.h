@@ -380,8 +380,8 @@ int nplda_adam_step_f32(float* const* params, const float* const* grads, float* 
                         float* const* exp_avg_sq, const int64_t* numel, int nseg, float* step, float lr,
                         float beta1, float beta2, float eps, float weight_decay, nplda_stream_t stream);
 
-/* One whole optimisation step on B <= 16384 pairs in FOUR launches: forward (training mode) -> data gradients with the
- * loss folded in (dL/ds of a pair needs its own score / target and the batch counts only) -> weight-gradient slabs ->
+/* One whole optimisation step on B <= 16384 pairs in THREE launches: forward + loss + data gradients in one kernel (dL/ds
+ * of a pair needs its own score / target and the batch counts only) -> weight-gradient slabs ->
  * slab sums + Adam + refreshed fragment image + loss / dL/dtheta / threshold update.  What the reference spends
  * `loss.backward(); optimizer.step()` on (xvector_NeuralPlda_pytorch.py:66-75: ~250 ATen launches).  Same arithmetic as
  * nplda_pack_params_f32 -> nplda_forward_train_f32 -> nplda_loss_fwd_bwd_f32 -> nplda_backward_f32 ->

@@ -633,7 +633,11 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
     const size_t nW1 = (size_t)D1 * D0, nW2 = (size_t)D2 * D1;
     const size_t ngrad = nW1 + D1 + nW2 + 3 * (size_t)D2;
     if (blockIdx.x < a.ngrad_blocks) {
-        const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+        // four elements per thread: the arrival tickets at the end are one atomic per block on one address (~10 ns each,
+        // serialised): 392 blocks of 256 elements spent 2 of the kernel's 10 us queueing there
+#pragma unroll
+        for (int e4 = 0; e4 < 4; ++e4) {
+        const size_t idx = ((size_t)blockIdx.x * 4 + e4) * 256 + threadIdx.x;
         if (idx < ngrad) {
             const float* src;
             size_t stride;
@@ -671,25 +675,27 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
                 pk0 = (sel == 0 ? a.L.ob2 : (sel == 1 ? a.L.oP : a.L.oQ)) + f;
                 which = sel == 1;
             }
-            // at most 16 slabs (ws_layout): all 16 loads in flight at once, summed in slab order like K-C
+            // at most 16 slabs (ws_layout): all 16 loads in flight at once — together with the element's parameter and
+            // moments (loaded here, ahead of the stores below that they might alias) — summed in slab order like K-C
             float part[16];
 #pragma unroll
             for (int k = 0; k < 16; ++k) part[k] = src[(k < a.r.ksplit ? k : 0) * stride];
+            const float p = *pp;
+            float m = a.m[idx], v = a.v[idx];
             float sum = 0.f;
 #pragma unroll
             for (int k = 0; k < 16; ++k) sum += k < a.r.ksplit ? part[k] : 0.f;
-            const float p = *pp;
             // the product is rounded on its own, as K-C stores it: left to the compiler it is contracted into Adam's g + wd p
             float g = which ? sum * (4.0f * p) : sum;
             asm volatile("" : "+v"(g));
             if (a.r.out) a.r.out[idx] = g;
-            float m = a.m[idx], v = a.v[idx];
             const float pn = nplda_adam::update(p, g, m, v, c);
             a.m[idx] = m;
             a.v[idx] = v;
             *pp = pn;
             a.packed[pk0] = which ? pn * pn : pn;  // P = P_sqrt^2 (utils/models.py:373)
             if (pk1 != (size_t)-1) a.packed[pk1] = pn;
+        }
         }
     } else {
         // ---- loss block: partials -> sums (fixed order: 8 interleaved chains per sum, then the chains in order) ----
@@ -1098,7 +1104,7 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
     ua.partial = ls.partial; ua.nblk = S.nblk; ua.K = nth; ua.kind = kind; ua.beta = ls.beta; ua.alpha = alpha;
     ua.loss = loss;
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
-    ua.ngrad_blocks = (unsigned)((ngrad + 255) / 256);
+    ua.ngrad_blocks = (unsigned)((ngrad + 1023) / 1024);
     hipLaunchKernelGGL(train_update_kernel, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
     return nplda_launch_status();
 }
