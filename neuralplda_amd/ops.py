@@ -438,7 +438,7 @@ def train_step_workspace(B, packed):
 def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
                weight_decay, packed, ws, loss, grad_out=None):
     """nplda_train_step_f32: forward -> loss -> backward -> Adam on `params` (the six parameter tensors, updated IN
-    PLACE) and `thetas`, `packed` refreshed to the updated parameters, `loss` (0-d device tensor) written.  Four launches."""
+    PLACE) and `thetas`, `packed` refreshed to the updated parameters, `loss` (0-d device tensor) written.  Three launches."""
     import ctypes
     lib = _lib.load()
     _need_fp32(packed, "train_step")

@@ -199,7 +199,7 @@ class GraphedTrainStep:
 class FusedTrainStep:
     """The whole optimisation step as direct C-ABI launches, no autograd and no torch optimiser.  Up to 16384 pairs on
     one rank it is ONE call, nplda_train_step_f32: forward(train) -> data gradients with the loss folded in -> weight
-    gradient slabs -> slab sums + Adam + refreshed parameter image + loss / dtheta (four launches; the update rule is
+    gradient slabs -> slab sums + Adam + refreshed parameter image + loss / dtheta (three launches: the first is forward, loss and data gradients in one kernel; the update rule is
     torch.optim.Adam(lr, weight_decay) of the reference, xvector_NeuralPlda_pytorch.py:139).  Larger batches and
     data-parallel models take the separate calls: pack -> forward(train) -> loss sums -> loss/g/dtheta -> backward (flat
     gradient) -> one-launch Adam (nplda_adam_step_f32).  Either form is optionally replayed from a HIP graph.
