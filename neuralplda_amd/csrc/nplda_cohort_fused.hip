@@ -4,24 +4,26 @@
 // reads it back for the row statistics: 1.76 GB of traffic for 22.5 MB of input.  Here the statistics are taken in the
 // GEMM's epilogue, from the accumulators:
 //
-//  * mean / std need sum and sum of squares: accumulated per lane, centred on the row's ANALYTIC mean c_r (so that the
-//    fp32 partial sums of a tile carry no cancellation), added to fp64 running sums once per tile and row;
+//  * the mean of a row's M scores is ANALYTIC: S[r, m] = q_r + q_m + a_r . z_m with a_r = 2 P z_r gives
+//    mean_m = q_r + mean(q) + a_r . mean(z), formed in fp64 on fp64 sums of the cohort (returned as is); the std needs the
+//    sum of squares: accumulated per lane centred on that mean (so that the fp32 partial sums of a tile carry no
+//    cancellation), added to fp64 running sums once per list band and row;
 //  * the top-N statistics (adaptive_score_normalization.py:32-36: the N smallest) need the N smallest scores of the row
 //    exactly.  A threshold t_r slightly above the N-th smallest is PROPOSED from the row's analytic mean and standard
-//    deviation — both follow from the cohort's first and second moments, S[r, m] = q_r + q_m + a_r . z_m with
-//    a_r = 2 P z_r:  mean_m = q_r + mean(q) + a_r . mean(z),  var_m = var(q) + 2 a_r . cov(z, q) + a_r^T cov(z) a_r —
+//    deviation — var_m = var(q) + 2 a_r . cov(z, q) + a_r^T cov(z) a_r from the cohort's second moments —
 //    and every score <= t_r is appended to a candidate list of that row.  The lists then hold ~2 N of the M scores; a
 //    small kernel selects the N smallest among them exactly (ties by count) and sums them in fp64.  The counts decide:
 //    a row whose list holds fewer than N scores, or more than fit, is recomputed by the exact general path
 //    (cohort_fallback_kernel in nplda_cohort.hip) — the proposal never changes a result, only who computes it.
-//  * no atomics on data, no run-to-run variation: a work item is (row tile of 128 rows, band of column tiles); ONE block
-//    walks the band's tiles in order, so every lane meets "its" columns of "its" rows in a fixed order and appends to
-//    a private sub-list (row, band, wave column, lane group): the lists' contents, their order and all sums are
+//  * no atomics on data, no run-to-run variation: a work item is (row tile of 256 rows, one or all list bands of a column
+//    band); ONE block walks the item's tiles in order, so every lane meets "its" columns of "its" rows in a fixed order
+//    and appends to a private sub-list (row, list band, lane group): the lists' contents, their order and all sums are
 //    independent of scheduling and of where a row sits in the table.
 //
-// Pre-pass (five small launches): Gram matrix of the cohort table by the split-K wgrad kernel (nplda_backward.hip) +
-// sums of q, q^2, q z; centred covariance folded with 2 P into a fragment image; (z_rows . C'') by the resident-matrix
-// GEMM (nplda_matmul.hip); one wave per row forms c_r and t_r.
+// Pre-pass (four small launches): Gram matrix of the cohort table by the split-K wgrad kernel (nplda_backward.hip) with
+// the first moments (sums of z, q in fp64; q^2, q z) as extra work items of the same launch; centred covariance folded
+// with 2 P into a fragment image; (z_rows . C'') by the resident-matrix GEMM (nplda_matmul.hip); one wave per row forms
+// the row's mean and t_r.
 
 #include <type_traits>
 
