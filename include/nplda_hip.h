@@ -395,6 +395,18 @@ int nplda_adam_step_f32(float* const* params, const float* const* grads, float* 
  *   loss:    device scalar;  grad_out: optional nplda_grad_floats + K floats (the gradient that was applied).
  * NPLDA_EUNSUPPORTED for B > 16384 or the hard cost (kind 2): use the separate entry points. */
 size_t nplda_train_step_workspace_bytes(int64_t B, int D0, int D1, int D2);
+/* The same step on the pairs (table[rows1[i]], table[rows2[i]]) of a resident (N, ldt) x-vector matrix — the form of the
+ * reference's training loop, which looks every pair's two utterances up in mega_xvec_dict (utils/sv_trials_loaders.py:418-437):
+ * the first kernel gathers the rows itself (and leaves them in the workspace for the weight gradients), so no gather
+ * launch and no (B, D0) staging tensors.  rows1 / rows2: B int64 device indices in [0, N) (the loaders check them; the
+ * kernel clamps).  D0 % 16 == 0 (else NPLDA_EUNSUPPORTED: gather with nplda_gather_rows_f32 and call nplda_train_step_f32). */
+size_t nplda_train_step_rows_workspace_bytes(int64_t B, int D0, int D1, int D2);
+int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                              int64_t B, const float* target, float* const* params, int D0, int D1, int D2,
+                              float* const* thetas, const float* betas, int K, float alpha, int kind, float* exp_avg,
+                              float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, float* grad_out,
+                              nplda_stream_t stream);
 int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,

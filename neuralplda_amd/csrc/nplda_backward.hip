@@ -1013,8 +1013,8 @@ int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void*
 
 // ---- the fused training step --------------------------------------------------------------------------------
 namespace {
-struct StepWs { size_t y, z, rn, s, g, partial, bwd, total; long long ldz; int nblk; };  // float offsets
-StepWs step_ws(long long B, const NpldaLayout& L) {
+struct StepWs { size_t y, z, rn, s, g, partial, xs, bwd, total; long long ldz, ldxs; int nblk; };  // float offsets
+StepWs step_ws(long long B, const NpldaLayout& L, bool rows) {
     StepWs w;
     w.ldz = 16 * L.NB;
     w.nblk = (int)((B + 15) / 16);
@@ -1025,7 +1025,9 @@ StepWs step_ws(long long B, const NpldaLayout& L) {
     w.s = al(w.rn + (size_t)2 * B);
     w.g = al(w.s + (size_t)B);
     w.partial = al(w.g + (size_t)B);
-    w.bwd = al(w.partial + (size_t)w.nblk * kLossNS * 2);
+    w.xs = al(w.partial + (size_t)w.nblk * kLossNS * 2);
+    w.ldxs = L.D0;
+    w.bwd = al(w.xs + (rows ? (size_t)2 * B * L.D0 : 0));  // indexed form: the gathered x1 / x2 rows
     w.total = w.bwd + ws_layout(2 * B, L, false).total;
     return w;
 }
@@ -1033,15 +1035,24 @@ StepWs step_ws(long long B, const NpldaLayout& L) {
 
 size_t nplda_train_step_workspace_bytes(int64_t B, int D0, int D1, int D2) {
     if (B < 1 || B > 16 * 1024 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
-    return step_ws(B, nplda_layout(D0, D1, D2)).total * sizeof(float);
+    return step_ws(B, nplda_layout(D0, D1, D2), false).total * sizeof(float);
 }
 
-int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+size_t nplda_train_step_rows_workspace_bytes(int64_t B, int D0, int D1, int D2) {
+    if (B < 1 || B > 16 * 1024 || (D0 % 16) != 0 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return step_ws(B, nplda_layout(D0, D1, D2), true).total * sizeof(float);
+}
+
+static int train_step_impl(const float* x1, const float* x2, const int64_t* rows1, const int64_t* rows2, int64_t ntab,
+                           int64_t B, int64_t ldx, const float* target,
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          float* grad_out, nplda_stream_t stream) {
+    const bool rows = rows1 != nullptr;
     if (int rc = check_model(D0, D1, D2)) return rc;
+    if (rows && (!rows2 || ntab < 1)) return NPLDA_EINVAL;
+    if (rows && (D0 % 16) != 0) return NPLDA_EUNSUPPORTED;  // the staged rows are written k16-step by k16-step
     if (B < 1) return NPLDA_EINVAL;
     if (B > 16 * 1024) return NPLDA_EUNSUPPORTED;  // larger batches: the separate launches (two-pass loss)
     if (kind != 0 && kind != 1) return kind == 2 ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
@@ -1053,7 +1064,7 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
     for (int i = 0; i < 6; ++i)
         if (!params[i]) return NPLDA_EINVAL;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
-    const StepWs S = step_ws(B, L);
+    const StepWs S = step_ws(B, L, rows);
     if (ws_bytes < S.total * sizeof(float)) return NPLDA_ENOSPC;
     hipStream_t st = (hipStream_t)stream;
     float* wsf = (float*)ws;
@@ -1076,6 +1087,10 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
         fb.oW2 = L.oW2; fb.oW2T = L.oW2T; fb.ob1 = L.ob1; fb.ob2 = L.ob2; fb.oQ = L.oQ; fb.oP = L.oP;
         fb.out_s = wsf + S.s; fb.out_y = wsf + S.y; fb.dz = bws + W.dz; fb.du = bws + W.du; fb.ldz = S.ldz;
         fb.pq = bws + W.pq; fb.ls = ls;
+        if (rows) {
+            fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = ntab;
+            fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs;
+        }
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
         const bool k32 = L.KS1 == 32 && L.D0 == 512;
 #define NPLDA_LAUNCH(NBV)                                                                                   \
@@ -1093,9 +1108,12 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
 #undef NPLDA_LAUNCH
         if (int rc = nplda_launch_status()) return rc;
     }
-    if (int rc = backward_launch(false, x1, x2, 2 * B, B, ldx, (const float*)packed, L, nullptr, wsf + S.y, wsf + S.z,
-                                 wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0, st, &ls, &ua.r,
-                                 true))
+    // the weight gradients read the x rows: the caller's, or the ones the first kernel gathered
+    const float* wx1 = rows ? wsf + S.xs : x1;
+    const float* wx2 = rows ? wsf + S.xs + (size_t)B * S.ldxs : x2;
+    if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, rows ? S.ldxs : ldx, (const float*)packed, L, nullptr,
+                                 wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
+                                 st, &ls, &ua.r, true))
         return rc;
     for (int i = 0; i < 6; ++i) ua.prm[i] = params[i];
     ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;
@@ -1107,6 +1125,28 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
     ua.ngrad_blocks = (unsigned)((ngrad + 1023) / 1024);
     hipLaunchKernelGGL(train_update_kernel, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
     return nplda_launch_status();
+}
+
+int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+                         float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
+                         float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                         float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
+                         float* grad_out, nplda_stream_t stream) {
+    return train_step_impl(x1, x2, nullptr, nullptr, 0, B, ldx, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
+                           exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
+                           grad_out, stream);
+}
+
+int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                              int64_t B, const float* target, float* const* params, int D0, int D1, int D2,
+                              float* const* thetas, const float* betas, int K, float alpha, int kind, float* exp_avg,
+                              float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps,
+                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, float* grad_out,
+                              nplda_stream_t stream) {
+    if (!rows1 || !rows2 || N < 1) return NPLDA_EINVAL;
+    return train_step_impl(table, table, rows1, rows2, N, B, ldt, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
+                           exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
+                           grad_out, stream);
 }
 
 size_t nplda_lda_wgrad_workspace_bytes(int64_t B, int D0, int D1) {

@@ -28,6 +28,15 @@ struct TrainFbArgs {
     long long ldz;
     float* pq;            // [blocks][2][ldz] per-block sums of g (z1^2 + z2^2) and g z1 z2
     BwdLoss ls;           // targets, thresholds, loss partials (ls.s and ls.g_out unused)
+    // Indexed form (the training loop's: pairs named by rows of a resident x-vector table, xa == xb == the table):
+    // pair i reads rows ia[i], ib[i] (clamped into [0, ntab): the loaders have checked them), and wave 0 leaves the rows it
+    // fetched in xsa / xsb (n, ldxs) for the weight-gradient kernel — the gather the step otherwise runs as two launches.
+    const long long* ia;
+    const long long* ib;
+    long long ntab;
+    float* xsa;
+    float* xsb;
+    long long ldxs;
 };
 
 template <int NB, int KS1C>
@@ -51,8 +60,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const bool ok = t0 + j < a.n;
     const long long rA = ok ? t0 + j : a.n - 1;  // x1-side row of y / dz / du; the x2 side sits n rows further
     const long long rB = a.n + rA;
-    const float* sa = a.xa + rA * a.ldx;
-    const float* sb = a.xb + rA * a.ldx;
+    long long xrA = rA, xrB = rA;
+    if (a.ia != nullptr) {
+        xrA = a.ia[rA];
+        xrB = a.ib[rA];
+        xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
+        xrB = xrB < 0 ? 0 : (xrB < a.ntab ? xrB : a.ntab - 1);
+    }
+    const float* sa = a.xa + xrA * a.ldx;
+    const float* sb = a.xb + xrB * a.ldx;
+    const bool stage = a.xsa != nullptr && wave == 0 && ok;  // (indexed form only; D0 % 16 == 0 there)
 
     const f32x4* W1p = reinterpret_cast<const f32x4*>(a.packed);
     const f32x4* W2p = reinterpret_cast<const f32x4*>(a.packed + a.oW2);
@@ -94,6 +111,10 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const float ti = a.ls.t[rA];
 
     auto step = [&](int ks, int slot, int rs) {
+        if (stage) {
+            *reinterpret_cast<f32x4*>(a.xsa + rA * a.ldxs + 16 * ks + 4 * g) = xa[slot];
+            *reinterpret_cast<f32x4*>(a.xsb + rA * a.ldxs + 16 * ks + 4 * g) = xb[slot];
+        }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll

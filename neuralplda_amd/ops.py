@@ -427,9 +427,12 @@ def pack_params_into(packed, W1, b1, W2, b2, P_sqrt, Q):
     return packed
 
 
-def train_step_workspace(B, packed):
-    """Workspace tensor for train_step at batch size B (None when the fused step does not cover this size)."""
-    n = _lib.load().nplda_train_step_workspace_bytes(B, packed.D0, packed.D1, packed.D2)
+def train_step_workspace(B, packed, rows=False):
+    """Workspace tensor for train_step (rows=True: train_step_rows) at batch size B (None when the fused step does not
+    cover this size / shape)."""
+    lib = _lib.load()
+    fn = lib.nplda_train_step_rows_workspace_bytes if rows else lib.nplda_train_step_workspace_bytes
+    n = fn(B, packed.D0, packed.D1, packed.D2)
     if n == 0:
         return None
     return torch.empty(n // 4, dtype=torch.float32, device=packed.buf.device)
@@ -468,6 +471,44 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
                                         ws.numel() * 4, _lib.ptr(loss), _lib.ptr(grad_out) if grad_out is not None else None,
                                         _lib.current_stream())
     _lib.check(code, "nplda_train_step_f32")
+    return loss
+
+
+def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1,
+                    beta2, eps, weight_decay, packed, ws, loss, grad_out=None):
+    """nplda_train_step_rows_f32: train_step on the pairs (table[rows1], table[rows2]) of a resident x-vector matrix; the
+    first kernel gathers the rows itself.  rows1 / rows2: int64 device tensors with values in [0, len(table))."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_rows")
+    table, ldt = _rows(table, "table", packed.D0)
+    dev = table.device
+    if rows1.dtype != torch.int64 or rows2.dtype != torch.int64 or rows1.device != dev or rows2.device != dev:
+        raise TypeError("rows must be int64 tensors on the table's device")
+    rows1, rows2 = rows1.contiguous(), rows2.contiguous()
+    B = rows1.shape[0]
+    if rows2.shape[0] != B or target.shape[0] != B:
+        raise ValueError("rows1, rows2 and target must have the same length")
+    _require_dev_f32(target, "target")
+    target = target.contiguous()
+    if target.data_ptr() % 16:
+        target = target.clone()
+    for q in list(params) + list(thetas):
+        _require_dev_f32(q, "parameter")
+        if not q.is_contiguous():
+            raise ValueError("train_step updates the parameter tensors in place: they must be contiguous")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(dev):
+        code = lib.nplda_train_step_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
+                                             _lib.ptr(target), parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas),
+                                             barr, K, float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                             _lib.ptr(step), float(lr), float(beta1), float(beta2), float(eps),
+                                             float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(ws), ws.numel() * 4,
+                                             _lib.ptr(loss), _lib.ptr(grad_out) if grad_out is not None else None,
+                                             _lib.current_stream())
+    _lib.check(code, "nplda_train_step_rows_f32")
     return loss
 
 

@@ -100,11 +100,12 @@ class TrialLoader(DataLoader):
             ii = perm[lo:lo + bs]
             yield ds.x1[ii], ds.x2[ii], ds.l[ii]
 
-    def device_batches(self, device, num_to_row=None):
+    def device_batches(self, device, num_to_row=None, pack=False):
         """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
         batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
         `num_to_row`: optional int64 device map applied to both index columns (trial number -> x-vector table row);
-        a negative entry (unknown utterance) raises KeyError like load_xvec_trials_from_numbatch."""
+        a negative entry (unknown utterance) raises KeyError like load_xvec_trials_from_numbatch.
+        pack=True also yields, per full batch, the batch as one contiguous uint8 record (None for a last partial batch)."""
         ds = self.dataset
         if not isinstance(ds, TrialIndexDataset) or self.num_workers != 0 or self.drop_last:
             raise TypeError("device_batches needs the vectorised TrialIndexDataset path")
@@ -122,6 +123,18 @@ class TrialLoader(DataLoader):
             if n and (int(e1.min()) < 0 or int(e2.min()) < 0):
                 raise KeyError("trial index refers to an utterance that is not in mega_dict")
         bs = self.batch_size
+        if pack:
+            # one contiguous record per full batch — [rows1 (int64) | rows2 (int64) | labels (float32)] — so that a consumer
+            # with static input buffers (FusedTrainStep.step_rows) stages a batch with ONE device copy instead of three
+            nb = n // bs
+            rec = torch.empty((nb, 20 * bs), dtype=torch.uint8, device=device)
+            if nb:
+                rec[:, :8 * bs].view(torch.int64).copy_(e1[:nb * bs].view(nb, bs))
+                rec[:, 8 * bs:16 * bs].view(torch.int64).copy_(e2[:nb * bs].view(nb, bs))
+                rec[:, 16 * bs:].view(torch.float32).copy_(el[:nb * bs].float().view(nb, bs))
+            for k, lo in enumerate(range(0, n, bs)):
+                yield e1[lo:lo + bs], e2[lo:lo + bs], el[lo:lo + bs], (rec[k] if k < nb else None)
+            return
         for lo in range(0, n, bs):
             yield e1[lo:lo + bs], e2[lo:lo + bs], el[lo:lo + bs]
 

@@ -45,13 +45,13 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             and not train_loader.drop_last)
     if fast:
         table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
-        batches = ((r1, r2, t, None, None) for r1, r2, t in train_loader.device_batches(device, row_map))
+        batches = ((r1, r2, t, None, rec) for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
     else:
         batches = ((None, None, t, d1, d2) for d1, d2, t in train_loader)
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
         if fast:
-            data1 = rows1  # len(data1) below
-            loss = step_fn.step_rows(table, rows1, rows2, target)
+            rec, data1 = data2, rows1  # (data2 carries the packed record here; len(data1) below)
+            loss = step_fn.step_rows(table, rows1, rows2, target, record=rec)
             losses.append(loss.detach())
             if batch_idx % nc.log_interval == 0:
                 _log_train(nc, epoch, batch_idx, len(data1), train_loader, losses)
@@ -359,10 +359,12 @@ class FusedTrainStep:
     def _capture(self):
         self._graph, self._loss = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
 
-    def step_rows(self, table, rows1, rows2, target):
+    def step_rows(self, table, rows1, rows2, target, record=None):
         """One step on the pairs (table[rows1], table[rows2]): `table` is the resident (N, D0) x-vector matrix, rows
-        int64 device tensors.  With graph replay the two gathers are part of the captured step and read their indices
-        from static buffers, so a step costs three small device copies and one graph launch on the host."""
+        int64 device tensors.  With graph replay the gather is part of the captured step (its first kernel reads the rows
+        through the indices) and the indices sit in static buffers, so a step costs three small device copies — ONE when
+        `record` (TrialLoader.device_batches(pack=True): [rows1 | rows2 | labels] as one uint8 tensor) is given — and one
+        graph launch on the host."""
         ops = self._ops
         B = rows1.shape[0]
         if not self.use_graph or B != self.batch_size:
@@ -373,22 +375,43 @@ class FusedTrainStep:
             self._capture_rows(table)
         if self._one_call:
             self._sync_packed()
-        self.i1.copy_(rows1, non_blocking=True)
-        self.i2.copy_(rows2, non_blocking=True)
-        self.t.copy_(target, non_blocking=True)
+        if record is not None:
+            self._rec.copy_(record, non_blocking=True)
+        else:
+            self.i1.copy_(rows1, non_blocking=True)
+            self.i2.copy_(rows2, non_blocking=True)
+            self._t_rows.copy_(target, non_blocking=True)
         self._graph_rows.replay()
         self._touched()
         return self._loss_rows
 
     def _eager_rows(self, table):
-        self._ops.gather_rows(table, self.i1, out=self.x1)
-        self._ops.gather_rows(table, self.i2, out=self.x2)
-        return self._eager(self.x1, self.x2, self.t)
+        ops = self._ops
+        if self._one_call and 0 < self.batch_size <= 16384 and self.dims[0] % 16 == 0:
+            # the step's first kernel gathers the rows itself (nplda_train_step_rows_f32): no gather launches
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            ws = self._ws.get(("rows", self.batch_size))
+            if ws is None:
+                ws = self._ws[("rows", self.batch_size)] = ops.train_step_workspace(self.batch_size, self._packed, rows=True)
+            with torch.no_grad():
+                ops.train_step_rows(table, self.i1, self.i2, self._t_rows, [q.detach() for q in self.params],
+                                    [th.detach() for th in self.thetas], self.betas_loss, self.alpha, self.kind, self.m,
+                                    self.v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                    self._packed, ws, self._loss_buf)
+            return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
+        ops.gather_rows(table, self.i1, out=self.x1)
+        ops.gather_rows(table, self.i2, out=self.x2)
+        return self._eager(self.x1, self.x2, self._t_rows)
 
     def _capture_rows(self, table):
         if self.i1 is None:
-            self.i1 = torch.zeros(self.batch_size, dtype=torch.int64, device=self.dev)
-            self.i2 = torch.zeros(self.batch_size, dtype=torch.int64, device=self.dev)
+            # one record [rows1 | rows2 | labels]: the three static inputs of the captured step are views of it
+            bs = self.batch_size
+            self._rec = torch.zeros(20 * bs, dtype=torch.uint8, device=self.dev)
+            self.i1 = self._rec[:8 * bs].view(torch.int64)
+            self.i2 = self._rec[8 * bs:16 * bs].view(torch.int64)
+            self._t_rows = self._rec[16 * bs:].view(torch.float32)
         self._graph_rows, self._loss_rows = self._capture_fn(lambda: self._eager_rows(table))
         self._graph_table = (table.data_ptr(), table.shape, table.stride(0))
         self._table_ref = table  # keeps the captured pointer alive

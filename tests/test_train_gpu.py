@@ -404,6 +404,30 @@ def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
     assert sa.step_count[0].item() == 4 and sa.step_count[1].item() == 0
 
 
+@pytest.mark.parametrize("graph", [False, True])
+def test_step_rows_gathers_inside_the_step(hip_lib, graph):
+    """step_rows (pairs named by rows of the resident x-vector table; the step's first kernel gathers them itself) gives
+    the same parameter bits as gathering with gather_rows and calling the step on the (B, D0) tensors."""
+    from neuralplda_amd import ops, train
+    rng = np.random.default_rng(91)
+    D, B, N = 170, 777 if not graph else 1024, 5000
+    p = rand_params(rng, 512, D, D)
+    table = torch.from_numpy(rng.standard_normal((N, 512)).astype(np.float32)).cuda()
+    batches = [(torch.from_numpy(rng.integers(0, N, B)).cuda(), torch.from_numpy(rng.integers(0, N, B)).cuda(),
+                torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    nc = NC(512, D, D)
+    m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    for r1, r2, t in batches:
+        la = sa.step_rows(table, r1, r2, t)
+        lb = sb(ops.gather_rows(table, r1), ops.gather_rows(table, r2), t)
+        assert la.item() == lb.item()
+        for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            assert torch.equal(a, b), k
+    assert sa.step_count[0].item() == 3
+
+
 def test_one_call_step_reports_the_applied_gradient(hip_lib):
     """grad_out of nplda_train_step_f32 = flat gradient of the separate backward + dtheta of the separate loss."""
     from neuralplda_amd import ops
@@ -644,8 +668,8 @@ def test_reference_driver_train_and_validate_g12(hip_lib, tmp_path):
                                         batch_size=int(g["batch_size"]), graph=True)
             inner = step.step_rows
 
-            def rec_rows(*a):
-                L = inner(*a)
+            def rec_rows(*a, **kw):
+                L = inner(*a, **kw)
                 losses.append(float(L))
                 return L
             step.step_rows = rec_rows

@@ -4,8 +4,8 @@
 Three ways of feeding the step, each timed over 200 replays:
   inplace : the minibatch is written into the step's own input buffers (step.x1 / .x2 / .t) — no staging copies;
   copy    : foreign tensors -> three device copies (2 x 8 MB + 16 KB) in front of every replay;
-  rows    : step_rows(table, rows1, rows2, t) — the training loop's form: index copies + in-graph gathers from the
-            resident x-vector table.
+  rows    : step_rows(table, rows1, rows2, t) — three index / label copies, the step's first kernel gathers the rows;
+  rows1   : the same with the batch as ONE packed record (TrialLoader.device_batches(pack=True)) — the training loop's form.
 (Run `rows` before `copy`: the first ~200 replays of the rows graph that follow a run of 8 MB device-to-device staging copies
 take 0.27 ms each, then drop back to 0.10 ms — a runtime effect of switching between the copy engine and blit kernels on
 the stream, not of the step's kernels; a training loop only ever uses step_rows.)
@@ -23,7 +23,7 @@ class NC:
 
 D = int(sys.argv[1]) if len(sys.argv) > 1 else 150
 graph = (sys.argv[2] != "eager") if len(sys.argv) > 2 else True
-modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["inplace", "rows", "copy"]
+modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["inplace", "rows1", "rows", "copy"]
 NC.layer1_LDA_dim = NC.layer2_PLDA_spkfactor_dim = D
 torch.manual_seed(0)
 m = models.NeuralPlda(NC()).cuda()
@@ -52,6 +52,9 @@ for mode in modes:
         ms = timed(lambda: step(step.x1, step.x2, step.t))
     elif mode == "rows":
         ms = timed(lambda: step.step_rows(table, r1, r2, t))
+    elif mode == "rows1":
+        rec = torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])
+        ms = timed(lambda: step.step_rows(table, r1, r2, t, record=rec))
     else:
         ms = timed(lambda: step(x1, x2, t))
     print(f"D={D} B={B} graph={graph} feed={mode}: {ms:.4f} ms/step (wall)")
