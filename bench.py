@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the NPLDA hot path on MI355X (BASELINE.json metric: scored trial-pairs/s).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg3] [--scaling weak|strong] [--dim D]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3] [--scaling weak|strong] [--dim D]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workloads (BASELINE.json `configs`):
@@ -9,6 +9,9 @@ Workloads (BASELINE.json `configs`):
         NeuralPlda.forward(x1, x2) — over a batch of synthetic trial pairs already resident in HBM, 512->150->150.
         --scaling weak  : 1 048 576 pairs PER GPU per step (the trial list shards across ranks, no data-path collective);
         --scaling strong: BASELINE's "1 M trial pairs" in total, split N ways (131 072 pairs per GPU at N = 8).
+  cfg2  NPLDA training: one step = one 4096-pair minibatch (drawn by row index from a resident 1.2 M-utterance x-vector
+        table) through forward, SoftCdet, backward and Adam (nplda_train_step_rows_f32, HIP-graph replay); data parallel
+        over the ranks with the two all-reduces inside the graph; value = trained pairs/s;
   cfg3  adaptive score normalisation, 10 000-utterance cohort x 22 000 enroll/test rows x 2 M trials: one step =
         embed this rank's row shard and the cohort -> cohort score matrix + per-row statistics (nplda_cohort_stats_f32)
         -> the ONE collective of the path, an all-gather of the (R, 4) fp64 statistics over RCCL -> normalise this rank's
@@ -458,16 +461,98 @@ def run_cfg3(args, ctx):
     }
 
 
+def run_cfg2(args, ctx):
+    """BASELINE configs[2]: NPLDA training, 4096-pair minibatches (SoftCdet + backward + Adam) drawn by row index from a
+    resident VoxCeleb-scale x-vector table; data-parallel over the ranks (batch sharded, loss sums and flat gradient
+    all-reduced inside the step's HIP graph)."""
+    from neuralplda_amd import dist as ndist
+    from neuralplda_amd import models, train
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    D0, D = 512, args.dim
+    Bg = args.batch * world if args.scaling == "weak" else args.batch
+    lo, hi = ndist.shard_bounds(Bg, world, rank)
+    Bl = hi - lo
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = D0, D, D
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, str(dev), "SoftCdet"
+
+    torch.manual_seed(0)
+    model = models.NeuralPlda(NC()).to(dev)
+    params, psrc = make_params(D, dev)
+    with torch.no_grad():
+        for q, v in zip(model._params(), params):
+            q.copy_(v)
+    if world > 1:
+        ndist.make_data_parallel(model)
+    gen = torch.Generator(device=dev).manual_seed(777)  # the same table on every rank
+    N = args.table
+    table = torch.empty(N, D0, device=dev)
+    for r0 in range(0, N, 1 << 18):
+        table[r0:r0 + (1 << 18)].normal_(generator=gen)
+    graph = ctx.backend == "nccl" or world == 1  # (the gloo dry run cannot capture its collectives)
+    step_fn = train.FusedTrainStep(model, 1e-4, weight_decay=1e-5, batch_size=Bl, graph=graph)
+    gen_r = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank its own shard of every minibatch
+    nbat = 32
+    recs = []
+    for _ in range(nbat):
+        r1 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
+        r2 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
+        t = (torch.rand(Bl, device=dev, generator=gen_r) < 0.1).float()
+        recs.append((r1, r2, t, torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])))
+    state = {"k": 0}
+
+    def step():
+        r1, r2, t, rec = recs[state["k"] % nbat]
+        state["k"] += 1
+        return step_fn.step_rows(table, r1, r2, t, record=rec)
+
+    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup)
+    if not torch.isfinite(loss).all():
+        raise SystemExit("non-finite training loss")
+    if rank != 0:
+        return None
+    # forward + weight gradients (the same two GEMMs) + the data gradient through layer 2; SURVEY.md section 8d: ~3x Regime A
+    fwd = 2 * (2 * D0 * D + 2 * D * D) + 8 * D
+    flops = 2 * fwd + 2 * (2 * D * D)
+    achieved = Bl * flops / (step_ms * 1e-3) / 1e12
+    return {
+        "metric": "trained trial-pairs/sec (4096-pair minibatches, SoftCdet + backward + Adam)",
+        "value": Bg * args.steps / elapsed,
+        "unit": "pairs/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True,
+        "scaling": args.scaling,
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": f"cfg2: {Bg}-pair minibatches by row index from a resident {N} x {D0} x-vector table, "
+                               f"512->{D}->{D}, SoftCdet (beta 99, 199; alpha 15), Adam(1e-4, wd 1e-5); batch sharded x{world}",
+                   "global_batch": Bg, "pairs_per_gpu_per_step": Bl, "table_utterances": N, "params": psrc,
+                   "parallelism": f"data parallel x{world}", "backend": ctx.backend if world > 1 else "single process",
+                   "graph_replay": bool(graph), "final_loss": float(loss)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "kernel": "nplda_train_step_rows_f32 (forward + loss + data gradients, weight-gradient slabs, update), "
+                               "whole step", "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["cfg1", "cfg3"], default="cfg1")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3"], default="cfg1")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="cfg1: weak = --pairs per GPU (default), strong = --pairs in total split over the ranks")
     ap.add_argument("--pairs", type=int, default=1 << 20, help="cfg1: trial pairs per GPU (weak) / in total (strong) per step")
     ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
+    ap.add_argument("--batch", type=int, default=4096, help="cfg2: minibatch pairs per GPU (weak) / in total (strong)")
+    ap.add_argument("--table", type=int, default=1200000, help="cfg2: utterances in the resident x-vector table")
     ap.add_argument("--cohort", type=int, default=10000, help="cfg3: cohort utterances")
     ap.add_argument("--enroll", type=int, default=2000, help="cfg3: enroll ids")
     ap.add_argument("--test", type=int, default=20000, help="cfg3: test ids")
@@ -517,7 +602,7 @@ def main():
     from neuralplda_amd import _lib
     _lib.load()  # fail loudly if libnplda_hip.so is missing
 
-    out = run_cfg1(args, ctx) if args.workload == "cfg1" else run_cfg3(args, ctx)
+    out = {"cfg1": run_cfg1, "cfg2": run_cfg2, "cfg3": run_cfg3}[args.workload](args, ctx)
     if rank == 0:
         out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
         print(json.dumps(out), flush=True)

@@ -1,6 +1,8 @@
 """bench.py's output contract: ONE JSON line with the driver's keys, the tier's `roofline` and `cpu_baseline` objects and
 consistent numbers — run as the driver runs it (plain python at N = 1, torch.distributed.run for the multi-rank form)."""
 import json
+
+import numpy as np
 import os
 import subprocess
 import sys
@@ -119,3 +121,21 @@ def test_bench_cfg3_full_size_line(hip_lib):
     d = json.loads(lines[0])
     assert d["config"]["cohort"] == 10000 and d["config"]["rows"] == 22000 and d["config"]["trials"] == 2000000
     assert d["ms_per_step"] < 20.0 and d["config"]["cohort_scores_per_s"] > 1e10
+
+
+def test_bench_cfg2_single_and_two_rank_dry_run(hip_lib):
+    """--workload cfg2: 4096-pair training minibatches from a resident table; two gloo ranks shard the batch (eager: the dry
+    run's collectives cannot be captured)."""
+    small = ["--workload", "cfg2", "--steps", "5", "--warmup", "2", "--table", "50000"]
+    out, lines = _run(small)
+    assert out.returncode == 0, out.stderr[-2000:]
+    d1 = json.loads(lines[0])
+    assert d1["n_gpus"] == 1 and d1["unit"] == "pairs/s" and d1["config"]["global_batch"] == 4096
+    assert d1["config"]["graph_replay"] is True and d1["roofline"]["bound"] == "mfma"
+    assert abs(d1["value"] - 4096 / (d1["ms_per_step"] * 1e-3)) <= 1e-6 * d1["value"]
+    assert d1["ms_per_step"] < 0.5 and np.isfinite(d1["config"]["final_loss"])
+    out, lines = _run(["--gpus", "2", "--scaling", "strong"] + small, env={"NPLDA_BENCH_BACKEND": "gloo"})
+    assert out.returncode == 0, out.stderr[-2000:]
+    d2 = json.loads(lines[0])
+    assert d2["n_gpus"] == 2 and d2["config"]["ranks_in_group"] == 2 and d2["config"]["pairs_per_gpu_per_step"] == 2048
+    assert d2["config"]["global_batch"] == 4096 and d2["config"]["parallelism"] == "data parallel x2"
