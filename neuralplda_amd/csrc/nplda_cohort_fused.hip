@@ -34,8 +34,6 @@
 namespace nplda {
 int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int ksplit, float* slab, float* ext,
                       const QzArgs* qz, hipStream_t st);
-int rows_matmul_launch(const float* in, long long ldin, long long R, int K, const float* frag, int N, float* out,
-                       long long ldout, hipStream_t st);
 }  // namespace nplda
 
 namespace {
@@ -116,39 +114,77 @@ __global__ __launch_bounds__(256) void cohort_prep_kernel(const PrepArgs a) {
     }
 }
 
-// one wave per row: c_r = the row's analytic mean and t_r = the candidate threshold, c_r + sgn * zhi * sd (zhi < 0: below the
-// mean for the N smallest, sgn = +1; above it for the N largest, sgn = -1)
-__global__ __launch_bounds__(256) void cohort_threshold_kernel(const float* __restrict__ zr, const float* __restrict__ qr,
-                                                               const float* __restrict__ tmp, long long R,
-                                                               long long ldz, int Mp, const float* __restrict__ vec,
-                                                               const double* __restrict__ vec64, float zhi, float sgn,
-                                                               float* __restrict__ crow, float* __restrict__ trow,
-                                                               double* __restrict__ mean64) {
-    const long long r = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    if (r >= R) return;
-    float quad = 0.f, lin = 0.f;
-    double mu = 0.0;  // the mean is an OUTPUT (stats[.][0]): fp64 on the fp64 cohort mean, exact to rounding of the inputs
-    for (int f = lane; f < Mp; f += 64) {
-        const float z = zr[r * ldz + f];
-        quad = fmaf(z, tmp[r * Mp + f], quad);
-        lin = fmaf(z, vec[Mp + f], lin);
-        mu = fma((double)z, vec64[f], mu);
-    }
-    mu = wave_sum_f64(mu);
+// Per row r: its mean over the cohort (fp64, returned), c_r = that mean in fp32, and the candidate threshold
+// t_r = c_r + sgn * zhi * sd_r with sd_r^2 = var(q) + z_r . v + z_r^T C'' z_r (zhi < 0: below the mean for the N smallest,
+// sgn = +1; above it for the N largest, sgn = -1).  The quadratic form is a (16 rows) x (Mp x Mp) MFMA product per wave with
+// the covariance image resident in LDS: the accumulators come out in the layout of the operand rows themselves (lane
+// (j, g) holds features 16 nb + 4 g + r of row j — the k-permutation of the forward kernels), so z_r . (C'' z_r) is an
+// in-lane dot product and two row exchanges.  (This was a generic rows x matrix GEMM into a scratch table and a second
+// kernel reading it back: 32 + 10 us and 28 MB of traffic for what is 7 us of MFMA work.)
+struct RowThrArgs {
+    const float* zr; const float* qr; long long R, ldz;
+    const float* frag;    // [KB][KB][64][4]: C''[16 kb + 4 g + e][16 xb + i16]  (symmetric)
+    const float* vec;     // see PrepArgs
+    const double* vec64;
+    float zhi, sgn;
+    float* crow; float* trow; double* mean64;
+    int ntiles;           // tiles of 128 rows (8 waves x 16)
+};
+
+template <int NB>
+__global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs a) {
+    extern __shared__ f32x4 cimg[];  // NB * NB fragments of 64 lanes
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15, g = lane >> 4;
+    constexpr int Mp = 16 * NB;
+    for (int i = tid; i < NB * NB * 64; i += 512) cimg[i] = reinterpret_cast<const f32x4*>(a.frag)[i];
+    __syncthreads();
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        const long long r0 = ((long long)tile * 8 + wave) * 16;
+        if (r0 >= a.R) continue;  // wave-uniform
+        const long long row = r0 + j < a.R ? r0 + j : a.R - 1;
+        const float* zp = a.zr + row * a.ldz + 4 * g;
+        f32x4 zf[NB], acc[NB];
 #pragma unroll
-    for (int m = 32; m >= 1; m >>= 1) {
-        quad += __shfl_xor(quad, m, 64);
-        lin += __shfl_xor(lin, m, 64);
-    }
-    if (lane == 0) {
-        const double m64 = (double)qr[r] + vec64[Mp] + mu;
-        mean64[r] = m64;
-        const float mean = (float)m64;
-        const float var = vec[2 * Mp + 1] + lin + quad;
-        const float sd = sqrtf(fmaxf(var, 0.f));
-        crow[r] = mean;
-        trow[r] = mean + sgn * zhi * sd;
+        for (int kb = 0; kb < NB; ++kb) {
+            zf[kb] = *reinterpret_cast<const f32x4*>(zp + 16 * kb);
+            acc[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+#pragma unroll
+            for (int nb = 0; nb < NB; ++nb) {
+                const f32x4 av = cimg[(kb * NB + nb) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+                    acc[nb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[r], zf[kb][r], acc[nb], 0, 0, 0);
+            }
+        }
+        float quad = 0.f, lin = 0.f;
+        double mu = 0.0;  // the mean is an OUTPUT (stats[.][0]): fp64 on the fp64 cohort mean
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(a.vec + Mp + 16 * nb + 4 * g);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                quad = fmaf(zf[nb][r], acc[nb][r], quad);
+                lin = fmaf(zf[nb][r], v[r], lin);
+                mu = fma((double)zf[nb][r], a.vec64[16 * nb + 4 * g + r], mu);
+            }
+        }
+        quad = wave_xor_add(quad, 16); quad = wave_xor_add(quad, 32);
+        lin = wave_xor_add(lin, 16); lin = wave_xor_add(lin, 32);
+        mu += __hiloint2double(__shfl_xor(__double2hiint(mu), 16, 64), __shfl_xor(__double2loint(mu), 16, 64));
+        mu += __hiloint2double(__shfl_xor(__double2hiint(mu), 32, 64), __shfl_xor(__double2loint(mu), 32, 64));
+        if (g == 0 && r0 + j < a.R) {
+            const double m64 = (double)a.qr[row] + a.vec64[Mp] + mu;
+            a.mean64[row] = m64;
+            const float mean = (float)m64;
+            const float var = a.vec[2 * Mp + 1] + lin + quad;
+            const float sd = sqrtf(fmaxf(var, 0.f));
+            a.crow[row] = mean;
+            a.trow[row] = mean + a.sgn * a.zhi * sd;
+        }
     }
 }
 
@@ -712,9 +748,9 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256((size_t)kQzBlocks * (Mp + 1) * 8) +
                     align256((size_t)(Mp + 1) * 8) + align256(kb * kb * 256 * 4) +
-                    align256((size_t)(2 * Mp + 2) * 4) + 9 * 256;  // + the alignment slack of the per-row arrays
+                    align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
     p.max_rows = ((1LL << 30) / ((long long)p.nsub * p.ksub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
-    p.row_bytes = (size_t)Mp * 4 + 8 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
+    p.row_bytes = 8 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
     p.eligible = true;
     return p;
 }
@@ -740,7 +776,6 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     double* mean64 = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * 8);
     float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * p.nsub * p.ksub * 4);
     unsigned* counts = reinterpret_cast<unsigned*>(q); q += align256((size_t)rows_cap * p.nsub * 4);
-    float* tmp = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * Mp * 4);
     float* crow = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * 4);
     float* trow = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * 4);
     unsigned* fail_rows = reinterpret_cast<unsigned*>(q);
@@ -763,10 +798,30 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
         hipLaunchKernelGGL(cohort_prep_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, pa);
         if (int rc = nplda_launch_status()) return rc;
     }
-    if (int rc = rows_matmul_launch(z_rows, ldz, R, Mp, frag, Mp, tmp, Mp, st)) return rc;
-    hipLaunchKernelGGL(cohort_threshold_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, z_rows, q_rows, tmp, R,
-                       ldz, Mp, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64);
-    if (int rc = nplda_launch_status()) return rc;
+    {   // row means and thresholds
+        RowThrArgs ra = {z_rows, q_rows, R, ldz, frag, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64,
+                         (int)((R + 127) / 128)};
+        const unsigned grid = (unsigned)(ra.ntiles < resident ? ra.ntiles : resident);
+        const size_t shm = (size_t)ksteps * ksteps * 1024;
+#define NPLDA_LAUNCH(NBV)                                                                                             \
+    {                                                                                                                 \
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&cohort_rowthr_kernel<NBV>),                             \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shm) != hipSuccess)                  \
+            return NPLDA_EINVAL;                                                                                      \
+        hipLaunchKernelGGL(cohort_rowthr_kernel<NBV>, dim3(grid), dim3(512), shm, st, ra);                            \
+    }
+        switch (ksteps) {
+            case 2: NPLDA_LAUNCH(2); break;
+            case 4: NPLDA_LAUNCH(4); break;
+            case 8: NPLDA_LAUNCH(8); break;
+            case 10: NPLDA_LAUNCH(10); break;
+            case 11: NPLDA_LAUNCH(11); break;
+            case 12: NPLDA_LAUNCH(12); break;
+            default: return NPLDA_EUNSUPPORTED;
+        }
+#undef NPLDA_LAUNCH
+        if (int rc = nplda_launch_status()) return rc;
+    }
 
     FusedArgs fa = {};
     fa.zr = z_rows; fa.qr = q_rows; fa.zc = z_coh; fa.qc = q_coh; fa.P = P;
