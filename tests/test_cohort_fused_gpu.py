@@ -29,7 +29,8 @@ def setup(D, R, M, seed, coh_fn=None):
 
 
 @pytest.mark.parametrize("D,R,M,topn", [(150, 300, 10000, 500), (170, 129, 4096, 100), (24, 260, 24700, 100),
-                                        (16, 128, 5000, 37), (170, 1, 10000, 500), (150, 517, 9999, 1)])
+                                        (16, 128, 5000, 37), (170, 1, 10000, 500), (150, 517, 9999, 1),
+                                        (64, 200, 4500, 50), (128, 150, 5000, 200), (192, 140, 4200, 64)])
 def test_fused_matches_oracle_and_the_spilling_path(hip_lib, D, R, M, topn):
     ops, packed, zr, qr, zc, qc, C = setup(D, R, M, D + R + M)
     lib = hip_lib
