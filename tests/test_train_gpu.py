@@ -404,6 +404,31 @@ def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
     assert sa.step_count[0].item() == 4 and sa.step_count[1].item() == 0
 
 
+@pytest.mark.parametrize("D0,D1,D2,betas,B", [(512, 128, 128, (99.0,), 333), (512, 192, 192, (9.9, 99.0, 199.0), 2048),
+                                               (256, 150, 100, (99.0, 199.0), 640), (72, 24, 20, (99.0, 199.0), 100)])
+def test_one_call_step_other_shapes(hip_lib, D0, D1, D2, betas, B):
+    """The remaining kernel instantiations of the one-call step (NB = 8, 12; D1 != D2; x-vector dims other than 512, one
+    not a multiple of 16; 1 and 3 thresholds): same parameter bits as the separate launches, which are pinned by the oracle."""
+    from neuralplda_amd import train
+    rng = np.random.default_rng(79)
+    p = rand_params(rng, D0, D1, D2)
+    xs = [(torch.from_numpy(rng.standard_normal((B, D0)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, D0)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.25).astype(np.float32)).cuda()) for _ in range(3)]
+    nc = NC(D0, D1, D2, beta=betas)
+    ths = [-0.5, -0.3, -0.1][:len(betas)]
+    m_a, m_b = model_from(p, nc, thetas=ths), model_from(p, nc, thetas=ths)
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    assert sa._one_call
+    sb._one_call = False
+    for x1, x2, t in xs:
+        la, lb = sa(x1, x2, t), sb(x1, x2, t)
+        assert abs(la.item() - lb.item()) <= 2e-7 * abs(lb.item())
+        for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            assert torch.equal(a, b), k
+
+
 @pytest.mark.parametrize("graph", [False, True])
 def test_step_rows_gathers_inside_the_step(hip_lib, graph):
     """step_rows (pairs named by rows of the resident x-vector table; the step's first kernel gathers them itself) gives
