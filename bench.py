@@ -310,8 +310,13 @@ def run_cfg1(args, ctx):
             ms170, s170 = kernel_ms_of(lambda: ops.score_pairs(x1, x2, pk170))
             f170 = algorithmic_flops_per_pair(D0, 170, 170)
             ach = B * f170 / (ms170 * 1e-3) / 1e12
+            t170 = None
+            try:
+                t170 = json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(f"score_pairs_D170_B{B}")
+            except Exception:
+                pass
             alt170 = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                      "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": t170,
                       "kernel": "nplda_fwd_v5_kernel<11, 8 waves, 2 k16-steps/barrier, groups of 4> (persistent)", "kernel_ms": ms170,
                       "pairs_per_s_1gpu": B / (ms170 * 1e-3), "flop_per_pair_algorithmic": f170,
                       "workload": f"{B} trial pairs, 512->170->170 (conf/voices_config.cfg:14-16), scoring only",

@@ -135,11 +135,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
             f32x4* nxt = wbuf[par ^ 1];
             if (more) dma_l1(c + 1, nxt);
             else dma_l2(0, (G < NB ? G : NB), 0, KH, nxt);
-            // x of the next chunk (after the last chunk: a harmless re-read of this tile's first steps)
+            // x of the next chunk (after the last chunk: a harmless re-read of the steps just fetched — still in cache;
+            // re-reading the tile's FIRST steps instead cost 6 % more HBM fetches, FETCH_SIZE 2.29e6 vs 2.15e6 KB)
             f32x4 xan[KPB], xbn[KPB];
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
-                const int ks = more ? KPB * (c + 1) + s : s;
+                const int ks = more ? KPB * (c + 1) + s : KPB * c + s;
                 xan[s] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
                 xbn[s] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
             }
