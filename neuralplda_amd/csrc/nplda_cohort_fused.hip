@@ -508,6 +508,15 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     if (row >= a.R) return;
     unsigned* kl = keys[wave];
     const unsigned* cnt = a.counts + (size_t)row * a.nsub;
+    // everything else the row needs from memory is asked for now, next to the counts: at their places of use (the
+    // bracket, the very end) each of these loads was a memory round trip of its own at the tail of the wave's life
+    const float c_row = a.crow[row], t_row = a.trow[row];
+    const double m64_row = a.mean64[row];
+    double d2 = 0.0;
+    {
+        const double* pr = a.part + (size_t)row * (a.nsub / 4);
+        for (int i = lane; i < a.nsub_valid / 4; i += 64) d2 += pr[i];
+    }
     // counts (lane l holds sub-lists l, l + 64, ...) -> total, overflow, exclusive prefix in sub-list order
     unsigned creg[4], pre[4];
     unsigned total = 0, ovf = 0;
@@ -599,7 +608,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     // fixed order) and the bisection runs on four registers per lane.  The counts decide; a miss takes the full search.
     unsigned rank = (unsigned)N;
     {
-        const float c = a.crow[row], t = a.trow[row];
+        const float c = c_row, t = t_row;
         const float sgn = a.lowest ? 1.f : -1.f;
         const float sd = (t - c) / (sgn * a.zhi);
         const float q = a.fhi * (float)N / (float)total;
@@ -663,16 +672,13 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     t1 = wave_sum_f64(t1);
     t2 = wave_sum_f64(t2);
     nless = wave_sum_u32(nless);
-    // whole-row sums: the (band, wave column) partials in their fixed order
-    double d2 = 0.0;
-    const double* pr = a.part + (size_t)row * (a.nsub / 4);
-    for (int i = lane; i < a.nsub_valid / 4; i += 64) d2 += pr[i];
+    // whole-row sum of squares: the list bands' partials (one per lane, loaded at the top) in their fixed order
     d2 = wave_sum_f64(d2);
     if (lane == 0) {
         const double n = (double)a.M, nn = (double)N;
         // mean: analytic, fp64 (cohort_threshold_kernel); the squares were centred on its fp32 rounding c_r
-        const double mean_s = a.mean64[row];
-        const double mw = mean_s - (double)a.crow[row];
+        const double mean_s = m64_row;
+        const double mw = mean_s - (double)c_row;
         double var = d2 / n - mw * mw;
         if (var < 0.0) var = 0.0;
         double tv = (double)key2f(tkey);           // the threshold in ordered space -> raw score
