@@ -323,3 +323,31 @@ def test_trial_loader_fast_iterator_equals_torch_dataloader():
         assert len(fast) == len(ref) and len(fast_batches) == len(ref_batches)
         for a, b in zip(fast_batches, ref_batches):
             assert all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+def test_device_batches_packed_records():
+    """TrialLoader.device_batches(pack=True): the same batches as the plain iterator under the same RNG state, plus one
+    contiguous record [rows1 (int64) | rows2 (int64) | labels (float32)] per FULL batch (None for a short last batch) — what
+    FusedTrainStep.step_rows stages with a single device copy.  The mapping num -> row is applied to both index columns."""
+    from neuralplda_amd import sv_trials_loaders as svl
+    n, bs = 1000, 64
+    ds = svl.TrialIndexDataset(torch.arange(n), torch.arange(n) * 2 % n, (torch.arange(n) % 3 == 0).float())
+    row_map = torch.arange(n, dtype=torch.int64) * 3 + 1
+    torch.manual_seed(5)
+    plain = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate))
+    torch.manual_seed(5)
+    packed = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", row_map, pack=True))
+    assert len(packed) == len(plain) == (n + bs - 1) // bs
+    for (d1, d2, t), (r1, r2, tl, rec) in zip(plain, packed):
+        assert torch.equal(r1, row_map[d1.long()]) and torch.equal(r2, row_map[d2.long()]) and torch.equal(tl, t)
+        if len(r1) == bs:
+            assert rec.dtype == torch.uint8 and rec.numel() == 20 * bs and rec.is_contiguous()
+            assert torch.equal(rec[:8 * bs].view(torch.int64), r1) and torch.equal(rec[8 * bs:16 * bs].view(torch.int64), r2)
+            assert torch.equal(rec[16 * bs:].view(torch.float32), tl.float())
+        else:
+            assert rec is None
+    assert packed[-1][3] is None and len(packed[-1][0]) == n % bs
+    with pytest.raises(KeyError):
+        bad = row_map.clone()
+        bad[7] = -1
+        list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", bad, pack=True))
