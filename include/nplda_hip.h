@@ -392,7 +392,10 @@ int nplda_adam_step_f32(float* const* params, const float* const* grads, float* 
  *            flat-gradient order followed by the thresholds;  step: as nplda_adam_step_f32;
  *   packed:  IN the image of the current parameters (nplda_pack_params_f32), OUT the image of the updated ones — the
  *            caller re-packs only when the parameters were changed by something else;
- *   loss:    device scalar;  grad_out: optional nplda_grad_floats + K floats (the gradient that was applied).
+ *   loss:    device scalar;  grad_out: optional nplda_grad_floats + K floats (the gradient that was applied);
+ *   loss_sum: optional device double, loss_sum[0] += loss — the training log prints the MEAN of the losses since its
+ *            previous line (xvector_NeuralPlda_pytorch.py:41-47), which a replayed step cannot collect one by one: its
+ *            loss lives at one address.  The caller zeroes it when it reads it.
  * NPLDA_EUNSUPPORTED for B > 16384 or the hard cost (kind 2): use the separate entry points. */
 size_t nplda_train_step_workspace_bytes(int64_t B, int D0, int D1, int D2);
 /* The same step on the pairs (table[rows1[i]], table[rows2[i]]) of a resident (N, ldt) x-vector matrix — the form of the
@@ -405,13 +408,13 @@ int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const 
                               int64_t B, const float* target, float* const* params, int D0, int D1, int D2,
                               float* const* thetas, const float* betas, int K, float alpha, int kind, float* exp_avg,
                               float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, float* grad_out,
-                              nplda_stream_t stream);
+                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, double* loss_sum,
+                              float* grad_out, nplda_stream_t stream);
 int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
-                         float* grad_out, nplda_stream_t stream);
+                         double* loss_sum, float* grad_out, nplda_stream_t stream);
 
 /* ---- split-bf16 scoring (opt-in) --------------------------------------------------------------------------- */
 

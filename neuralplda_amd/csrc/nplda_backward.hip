@@ -23,6 +23,7 @@
 #include "nplda_cohort_qz.h"
 #include "nplda_bwd_loss.h"
 #include "nplda_train_fb_small.h"
+#include "nplda_wgrad_fm.h"
 
 namespace nplda {  // nplda_matmul.hip
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
@@ -331,40 +332,6 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
 // ------------------------------------------------------------------------------------------------
 // K-B : C[m][n] = sum_k A[k][m] * Bm[k][n]   (K = 2n rows; Bm rows come from two segments)
 // ------------------------------------------------------------------------------------------------
-struct WgradProblem {
-    const float* A;       // (2n, lda): dz or du
-    long long lda;
-    const float* B0;      // rows [0, n)
-    const float* B1;      // rows [n, 2n)
-    long long ldb;
-    int M, N;             // valid columns of A / of B (multiples of 4)
-    int MT, NT;           // 64-wide tiles
-    float* slab;          // [ksplit][Mp][Np]
-    int Mp, Np;
-    int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}, 3 = {db2 from A; dQ = dP = 0},
-                          // 4 = {db2 from A; the dQ / dP rows are summed by the pair-sum blocks from K-A's per-block sums}
-};
-
-struct WgradArgs {
-    WgradProblem p[2];
-    long long K;          // rows of the "A^T B" products (2 B for pair scoring, N for embedding rows)
-    long long nsplit;     // rows [0, nsplit) of B come from B0, the rest from B1 (= pairs for pair scoring)
-    int ksplit;
-    long long rows_per_split;  // multiple of 4
-    const float* z;       // (2n, ldz)
-    const float* g;       // (n)
-    long long ldz;
-    float* ext;           // [ksplit][4][Mp] : dQraw, dPraw, db2, db1
-    int Mp;
-    int nw0;              // work items of problem 0 = MT0*NT0*ksplit
-    int nw;               // total work items
-    const float* pq;      // [nblk][2][ldz] per-block dQ / dP sums of K-A (small-batch pair scoring), else null
-    int nblk;
-    int nw_mm;            // work items of the two GEMMs
-    int nw_ps;            // items [nw_mm, nw_ps) = one pair-sum block per k-group; items [nw_ps, nw) = cohort first-moment
-    nplda::QzArgs qz;     // blocks of the fused AS-norm pre-pass (nplda_cohort_qz.h), riding in the Gram matrix's launch
-};
-
 constexpr int kPF = 4;  // k4-steps of operand prefetch per wave (8 needed 330 registers: one block per CU; at 4 two are resident)
 
 // One block = one (problem, 64x64 tile, k-group) work item; its 4 waves take the 4 quarters of the k-group's
@@ -551,6 +518,38 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     else wgrad_body<4>(a, P, w, red, rede);
 }
 
+constexpr long long kFmMaxRows = 32 * 1024;  // minibatch-sized products (larger K: the 64 x 64 form's grid is already even)
+
+static inline bool wgrad_fm_rows(long long K, int NB) { return NB >= 10 && NB <= 12 && K >= 4 && K <= kFmMaxRows; }
+
+// The weight-gradient launch: full-M form where it applies, the 64 x 64 form otherwise.  nprob: problems in use (1 or 2).
+static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st) {
+    bool fm = wgrad_fm_rows(wa.K, NB) && (wa.K % 4) == 0 && (wa.nsplit % 4) == 0 && wa.nw == wa.nw_ps;
+    for (int i = 0; i < nprob; ++i) {
+        const WgradProblem& P = wa.p[i];
+        fm = fm && P.extras != 2 && P.Mp == 16 * NB && P.M == P.Mp && P.lda >= P.Mp && (P.lda % 4) == 0 && (P.ldb % 2) == 0 &&
+             (P.N % 2) == 0 && (P.Np % 2) == 0 && P.lda * 4 < (1 << 20) && P.ldb * 4 < (1 << 20);
+    }
+    if (!fm) {
+        hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
+        return nplda_launch_status();
+    }
+    WgradFmArgs fa = {};
+    fa.w = wa;
+    fa.nt0 = (wa.p[0].N + 31) / 32;
+    fa.nt1 = nprob > 1 ? (wa.p[1].N + 31) / 32 : 0;
+    const int tiles = fa.nt0 + fa.nt1;
+    fa.ps_cols = wa.pq ? (2 * wa.Mp + tiles - 1) / tiles : 0;
+    if (fa.ps_cols > kFmWaves * 64) return NPLDA_EUNSUPPORTED;
+    const dim3 grid((unsigned)(tiles * wa.ksplit)), block(kFmWaves * 64);
+    switch (NB) {
+        case 10: hipLaunchKernelGGL(wgrad_fm_kernel<10>, grid, block, 0, st, fa); break;
+        case 11: hipLaunchKernelGGL(wgrad_fm_kernel<11>, grid, block, 0, st, fa); break;
+        default: hipLaunchKernelGGL(wgrad_fm_kernel<12>, grid, block, 0, st, fa); break;
+    }
+    return nplda_launch_status();
+}
+
 // ------------------------------------------------------------------------------------------------
 // K-C : slabs -> flat gradient [dW1 (D1 x D0) | db1 | dW2 (D2 x D1) | db2 | dP_sqrt | dQ]
 // ------------------------------------------------------------------------------------------------
@@ -618,6 +617,7 @@ struct UpdateArgs {
     float alpha;
     float* theta[nplda_loss::kMaxK];
     float* loss;
+    double* loss_sum;          // optional fp64: loss_sum[0] += the step's loss (interval means of the training log)
     unsigned ngrad_blocks;
 };
 
@@ -730,6 +730,7 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
             else if (a.K == 2) nplda_loss::softcdet_scalars<2>(sums, a.beta, a.alpha, a.loss, dth);
             else if (a.K == 3) nplda_loss::softcdet_scalars<3>(sums, a.beta, a.alpha, a.loss, dth);
             else nplda_loss::softcdet_scalars<4>(sums, a.beta, a.alpha, a.loss, dth);
+            if (a.loss_sum) a.loss_sum[0] += (double)a.loss[0];
         }
         __syncthreads();
         const int nth = a.kind == 1 ? 1 : a.K;
@@ -775,6 +776,13 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     long long ks = (K + 511) / 512;
     if (ks > 16) ks = 16;
     if (ks * tiles > 512) ks = 512 / tiles;
+    if (wgrad_fm_rows(K, L.NB)) {
+        // full-M form: (32-column tiles) x (k-groups) 8-wave blocks, ONE per CU; every wave at least one k4-step
+        const long long tiles32 = (L.D0 + 31) / 32 + (w.Mp + 31) / 32;
+        ks = 256 / tiles32;
+        if (ks > 16) ks = 16;
+        if (ks > (K / 4 + kFmWaves - 1) / kFmWaves) ks = (K / 4 + kFmWaves - 1) / kFmWaves;
+    }
     if (ks < 1) ks = 1;
     long long rps = (K + ks - 1) / ks;
     rps = (rps + 16 * kPF - 1) / (16 * kPF) * (16 * kPF);  // 4 quarters, each a multiple of 4 * kPF rows
@@ -858,8 +866,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
     wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
     wa.pq = b.pq; wa.nblk = (int)((b.nA + 15) / 16);
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
-    if (int rc = nplda_launch_status()) return rc;
+    if (int rc = wgrad_launch(wa, L.NB, 2, st)) return rc;
     // K-C
     ReduceArgs ra = {};
     ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
@@ -1048,7 +1055,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
-                         float* grad_out, nplda_stream_t stream) {
+                         double* loss_sum, float* grad_out, nplda_stream_t stream) {
     const bool rows = rows1 != nullptr;
     if (int rc = check_model(D0, D1, D2)) return rc;
     if (rows && (!rows2 || ntab < 1)) return NPLDA_EINVAL;
@@ -1120,7 +1127,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
     ua.L = L; ua.packed = (float*)packed;
     ua.partial = ls.partial; ua.nblk = S.nblk; ua.K = nth; ua.kind = kind; ua.beta = ls.beta; ua.alpha = alpha;
-    ua.loss = loss;
+    ua.loss = loss; ua.loss_sum = loss_sum;
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
     ua.ngrad_blocks = (unsigned)((ngrad + 1023) / 1024);
     hipLaunchKernelGGL(train_update_kernel, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
@@ -1131,22 +1138,22 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
-                         float* grad_out, nplda_stream_t stream) {
+                         double* loss_sum, float* grad_out, nplda_stream_t stream) {
     return train_step_impl(x1, x2, nullptr, nullptr, 0, B, ldx, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
                            exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
-                           grad_out, stream);
+                           loss_sum, grad_out, stream);
 }
 
 int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
                               int64_t B, const float* target, float* const* params, int D0, int D1, int D2,
                               float* const* thetas, const float* betas, int K, float alpha, int kind, float* exp_avg,
                               float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps,
-                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, float* grad_out,
-                              nplda_stream_t stream) {
+                              float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, double* loss_sum,
+                              float* grad_out, nplda_stream_t stream) {
     if (!rows1 || !rows2 || N < 1) return NPLDA_EINVAL;
     return train_step_impl(table, table, rows1, rows2, N, B, ldt, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
                            exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
-                           grad_out, stream);
+                           loss_sum, grad_out, stream);
 }
 
 size_t nplda_lda_wgrad_workspace_bytes(int64_t B, int D0, int D1) {
@@ -1182,8 +1189,7 @@ int nplda_lda_wgrad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx
     wa.p[1] = p1;  // never scheduled (nw == nw0)
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw = wa.nw_mm = wa.nw_ps = wa.nw0;
-    hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
-    if (int rc = nplda_launch_status()) return rc;
+    if (int rc = wgrad_launch(wa, L.NB, 1, st)) return rc;
     ReduceArgs ra = {};
     ra.slab1 = slab; ra.slab2 = slab; ra.ext = ext; ra.P_sqrt = nullptr;
     ra.ksplit = W.ksplit; ra.Mp = W.Mp; ra.Np1 = W.Np1; ra.D0 = D0; ra.D1 = D1; ra.D2 = 0; ra.out = out;

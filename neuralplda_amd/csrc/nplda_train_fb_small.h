@@ -14,6 +14,13 @@
 
 namespace nplda {
 
+#ifdef NPLDA_FB_STAMPS  // tools/exp_fb.hip only: 100 MHz time stamps of one wave at the phase boundaries
+__device__ unsigned long long g_fb_stamps[32];
+#define NPLDA_FB_STAMP(i) do { if (blockIdx.x == gridDim.x / 2 && threadIdx.x == NPLDA_FB_STAMPS) { g_fb_stamps[i] = __builtin_amdgcn_s_memrealtime(); g_fb_stamps[16 + i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define NPLDA_FB_STAMP(i) do {} while (0)
+#endif
+
 struct TrainFbArgs {
     const float* xa;      // (n, ldx) x1 rows
     const float* xb;      // (n, ldx) x2 rows
@@ -80,6 +87,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
     const int KS1 = KS1C ? KS1C : a.KS1;
     const int D0 = a.D0;
+    NPLDA_FB_STAMP(0);
 
     // ---- layer 1 (nplda_fwd_small.h) -----------------------------------------------------------------------------
     f32x4 accA[NBW], accB[NBW];
@@ -105,10 +113,12 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
         fetchx(s, s);
     }
+    NPLDA_FB_STAMP(1);
     // the batch's target count, while the first fragments are on their way (one block-wide exchange)
     const double Nt = block_target_count(a.ls, cnt_s);
     const double Nn = (double)a.ls.B - Nt;
     const float ti = a.ls.t[rA];
+    NPLDA_FB_STAMP(2);
 
     auto step = [&](int ks, int slot, int rs) {
         if (stage) {
@@ -138,6 +148,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         }
     }
 
+    NPLDA_FB_STAMP(3);
     // ---- F.normalize ------------------------------------------------------------------------------------------------
     {
         float ssA = 0.f, ssB = 0.f;
@@ -196,6 +207,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch2(W2p, s, s);
     __syncthreads();  // ylds complete (also orders the `red` reuse below after every wave's norm reads)
+    NPLDA_FB_STAMP(4);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
@@ -212,6 +224,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    NPLDA_FB_STAMP(5);
     // ---- score ----------------------------------------------------------------------------------------------------------
     {
         float part = 0.f;
@@ -237,6 +250,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch2(W2T, s, s);
     __syncthreads();  // scores of the tile; every wave is past layer 2: ylds is free for dz
+    NPLDA_FB_STAMP(6);
     const float si = ((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j];
     if (a.out_s != nullptr && wave == 0 && g == 0 && ok) a.out_s[t0 + j] = si;
 
@@ -282,6 +296,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         }
     }
     __syncthreads();  // dz of the tile in LDS, the loss terms of its pairs
+    NPLDA_FB_STAMP(7);
     if (tid < kLossNS) {
         double v = 0.0;
 #pragma unroll
@@ -312,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         __builtin_amdgcn_sched_barrier(0);
     }
 
+    NPLDA_FB_STAMP(8);
     // ---- F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); y is still in accA / accB ------------------------
     float dotA = 0.f, dotB = 0.f;
 #pragma unroll
@@ -343,6 +359,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g) = du_of(dyB[i], accB[i], dotB, invB);
         }
     }
+    NPLDA_FB_STAMP(9);
 }
 
 }  // namespace nplda

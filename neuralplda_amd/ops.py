@@ -439,9 +439,9 @@ def train_step_workspace(B, packed, rows=False):
 
 
 def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
-               weight_decay, packed, ws, loss, grad_out=None):
+               weight_decay, packed, ws, loss, grad_out=None, loss_sum=None):
     """nplda_train_step_f32: forward -> loss -> backward -> Adam on `params` (the six parameter tensors, updated IN
-    PLACE) and `thetas`, `packed` refreshed to the updated parameters, `loss` (0-d device tensor) written.  Three launches."""
+    PLACE) and `thetas`, `packed` refreshed to the updated parameters, `loss` (0-d device tensor) written; `loss_sum` (optional 1-element fp64 device tensor) += loss.  Three launches."""
     import ctypes
     lib = _lib.load()
     _need_fp32(packed, "train_step")
@@ -468,14 +468,14 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
                                         packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha), kind,
                                         _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step), float(lr), float(beta1),
                                         float(beta2), float(eps), float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(ws),
-                                        ws.numel() * 4, _lib.ptr(loss), _lib.ptr(grad_out) if grad_out is not None else None,
-                                        _lib.current_stream())
+                                        ws.numel() * 4, _lib.ptr(loss), _lib.ptr(loss_sum) if loss_sum is not None else None,
+                                        _lib.ptr(grad_out) if grad_out is not None else None, _lib.current_stream())
     _lib.check(code, "nplda_train_step_f32")
     return loss
 
 
 def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1,
-                    beta2, eps, weight_decay, packed, ws, loss, grad_out=None):
+                    beta2, eps, weight_decay, packed, ws, loss, grad_out=None, loss_sum=None):
     """nplda_train_step_rows_f32: train_step on the pairs (table[rows1], table[rows2]) of a resident x-vector matrix; the
     first kernel gathers the rows itself.  rows1 / rows2: int64 device tensors with values in [0, len(table))."""
     import ctypes
@@ -506,7 +506,8 @@ def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, k
                                              barr, K, float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                              _lib.ptr(step), float(lr), float(beta1), float(beta2), float(eps),
                                              float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(ws), ws.numel() * 4,
-                                             _lib.ptr(loss), _lib.ptr(grad_out) if grad_out is not None else None,
+                                             _lib.ptr(loss), _lib.ptr(loss_sum) if loss_sum is not None else None,
+                                             _lib.ptr(grad_out) if grad_out is not None else None,
                                              _lib.current_stream())
     _lib.check(code, "nplda_train_step_rows_f32")
     return loss

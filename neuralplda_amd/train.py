@@ -51,11 +51,9 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
         if fast:
             rec, data1 = data2, rows1  # (data2 carries the packed record here; len(data1) below)
-            loss = step_fn.step_rows(table, rows1, rows2, target, record=rec)
-            losses.append(loss.detach())
-            if batch_idx % nc.log_interval == 0:
-                _log_train(nc, epoch, batch_idx, len(data1), train_loader, losses)
-                losses = []
+            step_fn.step_rows(table, rows1, rows2, target, record=rec)
+            if batch_idx % nc.log_interval == 0:  # (the step keeps the interval's loss sum on the device)
+                _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean())
             continue
         data1, data2, target = data1.to(device), data2.to(device), target.to(device)
         data1_xvec, data2_xvec = load_xvec_trials_from_numbatch(mega_xvec_dict, num_to_id_dict, data1, data2, device)
@@ -68,9 +66,11 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             loss = model.loss(output, target)
             loss.backward()
             optimizer.step()
-        losses.append(loss.detach())
+        fused = isinstance(step_fn, FusedTrainStep)
+        if not fused:
+            losses.append(loss.detach())
         if batch_idx % nc.log_interval == 0:
-            _log_train(nc, epoch, batch_idx, len(data1), train_loader, losses)
+            _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean() if fused else losses)
             losses = []
 
 
@@ -85,8 +85,12 @@ def _device_table(mega_xvec_dict, num_to_id_dict, device):
 
 
 def _log_train(nc, epoch, batch_idx, batch_len, train_loader, losses):
-    """The progress line of xvector_NeuralPlda_pytorch.py:44-50 (mean of the losses since the previous line)."""
-    mean_loss = float(torch.stack([l.reshape(()).float() for l in losses]).mean().item())
+    """The progress line of xvector_NeuralPlda_pytorch.py:44-50 (mean of the losses since the previous line: a list of
+    0-d tensors, each with storage of its own, or the mean itself)."""
+    if isinstance(losses, float):
+        mean_loss = losses
+    else:  # sum(losses) / len(losses) of the reference, in double like its Python floats
+        mean_loss = float(torch.stack([l.reshape(()).double() for l in losses]).sum().item()) / len(losses)
     msg = 'Train Epoch: {} [{}/{} ({:.0f}%)]\t {}: {:.6f}'.format(
         epoch, batch_idx * batch_len, len(train_loader.dataset), 100. * batch_idx / len(train_loader),
         nc.loss, mean_loss)
@@ -134,7 +138,7 @@ class GraphedTrainStep:
 
     x1, x2: (B, D0) float32, target: (B,) float32 on the model's device, fixed B.  The optimiser must be
     capture-safe (torch.optim.Adam(..., capturable=True); `make_optimizer` builds one).  Returns the loss of the
-    step as a 0-d device tensor (valid until the next call)."""
+    step as a 0-d device tensor of its own (a copy of the graph's output: callers collect losses in lists)."""
 
     def __init__(self, model, optimizer, batch_size, xvector_dim=None, warmup=3):
         p = next(model.parameters())
@@ -193,7 +197,7 @@ class GraphedTrainStep:
         self.x2.copy_(x2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self._graph.replay()
-        return self._loss
+        return self._loss.clone()
 
 
 class FusedTrainStep:
@@ -210,6 +214,7 @@ class FusedTrainStep:
 
     _one_call = False  # subclasses with their own kernels (FusedDPldaStep) keep the separate calls
     _packed = _packed_key = None
+    _loss_acc, _acc_n = None, 0  # fp64 device sum of the losses since pop_loss_mean(), number of steps in it
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
         from . import _lib, ops
@@ -258,6 +263,29 @@ class FusedTrainStep:
             self.t = torch.zeros(batch_size, device=self.dev)
             self.t[::2] = 1
 
+    def _acc(self):
+        if self._loss_acc is None:
+            self._loss_acc = torch.zeros(1, dtype=torch.float64, device=self.dev)
+        return self._loss_acc
+
+    def _account(self, loss, B):
+        """Every step adds its loss to a device-side fp64 sum: the one-call step inside its last kernel (loss_sum of
+        nplda_train_step_f32), the separate-launch forms here.  A replayed step hands out ONE loss tensor, rewritten by
+        every replay, so the losses of a logging interval cannot be collected as a list of tensors."""
+        self._acc_n += 1
+        if not (self._one_call and 0 < B <= 16384):
+            self._acc().add_(loss.detach().reshape(1))
+
+    def pop_loss_mean(self):
+        """Mean of the losses of the steps since the previous call (the figure of the reference's progress line,
+        xvector_NeuralPlda_pytorch.py:41-47: sum(losses) / len(losses)); one device read-back, then the sum starts over."""
+        n, self._acc_n = self._acc_n, 0
+        if n == 0:
+            return float("nan")
+        total = float(self._acc().item())
+        self._loss_acc.zero_()
+        return total / n
+
     def _sync_packed(self):
         """The step's parameter image, re-packed if anything but the step itself changed the parameters."""
         key = tuple(q._version for q in self.params)
@@ -270,8 +298,7 @@ class FusedTrainStep:
     def _touched(self):
         """The raw kernels have rewritten the parameters: bump their version counters (autograd's saved-tensor
         checks, the model's packed-image cache); the step's own image was refreshed by the same launch."""
-        for q in self.params + self.thetas:
-            torch.autograd.graph.increment_version(q)
+        torch.autograd.graph.increment_version(self.params + self.thetas)
         self._packed_key = tuple(q._version for q in self.params)
 
     def _one_call_step(self, x1, x2, t):
@@ -283,7 +310,7 @@ class FusedTrainStep:
         with torch.no_grad():
             ops.train_step(x1, x2, t, [q.detach() for q in self.params], [th.detach() for th in self.thetas],
                            self.betas_loss, self.alpha, self.kind, self.m, self.v, self.step_count, self.lr, self.betas[0],
-                           self.betas[1], self.eps, self.wd, self._packed, ws, self._loss_buf)
+                           self.betas[1], self.eps, self.wd, self._packed, ws, self._loss_buf, loss_sum=self._acc())
         # the captured step hands out its static output; an eager step a tensor of its own (callers keep losses around)
         return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
 
@@ -332,7 +359,7 @@ class FusedTrainStep:
     def _capture_fn(self, fn):
         """Warm `fn` up on a side stream (optimiser state restored afterwards), then capture one call of it."""
         state = [q.detach().clone() for q in self.params + self.thetas]
-        m0, v0, s0 = self.m.clone(), self.v.clone(), self.step_count.clone()
+        m0, v0, s0, a0 = self.m.clone(), self.v.clone(), self.step_count.clone(), self._acc().clone()
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
@@ -346,6 +373,7 @@ class FusedTrainStep:
             self.m.copy_(m0)
             self.v.copy_(v0)
             self.step_count.copy_(s0)
+            self._loss_acc.copy_(a0)
         if self._one_call:
             self._sync_packed()  # the warm-up moved the image along with the parameters: back to the restored values
         graph = torch.cuda.CUDAGraph()
@@ -370,6 +398,7 @@ class FusedTrainStep:
         if not self.use_graph or B != self.batch_size:
             loss = self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
             self._touched()
+            self._account(loss, B)
             return loss
         if self._graph_rows is None or self._graph_table != (table.data_ptr(), table.shape, table.stride(0)):
             self._capture_rows(table)
@@ -383,6 +412,7 @@ class FusedTrainStep:
             self._t_rows.copy_(target, non_blocking=True)
         self._graph_rows.replay()
         self._touched()
+        self._account(self._loss_rows, B)
         return self._loss_rows
 
     def _eager_rows(self, table):
@@ -398,7 +428,7 @@ class FusedTrainStep:
                 ops.train_step_rows(table, self.i1, self.i2, self._t_rows, [q.detach() for q in self.params],
                                     [th.detach() for th in self.thetas], self.betas_loss, self.alpha, self.kind, self.m,
                                     self.v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
-                                    self._packed, ws, self._loss_buf)
+                                    self._packed, ws, self._loss_buf, loss_sum=self._acc())
             return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
         ops.gather_rows(table, self.i1, out=self.x1)
         ops.gather_rows(table, self.i2, out=self.x2)
@@ -420,6 +450,7 @@ class FusedTrainStep:
         if not self.use_graph or x1.shape[0] != self.batch_size:
             loss = self._eager(x1, x2, target)
             self._touched()
+            self._account(loss, x1.shape[0])
             return loss
         if self._graph is None:
             self._capture()
@@ -435,6 +466,7 @@ class FusedTrainStep:
             self.t.copy_(target, non_blocking=True)
         self._graph.replay()
         self._touched()
+        self._account(self._loss, self.batch_size)
         return self._loss
 
 

@@ -474,7 +474,8 @@ def test_one_call_step_reports_the_applied_gradient(hip_lib):
     out, lbuf = torch.zeros(n + 2, device="cuda"), torch.zeros((), device="cuda")
     ws = ops.train_step_workspace(B, packed)
     ops.train_step(x1, x2, t, prm, ths, betas, alpha, ops.LOSS_SOFTCDET, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-5, packed,
-                   ws, lbuf, grad_out=out)
+                   ws, lbuf, grad_out=out, loss_sum=(acc := torch.full((1,), 2.5, dtype=torch.float64, device="cuda")))
+    assert acc.item() == 2.5 + float(lbuf.item())  # the running loss sum of the training log: += loss, in fp64
     assert torch.equal(out[:n], flat)
     np.testing.assert_allclose(out[n:].cpu().numpy(), dth.cpu().numpy(), rtol=1e-6)
     assert abs(lbuf.item() - loss.item()) <= 2e-7 * abs(loss.item())
@@ -554,6 +555,7 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
     including the ragged last batch (eager fall-back of the graph path)."""
     import contextlib
     import io
+    from neuralplda_amd import sv_trials_loaders as svl
     from neuralplda_amd import train
     rng = np.random.default_rng(5)
     B = 128
@@ -582,6 +584,23 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
     sd_gen, log_gen, _ = run(False)
     assert step_fast._graph_rows is not None and step_fast.step_count[0].item() == 8  # 7 replays + 1 ragged eager step
     assert log_fast == log_gen and log_fast.count("Train Epoch") == 3
+    # the figure on each progress line is the MEAN of the losses since the previous line (xvector_NeuralPlda_pytorch.py:
+    # 41-47), also when the step is a replayed graph whose loss tensor is rewritten in place by every replay
+    m = model_from(p, nc, thetas=[-0.5, -0.3])
+    step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, graph=False)
+    torch.manual_seed(11)
+    per_step = []
+    for d1, d2, t in loader:
+        x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, d1, d2, "cuda")
+        per_step.append(float(step(x1, x2, t.cuda())))
+    want, acc = [], []
+    for i, l in enumerate(per_step):
+        acc.append(l)
+        if i % nc.log_interval == 0:
+            want.append("{:.6f}".format(sum(acc) / len(acc)))
+            acc = []
+    got = [ln.rsplit(" ", 1)[1] for ln in log_fast.strip().splitlines()]
+    assert got == want and "{:.6f}".format(per_step[6]) != want[2]  # (a mean, not the interval's last loss)
     for k in sd_gen:
         assert np.array_equal(sd_fast[k], sd_gen[k]), k
     # an index that maps to no utterance raises like the reference-shaped gather

@@ -9,7 +9,7 @@ Three ways of feeding the step, each timed over 200 replays:
 (Run `rows` before `copy`: the first ~200 replays of the rows graph that follow a run of 8 MB device-to-device staging copies
 take 0.27 ms each, then drop back to 0.10 ms — a runtime effect of switching between the copy engine and blit kernels on
 the stream, not of the step's kernels; a training loop only ever uses step_rows.)
-usage: fused_step_profile.py [D=150] [graph|eager] [modes=inplace,rows,copy]"""
+usage: fused_step_profile.py [D=150] [graph|eager] [modes=inplace,rows,copy] [B=4096]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -27,7 +27,7 @@ modes = sys.argv[3].split(",") if len(sys.argv) > 3 else ["inplace", "rows1", "r
 NC.layer1_LDA_dim = NC.layer2_PLDA_spkfactor_dim = D
 torch.manual_seed(0)
 m = models.NeuralPlda(NC()).cuda()
-B = 4096
+B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 x1 = torch.randn(B, 512, device="cuda"); x2 = torch.randn(B, 512, device="cuda")
 t = (torch.rand(B, device="cuda") < 0.1).float()
 table = torch.randn(200000, 512, device="cuda")
