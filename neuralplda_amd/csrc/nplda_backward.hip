@@ -244,12 +244,9 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
                 f32x4 eq, ep;
                 pair_sum_terms(gh, zA, zB, eq, ep);
 #pragma unroll
-                for (int msk = 1; msk < 16; msk <<= 1) {
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        eq[r] += __shfl_xor(eq[r], msk, 64);
-                        ep[r] += __shfl_xor(ep[r], msk, 64);
-                    }
+                for (int r = 0; r < 4; ++r) {
+                    eq[r] = row16_sum(eq[r]);
+                    ep[r] = row16_sum(ep[r]);
                 }
                 if (j == 0) {
                     float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * nb + 4 * g4;
@@ -616,6 +613,7 @@ struct UpdateArgs {
     nplda_loss::BetaVals beta;
     float alpha;
     float* theta[nplda_loss::kMaxK];
+    int bumped;               // step[0] already counts this step (train_fb_small_kernel): no arrival tickets
     float* loss;
     double* loss_sum;          // optional fp64: loss_sum[0] += the step's loss (interval means of the training log)
     unsigned ngrad_blocks;
@@ -626,8 +624,9 @@ __device__ __forceinline__ size_t frag_pos(int f, int k, int NB) {
     return ((((size_t)(k >> 4) * NB + (f >> 4)) * 64 + (((k & 15) >> 2) << 4) + (f & 15)) << 2) + (k & 3);
 }
 
+template <int E>  // elements per thread
 __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
-    const float t = a.step[0] + 1.0f;
+    const float t = a.bumped ? a.step[0] : a.step[0] + 1.0f;
     const nplda_adam::Consts c = nplda_adam::consts_for(t, a.lr, a.beta1, a.beta2, a.eps, a.wd);
     const int D0 = a.r.D0, D1 = a.r.D1, D2 = a.r.D2;
     const size_t nW1 = (size_t)D1 * D0, nW2 = (size_t)D2 * D1;
@@ -636,8 +635,8 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
         // four elements per thread: the arrival tickets at the end are one atomic per block on one address (~10 ns each,
         // serialised): 392 blocks of 256 elements spent 2 of the kernel's 10 us queueing there
 #pragma unroll
-        for (int e4 = 0; e4 < 4; ++e4) {
-        const size_t idx = ((size_t)blockIdx.x * 4 + e4) * 256 + threadIdx.x;
+        for (int e4 = 0; e4 < E; ++e4) {
+        const size_t idx = ((size_t)blockIdx.x * E + e4) * 256 + threadIdx.x;
         if (idx < ngrad) {
             const float* src;
             size_t stride;
@@ -744,6 +743,7 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
             a.v[ngrad + k] = v;
         }
     }
+    if (a.bumped) return;
     __syncthreads();  // the whole block has read step[0]
     if (threadIdx.x == 0) {
         unsigned* ticket = reinterpret_cast<unsigned*>(a.step + 1);
@@ -1093,7 +1093,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
         fb.oW2 = L.oW2; fb.oW2T = L.oW2T; fb.ob1 = L.ob1; fb.ob2 = L.ob2; fb.oQ = L.oQ; fb.oP = L.oP;
         fb.out_s = wsf + S.s; fb.out_y = wsf + S.y; fb.dz = bws + W.dz; fb.du = bws + W.du; fb.ldz = S.ldz;
-        fb.pq = bws + W.pq; fb.ls = ls;
+        fb.pq = bws + W.pq; fb.ls = ls; fb.step_bump = step;
         if (rows) {
             fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = ntab;
             fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs;
@@ -1127,10 +1127,14 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
     ua.L = L; ua.packed = (float*)packed;
     ua.partial = ls.partial; ua.nblk = S.nblk; ua.K = nth; ua.kind = kind; ua.beta = ls.beta; ua.alpha = alpha;
-    ua.loss = loss; ua.loss_sum = loss_sum;
+    ua.loss = loss; ua.loss_sum = loss_sum; ua.bumped = 1;
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
-    ua.ngrad_blocks = (unsigned)((ngrad + 1023) / 1024);
-    hipLaunchKernelGGL(train_update_kernel, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
+#ifndef NPLDA_UPDATE_E
+#define NPLDA_UPDATE_E 2
+#endif
+    constexpr int E = NPLDA_UPDATE_E;  // without arrival tickets (the first kernel has counted the step) small blocks are free
+    ua.ngrad_blocks = (unsigned)((ngrad + 256 * E - 1) / (256 * E));
+    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
     return nplda_launch_status();
 }
 

@@ -21,40 +21,84 @@ struct BwdLoss {
 };
 
 
+// What a pair's loss step needs besides its score and target, in three parts so that a kernel can place each where it
+// is free: the thresholds (global loads — early), the batch constants of dL/ds (fp64 divisions — once the counts are
+// known), the pair itself.
+struct PairLossConsts {
+    float theta[nplda_loss::kMaxK];
+    float cn[nplda_loss::kMaxK];  // SoftCdet: beta_k alpha / (N_n K);  BCE: cn[0] = 1 / N
+    float ct;                     // SoftCdet: -alpha / (N_t K)
+};
+
+__device__ __forceinline__ void loss_consts_theta(const BwdLoss& L, PairLossConsts& c) {
+    const int nth = L.kind == 1 ? 1 : L.K;
+#pragma unroll
+    for (int k = 0; k < nplda_loss::kMaxK; ++k) {
+        c.theta[k] = L.th.p[k < nth ? k : 0][0];
+        c.cn[k] = 0.f;
+    }
+    c.ct = 0.f;
+}
+
+template <int K>
+__device__ __forceinline__ void loss_consts_counts_k(const BwdLoss& L, double Nt, double Nn, PairLossConsts& c) {
+    float cn[K];
+    nplda_loss::softcdet_consts<K>(Nt, Nn, L.beta, L.alpha, cn, c.ct);
+#pragma unroll
+    for (int k = 0; k < K; ++k) c.cn[k] = cn[k];
+}
+
+__device__ __forceinline__ void loss_consts_counts(const BwdLoss& L, double Nt, double Nn, PairLossConsts& c) {
+    if (L.kind == 1) c.cn[0] = (float)(1.0 / (Nt + Nn));
+    else if (L.K == 1) loss_consts_counts_k<1>(L, Nt, Nn, c);
+    else if (L.K == 2) loss_consts_counts_k<2>(L, Nt, Nn, c);
+    else if (L.K == 3) loss_consts_counts_k<3>(L, Nt, Nn, c);
+    else loss_consts_counts_k<4>(L, Nt, Nn, c);
+}
+
 // g_i and the pair's contribution to the loss sums (SoftCdet with K thresholds)
 template <int K>
-__device__ __forceinline__ float loss_pair_softcdet(const BwdLoss& L, double Nt, double Nn, float si, float ti,
+__device__ __forceinline__ float loss_pair_softcdet(const BwdLoss& L, const PairLossConsts& c, float si, float ti,
                                                     double (&acc)[kLossNS]) {
-    float theta[K], cn[K], ct;
+    float theta[K], cn[K];
 #pragma unroll
-    for (int k = 0; k < K; ++k) theta[k] = L.th.p[k][0];
-    nplda_loss::softcdet_consts<K>(Nt, Nn, L.beta, L.alpha, cn, ct);
+    for (int k = 0; k < K; ++k) {
+        theta[k] = c.theta[k];
+        cn[k] = c.cn[k];
+    }
     double a2[2 + 4 * K];
 #pragma unroll
     for (int i = 0; i < 2 + 4 * K; ++i) a2[i] = 0.0;
     nplda_loss::softcdet_accumulate<K, false>(si, ti, theta, L.alpha, a2);
 #pragma unroll
     for (int i = 0; i < 2 + 4 * K; ++i) acc[i] = a2[i];
-    return nplda_loss::softcdet_gi<K>(si, ti, theta, cn, ct, L.alpha);
+    return nplda_loss::softcdet_gi<K>(si, ti, theta, cn, c.ct, L.alpha);
 }
 
-
 // The per-pair loss step shared by the kernels: returns g_i = dL/ds_i, fills acc with the pair's terms of the loss sums.
-__device__ __forceinline__ float loss_pair(const BwdLoss& L, double Nt, double Nn, float si, float ti, double (&acc)[kLossNS]) {
+__device__ __forceinline__ float loss_pair(const BwdLoss& L, const PairLossConsts& c, float si, float ti,
+                                           double (&acc)[kLossNS]) {
 #pragma unroll
     for (int i = 0; i < kLossNS; ++i) acc[i] = 0.0;
     if (L.kind == 1) {
         double a4[4] = {0.0, 0.0, 0.0, 0.0};
-        const float theta = L.th.p[0][0];
-        nplda_loss::bce_accumulate(si, ti, theta, a4);
+        nplda_loss::bce_accumulate(si, ti, c.theta[0], a4);
 #pragma unroll
         for (int i = 0; i < 4; ++i) acc[i] = a4[i];
-        return nplda_loss::bce_gi(si, ti, theta, (float)(1.0 / (Nt + Nn)));
+        return nplda_loss::bce_gi(si, ti, c.theta[0], c.cn[0]);
     }
-    if (L.K == 1) return loss_pair_softcdet<1>(L, Nt, Nn, si, ti, acc);
-    if (L.K == 2) return loss_pair_softcdet<2>(L, Nt, Nn, si, ti, acc);
-    if (L.K == 3) return loss_pair_softcdet<3>(L, Nt, Nn, si, ti, acc);
-    return loss_pair_softcdet<4>(L, Nt, Nn, si, ti, acc);
+    if (L.K == 1) return loss_pair_softcdet<1>(L, c, si, ti, acc);
+    if (L.K == 2) return loss_pair_softcdet<2>(L, c, si, ti, acc);
+    if (L.K == 3) return loss_pair_softcdet<3>(L, c, si, ti, acc);
+    return loss_pair_softcdet<4>(L, c, si, ti, acc);
+}
+
+// all three parts at once
+__device__ __forceinline__ float loss_pair(const BwdLoss& L, double Nt, double Nn, float si, float ti, double (&acc)[kLossNS]) {
+    PairLossConsts c;
+    loss_consts_theta(L, c);
+    loss_consts_counts(L, Nt, Nn, c);
+    return loss_pair(L, c, si, ti, acc);
 }
 
 // The element formulas of the data gradients with every contraction spelled out, shared by the kernels that must agree
@@ -96,6 +140,43 @@ __device__ __forceinline__ double block_target_count(const BwdLoss& L, float* cn
     if (lane == 0) cnt_s[wave] = cnt;
     __syncthreads();
     return (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // exact: a count below 2^24
+}
+
+// The same count in two parts, for a kernel that has better things to do while the targets are on their way
+// (train_fb_small_kernel): target_count_issue only LOADS — the first 4096 targets, four float4 per thread, the whole batch
+// at the recipe sizes — and target_count_wave, called once those have long landed, sums them (and synchronously whatever
+// a larger batch has left) over the wave.  The caller adds the four wave sums (a count below 2^24 is exact in any order).
+// (64 lanes of ds_add_f32 on one LDS word instead of the cross-lane steps: 1.5 us slower.)
+struct TargetEarly { f32x4 v[4]; };
+
+__device__ __forceinline__ void target_count_issue(const BwdLoss& L, TargetEarly& e) {
+    const int nv = (int)(L.B / 4);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(L.t);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int i = (int)threadIdx.x + 256 * q;
+        e.v[q] = t4[i < nv ? i : 0];  // (B >= 4 rows are always readable: the tail below covers B < 4)
+    }
+}
+
+__device__ __forceinline__ float target_count_wave(const BwdLoss& L, const TargetEarly& e) {
+    const int tid = threadIdx.x;
+    const int nv = (int)(L.B / 4);
+    const f32x4* t4 = reinterpret_cast<const f32x4*>(L.t);
+    float cnt = 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = e.v[q];
+        cnt += tid + 256 * q < nv ? (v[0] + v[1]) + (v[2] + v[3]) : 0.f;
+    }
+    for (int i = tid + 1024; i < nv; i += 256) {
+        const f32x4 v = t4[i];
+        cnt += (v[0] + v[1]) + (v[2] + v[3]);
+    }
+    for (long long i = 4LL * nv + tid; i < L.B; i += 256) cnt += L.t[i];
+    cnt = row16_sum(cnt);
+    cnt = wave_xor_add(cnt, 16);
+    return wave_xor_add(cnt, 32);
 }
 
 }  // namespace nplda

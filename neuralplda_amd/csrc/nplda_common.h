@@ -84,3 +84,18 @@ __device__ __forceinline__ float wave_xor_add(float v, int mask) {
     }
     return v + __shfl_xor(v, mask, 64);
 }
+
+// Sum over the 16 lanes of a DPP row, every lane of the row getting the result: the four steps of the xor butterfly
+// (masks 1, 2, 4, 8 — the same pairs of partial sums at every level, hence the same bits: fp add commutes) as quad_perm /
+// row_half_mirror / row_mirror operand modifiers instead of four ds_bpermute round trips.
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), CTRL, 0xf, 0xf, false));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror: quads 0 <-> 1, 2 <-> 3 (every lane of a quad holds the quad's sum)
+    v += dpp_f32<0x140>(v);  // row_mirror: halves
+    return v;
+}

@@ -44,6 +44,7 @@ struct TrainFbArgs {
     float* xsa;
     float* xsb;
     long long ldxs;
+    float* step_bump;     // optional: Adam's step counter, incremented here (one thread) for the update kernel of this step
 };
 
 template <int NB, int KS1C>
@@ -56,6 +57,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     __shared__ float red[NW][2][16];
     __shared__ float cnt_s[NW];
     __shared__ double lacc[16][kLossNS];
+    __shared__ float lcs[nplda_loss::kMaxK + 1];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -87,6 +89,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
     const int KS1 = KS1C ? KS1C : a.KS1;
     const int D0 = a.D0;
+    if (a.step_bump != nullptr && blockIdx.x == 0 && tid == 0) a.step_bump[0] += 1.0f;
     NPLDA_FB_STAMP(0);
 
     // ---- layer 1 (nplda_fwd_small.h) -----------------------------------------------------------------------------
@@ -114,10 +117,13 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         fetchx(s, s);
     }
     NPLDA_FB_STAMP(1);
-    // the batch's target count, while the first fragments are on their way (one block-wide exchange)
-    const double Nt = block_target_count(a.ls, cnt_s);
-    const double Nn = (double)a.ls.B - Nt;
+    // the batch's targets: loaded now, behind the first fragments, counted after layer 1 (no wait, no barrier of their own)
+    TargetEarly te;
+    if (a.ls.B >= 4) target_count_issue(a.ls, te);
     const float ti = a.ls.t[rA];
+    PairLossConsts lc;
+    loss_consts_theta(a.ls, lc);
+    __builtin_amdgcn_sched_barrier(0);
     NPLDA_FB_STAMP(2);
 
     auto step = [&](int ks, int slot, int rs) {
@@ -168,8 +174,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             red[wave][0][j] = ssA;
             red[wave][1][j] = ssB;
         }
+        if (a.ls.B < 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) te.v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+        const float cw = target_count_wave(a.ls, te);
+        if (lane == 0) cnt_s[wave] = cw;
     }
     __syncthreads();
+    const double Nt = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // as block_target_count
+    const double Nn = (double)a.ls.B - Nt;
     const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
     const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
 #pragma unroll
@@ -207,6 +221,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch2(W2p, s, s);
     __syncthreads();  // ylds complete (also orders the `red` reuse below after every wave's norm reads)
+    // the batch constants of dL/ds (fp64 divisions): by the last wave, which has the fewest feature blocks at NB = 10 / 11
+    // and would otherwise wait for the others at the score barrier; they reach the other waves through LDS there
+    if (wave == NW - 1) {
+        loss_consts_counts(a.ls, Nt, Nn, lc);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < nplda_loss::kMaxK; ++k) lcs[k] = lc.cn[k];
+            lcs[nplda_loss::kMaxK] = lc.ct;
+        }
+    }
     NPLDA_FB_STAMP(4);
 #pragma unroll
     for (int kb = 0; kb < NB; ++kb) {
@@ -256,7 +280,10 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 
     // ---- loss: dL/ds of the tile's pairs, their terms of the loss sums (nplda_bwd_loss.h) ------------------------------
     double lsum[kLossNS];
-    const float gi = loss_pair(a.ls, Nt, Nn, si, ti, lsum);
+#pragma unroll
+    for (int k = 0; k < nplda_loss::kMaxK; ++k) lc.cn[k] = lcs[k];
+    lc.ct = lcs[nplda_loss::kMaxK];
+    const float gi = loss_pair(a.ls, lc, si, ti, lsum);
     const float tg = ok ? 2.0f * gi : 0.f;
     if (wave == 0 && g == 0) {
 #pragma unroll
@@ -281,12 +308,9 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             f32x4 eq, ep;
             pair_sum_terms(gh, zA[i], zB[i], eq, ep);
 #pragma unroll
-            for (int msk = 1; msk < 16; msk <<= 1) {
-#pragma unroll
-                for (int r = 0; r < 4; ++r) {
-                    eq[r] += __shfl_xor(eq[r], msk, 64);
-                    ep[r] += __shfl_xor(ep[r], msk, 64);
-                }
+            for (int r = 0; r < 4; ++r) {
+                eq[r] = row16_sum(eq[r]);
+                ep[r] = row16_sum(ep[r]);
             }
             if (j == 0) {
                 float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * nb + 4 * g;
