@@ -1101,8 +1101,10 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
         const bool k32 = L.KS1 == 32 && L.D0 == 512;
 #define NPLDA_LAUNCH(NBV)                                                                                   \
-    if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32>), grid, block, 0, st, fb);                    \
-    else hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0>), grid, block, 0, st, fb)
+    if (k32 && rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, true>), grid, block, 0, st, fb);      \
+    else if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, false>), grid, block, 0, st, fb);        \
+    else if (rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, true>), grid, block, 0, st, fb);         \
+    else hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, false>), grid, block, 0, st, fb)
         switch (L.NB) {
             case 2: NPLDA_LAUNCH(2); break;
             case 4: NPLDA_LAUNCH(4); break;

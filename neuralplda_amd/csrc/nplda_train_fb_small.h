@@ -47,10 +47,19 @@ struct TrainFbArgs {
     float* step_bump;     // optional: Adam's step counter, incremented here (one thread) for the update kernel of this step
 };
 
-template <int NB, int KS1C>
+template <int NB, int KS1C, bool ROWS>  // ROWS: the indexed form (pairs named by table rows, x rows staged for K-B)
 __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArgs a) {
     constexpr int NW = 4;
-    constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
+    constexpr int NBW = (NB + NW - 1) / NW;  // feature-block slots per wave
+    // NB = 10: blocks 0 .. 7 go two to a wave, and the two left-over blocks are split by SIDE — wave w takes block
+    // 8 + w / 2 for the x1 rows (w even) or the x2 rows (w odd) — so that every wave issues 5 MFMAs per k4-step instead of
+    // 6, 6, 4, 4.  The slot's accumulators live in the "A" arrays whatever its side.  A block's two sides then sit in two
+    // waves: z crosses once through LDS (score, dz and the pair sums need both).  The per-wave partial sums of the three
+    // cross-wave reductions (||u||^2, score, y . dy) follow this assignment, so at NB = 10 the last bits differ from the
+    // separate forward / backward kernels, which keep whole blocks per wave.
+    constexpr bool HALF = NB == 10;
+    constexpr int NBF = HALF ? NB / NW : NBW;  // slots holding a whole block (both sides)
+    constexpr int HS = NBF;                    // the half slot (HALF only)
     constexpr int PF = 4, PF1 = PF + 1;
     static_assert(NBW <= 3, "one weight load per MFMA quarter, the x loads after the last");
     __shared__ f32x4 ylds[2][NB][64];        // y for layer 2 (accumulator layout), then dz for the dy chain
@@ -58,19 +67,30 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     __shared__ float cnt_s[NW];
     __shared__ double lacc[16][kLossNS];
     __shared__ float lcs[nplda_loss::kMaxK + 1];
+    __shared__ f32x4 zx[HALF ? NW : 1][64];  // z of the half slots, for the wave holding the block's other side
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;
     const int g = lane >> 4;
+    const int hb = NW * NBF + (wave >> 1);   // HALF: block of the half slot,
+    const bool hside = (wave & 1) != 0;      //       and its side (false: x1 rows)
+    auto blk = [&](int i) { return HALF && i == HS ? hb : wave + NW * i; };
+    // one 64-lane weight fragment at a wave-uniform address: uniform base + 32-bit lane offset (the SGPR-base form of the
+    // load; the offset is made opaque at every use, or hipcc folds it into one 64-bit vector add per load)
+    auto frag = [&](const f32x4* base) {
+        unsigned lo = (unsigned)lane * 16u;
+        asm volatile("" : "+v"(lo));
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + lo);
+    };
 
     const long long t0 = (long long)blockIdx.x * 16;
     const bool ok = t0 + j < a.n;
     const long long rA = ok ? t0 + j : a.n - 1;  // x1-side row of y / dz / du; the x2 side sits n rows further
     const long long rB = a.n + rA;
     long long xrA = rA, xrB = rA;
-    if (a.ia != nullptr) {
+    if constexpr (ROWS) {
         xrA = a.ia[rA];
         xrB = a.ib[rA];
         xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
@@ -78,7 +98,6 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     }
     const float* sa = a.xa + xrA * a.ldx;
     const float* sb = a.xb + xrB * a.ldx;
-    const bool stage = a.xsa != nullptr && wave == 0 && ok;  // (indexed form only; D0 % 16 == 0 there)
 
     const f32x4* W1p = reinterpret_cast<const f32x4*>(a.packed);
     const f32x4* W2p = reinterpret_cast<const f32x4*>(a.packed + a.oW2);
@@ -96,19 +115,30 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     f32x4 accA[NBW], accB[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int nb = wave + NW * i;
+        const int nb = blk(i);
         accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         accB[i] = accA[i];
     }
-    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1], xh[HALF ? PF1 : 1];  // (xh: the half slot's side, loaded again rather than selected)
     auto fetchw = [&](int slot, int ks, int i) {
         const int ksc = ks < KS1 ? ks : KS1 - 1;
-        const int nb = wave + NW * i;
-        wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        const int nb = blk(i);
+        wf[slot][i] = frag(W1p + ((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64);
     };
+    const float* sa4 = sa + 4 * g;
+    const float* sb4 = sb + 4 * g;
+    const float* sh4 = hside ? sb4 : sa4;
     auto fetchx = [&](int slot, int ks) {
-        xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
-        xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
+        if constexpr (KS1C > 0) {  // D0 = 16 KS1C: whole k16-steps only, the column offset is an immediate of the load
+            const int kc = ks < KS1C ? ks : KS1C - 1;
+            xa[slot] = *reinterpret_cast<const f32x4*>(sa4 + 16 * kc);
+            xb[slot] = *reinterpret_cast<const f32x4*>(sb4 + 16 * kc);
+            if constexpr (HALF) xh[slot] = *reinterpret_cast<const f32x4*>(sh4 + 16 * kc);
+        } else {
+            xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
+            xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
+            if constexpr (HALF) xh[slot] = load_x4c<false>(hside ? sb : sa, 16 * ks + 4 * g, D0);
+        }
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
@@ -127,17 +157,20 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     NPLDA_FB_STAMP(2);
 
     auto step = [&](int ks, int slot, int rs) {
-        if (stage) {
-            *reinterpret_cast<f32x4*>(a.xsa + rA * a.ldxs + 16 * ks + 4 * g) = xa[slot];
-            *reinterpret_cast<f32x4*>(a.xsb + rA * a.ldxs + 16 * ks + 4 * g) = xb[slot];
+        if constexpr (ROWS) {  // every wave leaves a quarter of the k16-steps of the fetched rows (D0 % 16 == 0 here)
+            if ((ks & (NW - 1)) == wave && ok) {
+                *reinterpret_cast<f32x4*>(a.xsa + rA * a.ldxs + 16 * ks + 4 * g) = xa[slot];
+                *reinterpret_cast<f32x4*>(a.xsb + rA * a.ldxs + 16 * ks + 4 * g) = xb[slot];
+            }
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
                 accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
             }
+            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[slot][r], accA[HS], 0, 0, 0);
             if (r < NBW) fetchw(rs, ks + PF, r);
             if (r == 3) fetchx(rs, ks + PF);
             __builtin_amdgcn_sched_barrier(0);
@@ -159,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     {
         float ssA = 0.f, ssB = 0.f;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
+        for (int i = 0; i < NBF; ++i) {
             if (wave + NW * i < NB) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -167,6 +200,13 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
                     ssB = fmaf(accB[i][r], accB[i][r], ssB);
                 }
             }
+        }
+        if constexpr (HALF) {
+            float sh = hside ? ssB : ssA;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh = fmaf(accA[HS][r], accA[HS][r], sh);
+            if (hside) ssB = sh;
+            else ssA = sh;
         }
         ssA = wave_xor_add(ssA, 16); ssA = wave_xor_add(ssA, 32);
         ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
@@ -186,8 +226,9 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const double Nn = (double)a.ls.B - Nt;
     const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
     const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
+    const long long rH = hside ? rB : rA;  // HALF: the row of the half slot's side
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
             accA[i] *= invA;
@@ -200,12 +241,17 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             }
         }
     }
+    if constexpr (HALF) {
+        accA[HS] *= hside ? invB : invA;
+        ylds[hside ? 1 : 0][hb][lane] = accA[HS];
+        if (ok) *reinterpret_cast<f32x4*>(a.out_y + rH * a.ldz + 16 * hb + 4 * g) = accA[HS];
+    }
 
     // ---- layer 2 ------------------------------------------------------------------------------------------------------
     f32x4 zA[NBW], zB[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int nb = wave + NW * i;
+        const int nb = blk(i);
         zA[i] = nb < NB ? b2p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         zB[i] = zA[i];
     }
@@ -214,8 +260,8 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         const int kbc = kb < NB ? kb : NB - 1;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int nb = wave + NW * i;
-            w2[slot][i] = Wp[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+            const int nb = blk(i);
+            w2[slot][i] = frag(Wp + ((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64);
         }
     };
 #pragma unroll
@@ -236,13 +282,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
         const f32x4 yA = ylds[0][kb][lane], yB = ylds[1][kb][lane];
+        f32x4 yH;
+        if constexpr (HALF) yH = ylds[hside ? 1 : 0][kb][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 zA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], yA[r], zA[i], 0, 0, 0);
                 zB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], yB[r], zB[i], 0, 0, 0);
             }
+            if constexpr (HALF) zA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][HS][r], yH[r], zA[HS], 0, 0, 0);
         }
         fetch2(W2p, s, kb + PF);
         __builtin_amdgcn_sched_barrier(0);
@@ -250,10 +299,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 
     NPLDA_FB_STAMP(5);
     // ---- score ----------------------------------------------------------------------------------------------------------
+    f32x4 zP;  // HALF: z of the half block's other side
+    if constexpr (HALF) {
+        zx[wave][lane] = zA[HS];
+        __syncthreads();
+        zP = zx[wave ^ 1][lane];
+    }
     {
         float part = 0.f;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
+        for (int i = 0; i < NBF; ++i) {
             const int nb = wave + NW * i;
             if (nb < NB) {
                 const f32x4 q = Qp[4 * nb + g];
@@ -261,6 +316,18 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const float z1 = zA[i][r], z2 = zB[i][r];
+                    part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
+                    part = fmaf(2.0f * p[r], z1 * z2, part);
+                }
+            }
+        }
+        if constexpr (HALF) {
+            if (!hside) {  // the block's term, once: by the wave of its x1 side
+                const f32x4 q = Qp[4 * hb + g];
+                const f32x4 p = Pp[4 * hb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = zA[HS][r], z2 = zP[r];
                     part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
                     part = fmaf(2.0f * p[r], z1 * z2, part);
                 }
@@ -292,7 +359,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 
     // ---- dz = 2 g (Q z + P z'), the pair sums for dQ / dP (K-A of nplda_backward.hip) ------------------------------------
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
             const f32x4 q = Qp[4 * nb + g], p = Pp[4 * nb + g];
@@ -319,6 +386,26 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             }
         }
     }
+    if constexpr (HALF) {
+        const f32x4 q = Qp[4 * hb + g], p = Pp[4 * hb + g];
+        const f32x4 dH = dz_of(tg, q, p, zA[HS], zP);  // own side's z, the other side's z
+        ylds[hside ? 1 : 0][hb][lane] = dH;
+        if (ok) *reinterpret_cast<f32x4*>(a.dz + rH * a.ldz + 16 * hb + 4 * g) = dH;
+        if (!hside) {
+            f32x4 eq, ep;
+            pair_sum_terms(0.5f * tg, zA[HS], zP, eq, ep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                eq[r] = row16_sum(eq[r]);
+                ep[r] = row16_sum(ep[r]);
+            }
+            if (j == 0) {
+                float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * hb + 4 * g;
+                *reinterpret_cast<f32x4*>(o) = eq;
+                *reinterpret_cast<f32x4*>(o + a.ldz) = ep;
+            }
+        }
+    }
     __syncthreads();  // dz of the tile in LDS, the loss terms of its pairs
     NPLDA_FB_STAMP(7);
     if (tid < kLossNS) {
@@ -339,13 +426,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
         const f32x4 dA = ylds[0][kb][lane], dB = ylds[1][kb][lane];
+        f32x4 dH;
+        if constexpr (HALF) dH = ylds[hside ? 1 : 0][kb][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 dyA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], dA[r], dyA[i], 0, 0, 0);
                 dyB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][i][r], dB[r], dyB[i], 0, 0, 0);
             }
+            if constexpr (HALF) dyA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][HS][r], dH[r], dyA[HS], 0, 0, 0);
         }
         fetch2(W2T, s, kb + PF);
         __builtin_amdgcn_sched_barrier(0);
@@ -355,7 +445,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     // ---- F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); y is still in accA / accB ------------------------
     float dotA = 0.f, dotB = 0.f;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         if (wave + NW * i < NB) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
@@ -363,6 +453,13 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
                 dotB = fmaf(accB[i][r], dyB[i][r], dotB);
             }
         }
+    }
+    if constexpr (HALF) {
+        float dh = hside ? dotB : dotA;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh = fmaf(accA[HS][r], dyA[HS][r], dh);
+        if (hside) dotB = dh;
+        else dotA = dh;
     }
     dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
     dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
@@ -376,12 +473,17 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     if (invA >= 1e12f) dotA = 0.f;  // the clamp branch of F.normalize: u / eps, no projection term
     if (invB >= 1e12f) dotB = 0.f;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB && ok) {
             *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g) = du_of(dyA[i], accA[i], dotA, invA);
             *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g) = du_of(dyB[i], accB[i], dotB, invB);
         }
+    }
+    if constexpr (HALF) {
+        if (ok)
+            *reinterpret_cast<f32x4*>(a.du + rH * a.ldz + 16 * hb + 4 * g) =
+                du_of(dyA[HS], accA[HS], hside ? dotB : dotA, hside ? invB : invA);
     }
     NPLDA_FB_STAMP(9);
 }

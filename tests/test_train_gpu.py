@@ -369,12 +369,26 @@ def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
     assert step.step_count[0].item() == 5 and step.step_count[1].item() == 0
 
 
+def _same_step(a, b, D1, what, scale=1.0):
+    """Two tensors left by the one-call step and by the separate launches.  Same bits — except at 10 feature blocks
+    (D1 in 145..160), where the one-call kernel splits the two left-over blocks by side (five MFMAs per k4-step on every
+    wave instead of 6, 6, 4, 4: csrc/nplda_train_fb_small.h), so three cross-wave sums associate differently and the
+    gradients agree to rounding only: there the gradient / moments must agree to 1e-4 of their scale, and the parameters
+    to 2 % of the learning rate of these tests (Adam's step lr m / (sqrt(v) + eps) amplifies rounding where |g| ~ eps)."""
+    if (D1 + 15) // 16 != 10:
+        assert torch.equal(a, b), (what, (a - b).abs().max().item())
+        return
+    tol = 1e-4 * scale * max(b.abs().max().item(), 1e-30) if scale else 2e-5
+    assert (a - b).abs().max().item() <= tol, (what, (a - b).abs().max().item(), tol)
+
+
 @pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("SoftCdet", 1003, 170), ("crossentropy", 250, 150),
                                           ("SoftCdet", 16, 40)])
 def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
     """nplda_train_step_f32 (loss folded into the data-gradient kernel, slab sums + Adam + re-pack in one launch) against
     the same step as separate C-ABI calls: the SAME parameter bits after every step (dL/ds, the slabs and Adam's update
-    are the same arithmetic); the loss scalar may differ in its last bit (fp64 sums taken per block of 16 pairs)."""
+    are the same arithmetic; D = 150: see _same_step); the loss scalar may differ in its last bit (fp64 sums taken per
+    block of 16 pairs)."""
     from neuralplda_amd import ops, train
     rng = np.random.default_rng(77)
     p = rand_params(rng, 512, D, D)
@@ -392,8 +406,9 @@ def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
         la, lb = sa(x1, x2, t), sb(x1, x2, t)
         assert abs(la.item() - lb.item()) <= 2e-7 * abs(lb.item())
         for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
-            assert torch.equal(a, b), (i, k, (a - b).abs().max().item())
-        assert torch.equal(sa.m, sb.m) and torch.equal(sa.v, sb.v)
+            _same_step(a, b, D, (i, k), scale=0)
+        _same_step(sa.m, sb.m, D, (i, "m"))
+        _same_step(sa.v, sb.v, D, (i, "v"))
         # the image the step carries along is the image of the updated parameters
         fresh = ops.pack_params(*[q.detach() for q in sa.params])
         assert torch.equal(sa._packed.buf, fresh.buf), i
@@ -426,7 +441,7 @@ def test_one_call_step_other_shapes(hip_lib, D0, D1, D2, betas, B):
         la, lb = sa(x1, x2, t), sb(x1, x2, t)
         assert abs(la.item() - lb.item()) <= 2e-7 * abs(lb.item())
         for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
-            assert torch.equal(a, b), k
+            _same_step(a, b, D1, k, scale=0)
 
 
 @pytest.mark.parametrize("graph", [False, True])
@@ -476,7 +491,7 @@ def test_one_call_step_reports_the_applied_gradient(hip_lib):
     ops.train_step(x1, x2, t, prm, ths, betas, alpha, ops.LOSS_SOFTCDET, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-5, packed,
                    ws, lbuf, grad_out=out, loss_sum=(acc := torch.full((1,), 2.5, dtype=torch.float64, device="cuda")))
     assert acc.item() == 2.5 + float(lbuf.item())  # the running loss sum of the training log: += loss, in fp64
-    assert torch.equal(out[:n], flat)
+    _same_step(out[:n], flat, D, "flat gradient")
     np.testing.assert_allclose(out[n:].cpu().numpy(), dth.cpu().numpy(), rtol=1e-6)
     assert abs(lbuf.item() - loss.item()) <= 2e-7 * abs(loss.item())
     assert ops.train_step_workspace(16385, packed) is None

@@ -32,7 +32,7 @@ __global__ void fill_targets(float* t, size_t n) {
 
 template <int NB>
 static void launch(const TrainFbArgs& fb, long long B, hipStream_t st) {
-    hipLaunchKernelGGL((train_fb_small_kernel<NB, 32>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, fb);
+    hipLaunchKernelGGL((train_fb_small_kernel<NB, 32, false>), dim3((unsigned)((B + 15) / 16)), dim3(256), 0, st, fb);
 }
 
 int main(int argc, char** argv) {
