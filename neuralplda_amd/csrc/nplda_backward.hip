@@ -174,10 +174,17 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;
     constexpr int PF = 4;
+    // pair scoring at NB = 10: the two left-over blocks split by side, as in nplda_fwd_small.h / nplda_train_fb_small.h
+    constexpr bool HALF = NB == 10 && !GIVEN;
+    constexpr int NBF = HALF ? NB / NW : NBW;
+    constexpr int HS = NBF;
     __shared__ f32x4 dzlds[2][NB][64];
     __shared__ float red[NW][2][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g4 = lane >> 4;
+    const int hb = NW * NBF + (wave >> 1);
+    const bool hside = (wave & 1) != 0;
+    auto blk = [&](int i) { return HALF && i == HS ? hb : wave + NW * i; };
     const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
     const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
@@ -192,7 +199,7 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
         const int kbc = kb < NB ? kb : NB - 1;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int nb = wave + NW * i;
+            const int nb = blk(i);
             wf[slot][i] = W2T[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
         }
     };
@@ -218,8 +225,9 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     } else {
         tg = (!GIVEN && okA) ? 2.0f * a.g[rA] : 0.f;
     }
+    const long long rH = hside ? rB : rA, rO = hside ? rA : rB;  // HALF: the half slot's row, its pair's other row
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
             if (GIVEN) {
@@ -256,6 +264,28 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
             }
         }
     }
+    if constexpr (HALF) {
+        const f32x4 zH = *reinterpret_cast<const f32x4*>(a.z + rH * a.ldz + 16 * hb + 4 * g4);
+        const f32x4 zO = *reinterpret_cast<const f32x4*>(a.z + rO * a.ldz + 16 * hb + 4 * g4);
+        const f32x4 q = Qp[4 * hb + g4], p = Pp[4 * hb + g4];
+        const f32x4 dH = dz_of(tg, q, p, zH, zO);
+        dzlds[hside ? 1 : 0][hb][lane] = dH;
+        if (okA) *reinterpret_cast<f32x4*>(a.dz + rH * a.ldz + 16 * hb + 4 * g4) = dH;
+        if (!hside) {
+            f32x4 eq, ep;
+            pair_sum_terms(0.5f * tg, zH, zO, eq, ep);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                eq[r] = row16_sum(eq[r]);
+                ep[r] = row16_sum(ep[r]);
+            }
+            if (j == 0) {
+                float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * hb + 4 * g4;
+                *reinterpret_cast<f32x4*>(o) = eq;
+                *reinterpret_cast<f32x4*>(o + a.ldz) = ep;
+            }
+        }
+    }
     __syncthreads();
     if constexpr (LOSS) {  // the block's 16 pairs, summed in pair order
         if (tid < kLossNS) {
@@ -276,13 +306,16 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
         const f32x4 dA = dzlds[0][kb][lane], dB = dzlds[1][kb][lane];
+        f32x4 dH;
+        if constexpr (HALF) dH = dzlds[hside ? 1 : 0][kb][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 dyA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], dA[r], dyA[i], 0, 0, 0);
                 dyB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], dB[r], dyB[i], 0, 0, 0);
             }
+            if constexpr (HALF) dyA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][HS][r], dH[r], dyA[HS], 0, 0, 0);
         }
         fetch(s, kb + PF);
     }
@@ -291,7 +324,7 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     f32x4 yA[NBW], yB[NBW];
     float dotA = 0.f, dotB = 0.f;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         const int nbc = nb < NB ? nb : NB - 1;
         yA[i] = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nbc + 4 * g4);
@@ -303,6 +336,14 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
                 dotB = fmaf(yB[i][r], dyB[i][r], dotB);
             }
         }
+    }
+    if constexpr (HALF) {
+        yA[HS] = *reinterpret_cast<const f32x4*>(a.y + rH * a.ldz + 16 * hb + 4 * g4);
+        float dh = hside ? dotB : dotA;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dh = fmaf(yA[HS][r], dyA[HS][r], dh);
+        if (hside) dotB = dh;
+        else dotA = dh;
     }
     dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
     dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
@@ -317,12 +358,17 @@ __global__ __launch_bounds__(256, 2) void bwd_data_small_kernel(const BwdArgs a)
     if (rnA >= 1e12f) dotA = 0.f;
     if (rnB >= 1e12f) dotB = 0.f;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
             if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = du_of(dyA[i], yA[i], dotA, rnA);
             if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = du_of(dyB[i], yB[i], dotB, rnB);
         }
+    }
+    if constexpr (HALF) {
+        if (okA)
+            *reinterpret_cast<f32x4*>(a.du + rH * a.ldz + 16 * hb + 4 * g4) =
+                du_of(dyA[HS], yA[HS], hside ? dotB : dotA, hside ? rnB : rnA);
     }
 }
 

@@ -34,16 +34,28 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     NPLDA_STAMP(0);
     static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN || MODE == MODE_GB, "small kernel modes");
     constexpr int NW = 4;
-    constexpr int NBW = (NB + NW - 1) / NW;  // feature blocks per wave
+    constexpr int NBW = (NB + NW - 1) / NW;  // feature-block slots per wave
     constexpr int PF = 4;                    // register-ring depth (k16-steps)
+    // Pair scoring at NB = 10: blocks 0 .. 7 go two to a wave and the two left-over blocks are split by SIDE — wave w takes
+    // block 8 + w / 2 for the x1 rows (w even) or the x2 rows (w odd): 5 MFMAs per k4-step on every wave instead of 6, 6, 4,
+    // 4.  The slot's accumulators live in the "A" arrays whatever its side; the block's two z halves meet through LDS for
+    // the score.  (train_fb_small_kernel and bwd_data_small_kernel use the same assignment: the same partial sums, the
+    // same bits.)
+    constexpr bool HALF = NB == 10 && (MODE == MODE_PAIR || MODE == MODE_TRAIN);
+    constexpr int NBF = HALF ? NB / NW : NBW;  // slots holding a whole block (both sides)
+    constexpr int HS = NBF;                    // the half slot (HALF only)
     __shared__ f32x4 ylds[2][NB][64];        // normalised layer-1 output, accumulator layout
     __shared__ float red[NW][2][16];         // cross-wave partials (norms, then scores)
+    __shared__ f32x4 zx[HALF ? NW : 1][64];  // z of the half slots, for the wave holding the block's other side
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches only
     const int j = lane & 15;
     const int g = lane >> 4;
+    const int hb = NW * NBF + (wave >> 1);   // HALF: block of the half slot,
+    const bool hside = (wave & 1) != 0;      //       and its side (false: x1 rows)
+    auto blk = [&](int i) { return HALF && i == HS ? hb : wave + NW * i; };
 
     long long t0A, t0B;
     if (MODE == MODE_EMBED) {
@@ -75,7 +87,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     f32x4 accA[NBW], accB[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int nb = wave + NW * i;
+        const int nb = blk(i);
         accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         accB[i] = accA[i];
     }
@@ -85,16 +97,17 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     // block after its 24 MFMAs cost 0.45 us per step against 0.32 us of MFMA time; spread through the step they issue in
     // the shadow of the MFMAs.  sched_barrier pins the pieces: left free, the scheduler sinks every load to its first use.
     constexpr int PF1 = PF + 1;
-    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1], xh[HALF ? PF1 : 1];  // (xh: the half slot's side, loaded again rather than selected)
     // every load is unconditional (indices clamped): predicated loads would make hipcc wait vmcnt(0) per step
     auto fetchw = [&](int slot, int ks, int i) {
         const int ksc = ks < KS1 ? ks : KS1 - 1;
-        const int nb = wave + NW * i;
+        const int nb = blk(i);
         wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
     };
     auto fetchx = [&](int slot, int ks) {
         xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
         xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
+        if constexpr (HALF) xh[slot] = load_x4c<false>(hside ? sb : sa, 16 * ks + 4 * g, D0);
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
@@ -106,12 +119,13 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 // no guard: a wave whose i-th block does not exist (nb >= NB) multiplies the clamped
                 // fragment into an accumulator that is never read — cheaper than a branch per MFMA
                 accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
                 accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
             }
+            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[slot][r], accA[HS], 0, 0, 0);
             if (r < NBW) fetchw(rs, ks + PF, r);
             if (r == 3) fetchx(rs, ks + PF);
             __builtin_amdgcn_sched_barrier(0);
@@ -138,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     {
         float ssA = 0.f, ssB = 0.f;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
+        for (int i = 0; i < NBF; ++i) {
             if (wave + NW * i < NB) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
@@ -146,6 +160,13 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
                     ssB = fmaf(accB[i][r], accB[i][r], ssB);
                 }
             }
+        }
+        if constexpr (HALF) {
+            float sh = hside ? ssB : ssA;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) sh = fmaf(accA[HS][r], accA[HS][r], sh);
+            if (hside) ssB = sh;
+            else ssA = sh;
         }
         ssA = wave_xor_add(ssA, 16); ssA = wave_xor_add(ssA, 32);
         ssB = wave_xor_add(ssB, 16); ssB = wave_xor_add(ssB, 32);
@@ -159,7 +180,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
     if (MODE == MODE_GB && a.no_norm) invA = invB = 1.0f;
 #pragma unroll
-    for (int i = 0; i < NBW; ++i) {
+    for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
         if (nb < NB) {
             accA[i] *= invA;
@@ -171,6 +192,12 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
                 if (okB) *reinterpret_cast<f32x4*>(a.out_y + (a.n + rowB) * a.ldz + 16 * nb + 4 * g) = accB[i];
             }
         }
+    }
+    const long long rowH = hside ? a.n + rowB : rowA;  // HALF (pair / train modes): the half slot's row of the (2n)-row outputs
+    if constexpr (HALF) {
+        accA[HS] *= hside ? invB : invA;
+        ylds[hside ? 1 : 0][hb][lane] = accA[HS];
+        if (MODE == MODE_TRAIN && okA) *reinterpret_cast<f32x4*>(a.out_y + rowH * a.ldz + 16 * hb + 4 * g) = accA[HS];
     }
     if (MODE == MODE_TRAIN && wave == 0 && g == 0 && okA) {
         a.out_rn[rowA] = invA;
@@ -272,7 +299,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     f32x4 zA[NBW], zB[NBW];
 #pragma unroll
     for (int i = 0; i < NBW; ++i) {
-        const int nb = wave + NW * i;
+        const int nb = blk(i);
         zA[i] = nb < NB ? b2p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         zB[i] = zA[i];
     }
@@ -280,7 +307,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         const int kbc = kb < NB ? kb : NB - 1;
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
-            const int nb = wave + NW * i;
+            const int nb = blk(i);
             wf[slot][i] = W2p[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
         }
     };
@@ -293,13 +320,16 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     for (int kb = 0; kb < NB; ++kb) {
         const int s = kb % PF;
         const f32x4 yA = ylds[0][kb][lane], yB = ylds[1][kb][lane];
+        f32x4 yH;
+        if constexpr (HALF) yH = ylds[hside ? 1 : 0][kb][lane];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
-            for (int i = 0; i < NBW; ++i) {
+            for (int i = 0; i < NBF; ++i) {
                 zA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yA[r], zA[i], 0, 0, 0);
                 zB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][i][r], yB[r], zB[i], 0, 0, 0);
             }
+            if constexpr (HALF) zA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[s][HS][r], yH[r], zA[HS], 0, 0, 0);
         }
         fetch2(s, kb + PF);
         __builtin_amdgcn_sched_barrier(0);
@@ -308,9 +338,15 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     NPLDA_STAMP(6);
     // ---- epilogue ---------------------------------------------------------------------------------------------------
     if (MODE == MODE_PAIR || MODE == MODE_TRAIN) {
+        f32x4 zP;  // HALF: z of the half block's other side
+        if constexpr (HALF) {
+            zx[wave][lane] = zA[HS];
+            __syncthreads();
+            zP = zx[wave ^ 1][lane];
+        }
         float part = 0.f;
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) {
+        for (int i = 0; i < NBF; ++i) {
             const int nb = wave + NW * i;
             if (nb < NB) {
                 const f32x4 q = Qp[4 * nb + g];
@@ -326,6 +362,19 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
                     if (okB) *reinterpret_cast<f32x4*>(a.out_z + (a.n + rowB) * a.ldz + 16 * nb + 4 * g) = zB[i];
                 }
             }
+        }
+        if constexpr (HALF) {
+            if (!hside) {  // the block's term, once: by the wave of its x1 side
+                const f32x4 q = Qp[4 * hb + g];
+                const f32x4 p = Pp[4 * hb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = zA[HS][r], z2 = zP[r];
+                    part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
+                    part = fmaf(2.0f * p[r], z1 * z2, part);
+                }
+            }
+            if (MODE == MODE_TRAIN && okA) *reinterpret_cast<f32x4*>(a.out_z + rowH * a.ldz + 16 * hb + 4 * g) = zA[HS];
         }
         part = wave_xor_add(part, 16);
         part = wave_xor_add(part, 32);

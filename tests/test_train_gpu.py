@@ -370,16 +370,9 @@ def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
 
 
 def _same_step(a, b, D1, what, scale=1.0):
-    """Two tensors left by the one-call step and by the separate launches.  Same bits — except at 10 feature blocks
-    (D1 in 145..160), where the one-call kernel splits the two left-over blocks by side (five MFMAs per k4-step on every
-    wave instead of 6, 6, 4, 4: csrc/nplda_train_fb_small.h), so three cross-wave sums associate differently and the
-    gradients agree to rounding only: there the gradient / moments must agree to 1e-4 of their scale, and the parameters
-    to 2 % of the learning rate of these tests (Adam's step lr m / (sqrt(v) + eps) amplifies rounding where |g| ~ eps)."""
-    if (D1 + 15) // 16 != 10:
-        assert torch.equal(a, b), (what, (a - b).abs().max().item())
-        return
-    tol = 1e-4 * scale * max(b.abs().max().item(), 1e-30) if scale else 2e-5
-    assert (a - b).abs().max().item() <= tol, (what, (a - b).abs().max().item(), tol)
+    """Two tensors left by the one-call step and by the separate launches: the same bits (the small-batch kernels of both
+    paths assign feature blocks to waves the same way, at D = 150 the two left-over blocks by side)."""
+    assert torch.equal(a, b), (what, (a - b).abs().max().item())
 
 
 @pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("SoftCdet", 1003, 170), ("crossentropy", 250, 150),
@@ -387,7 +380,7 @@ def _same_step(a, b, D1, what, scale=1.0):
 def test_one_call_step_equals_the_separate_launches(hip_lib, lossname, B, D):
     """nplda_train_step_f32 (loss folded into the data-gradient kernel, slab sums + Adam + re-pack in one launch) against
     the same step as separate C-ABI calls: the SAME parameter bits after every step (dL/ds, the slabs and Adam's update
-    are the same arithmetic; D = 150: see _same_step); the loss scalar may differ in its last bit (fp64 sums taken per
+    are the same arithmetic); the loss scalar may differ in its last bit (fp64 sums taken per
     block of 16 pairs)."""
     from neuralplda_amd import ops, train
     rng = np.random.default_rng(77)
