@@ -22,6 +22,7 @@
 #include "nplda_loss_math.h"
 #include "nplda_cohort_qz.h"
 #include "nplda_bwd_loss.h"
+#include "nplda_loss_tail.h"
 #include "nplda_train_fb_small.h"
 #include "nplda_wgrad_fm.h"
 
@@ -566,7 +567,10 @@ constexpr long long kFmMaxRows = 32 * 1024;  // minibatch-sized products (larger
 static inline bool wgrad_fm_rows(long long K, int NB) { return NB >= 10 && NB <= 12 && K >= 4 && K <= kFmMaxRows; }
 
 // The weight-gradient launch: full-M form where it applies, the 64 x 64 form otherwise.  nprob: problems in use (1 or 2).
-static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st) {
+// tail: the training step's loss tail, to ride along if the full-M form runs (*tail_done reports it).
+static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const LossTail* tail = nullptr,
+                        bool* tail_done = nullptr) {
+    if (tail_done) *tail_done = false;
     bool fm = wgrad_fm_rows(wa.K, NB) && (wa.K % 4) == 0 && (wa.nsplit % 4) == 0 && wa.nw == wa.nw_ps;
     for (int i = 0; i < nprob; ++i) {
         const WgradProblem& P = wa.p[i];
@@ -584,7 +588,12 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st) {
     const int tiles = fa.nt0 + fa.nt1;
     fa.ps_cols = wa.pq ? (2 * wa.Mp + tiles - 1) / tiles : 0;
     if (fa.ps_cols > kFmWaves * 64) return NPLDA_EUNSUPPORTED;
-    const dim3 grid((unsigned)(tiles * wa.ksplit)), block(kFmWaves * 64);
+    if (tail) {
+        fa.has_tail = 1;
+        fa.tail = *tail;
+        if (tail_done) *tail_done = true;
+    }
+    const dim3 grid((unsigned)(tiles * wa.ksplit + (tail ? 1 : 0))), block(kFmWaves * 64);
     switch (NB) {
         case 10: hipLaunchKernelGGL(wgrad_fm_kernel<10>, grid, block, 0, st, fa); break;
         case 11: hipLaunchKernelGGL(wgrad_fm_kernel<11>, grid, block, 0, st, fa); break;
@@ -654,14 +663,9 @@ struct UpdateArgs {
     float lr, beta1, beta2, eps, wd;
     NpldaLayout L;
     float* packed;
-    const double* partial;    // [nblk][kLossNS]
-    int nblk, K, kind;
-    nplda_loss::BetaVals beta;
-    float alpha;
-    float* theta[nplda_loss::kMaxK];
     int bumped;               // step[0] already counts this step (train_fb_small_kernel): no arrival tickets
-    float* loss;
-    double* loss_sum;          // optional fp64: loss_sum[0] += the step's loss (interval means of the training log)
+    LossTail tail;            // the loss / threshold tail (nplda_loss_tail.h),
+    int tail_here;            // done by this kernel's last block (0: it rode in the weight-gradient launch)
     unsigned ngrad_blocks;
 };
 
@@ -743,51 +747,8 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
         }
         }
     } else {
-        // ---- loss block: partials -> sums (fixed order: 8 interleaved chains per sum, then the chains in order) ----
-        __shared__ double tile[256][kLossNS + 1];
-        __shared__ double chain[kLossNS][8];
-        __shared__ double sums[kLossNS];
-        __shared__ float dth[nplda_loss::kMaxK];
-        const int ns = nplda_loss::nsums(a.K, a.kind);
-        const int i = threadIdx.x >> 3, cc = threadIdx.x & 7;
-        double vv = 0.0;
-        for (int base = 0; base < a.nblk; base += 256) {  // 256 partial rows at a time through LDS
-            const int b = base + threadIdx.x;
-#pragma unroll
-            for (int q = 0; q < kLossNS; ++q) tile[threadIdx.x][q] = b < a.nblk ? a.partial[(size_t)b * kLossNS + q] : 0.0;
-            __syncthreads();
-            if (i < ns)
-                for (int r = cc; r < 256; r += 8) vv += tile[r][i];
-            __syncthreads();
-        }
-        if (i < ns) chain[i][cc] = vv;
-        __syncthreads();
-        if (threadIdx.x < ns) {
-            double w = 0.0;
-#pragma unroll
-            for (int c8 = 0; c8 < 8; ++c8) w += chain[threadIdx.x][c8];
-            sums[threadIdx.x] = w;
-        }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            if (a.kind == 1) nplda_loss::bce_scalars(sums, a.loss, dth);
-            else if (a.K == 1) nplda_loss::softcdet_scalars<1>(sums, a.beta, a.alpha, a.loss, dth);
-            else if (a.K == 2) nplda_loss::softcdet_scalars<2>(sums, a.beta, a.alpha, a.loss, dth);
-            else if (a.K == 3) nplda_loss::softcdet_scalars<3>(sums, a.beta, a.alpha, a.loss, dth);
-            else nplda_loss::softcdet_scalars<4>(sums, a.beta, a.alpha, a.loss, dth);
-            if (a.loss_sum) a.loss_sum[0] += (double)a.loss[0];
-        }
-        __syncthreads();
-        const int nth = a.kind == 1 ? 1 : a.K;
-        if (threadIdx.x < nth) {
-            const int k = threadIdx.x;
-            const float g = dth[k];
-            if (a.r.out) a.r.out[ngrad + k] = g;
-            float m = a.m[ngrad + k], v = a.v[ngrad + k];
-            a.theta[k][0] = nplda_adam::update(a.theta[k][0], g, m, v, c);
-            a.m[ngrad + k] = m;
-            a.v[ngrad + k] = v;
-        }
+        __shared__ double tail_smem[(kLossTailSmem + 7) / 8];
+        loss_tail_block(a.tail, tail_smem);
     }
     if (a.bumped) return;
     __syncthreads();  // the whole block has read step[0]
@@ -855,7 +816,8 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
                     const float* packed, const NpldaLayout& L, const float* g, const float* y, const float* z,
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
                     float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
-                    ReduceArgs* defer_reduce = nullptr, bool data_done = false) {
+                    ReduceArgs* defer_reduce = nullptr, bool data_done = false, const LossTail* tail = nullptr,
+                    bool* tail_done = nullptr) {
     BwdArgs b = {};
     if (ls) {
         if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
@@ -912,7 +874,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
     wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
     wa.pq = b.pq; wa.nblk = (int)((b.nA + 15) / 16);
-    if (int rc = wgrad_launch(wa, L.NB, 2, st)) return rc;
+    if (int rc = wgrad_launch(wa, L.NB, 2, st, tail, tail_done)) return rc;
     // K-C
     ReduceArgs ra = {};
     ra.slab1 = wsf + W.slab1; ra.slab2 = wsf + W.slab2; ra.ext = wsf + W.ext; ra.P_sqrt = P_sqrt;
@@ -1129,7 +1091,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     for (int k = 0; k < nth; ++k) {
         if (!thetas[k]) return NPLDA_EINVAL;
         ls.th.p[k] = thetas[k];
-        ua.theta[k] = thetas[k];
+        ua.tail.theta[k] = thetas[k];
         if (kind == 0) ls.beta.b[k] = betas[k];
     }
     const WsLayout W = ws_layout(2 * B, L, false);
@@ -1163,26 +1125,35 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
 #undef NPLDA_LAUNCH
         if (int rc = nplda_launch_status()) return rc;
     }
+    {   // the loss / threshold tail: in the weight-gradient launch where the full-M kernel runs, else in the update kernel
+        LossTail& t = ua.tail;
+        const size_t ngrad0 = nplda_grad_floats(D0, D1, D2);
+        t.partial = ls.partial; t.nblk = S.nblk; t.K = nth; t.kind = kind; t.beta = ls.beta; t.alpha = alpha;
+        t.loss = loss; t.loss_sum = loss_sum; t.m = exp_avg + ngrad0; t.v = exp_avg_sq + ngrad0;
+        t.gout = grad_out ? grad_out + ngrad0 : nullptr; t.step = step; t.bumped = 1;
+        t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
+    }
+    bool tail_done = false;
     // the weight gradients read the x rows: the caller's, or the ones the first kernel gathered
     const float* wx1 = rows ? wsf + S.xs : x1;
     const float* wx2 = rows ? wsf + S.xs + (size_t)B * S.ldxs : x2;
     if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, rows ? S.ldxs : ldx, (const float*)packed, L, nullptr,
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
-                                 st, &ls, &ua.r, true))
+                                 st, &ls, &ua.r, true, &ua.tail, &tail_done))
         return rc;
     for (int i = 0; i < 6; ++i) ua.prm[i] = params[i];
     ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;
     ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
     ua.L = L; ua.packed = (float*)packed;
-    ua.partial = ls.partial; ua.nblk = S.nblk; ua.K = nth; ua.kind = kind; ua.beta = ls.beta; ua.alpha = alpha;
-    ua.loss = loss; ua.loss_sum = loss_sum; ua.bumped = 1;
+    ua.bumped = 1;
+    ua.tail_here = tail_done ? 0 : 1;
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
 #ifndef NPLDA_UPDATE_E
 #define NPLDA_UPDATE_E 2
 #endif
     constexpr int E = NPLDA_UPDATE_E;  // without arrival tickets (the first kernel has counted the step) small blocks are free
     ua.ngrad_blocks = (unsigned)((ngrad + 256 * E - 1) / (256 * E));
-    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + 1), dim3(256), 0, st, ua);
+    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + (unsigned)ua.tail_here), dim3(256), 0, st, ua);
     return nplda_launch_status();
 }
 

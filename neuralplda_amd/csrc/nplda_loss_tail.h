@@ -1,0 +1,84 @@
+// nplda_loss_tail.h — the scalar tail of the one-call training step: the per-block loss partials of K-A -> the loss, dL/dtheta
+// and torch.optim.Adam's update of the thresholds.  One block's work that depends on K-A only: it rides in the weight-gradient
+// launch as an extra block (nplda_wgrad_fm.h) — on a CU of its own, off the critical path — or, where that kernel does not
+// apply, in the last block of the update kernel (nplda_backward.hip).
+#pragma once
+#include "nplda_adam_math.h"
+#include "nplda_bwd_loss.h"
+#include "nplda_loss_math.h"
+
+namespace nplda {
+
+struct LossTail {
+    const double* partial;    // [nblk][kLossNS] loss sums of K-A's blocks of 16 pairs
+    int nblk, K, kind;
+    nplda_loss::BetaVals beta;
+    float alpha;
+    float* theta[nplda_loss::kMaxK];
+    float* loss;              // the step's loss
+    double* loss_sum;         // optional fp64: loss_sum[0] += loss (interval means of the training log)
+    float* m;                 // the thresholds' exp_avg / exp_avg_sq (K floats each)
+    float* v;
+    float* gout;              // optional: dL/dtheta (K floats)
+    const float* step;        // Adam's step counter
+    int bumped;               // step[0] already counts this step (train_fb_small_kernel)
+    float lr, beta1, beta2, eps, wd;
+};
+
+constexpr int kLossTailSmem = (256 * (kLossNS + 1) + kLossNS * 8 + kLossNS) * 8 + nplda_loss::kMaxK * 4;  // bytes
+
+// Called by EVERY thread of a block of >= 256 threads (barriers inside); the first 256 do the work.
+// Fixed order: 256 partial rows at a time through LDS, 8 interleaved chains per sum, then the chains in order.
+__device__ __forceinline__ void loss_tail_block(const LossTail& a, void* smem) {
+    double (*tile)[kLossNS + 1] = reinterpret_cast<double (*)[kLossNS + 1]>(smem);
+    double (*chain)[8] = reinterpret_cast<double (*)[8]>(tile + 256);
+    double* sums = reinterpret_cast<double*>(chain + kLossNS);
+    float* dth = reinterpret_cast<float*>(sums + kLossNS);
+    const int tid = threadIdx.x;
+    const bool on = tid < 256;
+    const int ns = nplda_loss::nsums(a.K, a.kind);
+    const int i = tid >> 3, cc = tid & 7;
+    double vv = 0.0;
+    for (int base = 0; base < a.nblk; base += 256) {
+        const int b = base + tid;
+        if (on) {
+#pragma unroll
+            for (int q = 0; q < kLossNS; ++q) tile[tid][q] = b < a.nblk ? a.partial[(size_t)b * kLossNS + q] : 0.0;
+        }
+        __syncthreads();
+        if (on && i < ns)
+            for (int r = cc; r < 256; r += 8) vv += tile[r][i];
+        __syncthreads();
+    }
+    if (on && i < ns) chain[i][cc] = vv;
+    __syncthreads();
+    if (tid < ns) {
+        double w = 0.0;
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) w += chain[tid][c8];
+        sums[tid] = w;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        if (a.kind == 1) nplda_loss::bce_scalars(sums, a.loss, dth);
+        else if (a.K == 1) nplda_loss::softcdet_scalars<1>(sums, a.beta, a.alpha, a.loss, dth);
+        else if (a.K == 2) nplda_loss::softcdet_scalars<2>(sums, a.beta, a.alpha, a.loss, dth);
+        else if (a.K == 3) nplda_loss::softcdet_scalars<3>(sums, a.beta, a.alpha, a.loss, dth);
+        else nplda_loss::softcdet_scalars<4>(sums, a.beta, a.alpha, a.loss, dth);
+        if (a.loss_sum) a.loss_sum[0] += (double)a.loss[0];
+    }
+    __syncthreads();
+    const int nth = a.kind == 1 ? 1 : a.K;
+    if (tid < nth) {
+        const float t = a.bumped ? a.step[0] : a.step[0] + 1.0f;
+        const nplda_adam::Consts c = nplda_adam::consts_for(t, a.lr, a.beta1, a.beta2, a.eps, a.wd);
+        const float g = dth[tid];
+        if (a.gout) a.gout[tid] = g;
+        float m = a.m[tid], v = a.v[tid];
+        a.theta[tid][0] = nplda_adam::update(a.theta[tid][0], g, m, v, c);
+        a.m[tid] = m;
+        a.v[tid] = v;
+    }
+}
+
+}  // namespace nplda

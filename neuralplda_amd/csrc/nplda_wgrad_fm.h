@@ -3,6 +3,7 @@
 #pragma once
 #include "nplda_cohort_qz.h"
 #include "nplda_common.h"
+#include "nplda_loss_tail.h"
 
 namespace nplda {
 
@@ -71,6 +72,8 @@ struct WgradFmArgs {
     WgradArgs w;
     int nt0, nt1;     // 32-column tiles of the two problems
     int ps_cols;      // pair-sum columns per block (of 2 Mp), 0 = none
+    int has_tail;     // one more block after the GEMM blocks: the loss / threshold tail of the training step
+    LossTail tail;
 };
 
 // CL consecutive floats in CL registers
@@ -300,6 +303,11 @@ __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradF
     __shared__ f32x4 rede[kFmWaves][3][16];
     __shared__ float psum[kFmWaves * 64];
     const int w = blockIdx.x;
+    if (fa.has_tail && w == (fa.nt0 + fa.nt1) * fa.w.ksplit) {  // on a CU of its own, done long before the GEMM blocks
+        static_assert(kLossTailSmem <= sizeof(red), "the tail's LDS fits in the reduction buffer");
+        loss_tail_block(fa.tail, red);
+        return;
+    }
     const int ks = w % fa.w.ksplit, tile = w / fa.w.ksplit;
     const int pi = tile >= fa.nt0 ? 1 : 0;
     const WgradProblem P = pi ? fa.w.p[1] : fa.w.p[0];
