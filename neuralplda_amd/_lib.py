@@ -89,6 +89,11 @@ SIGNATURES = {
                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
                                            ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp] + [ctypes.c_float] * 5 +
                                   [_c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "nplda_train_step_records_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64,
+                                              ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
+                                              ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp] + [ctypes.c_float] * 5 +
+                                     [_c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp, _c_vp]),
     "nplda_bf16x3_packed_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "nplda_pack_params_bf16x3": (_c_int, [_c_f32p] * 6 + [_c_int] * 3 + [_c_vp, _c_sz, _c_vp]),
     "nplda_score_pairs_bf16x3": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p,

@@ -45,6 +45,12 @@ struct TrainFbArgs {
     float* xsb;
     long long ldxs;
     float* step_bump;     // optional: Adam's step counter, incremented here (one thread) for the update kernel of this step
+    // Indexed form, batches taken from a device-resident epoch: cursor[0] = address of record 0, cursor[1] = index of the
+    // record to use; a record is [rows1 (n int64) | rows2 (n int64) | labels (n float32)], rec_stride bytes apart.  Then
+    // ia / ib / ls.t are ignored.  (The update kernel of the step advances cursor[1]: a replayed graph walks the epoch
+    // without a host-side copy per step.)
+    const long long* cursor;
+    long long rec_stride;
 };
 
 template <int NB, int KS1C, bool ROWS>  // ROWS: the indexed form (pairs named by table rows, x rows staged for K-B)
@@ -90,9 +96,18 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const long long rA = ok ? t0 + j : a.n - 1;  // x1-side row of y / dz / du; the x2 side sits n rows further
     const long long rB = a.n + rA;
     long long xrA = rA, xrB = rA;
+    BwdLoss ls = a.ls;
     if constexpr (ROWS) {
-        xrA = a.ia[rA];
-        xrB = a.ib[rA];
+        const long long* ia = a.ia;
+        const long long* ib = a.ib;
+        if (a.cursor != nullptr) {
+            const char* rec = reinterpret_cast<const char*>(a.cursor[0]) + a.cursor[1] * a.rec_stride;
+            ia = reinterpret_cast<const long long*>(rec);
+            ib = ia + a.n;
+            ls.t = reinterpret_cast<const float*>(ib + a.n);
+        }
+        xrA = ia[rA];
+        xrB = ib[rA];
         xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
         xrB = xrB < 0 ? 0 : (xrB < a.ntab ? xrB : a.ntab - 1);
     }
@@ -149,10 +164,10 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     NPLDA_FB_STAMP(1);
     // the batch's targets: loaded now, behind the first fragments, counted after layer 1 (no wait, no barrier of their own)
     TargetEarly te;
-    if (a.ls.B >= 4) target_count_issue(a.ls, te);
-    const float ti = a.ls.t[rA];
+    if (ls.B >= 4) target_count_issue(ls, te);
+    const float ti = ls.t[rA];
     PairLossConsts lc;
-    loss_consts_theta(a.ls, lc);
+    loss_consts_theta(ls, lc);
     __builtin_amdgcn_sched_barrier(0);
     NPLDA_FB_STAMP(2);
 
@@ -214,16 +229,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             red[wave][0][j] = ssA;
             red[wave][1][j] = ssB;
         }
-        if (a.ls.B < 4) {
+        if (ls.B < 4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) te.v[q] = f32x4{0.f, 0.f, 0.f, 0.f};
         }
-        const float cw = target_count_wave(a.ls, te);
+        const float cw = target_count_wave(ls, te);
         if (lane == 0) cnt_s[wave] = cw;
     }
     __syncthreads();
     const double Nt = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // as block_target_count
-    const double Nn = (double)a.ls.B - Nt;
+    const double Nn = (double)ls.B - Nt;
     const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
     const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
     const long long rH = hside ? rB : rA;  // HALF: the row of the half slot's side
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     // the batch constants of dL/ds (fp64 divisions): by the last wave, which has the fewest feature blocks at NB = 10 / 11
     // and would otherwise wait for the others at the score barrier; they reach the other waves through LDS there
     if (wave == NW - 1) {
-        loss_consts_counts(a.ls, Nt, Nn, lc);
+        loss_consts_counts(ls, Nt, Nn, lc);
         if (lane == 0) {
 #pragma unroll
             for (int k = 0; k < nplda_loss::kMaxK; ++k) lcs[k] = lc.cn[k];
@@ -350,7 +365,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
     for (int k = 0; k < nplda_loss::kMaxK; ++k) lc.cn[k] = lcs[k];
     lc.ct = lcs[nplda_loss::kMaxK];
-    const float gi = loss_pair(a.ls, lc, si, ti, lsum);
+    const float gi = loss_pair(ls, lc, si, ti, lsum);
     const float tg = ok ? 2.0f * gi : 0.f;
     if (wave == 0 && g == 0) {
 #pragma unroll
@@ -412,7 +427,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         double v = 0.0;
 #pragma unroll
         for (int p = 0; p < 16; ++p) v += lacc[p][tid];
-        a.ls.partial[(size_t)blockIdx.x * kLossNS + tid] = v;
+        ls.partial[(size_t)blockIdx.x * kLossNS + tid] = v;
     }
 
     // ---- dy = dz W2 (chained MFMA: A = W2^T fragments, B = dz from LDS) ---------------------------------------------------

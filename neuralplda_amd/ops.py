@@ -513,6 +513,36 @@ def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, k
     return loss
 
 
+def train_step_records(table, cursor, B, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
+                       eps, weight_decay, packed, ws, loss, grad_out=None, loss_sum=None):
+    """nplda_train_step_records_f32: train_step_rows on record cursor[1] of a device-resident epoch (cursor: int64 device
+    tensor [address of record 0, record index]; a record = [rows1 (B int64) | rows2 (B int64) | labels (B float32)]); the
+    step's last kernel advances cursor[1]."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_records")
+    table, ldt = _rows(table, "table", packed.D0)
+    if cursor.dtype != torch.int64 or cursor.device != table.device or cursor.numel() != 2 or not cursor.is_contiguous():
+        raise TypeError("cursor must be a contiguous int64 tensor of 2 elements on the table's device")
+    for q in list(params) + list(thetas):
+        _require_dev_f32(q, "parameter")
+        if not q.is_contiguous():
+            raise ValueError("train_step updates the parameter tensors in place: they must be contiguous")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(table.device):
+        code = lib.nplda_train_step_records_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(cursor), int(B), parr,
+                                                packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K,
+                                                float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step),
+                                                float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                                                _lib.ptr(packed.buf), _lib.ptr(ws), ws.numel() * 4, _lib.ptr(loss),
+                                                _lib.ptr(loss_sum) if loss_sum is not None else None,
+                                                _lib.ptr(grad_out) if grad_out is not None else None, _lib.current_stream())
+    _lib.check(code, "nplda_train_step_records_f32")
+    return loss
+
+
 # ---- indexed scoring / gather -------------------------------------------------------------------
 
 def _idx(t, name, dev):

@@ -100,12 +100,8 @@ class TrialLoader(DataLoader):
             ii = perm[lo:lo + bs]
             yield ds.x1[ii], ds.x2[ii], ds.l[ii]
 
-    def device_batches(self, device, num_to_row=None, pack=False):
-        """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
-        batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
-        `num_to_row`: optional int64 device map applied to both index columns (trial number -> x-vector table row);
-        a negative entry (unknown utterance) raises KeyError like load_xvec_trials_from_numbatch.
-        pack=True also yields, per full batch, the batch as one contiguous uint8 record (None for a last partial batch)."""
+    def _device_epoch_arrays(self, device, num_to_row):
+        """One epoch's permuted index / label arrays on `device` (the draws of __iter__: same permutation)."""
         ds = self.dataset
         if not isinstance(ds, TrialIndexDataset) or self.num_workers != 0 or self.drop_last:
             raise TypeError("device_batches needs the vectorised TrialIndexDataset path")
@@ -122,16 +118,41 @@ class TrialLoader(DataLoader):
             e1, e2 = num_to_row[e1.long()], num_to_row[e2.long()]
             if n and (int(e1.min()) < 0 or int(e2.min()) < 0):
                 raise KeyError("trial index refers to an utterance that is not in mega_dict")
+        return n, e1, e2, el
+
+    def _pack_records(self, n, e1, e2, el, device):
+        """One contiguous record per full batch — [rows1 (int64) | rows2 (int64) | labels (float32)], back to back."""
+        bs = self.batch_size
+        nb = n // bs
+        rec = torch.empty((nb, 20 * bs), dtype=torch.uint8, device=device)
+        if nb:
+            rec[:, :8 * bs].view(torch.int64).copy_(e1[:nb * bs].view(nb, bs))
+            rec[:, 8 * bs:16 * bs].view(torch.int64).copy_(e2[:nb * bs].view(nb, bs))
+            rec[:, 16 * bs:].view(torch.float32).copy_(el[:nb * bs].float().view(nb, bs))
+        return rec
+
+    def device_epoch(self, device, num_to_row=None):
+        """The epoch as (records, tail): `records` a (full batches, 20 * batch_size) uint8 device tensor of packed batch
+        records, `tail` the last partial batch as (rows1, rows2, labels) device views or None.  A consumer that walks the
+        records on the device (FusedTrainStep.begin_epoch / step_record) needs no per-batch copy at all."""
+        n, e1, e2, el = self._device_epoch_arrays(device, num_to_row)
+        bs = self.batch_size
+        lo = n // bs * bs
+        tail = (e1[lo:], e2[lo:], el[lo:]) if lo < n else None
+        return self._pack_records(n, e1, e2, el, device), tail
+
+    def device_batches(self, device, num_to_row=None, pack=False):
+        """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
+        batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
+        `num_to_row`: optional int64 device map applied to both index columns (trial number -> x-vector table row);
+        a negative entry (unknown utterance) raises KeyError like load_xvec_trials_from_numbatch.
+        pack=True also yields, per full batch, the batch as one contiguous uint8 record (None for a last partial batch)."""
+        n, e1, e2, el = self._device_epoch_arrays(device, num_to_row)
         bs = self.batch_size
         if pack:
-            # one contiguous record per full batch — [rows1 (int64) | rows2 (int64) | labels (float32)] — so that a consumer
-            # with static input buffers (FusedTrainStep.step_rows) stages a batch with ONE device copy instead of three
+            # a consumer with static input buffers (FusedTrainStep.step_rows) stages a batch with ONE device copy instead of three
+            rec = self._pack_records(n, e1, e2, el, device)
             nb = n // bs
-            rec = torch.empty((nb, 20 * bs), dtype=torch.uint8, device=device)
-            if nb:
-                rec[:, :8 * bs].view(torch.int64).copy_(e1[:nb * bs].view(nb, bs))
-                rec[:, 8 * bs:16 * bs].view(torch.int64).copy_(e2[:nb * bs].view(nb, bs))
-                rec[:, 16 * bs:].view(torch.float32).copy_(el[:nb * bs].float().view(nb, bs))
             for k, lo in enumerate(range(0, n, bs)):
                 yield e1[lo:lo + bs], e2[lo:lo + bs], el[lo:lo + bs], (rec[k] if k < nb else None)
             return

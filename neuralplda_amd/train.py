@@ -45,7 +45,27 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             and not train_loader.drop_last)
     if fast:
         table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
-        batches = ((r1, r2, t, None, rec) for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
+        if step_fn.batch_size == train_loader.batch_size:
+            # the whole epoch as packed records on the device; the captured step walks them through a device-side cursor
+            # (no copy and no host write per step), the ragged last batch takes the eager step
+            records, tail = train_loader.device_epoch(device, row_map)
+            if step_fn.records_ok(table, records):
+                nb, bs = records.shape[0], train_loader.batch_size
+                if nb:
+                    step_fn.begin_epoch(table, records)
+                for batch_idx in range(nb):
+                    step_fn.step_record()
+                    if batch_idx % nc.log_interval == 0:
+                        _log_train(nc, epoch, batch_idx, bs, train_loader, step_fn.pop_loss_mean())
+                if tail is not None:
+                    step_fn.step_rows(table, *tail)
+                    if nb % nc.log_interval == 0:
+                        _log_train(nc, epoch, nb, len(tail[0]), train_loader, step_fn.pop_loss_mean())
+                return
+            batches = _record_batches(records, tail, train_loader.batch_size)
+        else:
+            batches = ((r1, r2, t, None, rec)
+                       for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
     else:
         batches = ((None, None, t, d1, d2) for d1, d2, t in train_loader)
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
@@ -72,6 +92,16 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
         if batch_idx % nc.log_interval == 0:
             _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean() if fused else losses)
             losses = []
+
+
+def _record_batches(records, tail, bs):
+    """(rows1, rows2, labels, None, record) per batch of a device_epoch, for the step_rows form of the loop."""
+    for k in range(records.shape[0]):
+        rec = records[k]
+        yield (rec[:8 * bs].view(torch.int64), rec[8 * bs:16 * bs].view(torch.int64), rec[16 * bs:].view(torch.float32),
+               None, rec)
+    if tail is not None:
+        yield tail[0], tail[1], tail[2], None, None
 
 
 def _device_table(mega_xvec_dict, num_to_id_dict, device):
@@ -215,6 +245,8 @@ class FusedTrainStep:
     _one_call = False  # subclasses with their own kernels (FusedDPldaStep) keep the separate calls
     _packed = _packed_key = None
     _loss_acc, _acc_n = None, 0  # fp64 device sum of the losses since pop_loss_mean(), number of steps in it
+    _cursor = _graph_rec = _loss_rec = _graph_rec_table = _records_ref = None
+    _records_left = 0
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
         from . import _lib, ops
@@ -414,6 +446,64 @@ class FusedTrainStep:
         self._touched()
         self._account(self._loss_rows, B)
         return self._loss_rows
+
+    # ---- a device-resident epoch: the batches as packed records, consumed through a device-side cursor ----------------
+    def records_ok(self, table, records):
+        """True if step_record can run `records` ((nb, 20 B) uint8: TrialLoader.device_epoch) against `table`."""
+        B = self.batch_size
+        return (self._one_call and self.use_graph and B is not None and 0 < B <= 16384 and B % 4 == 0
+                and self.dims[0] % 16 == 0 and records is not None and records.dim() == 2 and records.shape[1] == 20 * B
+                and records.dtype == torch.uint8 and records.is_contiguous() and records.device == table.device)
+
+    def begin_epoch(self, table, records):
+        """Point the step at an epoch of packed batch records ([rows1 | rows2 | labels] each, back to back on the device).
+        Every step_record() then trains on the next record: the captured graph reads the batch through a two-word device
+        cursor that its own last kernel advances (nplda_train_step_records_f32) — no copy and no host write per step."""
+        if not self.records_ok(table, records):
+            raise ValueError("begin_epoch: records / table do not fit this step (see records_ok)")
+        if self._cursor is None:
+            self._cursor = torch.zeros(2, dtype=torch.int64, device=self.dev)
+        if self._graph_rec is None or self._graph_rec_table != (table.data_ptr(), table.shape, table.stride(0)):
+            # warm-up and capture against two stand-in records (row 0, both classes present)
+            B = self.batch_size
+            warm = torch.zeros((2, 20 * B), dtype=torch.uint8, device=self.dev)
+            lab = warm[:, 16 * B:].view(torch.float32)
+            lab[:, ::2] = 1
+            self._set_cursor(warm)
+            self._sync_packed()
+            self._graph_rec, self._loss_rec = self._capture_fn(lambda: self._eager_records(table))
+            self._graph_rec_table = (table.data_ptr(), table.shape, table.stride(0))
+            self._table_ref = table
+        self._set_cursor(records)
+        self._records_ref, self._records_left = records, records.shape[0]
+
+    def _set_cursor(self, records):
+        self._cursor.copy_(torch.tensor([records.data_ptr(), 0], dtype=torch.int64))
+        torch.cuda.current_stream().synchronize()  # (the source is a temporary host tensor)
+
+    def _eager_records(self, table):
+        ops = self._ops
+        B = self.batch_size
+        ws = self._ws.get(("rows", B))
+        if ws is None:
+            ws = self._ws[("rows", B)] = ops.train_step_workspace(B, self._packed, rows=True)
+        with torch.no_grad():
+            ops.train_step_records(table, self._cursor, B, [q.detach() for q in self.params],
+                                   [th.detach() for th in self.thetas], self.betas_loss, self.alpha, self.kind, self.m,
+                                   self.v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
+                                   self._packed, ws, self._loss_buf, loss_sum=self._acc())
+        return self._loss_buf
+
+    def step_record(self):
+        """One step on the epoch's next record (begin_epoch): one graph launch on the host."""
+        if self._records_left <= 0:
+            raise RuntimeError("step_record: the epoch's records are used up (begin_epoch)")
+        self._records_left -= 1
+        self._sync_packed()
+        self._graph_rec.replay()
+        self._touched()
+        self._account(self._loss_rec, self.batch_size)
+        return self._loss_rec
 
     def _eager_rows(self, table):
         ops = self._ops

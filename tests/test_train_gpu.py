@@ -461,6 +461,44 @@ def test_step_rows_gathers_inside_the_step(hip_lib, graph):
     assert sa.step_count[0].item() == 3
 
 
+def test_step_record_walks_a_device_resident_epoch(hip_lib):
+    """begin_epoch / step_record (nplda_train_step_records_f32: the captured step reads its batch through a device cursor
+    that its own last kernel advances) leaves the same parameter bits as step_rows fed the same batches one by one; the
+    cursor ends on the record count; one record too many raises."""
+    from neuralplda_amd import train
+    rng = np.random.default_rng(91)
+    B, nb, N = 256, 5, 3000
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    table = torch.from_numpy(rng.standard_normal((N, 512)).astype(np.float32)).cuda()
+    r1 = torch.from_numpy(rng.integers(0, N, (nb, B))).cuda()
+    r2 = torch.from_numpy(rng.integers(0, N, (nb, B))).cuda()
+    lab = torch.from_numpy((rng.random((nb, B)) < 0.2).astype(np.float32)).cuda()
+    records = torch.empty((nb, 20 * B), dtype=torch.uint8, device="cuda")
+    records[:, :8 * B].view(torch.int64).copy_(r1)
+    records[:, 8 * B:16 * B].view(torch.int64).copy_(r2)
+    records[:, 16 * B:].view(torch.float32).copy_(lab)
+    m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+    assert sa.records_ok(table, records) and not sa.records_ok(table, records[:, :-4])
+    sa.begin_epoch(table, records)
+    for k in range(nb):
+        la = sa.step_record().item()
+        lb = sb.step_rows(table, r1[k], r2[k], lab[k]).item()
+        assert la == lb, k
+        for (key, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            assert torch.equal(a, b), (k, key)
+    assert sa._cursor[1].item() == nb and sa.step_count[0].item() == nb
+    assert abs(sa.pop_loss_mean() - sb.pop_loss_mean()) < 1e-12
+    with pytest.raises(RuntimeError):
+        sa.step_record()
+    sa.begin_epoch(table, records[1:3])  # a second epoch on the same graph: only the cursor moves
+    sa.step_record()
+    sb.step_rows(table, r1[1], r2[1], lab[1])
+    assert torch.equal(next(iter(m_a.state_dict().values())), next(iter(m_b.state_dict().values())))
+
+
 def test_one_call_step_reports_the_applied_gradient(hip_lib):
     """grad_out of nplda_train_step_f32 = flat gradient of the separate backward + dtheta of the separate loss."""
     from neuralplda_amd import ops
@@ -590,7 +628,7 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
 
     sd_fast, log_fast, step_fast = run(True)
     sd_gen, log_gen, _ = run(False)
-    assert step_fast._graph_rows is not None and step_fast.step_count[0].item() == 8  # 7 replays + 1 ragged eager step
+    assert step_fast._graph_rec is not None and step_fast.step_count[0].item() == 8  # 7 replays + 1 ragged eager step
     assert log_fast == log_gen and log_fast.count("Train Epoch") == 3
     # the figure on each progress line is the MEAN of the losses since the previous line (xvector_NeuralPlda_pytorch.py:
     # 41-47), also when the step is a replayed graph whose loss tensor is rewritten in place by every replay
@@ -725,6 +763,13 @@ def test_reference_driver_train_and_validate_g12(hip_lib, tmp_path):
                 losses.append(float(L))
                 return L
             step.step_rows = rec_rows
+            inner_rec = step.step_record
+
+            def rec_record():  # (the device-resident epoch of train(): records walked by the captured step)
+                L = inner_rec()
+                losses.append(float(L))
+                return L
+            step.step_record = rec_record
             opt = None
         else:
             step = None
