@@ -498,7 +498,9 @@ def run_cfg2(args, ctx):
     graph = ctx.backend == "nccl" or world == 1  # (the gloo dry run cannot capture its collectives)
     step_fn = train.FusedTrainStep(model, 1e-4, weight_decay=1e-5, batch_size=Bl, graph=graph)
     gen_r = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank its own shard of every minibatch
-    nbat = 32
+    # one rank: the epoch's batches as packed records on the device, walked by the captured step through its cursor
+    # (FusedTrainStep.begin_epoch / step_record: the training loop's form, train.train); data parallel: step_rows
+    nbat = min(args.steps + args.warmup + 1, 4096) if world == 1 else 32
     recs = []
     for _ in range(nbat):
         r1 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
@@ -506,8 +508,14 @@ def run_cfg2(args, ctx):
         t = (torch.rand(Bl, device=dev, generator=gen_r) < 0.1).float()
         recs.append((r1, r2, t, torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])))
     state = {"k": 0}
+    records = torch.stack([r[3] for r in recs]) if world == 1 else None
+    by_cursor = world == 1 and step_fn.records_ok(table, records)
 
     def step():
+        if by_cursor:
+            if step_fn._records_left == 0:
+                step_fn.begin_epoch(table, records)
+            return step_fn.step_record()
         r1, r2, t, rec = recs[state["k"] % nbat]
         state["k"] += 1
         return step_fn.step_rows(table, r1, r2, t, record=rec)
@@ -538,11 +546,13 @@ def run_cfg2(args, ctx):
                                f"512->{D}->{D}, SoftCdet (beta 99, 199; alpha 15), Adam(1e-4, wd 1e-5); batch sharded x{world}",
                    "global_batch": Bg, "pairs_per_gpu_per_step": Bl, "table_utterances": N, "params": psrc,
                    "parallelism": f"data parallel x{world}", "backend": ctx.backend if world > 1 else "single process",
-                   "graph_replay": bool(graph), "final_loss": float(loss)},
+                   "graph_replay": bool(graph), "final_loss": float(loss),
+                   "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32)"
+                                 if by_cursor else "one 20 B-byte record copy per step (nplda_train_step_rows_f32)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
-                     "kernel": "nplda_train_step_rows_f32 (forward + loss + data gradients, weight-gradient slabs, update), "
-                               "whole step", "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
+                     "kernel": ("nplda_train_step_records_f32" if by_cursor else "nplda_train_step_rows_f32") +
+                               " (forward + loss + data gradients, weight-gradient slabs, update), whole step", "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
     }
 
 

@@ -410,14 +410,16 @@ int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const 
                               float* exp_avg_sq, float* step, float lr, float beta1, float beta2, float eps,
                               float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, double* loss_sum,
                               float* grad_out, nplda_stream_t stream);
-/* The same step with the batch taken from a device-resident epoch: `cursor` is a DEVICE array of two int64 — [0] the
- * address of record 0, [1] the index of the record to train on — and a record is [rows1 (B int64) | rows2 (B int64) | labels
- * (B float32)], 20 B bytes, records back to back (TrialLoader.device_batches(pack=True) lays an epoch out this way).  The
- * step's last kernel advances cursor[1], so a captured graph of this call walks the epoch replay by replay with no copy and
- * no host write per step (the reference's loop moves three host tensors to the device per batch,
- * xvector_NeuralPlda_pytorch.py:38).  B % 4 == 0 and D0 % 16 == 0 (else NPLDA_EUNSUPPORTED).  Workspace: as
- * nplda_train_step_rows_f32. */
-int nplda_train_step_records_f32(const float* table, int64_t N, int64_t ldt, int64_t* cursor, int64_t B,
+/* The same step for a device-resident epoch of batches.  A record is [rows1 (B int64) | rows2 (B int64) | labels (B float32)],
+ * 20 B bytes, records back to back (TrialLoader.device_epoch lays an epoch out this way).  The step trains on the record in
+ * `stage` (device, 20 B bytes, 16-byte aligned) and its last kernel copies the epoch's NEXT record there: `cursor` is a
+ * DEVICE array of three int64 — [0] the address of record 0, [1] the index of the next record to stage, [2] the record
+ * count; the first kernel counts cursor[1] up, the update kernel stages record cursor[1] while cursor[1] < cursor[2].  The
+ * caller stages record 0 and sets cursor = {base, 0, count} once per epoch; a captured graph of this call then walks the
+ * epoch replay by replay with no copy launch and no host write per step (the reference's loop moves three host tensors to
+ * the device per batch, xvector_NeuralPlda_pytorch.py:38).  B % 4 == 0 and D0 % 16 == 0 (else NPLDA_EUNSUPPORTED).
+ * Workspace: as nplda_train_step_rows_f32. */
+int nplda_train_step_records_f32(const float* table, int64_t N, int64_t ldt, int64_t* cursor, void* stage, int64_t B,
                                  float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas,
                                  int K, float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr,
                                  float beta1, float beta2, float eps, float weight_decay, void* packed, void* ws,

@@ -666,7 +666,10 @@ struct UpdateArgs {
     int bumped;               // step[0] already counts this step (train_fb_small_kernel): no arrival tickets
     LossTail tail;            // the loss / threshold tail (nplda_loss_tail.h),
     int tail_here;            // done by this kernel's last block (0: it rode in the weight-gradient launch)
-    long long* cursor;        // optional (nplda_train_step_records_f32): cursor[1] += 1, the epoch's next record
+    const long long* cursor;  // optional (nplda_train_step_records_f32): [address of record 0, next record, record count]
+    char* stage;              //   the record the NEXT step trains on is copied here by `ncopy` extra blocks
+    long long rec_bytes;
+    unsigned ncopy;
     unsigned ngrad_blocks;
 };
 
@@ -682,7 +685,16 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
     const int D0 = a.r.D0, D1 = a.r.D1, D2 = a.r.D2;
     const size_t nW1 = (size_t)D1 * D0, nW2 = (size_t)D2 * D1;
     const size_t ngrad = nW1 + D1 + nW2 + 3 * (size_t)D2;
-    if (a.cursor != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.cursor[1] += 1;  // (every reader ran a launch ago)
+    if (blockIdx.x >= gridDim.x - a.ncopy) {  // stage the epoch's next record (the first kernel has counted this one)
+        const long long k = a.cursor[1];
+        if (k >= a.cursor[2]) return;
+        const f32x4* src = reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(a.cursor[0]) + k * a.rec_bytes);
+        f32x4* dst = reinterpret_cast<f32x4*>(a.stage);
+        const long long n16 = a.rec_bytes / 16;
+        for (long long i = (long long)(blockIdx.x - (gridDim.x - a.ncopy)) * 256 + threadIdx.x; i < n16; i += 256LL * a.ncopy)
+            dst[i] = src[i];
+        return;
+    }
     if (blockIdx.x < a.ngrad_blocks) {
         // four elements per thread: the arrival tickets at the end are one atomic per block on one address (~10 ns each,
         // serialised): 392 blocks of 256 elements spent 2 of the kernel's 10 us queueing there
@@ -1061,23 +1073,29 @@ size_t nplda_train_step_rows_workspace_bytes(int64_t B, int D0, int D1, int D2) 
 }
 
 static int train_step_impl(const float* x1, const float* x2, const int64_t* rows1, const int64_t* rows2, int64_t ntab,
-                           long long* cursor, int64_t B, int64_t ldx, const float* target,
+                           long long* cursor, void* stage, int64_t B, int64_t ldx, const float* target,
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          double* loss_sum, float* grad_out, nplda_stream_t stream) {
-    const bool rows = rows1 != nullptr || cursor != nullptr;
+    if (cursor) {  // the batch sits in the staging record [rows1 | rows2 | labels]
+        if (!stage || !nplda_aligned16(stage) || B < 1) return NPLDA_EINVAL;
+        if ((B % 4) != 0) return NPLDA_EUNSUPPORTED;  // 16-byte pieces: the labels sit behind 16 B bytes of indices
+        rows1 = (const int64_t*)stage;
+        rows2 = rows1 + B;
+        target = (const float*)(rows2 + B);
+    }
+    const bool rows = rows1 != nullptr;
     if (int rc = check_model(D0, D1, D2)) return rc;
-    if (rows && ((!cursor && !rows2) || ntab < 1)) return NPLDA_EINVAL;
+    if (rows && (!rows2 || ntab < 1)) return NPLDA_EINVAL;
     if (rows && (D0 % 16) != 0) return NPLDA_EUNSUPPORTED;  // the staged rows are written k16-step by k16-step
     if (B < 1) return NPLDA_EINVAL;
     if (B > 16 * 1024) return NPLDA_EUNSUPPORTED;  // larger batches: the separate launches (two-pass loss)
     if (kind != 0 && kind != 1) return kind == 2 ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
     const int nth = kind == 1 ? 1 : K;
     if (nth < 1 || nth > nplda_loss::kMaxK || !thetas || !params || (kind == 0 && !betas)) return NPLDA_EINVAL;
-    if ((!target && !cursor) || !exp_avg || !exp_avg_sq || !step || !packed || !ws || !loss) return NPLDA_EINVAL;
-    if (!nplda_aligned16(packed) || !nplda_aligned16(ws) || (target && !nplda_aligned16(target))) return NPLDA_EINVAL;
-    if (cursor && (B % 4) != 0) return NPLDA_EUNSUPPORTED;  // the labels of a record sit behind 16 B int64s: 16-byte aligned iff B % 4 == 0
+    if (!target || !exp_avg || !exp_avg_sq || !step || !packed || !ws || !loss) return NPLDA_EINVAL;
+    if (!nplda_aligned16(packed) || !nplda_aligned16(ws) || !nplda_aligned16(target)) return NPLDA_EINVAL;
     if (!rows_ok(x1, ldx, D0) || !rows_ok(x2, ldx, D0)) return NPLDA_EINVAL;
     for (int i = 0; i < 6; ++i)
         if (!params[i]) return NPLDA_EINVAL;
@@ -1107,7 +1125,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         fb.pq = bws + W.pq; fb.ls = ls; fb.step_bump = step;
         if (rows) {
             fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = ntab;
-            fb.cursor = cursor; fb.rec_stride = 20 * (long long)B;
+            fb.rec_bump = cursor ? cursor + 1 : nullptr;
             fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs;
         }
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
@@ -1151,14 +1169,18 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     ua.L = L; ua.packed = (float*)packed;
     ua.bumped = 1;
     ua.tail_here = tail_done ? 0 : 1;
-    ua.cursor = cursor;
+    if (cursor) {
+        ua.cursor = cursor; ua.stage = (char*)stage; ua.rec_bytes = 20 * (long long)B;
+        ua.ncopy = (unsigned)((ua.rec_bytes / 16 + 255) / 256);
+        if (ua.ncopy > 32) ua.ncopy = 32;
+    }
     const size_t ngrad = nplda_grad_floats(D0, D1, D2);
 #ifndef NPLDA_UPDATE_E
 #define NPLDA_UPDATE_E 2
 #endif
     constexpr int E = NPLDA_UPDATE_E;  // without arrival tickets (the first kernel has counted the step) small blocks are free
     ua.ngrad_blocks = (unsigned)((ngrad + 256 * E - 1) / (256 * E));
-    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + (unsigned)ua.tail_here), dim3(256), 0, st, ua);
+    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + (unsigned)ua.tail_here + ua.ncopy), dim3(256), 0, st, ua);
     return nplda_launch_status();
 }
 
@@ -1167,7 +1189,7 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          double* loss_sum, float* grad_out, nplda_stream_t stream) {
-    return train_step_impl(x1, x2, nullptr, nullptr, 0, nullptr, B, ldx, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
+    return train_step_impl(x1, x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
                            exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
                            loss_sum, grad_out, stream);
 }
@@ -1179,18 +1201,18 @@ int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const 
                               float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss, double* loss_sum,
                               float* grad_out, nplda_stream_t stream) {
     if (!rows1 || !rows2 || N < 1) return NPLDA_EINVAL;
-    return train_step_impl(table, table, rows1, rows2, N, nullptr, B, ldt, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
+    return train_step_impl(table, table, rows1, rows2, N, nullptr, nullptr, B, ldt, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
                            exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
                            loss_sum, grad_out, stream);
 }
 
-int nplda_train_step_records_f32(const float* table, int64_t N, int64_t ldt, int64_t* cursor, int64_t B,
+int nplda_train_step_records_f32(const float* table, int64_t N, int64_t ldt, int64_t* cursor, void* stage, int64_t B,
                                  float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas,
                                  int K, float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr,
                                  float beta1, float beta2, float eps, float weight_decay, void* packed, void* ws,
                                  size_t ws_bytes, float* loss, double* loss_sum, float* grad_out, nplda_stream_t stream) {
-    if (!cursor || N < 1) return NPLDA_EINVAL;
-    return train_step_impl(table, table, nullptr, nullptr, N, (long long*)cursor, B, ldt, nullptr, params, D0, D1, D2, thetas,
+    if (!cursor || !stage || N < 1) return NPLDA_EINVAL;
+    return train_step_impl(table, table, nullptr, nullptr, N, (long long*)cursor, stage, B, ldt, nullptr, params, D0, D1, D2, thetas,
                            betas, K, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws,
                            ws_bytes, loss, loss_sum, grad_out, stream);
 }

@@ -45,12 +45,8 @@ struct TrainFbArgs {
     float* xsb;
     long long ldxs;
     float* step_bump;     // optional: Adam's step counter, incremented here (one thread) for the update kernel of this step
-    // Indexed form, batches taken from a device-resident epoch: cursor[0] = address of record 0, cursor[1] = index of the
-    // record to use; a record is [rows1 (n int64) | rows2 (n int64) | labels (n float32)], rec_stride bytes apart.  Then
-    // ia / ib / ls.t are ignored.  (The update kernel of the step advances cursor[1]: a replayed graph walks the epoch
-    // without a host-side copy per step.)
-    const long long* cursor;
-    long long rec_stride;
+    long long* rec_bump;  // optional (nplda_train_step_records_f32): rec_bump[0] += 1 — the epoch's record counter, read by
+                          // the update kernel of this step, which stages the next record (a launch later: no race)
 };
 
 template <int NB, int KS1C, bool ROWS>  // ROWS: the indexed form (pairs named by table rows, x rows staged for K-B)
@@ -96,18 +92,10 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const long long rA = ok ? t0 + j : a.n - 1;  // x1-side row of y / dz / du; the x2 side sits n rows further
     const long long rB = a.n + rA;
     long long xrA = rA, xrB = rA;
-    BwdLoss ls = a.ls;
+    const BwdLoss& ls = a.ls;
     if constexpr (ROWS) {
-        const long long* ia = a.ia;
-        const long long* ib = a.ib;
-        if (a.cursor != nullptr) {
-            const char* rec = reinterpret_cast<const char*>(a.cursor[0]) + a.cursor[1] * a.rec_stride;
-            ia = reinterpret_cast<const long long*>(rec);
-            ib = ia + a.n;
-            ls.t = reinterpret_cast<const float*>(ib + a.n);
-        }
-        xrA = ia[rA];
-        xrB = ib[rA];
+        xrA = a.ia[rA];
+        xrB = a.ib[rA];
         xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
         xrB = xrB < 0 ? 0 : (xrB < a.ntab ? xrB : a.ntab - 1);
     }
@@ -124,6 +112,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const int KS1 = KS1C ? KS1C : a.KS1;
     const int D0 = a.D0;
     if (a.step_bump != nullptr && blockIdx.x == 0 && tid == 0) a.step_bump[0] += 1.0f;
+    if (a.rec_bump != nullptr && blockIdx.x == 0 && tid == 0) a.rec_bump[0] += 1;
     NPLDA_FB_STAMP(0);
 
     // ---- layer 1 (nplda_fwd_small.h) -----------------------------------------------------------------------------

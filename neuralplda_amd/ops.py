@@ -513,17 +513,19 @@ def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, k
     return loss
 
 
-def train_step_records(table, cursor, B, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
+def train_step_records(table, cursor, stage, B, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2,
                        eps, weight_decay, packed, ws, loss, grad_out=None, loss_sum=None):
-    """nplda_train_step_records_f32: train_step_rows on record cursor[1] of a device-resident epoch (cursor: int64 device
-    tensor [address of record 0, record index]; a record = [rows1 (B int64) | rows2 (B int64) | labels (B float32)]); the
-    step's last kernel advances cursor[1]."""
+    """nplda_train_step_records_f32: train_step_rows on the record in `stage` (uint8 device tensor of 20 B bytes:
+    [rows1 (B int64) | rows2 (B int64) | labels (B float32)]); the step's last kernel copies the epoch's next record there
+    (cursor: int64 device tensor [address of record 0, next record to stage, record count])."""
     import ctypes
     lib = _lib.load()
     _need_fp32(packed, "train_step_records")
     table, ldt = _rows(table, "table", packed.D0)
-    if cursor.dtype != torch.int64 or cursor.device != table.device or cursor.numel() != 2 or not cursor.is_contiguous():
-        raise TypeError("cursor must be a contiguous int64 tensor of 2 elements on the table's device")
+    if cursor.dtype != torch.int64 or cursor.device != table.device or cursor.numel() != 3 or not cursor.is_contiguous():
+        raise TypeError("cursor must be a contiguous int64 tensor of 3 elements on the table's device")
+    if stage.dtype != torch.uint8 or stage.device != table.device or stage.numel() != 20 * int(B) or not stage.is_contiguous():
+        raise TypeError("stage must be a contiguous uint8 tensor of 20 B bytes on the table's device")
     for q in list(params) + list(thetas):
         _require_dev_f32(q, "parameter")
         if not q.is_contiguous():
@@ -532,7 +534,7 @@ def train_step_records(table, cursor, B, params, thetas, betas, alpha, kind, exp
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
     with torch.cuda.device(table.device):
-        code = lib.nplda_train_step_records_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(cursor), int(B), parr,
+        code = lib.nplda_train_step_records_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(cursor), _lib.ptr(stage), int(B), parr,
                                                 packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K,
                                                 float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step),
                                                 float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),

@@ -245,7 +245,7 @@ class FusedTrainStep:
     _one_call = False  # subclasses with their own kernels (FusedDPldaStep) keep the separate calls
     _packed = _packed_key = None
     _loss_acc, _acc_n = None, 0  # fp64 device sum of the losses since pop_loss_mean(), number of steps in it
-    _cursor = _graph_rec = _loss_rec = _graph_rec_table = _records_ref = None
+    _cursor = _stage = _graph_rec = _loss_rec = _graph_rec_table = _records_ref = None
     _records_left = 0
 
     def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
@@ -457,29 +457,32 @@ class FusedTrainStep:
 
     def begin_epoch(self, table, records):
         """Point the step at an epoch of packed batch records ([rows1 | rows2 | labels] each, back to back on the device).
-        Every step_record() then trains on the next record: the captured graph reads the batch through a two-word device
-        cursor that its own last kernel advances (nplda_train_step_records_f32) — no copy and no host write per step."""
+        Every step_record() then trains on the next record: the captured graph reads its batch from the step's staging
+        record, and the graph's own last kernel copies the epoch's next record there, counted by a three-word device cursor
+        (nplda_train_step_records_f32) — no copy launch and no host write per step."""
         if not self.records_ok(table, records):
             raise ValueError("begin_epoch: records / table do not fit this step (see records_ok)")
+        B = self.batch_size
         if self._cursor is None:
-            self._cursor = torch.zeros(2, dtype=torch.int64, device=self.dev)
+            self._cursor = torch.zeros(3, dtype=torch.int64, device=self.dev)
+            self._stage = torch.zeros(20 * B, dtype=torch.uint8, device=self.dev)
         if self._graph_rec is None or self._graph_rec_table != (table.data_ptr(), table.shape, table.stride(0)):
-            # warm-up and capture against two stand-in records (row 0, both classes present)
-            B = self.batch_size
-            warm = torch.zeros((2, 20 * B), dtype=torch.uint8, device=self.dev)
-            lab = warm[:, 16 * B:].view(torch.float32)
-            lab[:, ::2] = 1
-            self._set_cursor(warm)
+            # warm-up and capture against stand-in records (row 0, both classes present)
+            warm = torch.zeros((3, 20 * B), dtype=torch.uint8, device=self.dev)
+            warm[:, 16 * B:].view(torch.float32)[:, ::2] = 1
+            self._set_epoch(warm)
             self._sync_packed()
             self._graph_rec, self._loss_rec = self._capture_fn(lambda: self._eager_records(table))
             self._graph_rec_table = (table.data_ptr(), table.shape, table.stride(0))
             self._table_ref = table
-        self._set_cursor(records)
+        self._set_epoch(records)
         self._records_ref, self._records_left = records, records.shape[0]
 
-    def _set_cursor(self, records):
-        self._cursor.copy_(torch.tensor([records.data_ptr(), 0], dtype=torch.int64))
-        torch.cuda.current_stream().synchronize()  # (the source is a temporary host tensor)
+    def _set_epoch(self, records):
+        """Stage record 0; cursor = [address of record 0, next record to stage, record count]."""
+        self._stage.copy_(records[0])
+        self._cursor.copy_(torch.tensor([records.data_ptr(), 0, records.shape[0]], dtype=torch.int64))
+        torch.cuda.current_stream().synchronize()  # (the cursor's source is a temporary host tensor)
 
     def _eager_records(self, table):
         ops = self._ops
@@ -488,7 +491,7 @@ class FusedTrainStep:
         if ws is None:
             ws = self._ws[("rows", B)] = ops.train_step_workspace(B, self._packed, rows=True)
         with torch.no_grad():
-            ops.train_step_records(table, self._cursor, B, [q.detach() for q in self.params],
+            ops.train_step_records(table, self._cursor, self._stage, B, [q.detach() for q in self.params],
                                    [th.detach() for th in self.thetas], self.betas_loss, self.alpha, self.kind, self.m,
                                    self.v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                    self._packed, ws, self._loss_buf, loss_sum=self._acc())

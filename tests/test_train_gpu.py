@@ -462,9 +462,9 @@ def test_step_rows_gathers_inside_the_step(hip_lib, graph):
 
 
 def test_step_record_walks_a_device_resident_epoch(hip_lib):
-    """begin_epoch / step_record (nplda_train_step_records_f32: the captured step reads its batch through a device cursor
-    that its own last kernel advances) leaves the same parameter bits as step_rows fed the same batches one by one; the
-    cursor ends on the record count; one record too many raises."""
+    """begin_epoch / step_record (nplda_train_step_records_f32: the captured step trains on its staging record and its own
+    last kernel copies the epoch's next record there, counted by a device cursor) leaves the same parameter bits as
+    step_rows fed the same batches one by one; the cursor ends on the record count; one record too many raises."""
     from neuralplda_amd import train
     rng = np.random.default_rng(91)
     B, nb, N = 256, 5, 3000

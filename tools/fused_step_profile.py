@@ -5,7 +5,9 @@ Three ways of feeding the step, each timed over 200 replays:
   inplace : the minibatch is written into the step's own input buffers (step.x1 / .x2 / .t) — no staging copies;
   copy    : foreign tensors -> three device copies (2 x 8 MB + 16 KB) in front of every replay;
   rows    : step_rows(table, rows1, rows2, t) — three index / label copies, the step's first kernel gathers the rows;
-  rows1   : the same with the batch as ONE packed record (TrialLoader.device_batches(pack=True)) — the training loop's form.
+  rows1   : the same with the batch as ONE packed record (TrialLoader.device_batches(pack=True));
+  records : begin_epoch / step_record — the records stay where the loader put them, the step walks them through its device
+            cursor: the training loop's form (train.train).
 (Run `rows` before `copy`: the first ~200 replays of the rows graph that follow a run of 8 MB device-to-device staging copies
 take 0.27 ms each, then drop back to 0.10 ms — a runtime effect of switching between the copy engine and blit kernels on
 the stream, not of the step's kernels; a training loop only ever uses step_rows.)
@@ -52,6 +54,14 @@ for mode in modes:
         ms = timed(lambda: step(step.x1, step.x2, step.t))
     elif mode == "rows":
         ms = timed(lambda: step.step_rows(table, r1, r2, t))
+    elif mode == "records":
+        recs = torch.stack([torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])] * 256)
+
+        def rec_step():
+            if step._records_left == 0:
+                step.begin_epoch(table, recs)
+            step.step_record()
+        ms = timed(rec_step)
     elif mode == "rows1":
         rec = torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])
         ms = timed(lambda: step.step_rows(table, r1, r2, t, record=rec))

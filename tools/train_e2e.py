@@ -51,21 +51,20 @@ def main():
     table, row_map = train._device_table(mega, num_to_id, torch.device("cuda"))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    it = loader.device_batches(torch.device("cuda"), row_map, pack=True)
-    first = next(it)
+    records, tail = loader.device_epoch(torch.device("cuda"), row_map)
+    step.begin_epoch(table, records)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t0
-    rest = list(it)
-    torch.cuda.synchronize()
+    n = records.shape[0]
     t0 = time.perf_counter()
-    for r1, r2, t, rec in rest:
-        step.step_rows(table, r1, r2, t, record=rec)
+    for _ in range(n):
+        step.step_record()
     t_host = time.perf_counter() - t0
     torch.cuda.synchronize()
     t_steps = time.perf_counter() - t0
     step.pop_loss_mean()
-    print(f"  of which epoch set-up {t_setup * 1e3:.1f} ms; {len(rest)} steps: host loop {t_host / len(rest) * 1e6:.1f} us/step, "
-          f"device-complete {t_steps / len(rest) * 1e6:.1f} us/step")
+    print(f"  of which epoch set-up {t_setup * 1e3:.1f} ms; {n} steps: host loop {t_host / n * 1e6:.1f} us/step, "
+          f"device-complete {t_steps / n * 1e6:.1f} us/step")
     print(f"loader from a {n_trials}-trial TSV: {t_load:.3f} s")
     print(f"epoch: {nb} batches of {NC.batch_size} in {t_epoch:.3f} s = {t_epoch / nb * 1e3:.3f} ms/step, "
           f"{len(loader.dataset) / t_epoch:.3e} pairs/s")

@@ -11,14 +11,14 @@ cd /tmp && export TMPDIR=/tmp
   echo "== wall per step, HIP-graph replay, 200 steps each (tools/fused_step_profile.py; one process per line)"
   for D in 150 170; do
     for B in 4096 2048; do
-      for mode in inplace rows1; do python $REPO/tools/fused_step_profile.py $D graph $mode $B 2>/dev/null | grep feed; done
+      for mode in inplace records rows1; do python $REPO/tools/fused_step_profile.py $D graph $mode $B 2>/dev/null | grep feed; done
     done
   done
   for D in 150 170; do
     echo
-    echo "== kernel times inside the graph, D = $D, B = 4096, step_rows with the packed record (rocprofv3 --kernel-trace)"
+    echo "== kernel times inside the graph, D = $D, B = 4096, begin_epoch / step_record (rocprofv3 --kernel-trace)"
     rm -rf $OUT/trace$D
-    rocprofv3 --kernel-trace -d $OUT/trace$D -o t -- python $REPO/tools/fused_step_profile.py $D graph rows1 4096 > /dev/null 2>&1
+    rocprofv3 --kernel-trace -d $OUT/trace$D -o t -- python $REPO/tools/fused_step_profile.py $D graph records 4096 > /dev/null 2>&1
     python $REPO/tools/rocpd_summary.py $(find $OUT/trace$D -name "*.db" | head -1) | head -7
   done
   echo
