@@ -351,3 +351,13 @@ def test_device_batches_packed_records():
         bad = row_map.clone()
         bad[7] = -1
         list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", bad, pack=True))
+    # device_epoch: the same epoch as (records of the full batches, the short last batch)
+    torch.manual_seed(5)
+    records, tail = svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_epoch("cpu", row_map)
+    assert records.shape == (n // bs, 20 * bs) and records.dtype == torch.uint8 and records.is_contiguous()
+    for k in range(n // bs):
+        assert torch.equal(records[k], packed[k][3])
+    assert all(torch.equal(a, b) for a, b in zip(tail, packed[-1][:3]))
+    torch.manual_seed(5)
+    full, none = svl.TrialLoader(ds, batch_size=100, shuffle=True, collate_fn=ds.collate).device_epoch("cpu", row_map)
+    assert full.shape == (10, 2000) and none is None
