@@ -207,15 +207,24 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True):
     for _ in range(warmup):
         out = step()
     torch.cuda.synchronize()
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    # per_step_events=False (steps of tens of microseconds): ONE event pair around the K steps — two event records per step
+    # are two more packets between the graph launches, 12 us on a 70 us training step
+    nev = steps if per_step_events else 1
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    if not per_step_events:
+        evs[0][0].record()
     for k in range(steps):
-        evs[k][0].record()
+        if per_step_events:
+            evs[k][0].record()
         out = step()
-        evs[k][1].record()
+        if per_step_events:
+            evs[k][1].record()
+    if not per_step_events:
+        evs[0][1].record()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
@@ -224,7 +233,7 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True):
         tt = torch.tensor([elapsed], dtype=torch.float64, device=ctx.dev if ctx.backend == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
-    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs]))
+    kern_ms = float(np.mean([a.elapsed_time(b) for a, b in evs])) / (1 if per_step_events else steps)
     return elapsed, kern_ms, out
 
 
@@ -520,7 +529,7 @@ def run_cfg2(args, ctx):
         state["k"] += 1
         return step_fn.step_rows(table, r1, r2, t, record=rec)
 
-    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup)
+    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False)
     if not torch.isfinite(loss).all():
         raise SystemExit("non-finite training loss")
     if rank != 0:

@@ -11,7 +11,7 @@ Three ways of feeding the step, each timed over 200 replays:
 (Run `rows` before `copy`: the first ~200 replays of the rows graph that follow a run of 8 MB device-to-device staging copies
 take 0.27 ms each, then drop back to 0.10 ms — a runtime effect of switching between the copy engine and blit kernels on
 the stream, not of the step's kernels; a training loop only ever uses step_rows.)
-usage: fused_step_profile.py [D=150] [graph|eager] [modes=inplace,rows,copy] [B=4096]"""
+usage: fused_step_profile.py [D=150] [graph|eager] [modes=inplace,rows,copy] [B=4096] [table rows=200000]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -32,7 +32,7 @@ m = models.NeuralPlda(NC()).cuda()
 B = int(sys.argv[4]) if len(sys.argv) > 4 else 4096
 x1 = torch.randn(B, 512, device="cuda"); x2 = torch.randn(B, 512, device="cuda")
 t = (torch.rand(B, device="cuda") < 0.1).float()
-table = torch.randn(200000, 512, device="cuda")
+table = torch.randn(int(sys.argv[5]) if len(sys.argv) > 5 else 200000, 512, device="cuda")
 r1 = torch.randint(0, table.shape[0], (B,), device="cuda"); r2 = torch.randint(0, table.shape[0], (B,), device="cuda")
 step = train.FusedTrainStep(m, 1e-4, weight_decay=1e-5, batch_size=B, graph=graph)
 
@@ -55,7 +55,10 @@ for mode in modes:
     elif mode == "rows":
         ms = timed(lambda: step.step_rows(table, r1, r2, t))
     elif mode == "records":
-        recs = torch.stack([torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])] * 256)
+        # 256 different minibatches (fresh table rows every step, as in an epoch)
+        recs = torch.stack([torch.cat([torch.randint(0, table.shape[0], (B,), device="cuda").view(torch.uint8),
+                                       torch.randint(0, table.shape[0], (B,), device="cuda").view(torch.uint8),
+                                       t.view(torch.uint8)]) for _ in range(256)])
 
         def rec_step():
             if step._records_left == 0:
