@@ -95,8 +95,11 @@ def test_bce_kernels(hip_lib, B):
     assert relmax(dth.cpu().numpy(), dref) <= 1e-4
 
 
-@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (64, 24, 20), (128, 40, 100)])
-@pytest.mark.parametrize("B", [3, 100, 4096])
+# (500, 150, 160) / (400, 180, 192): the full-M weight-gradient kernel (NB = 10 / 12) with a last 32-column tile that is
+# only partly there (500 = 15 x 32 + 20 columns; 400 = 12 x 32 + 16); B = 3 and 4097 rows odd: its 64 x 64 fall-back
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (64, 24, 20), (128, 40, 100), (500, 150, 160),
+                                      (400, 180, 192)])
+@pytest.mark.parametrize("B", [3, 100, 4096, 4097])
 def test_backward_matches_oracle(hip_lib, D0, D1, D2, B):
     from neuralplda_amd import ops
     rng = np.random.default_rng(D1 * 7 + B)
