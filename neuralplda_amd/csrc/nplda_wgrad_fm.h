@@ -133,7 +133,6 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     typedef typename FmVec<CL>::type fvCL;
     struct Ops { f32x4 a0, a1; fvCL a2; f32x2 b; };
     constexpr int NLD = 4;                                                 // loads per unit
-    constexpr int kWaitImm = 0x0F70 | ((PF - 2) * NLD);                    // s_waitcnt vmcnt((PF - 2) NLD) only
     static_assert((PF - 2) * NLD < 16, "vmcnt immediate");
     unsigned offA = (unsigned)((g4 * lda + 4 * i16) * 4);
     unsigned offA2 = (unsigned)((g4 * lda + 128 + CL * i16) * 4);
@@ -155,7 +154,6 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     auto wait = [&](Ops& o) {  // every load older than the last PF - 2 units has landed: this set is valid
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(o.a0), "+v"(o.a1), "+v"(o.a2), "+v"(o.b) : "n"((PF - 2) * NLD) : "memory");
     };
-    (void)kWaitImm;
 
     f32x4 acc[NB][2];
 #pragma unroll
