@@ -97,7 +97,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     // block after its 24 MFMAs cost 0.45 us per step against 0.32 us of MFMA time; spread through the step they issue in
     // the shadow of the MFMAs.  sched_barrier pins the pieces: left free, the scheduler sinks every load to its first use.
     constexpr int PF1 = PF + 1;
-    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1], xh[HALF ? PF1 : 1];  // (xh: the half slot's side, loaded again rather than selected)
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
     // every load is unconditional (indices clamped): predicated loads would make hipcc wait vmcnt(0) per step
     auto fetchw = [&](int slot, int ks, int i) {
         const int ksc = ks < KS1 ? ks : KS1 - 1;
@@ -107,7 +107,6 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     auto fetchx = [&](int slot, int ks) {
         xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
         xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
-        if constexpr (HALF) xh[slot] = load_x4c<false>(hside ? sb : sa, 16 * ks + 4 * g, D0);
     };
 #pragma unroll
     for (int s = 0; s < PF; ++s) {
@@ -116,6 +115,8 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         fetchx(s, s);
     }
     auto step = [&](int ks, int slot, int rs) {
+        f32x4 xh;  // the half slot's side: a select (4 VALU) — a third x load per step cost more (every load instruction of
+        if constexpr (HALF) xh = hside ? xb[slot] : xa[slot];  // a one-wave-per-SIMD kernel idles the matrix pipe ~49 cycles)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
                 accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
                 accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
             }
-            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[slot][r], accA[HS], 0, 0, 0);
+            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[r], accA[HS], 0, 0, 0);
             if (r < NBW) fetchw(rs, ks + PF, r);
             if (r == 3) fetchx(rs, ks + PF);
             __builtin_amdgcn_sched_barrier(0);

@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         accA[i] = nb < NB ? b1p[4 * nb + g] : f32x4{0.f, 0.f, 0.f, 0.f};
         accB[i] = accA[i];
     }
-    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1], xh[HALF ? PF1 : 1];  // (xh: the half slot's side, loaded again rather than selected)
+    f32x4 wf[PF1][NBW], xa[PF1], xb[PF1];
     auto fetchw = [&](int slot, int ks, int i) {
         const int ksc = ks < KS1 ? ks : KS1 - 1;
         const int nb = blk(i);
@@ -131,17 +131,14 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     };
     const float* sa4 = sa + 4 * g;
     const float* sb4 = sb + 4 * g;
-    const float* sh4 = hside ? sb4 : sa4;
     auto fetchx = [&](int slot, int ks) {
         if constexpr (KS1C > 0) {  // D0 = 16 KS1C: whole k16-steps only, the column offset is an immediate of the load
             const int kc = ks < KS1C ? ks : KS1C - 1;
             xa[slot] = *reinterpret_cast<const f32x4*>(sa4 + 16 * kc);
             xb[slot] = *reinterpret_cast<const f32x4*>(sb4 + 16 * kc);
-            if constexpr (HALF) xh[slot] = *reinterpret_cast<const f32x4*>(sh4 + 16 * kc);
         } else {
             xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
             xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
-            if constexpr (HALF) xh[slot] = load_x4c<false>(hside ? sb : sa, 16 * ks + 4 * g, D0);
         }
     };
 #pragma unroll
@@ -167,6 +164,8 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
                 *reinterpret_cast<f32x4*>(a.xsb + rA * a.ldxs + 16 * ks + 4 * g) = xb[slot];
             }
         }
+        f32x4 xh;  // the half slot's side: a select (4 VALU) — a third x load per step cost more (every load instruction of
+        if constexpr (HALF) xh = hside ? xb[slot] : xa[slot];  // a one-wave-per-SIMD kernel idles the matrix pipe ~49 cycles)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
                 accA[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xa[slot][r], accA[i], 0, 0, 0);
                 accB[i] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][i][r], xb[slot][r], accB[i], 0, 0, 0);
             }
-            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[slot][r], accA[HS], 0, 0, 0);
+            if constexpr (HALF) accA[HS] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[slot][HS][r], xh[r], accA[HS], 0, 0, 0);
             if (r < NBW) fetchw(rs, ks + PF, r);
             if (r == 3) fetchx(rs, ks + PF);
             __builtin_amdgcn_sched_barrier(0);
