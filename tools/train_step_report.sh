@@ -7,6 +7,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
+python $REPO/tools/fused_step_profile.py 150 graph inplace 4096 > /dev/null 2>&1  # (the first process on a fresh box reads 3x slow)
 {
   echo "== wall per step, HIP-graph replay, 200 steps each (tools/fused_step_profile.py; one process per line)"
   for D in 150 170; do
