@@ -125,7 +125,7 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     // round is waited for before its first MFMA, and the two waves of a SIMD fall into lockstep (each slows the other's
     // MFMA phase down until both reach the load phase together).  Here the loads are inline assembly, invisible to the
     // wait-count pass, and the waits are explicit (vmcnt counts in order): at step j the set j % PF is waited for, and
-    // in the middle of the step's MFMAs — in-order issue: what follows an MFMA runs in its 32-cycle shadow — the set of
+    // between the step's MFMAs — in-order issue: what follows an MFMA runs in its 32-cycle shadow — the set of
     // step j - 1 is refilled for the unit PF - 1 steps ahead.  One wave keeps the matrix pipe busy by itself; the second
     // wave of the SIMD covers what is left.  (Staging the operands through LDS by DMA, global_load ... lds, with the same
     // explicit waits was measured too: 27.6 us instead of 24.9 for the plain register ring at B = 4096 — six DMA
@@ -140,16 +140,24 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     const char* PA = reinterpret_cast<const char*>(P.A);
     const char* PB0 = reinterpret_cast<const char*>(P.B0);
     const char* PB1 = reinterpret_cast<const char*>(P.B1) - nsplit * ldb * 4;  // row r >= nsplit: PB1 + r ldb
-    auto load = [&](Ops& o, long long u) {  // unit u (4 rows) -> register set
+    // the four loads of unit u (4 rows) into a register set, one at a time: piece 0, 1 = A columns 0..63, 64..127,
+    // 2 = the last A group, 3 = B
+    auto load1 = [&](Ops& o, long long u, int piece) {
         const long long row = u << 2;
         const char* ab = PA + row * lda * 4;
         const char* bb = (row < nsplit ? PB0 : PB1) + row * ldb * 4;
-        asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a0) : "v"(offA), "s"(ab) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(o.a1) : "v"(offA), "s"(ab) : "memory");
-        if constexpr (CL == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
-        else if constexpr (CL == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
-        else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
-        asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+        if (piece == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a0) : "v"(offA), "s"(ab) : "memory");
+        if (piece == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(o.a1) : "v"(offA), "s"(ab) : "memory");
+        if (piece == 2) {
+            if constexpr (CL == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
+            else if constexpr (CL == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
+        }
+        if (piece == 3) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+    };
+    auto load = [&](Ops& o, long long u) {
+#pragma unroll
+        for (int piece = 0; piece < 4; ++piece) load1(o, u, piece);
     };
     auto wait = [&](Ops& o) {  // every load older than the last PF - 2 units has landed: this set is valid
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(o.a0), "+v"(o.a1), "+v"(o.a2), "+v"(o.b) : "n"((PF - 2) * NLD) : "memory");
@@ -187,11 +195,19 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
                     Ops& o = ring[s];
                     wait(o);
                     const float b0 = nval ? o.b[0] : 0.f, b1 = nval ? o.b[1] : 0.f;
-                    mfmas(o, b0, b1, 0, 3);
-                    __builtin_amdgcn_sched_barrier(0);
-                    load(ring[(s + PF - 1) % PF], unit(u + s + PF - 1));  // the set of the previous step
-                    __builtin_amdgcn_sched_barrier(0);
-                    mfmas(o, b0, b1, 3, NB);
+                    // the set of the previous step is refilled one load at a time between groups of MFMAs (all four in one
+                    // place: 2-3 % slower)
+                    Ops& n = ring[(s + PF - 1) % PF];
+                    const long long un = unit(u + s + PF - 1);
+                    constexpr int cut[5] = {0, 2, 5, 7, 9};
+#pragma unroll
+                    for (int piece = 0; piece < 4; ++piece) {
+                        mfmas(o, b0, b1, cut[piece], cut[piece + 1]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        load1(n, un, piece);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+                    mfmas(o, b0, b1, cut[4], NB);
                     if (EXT) {
                         e0 += o.a0;
                         e1 += o.a1;
