@@ -662,6 +662,44 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
             train.train(nc, m, torch.device("cuda"), loader, mega, bad, None, 1, step_fn=step)
 
 
+@pytest.mark.parametrize("B", [130, 250, 1000, 2000])
+def test_device_resident_epoch_other_batch_sizes(hip_lib, tmp_path, B):
+    """The forms of train()'s device-resident epoch the main test does not reach: a batch size that is not a multiple of 4
+    (no packed records on the cursor path: one record copy per step instead), an epoch of exactly full batches (no ragged
+    tail), and an epoch shorter than one batch (only the tail).  Same parameters and log lines as the generic loop."""
+    import contextlib
+    import io
+    from neuralplda_amd import train
+    rng = np.random.default_rng(6)
+    mega, num_to_id, loader = _tiny_trial_set(tmp_path, rng, B)
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    nc.log_interval = 2
+
+    def run(fast):
+        m = model_from(p, nc, thetas=[-0.5, -0.3])
+        step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+        torch.manual_seed(13)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            if fast:
+                train.train(nc, m, torch.device("cuda"), loader, mega, num_to_id, None, 1, step_fn=step)
+            else:
+                class Plain(list):
+                    dataset = loader.dataset
+                train.train(nc, m, torch.device("cuda"), Plain(list(loader)), mega, num_to_id, None, 1, step_fn=step)
+        return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, out.getvalue(), step
+
+    sd_fast, log_fast, step_fast = run(True)
+    sd_gen, log_gen, _ = run(False)
+    n = len(loader.dataset)
+    assert step_fast.step_count[0].item() == (n + B - 1) // B
+    assert (step_fast._graph_rec is not None) == (B % 4 == 0 and n >= B)
+    assert log_fast == log_gen and log_fast.count("Train Epoch") >= 1
+    for k in sd_gen:
+        assert np.array_equal(sd_fast[k], sd_gen[k]), k
+
+
 def test_validate_device_resident_pass_equals_the_generic_loop(hip_lib, tmp_path):
     """validate() over the vectorised loader gathers from the resident table on the device; scores, metrics, thresholds
     written back and the printed report must equal the generic loop's (same batches -> same forward launches)."""
