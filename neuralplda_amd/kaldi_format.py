@@ -245,7 +245,7 @@ def _vec_at(buf, off):
         n = int(np.frombuffer(buf, dtype="<i4", count=1, offset=off + 6)[0])
         dt = "<f4" if tok == b"FV " else "<f8"
         return np.frombuffer(buf, dtype=dt, count=n, offset=off + 10)
-    end = bytes(buf[off:off + 1 << 16]).find(b"]")
+    end = bytes(buf[off:off + (1 << 16)]).find(b"]")
     return _read_text_vector_body(io.BytesIO(bytes(buf[off:off + end + 1])))
 
 

@@ -349,6 +349,18 @@ class NeuralPlda(nn.Module):
         return (self.centering_and_LDA.weight, self.centering_and_LDA.bias, self.centering_and_wccn_plda.weight,
                 self.centering_and_wccn_plda.bias, self.P_sqrt, self.Q)
 
+    def invalidate_packed(self):
+        """Drop the cached MFMA-fragment image of the parameters.  The cache (`_packed_for`) is keyed on the parameters'
+        autograd version counters, which every in-place op, optimizer step and load_state_dict bumps — but a write
+        through `p.data` (`p.data.copy_(w)`, an EMA swap) or by a foreign captured graph does not.  Call this after such
+        a write; `train()` / `eval()` mode switches call it too, so the usual train -> eval -> score sequence is safe
+        whatever touched the weights in between."""
+        self.__dict__["_pack_cache"] = {}
+
+    def train(self, mode=True):
+        self.invalidate_packed()
+        return super(NeuralPlda, self).train(mode)
+
     def extract_plda_embeddings(self, x):
         """utils/models.py:366-370 -> (B, D2)."""
         x = x.reshape(-1, self.centering_and_LDA.in_features) if x.dim() != 2 else x

@@ -134,6 +134,9 @@ class TrialLoader(DataLoader):
     def _pack_records(self, n, e1, e2, el, device):
         """One contiguous record per full batch — [rows1 (int64) | rows2 (int64) | labels (float32)], back to back."""
         bs = self.batch_size
+        if bs % 2:
+            # record k starts at 20 * bs * k bytes: with an odd batch size every other record's int64 fields are misaligned
+            raise ValueError("packed batch records need an even batch_size (use device_batches(pack=False))")
         nb = n // bs
         rec = torch.empty((nb, 20 * bs), dtype=torch.uint8, device=device)
         if nb:
@@ -160,6 +163,12 @@ class TrialLoader(DataLoader):
         pack=True also yields, per full batch, the batch as one contiguous uint8 record (None for a last partial batch)."""
         n, e1, e2, el = self._device_epoch_arrays(device, num_to_row)
         bs = self.batch_size
+        if pack and bs % 2:
+            pack = None  # no aligned record layout for an odd batch size: the consumer gets record=None and copies the views
+        if pack is None:
+            for lo in range(0, n, bs):
+                yield e1[lo:lo + bs], e2[lo:lo + bs], el[lo:lo + bs], None
+            return
         if pack:
             # a consumer with static input buffers (FusedTrainStep.step_rows) stages a batch with ONE device copy instead of three
             rec = self._pack_records(n, e1, e2, el, device)

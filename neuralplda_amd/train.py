@@ -45,27 +45,35 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
             and not train_loader.drop_last)
     if fast:
         table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
-        if step_fn.batch_size == train_loader.batch_size:
+        bs = train_loader.batch_size
+        same = step_fn.batch_size == bs
+        # decide the path BEFORE building anything: packed records are only made when something will consume them
+        if same and step_fn.cursor_ok(table):
             # the whole epoch as packed records on the device; the captured step walks them through a device-side cursor
             # (no copy and no host write per step), the ragged last batch takes the eager step
             records, tail = train_loader.device_epoch(device, row_map)
-            if step_fn.records_ok(table, records):
-                nb, bs = records.shape[0], train_loader.batch_size
-                if nb:
-                    step_fn.begin_epoch(table, records)
-                for batch_idx in range(nb):
-                    step_fn.step_record()
-                    if batch_idx % nc.log_interval == 0:
-                        _log_train(nc, epoch, batch_idx, bs, train_loader, step_fn.pop_loss_mean())
-                if tail is not None:
-                    step_fn.step_rows(table, *tail)
-                    if nb % nc.log_interval == 0:
-                        _log_train(nc, epoch, nb, len(tail[0]), train_loader, step_fn.pop_loss_mean())
-                return
-            batches = _record_batches(records, tail, train_loader.batch_size)
-        else:
+            if not step_fn.records_ok(table, records):
+                raise RuntimeError("device_epoch records do not fit the step that asked for them")
+            nb = records.shape[0]
+            if nb:
+                step_fn.begin_epoch(table, records)
+            for batch_idx in range(nb):
+                step_fn.step_record()
+                if batch_idx % nc.log_interval == 0:
+                    _log_train(nc, epoch, batch_idx, bs, train_loader, step_fn.pop_loss_mean())
+            if tail is not None:
+                step_fn.step_rows(table, *tail)
+                if nb % nc.log_interval == 0:
+                    _log_train(nc, epoch, nb, len(tail[0]), train_loader, step_fn.pop_loss_mean())
+            return
+        # graph replay from static index buffers: one record copy per step instead of three (records need an even batch
+        # size: int64 fields at 20 * bs * k bytes); the eager step gathers from the views and never looks at a record
+        pack = same and step_fn.use_graph and bs % 2 == 0
+        if pack:
             batches = ((r1, r2, t, None, rec)
                        for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
+        else:
+            batches = ((r1, r2, t, None, None) for r1, r2, t in train_loader.device_batches(device, row_map))
     else:
         batches = ((None, None, t, d1, d2) for d1, d2, t in train_loader)
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
@@ -92,16 +100,6 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
         if batch_idx % nc.log_interval == 0:
             _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean() if fused else losses)
             losses = []
-
-
-def _record_batches(records, tail, bs):
-    """(rows1, rows2, labels, None, record) per batch of a device_epoch, for the step_rows form of the loop."""
-    for k in range(records.shape[0]):
-        rec = records[k]
-        yield (rec[:8 * bs].view(torch.int64), rec[8 * bs:16 * bs].view(torch.int64), rec[16 * bs:].view(torch.float32),
-               None, rec)
-    if tail is not None:
-        yield tail[0], tail[1], tail[2], None, None
 
 
 def _device_table(mega_xvec_dict, num_to_id_dict, device):
@@ -227,6 +225,10 @@ class GraphedTrainStep:
         self.x2.copy_(x2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self._graph.replay()
+        # a replay rewrites the parameters on the device without touching any Python-side version counter, and the
+        # model's packed-image cache (models._packed_for) is keyed on exactly those counters: bump them, or the next
+        # forward() / validate() would score with the image of the weights from before the replay
+        torch.autograd.graph.increment_version(list(self.model.parameters()))
         return self._loss.clone()
 
 
@@ -448,12 +450,18 @@ class FusedTrainStep:
         return self._loss_rows
 
     # ---- a device-resident epoch: the batches as packed records, consumed through a device-side cursor ----------------
-    def records_ok(self, table, records):
-        """True if step_record can run `records` ((nb, 20 B) uint8: TrialLoader.device_epoch) against `table`."""
+    def cursor_ok(self, table):
+        """True if this step can walk an epoch of packed records on `table`'s device (begin_epoch / step_record): the
+        one-call graph-replayed step, 4 | B <= 16384, 16 | D0.  Knowable before any record is built."""
         B = self.batch_size
         return (self._one_call and self.use_graph and B is not None and 0 < B <= 16384 and B % 4 == 0
-                and self.dims[0] % 16 == 0 and records is not None and records.dim() == 2 and records.shape[1] == 20 * B
-                and records.dtype == torch.uint8 and records.is_contiguous() and records.device == table.device)
+                and self.dims[0] % 16 == 0 and table.device == self.dev)
+
+    def records_ok(self, table, records):
+        """True if step_record can run `records` ((nb, 20 B) uint8: TrialLoader.device_epoch) against `table`."""
+        return (self.cursor_ok(table) and records is not None and records.dim() == 2
+                and records.shape[1] == 20 * self.batch_size and records.dtype == torch.uint8
+                and records.is_contiguous() and records.device == table.device)
 
     def begin_epoch(self, table, records):
         """Point the step at an epoch of packed batch records ([rows1 | rows2 | labels] each, back to back on the device).

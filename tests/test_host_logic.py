@@ -361,3 +361,40 @@ def test_device_batches_packed_records():
     torch.manual_seed(5)
     full, none = svl.TrialLoader(ds, batch_size=100, shuffle=True, collate_fn=ds.collate).device_epoch("cpu", row_map)
     assert full.shape == (10, 2000) and none is None
+
+
+def test_odd_batch_size_has_no_packed_records():
+    """Record k of an epoch starts at 20 * bs * k bytes: an odd batch size cannot hold aligned int64 fields.
+    device_batches(pack=True) then yields the same batches with record None (the consumer copies the three views);
+    device_epoch refuses with a clear error instead of a stride RuntimeError from deep inside torch."""
+    from neuralplda_amd import sv_trials_loaders as svl
+    n, bs = 50, 3
+    ds = svl.TrialIndexDataset(torch.arange(n), torch.arange(n) * 2 % n, (torch.arange(n) % 3 == 0).float())
+    torch.manual_seed(9)
+    plain = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate))
+    torch.manual_seed(9)
+    packed = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", None, pack=True))
+    assert len(packed) == len(plain)
+    for (d1, d2, t), (r1, r2, tl, rec) in zip(plain, packed):
+        assert torch.equal(r1, d1) and torch.equal(r2, d2) and torch.equal(tl, t) and rec is None
+    with pytest.raises(ValueError, match="even batch_size"):
+        svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_epoch("cpu", None)
+
+
+def test_mode_switch_drops_the_packed_image_cache():
+    """NeuralPlda.invalidate_packed / train() / eval(): a `.data` write does not bump a parameter's version counter, so the
+    mode switches drop the cached image (models._packed_for) unconditionally."""
+    from neuralplda_amd import models
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 32, 16, 16
+        beta, alpha, device, loss = [99.0], 15.0, "cpu", "SoftCdet"
+
+    m = models.NeuralPlda(NC())
+    v0 = m.Q._version
+    m.Q.data.mul_(2.0)
+    assert m.Q._version == v0  # the hazard: invisible to a version-keyed cache
+    for switch in (m.eval, m.train, m.invalidate_packed):
+        m._pack_cache["key"] = "stale"
+        switch()
+        assert m._pack_cache == {}

@@ -342,6 +342,38 @@ def test_graphed_step_matches_eager(hip_lib):
         np.testing.assert_allclose(pg[k], pe[k], rtol=1e-4, atol=1e-6, err_msg=k)
 
 
+def test_forward_after_graph_replay_scores_with_the_new_weights(hip_lib):
+    """A graph replay rewrites the parameters without Python seeing it; the model's packed-image cache must notice
+    (GraphedTrainStep bumps the version counters): replay -> forward -> replay -> forward, each forward equal to an
+    eager model stepped the same way."""
+    from neuralplda_amd import train
+    rng = np.random.default_rng(22)
+    p = rand_params(rng, 512, 150, 150)
+    B = 256
+    xs = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    v1 = torch.from_numpy(rng.standard_normal((300, 512)).astype(np.float32)).cuda()
+    v2 = torch.from_numpy(rng.standard_normal((300, 512)).astype(np.float32)).cuda()
+    mg = model_from(p, NC(512, 150, 150), thetas=[-0.5, -0.3])
+    me = model_from(p, NC(512, 150, 150), thetas=[-0.5, -0.3])
+    og = train.make_optimizer(mg, 1e-2, capturable=True)
+    oe = train.make_optimizer(me, 1e-2, capturable=False)
+    step = train.GraphedTrainStep(mg, og, B)
+    with torch.no_grad():
+        s_prev = mg(v1, v2).clone()  # fills the cache with the initial image
+    for x1, x2, t in xs:
+        step(x1, x2, t)
+        oe.zero_grad()
+        me.loss(me(x1, x2), t).backward()
+        oe.step()
+        with torch.no_grad():
+            sg, se = mg(v1, v2), me(v1, v2)
+        assert (sg - s_prev).abs().max().item() > 1e-4, "forward after a replay returned the previous weights' scores"
+        np.testing.assert_allclose(sg.cpu().numpy(), se.cpu().numpy(), rtol=1e-4, atol=2e-5)
+        s_prev = sg.clone()
+
+
 @pytest.mark.parametrize("graph", [False, True])
 @pytest.mark.parametrize("lossname", ["SoftCdet", "crossentropy"])
 def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
@@ -662,10 +694,11 @@ def test_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
             train.train(nc, m, torch.device("cuda"), loader, mega, bad, None, 1, step_fn=step)
 
 
-@pytest.mark.parametrize("B", [130, 250, 1000, 2000])
+@pytest.mark.parametrize("B", [129, 130, 131, 250, 1000, 2000])
 def test_device_resident_epoch_other_batch_sizes(hip_lib, tmp_path, B):
     """The forms of train()'s device-resident epoch the main test does not reach: a batch size that is not a multiple of 4
-    (no packed records on the cursor path: one record copy per step instead), an epoch of exactly full batches (no ragged
+    (no packed records on the cursor path: one record copy per step instead), an ODD batch size (no packed record at all: three
+    index copies per step), an epoch of exactly full batches (no ragged
     tail), and an epoch shorter than one batch (only the tail).  Same parameters and log lines as the generic loop."""
     import contextlib
     import io
