@@ -40,6 +40,9 @@ typedef void* nplda_stream_t;
 int nplda_abi_version(void);
 /* Largest layer1/layer2 dimension the compiled MFMA kernels accept (padded to 16). */
 int nplda_max_dim(void);
+/* Digest of the sources this library was built from (sha256 of csrc/ and this header, first 16 hex digits; "unknown" if
+ * it was not built by neuralplda_amd/build.py).  Static storage. */
+const char* nplda_build_id(void);
 /* Human-readable text for a return code (host string, static storage). */
 const char* nplda_strerror(int code);
 
@@ -63,6 +66,11 @@ int nplda_pack_params_f32(const float* W1, const float* b1, const float* W2, con
 int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t ldx,
                           const void* packed, int D0, int D1, int D2, float* s,
                           nplda_stream_t stream);
+
+/* Name of the kernel nplda_score_pairs_f32 launches for a batch of B pairs of a D0 -> D1 -> D2 model on the current
+ * device (the batch decides between the small-batch, the balanced-tile and the streaming schedule); "" for B <= 0 or an
+ * unsupported model.  Reporting only (bench.py labels its roofline object with it); static storage. */
+const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2);
 
 /* NeuralPlda.extract_plda_embeddings(x) (utils/models.py:366-370) for N rows, plus the per-row
  * self term q[n] = sum_d Q_d z_nd^2 used by the indexed scorer.  z: (N, ldz) with

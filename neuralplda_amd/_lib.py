@@ -20,6 +20,8 @@ SIGNATURES = {
     "nplda_abi_version": (_c_int, []),
     "nplda_max_dim": (_c_int, []),
     "nplda_strerror": (ctypes.c_char_p, [_c_int]),
+    "nplda_build_id": (ctypes.c_char_p, []),
+    "nplda_score_pairs_kernel_name": (ctypes.c_char_p, [_c_i64, _c_int, _c_int, _c_int]),
     "nplda_padded_dim": (_c_int, [_c_int, _c_int]),
     "nplda_packed_bytes": (_c_sz, [_c_int, _c_int, _c_int]),
     "nplda_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int] * 3 + [_c_vp, _c_sz, _c_vp]),
@@ -160,6 +162,18 @@ def load():
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def build_info():
+    """{abi_version, csrc_sha (what the loaded library was built from), tree_sha (the sources next to it, None if absent),
+    stale}: a library that travelled to a box without hipcc may be older than the tree it sits in."""
+    from . import build as nbuild
+    lib = load()
+    sha = lib.nplda_build_id()
+    sha = sha.decode() if sha else "unknown"
+    tree = nbuild.source_sha()
+    return {"abi_version": int(lib.nplda_abi_version()), "csrc_sha": sha, "tree_sha": tree,
+            "stale": bool(tree is not None and tree != sha)}
 
 
 def check(code, what):

@@ -5,6 +5,7 @@ pybind — it is bound from Python with ctypes (neuralplda_amd/_lib.py).  hipcc 
 for gfx950 without a GPU, so this runs in the CPU-only build container too.
 """
 import glob
+import hashlib
 import os
 import shutil
 import subprocess
@@ -28,6 +29,21 @@ def sources():
     return sorted(glob.glob(os.path.join(CSRC, "*.hip"))) + sorted(glob.glob(os.path.join(CSRC, "*.cpp")))
 
 
+def source_sha():
+    """sha256 over csrc/* and include/nplda_hip.h (names and contents, sorted), first 16 hex digits; None without sources."""
+    files = sorted(glob.glob(os.path.join(CSRC, "*")) + glob.glob(os.path.join(PKG_DIR, "..", "include", "*.h")))
+    files = [f for f in files if os.path.isfile(f)]
+    if not files:
+        return None
+    h = hashlib.sha256()
+    for f in files:
+        h.update(os.path.basename(f).encode() + b"\0")
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+        h.update(b"\0")
+    return h.hexdigest()[:16]
+
+
 def _stale(out, deps):
     if not os.path.exists(out):
         return True
@@ -44,11 +60,23 @@ def build(force=False, verbose=False):
     os.makedirs(objdir, exist_ok=True)
     objs = []
     procs = []
+    sha = source_sha() or "unknown"
     for src in srcs:
         obj = os.path.join(objdir, os.path.splitext(os.path.basename(src))[0] + ".o")
         objs.append(obj)
-        if force or _stale(obj, [src] + hdrs):
+        is_id = os.path.basename(src) == "nplda_build_id.cpp"
+        if is_id:  # rebuilt whenever the digest of the sources changes
+            stamp = os.path.join(objdir, "build_id.txt")
+            have = open(stamp).read().strip() if os.path.exists(stamp) else ""
+            need = have != sha or not os.path.exists(obj)
+        else:
+            need = _stale(obj, [src] + hdrs)
+        if force or need:
             cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            if is_id:
+                cmd.insert(1, f'-DNPLDA_SRC_SHA="{sha}"')
+                with open(stamp, "w") as fh:
+                    fh.write(sha)
             if verbose:
                 print(" ".join(cmd), file=sys.stderr)
             procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))

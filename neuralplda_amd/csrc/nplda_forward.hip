@@ -55,6 +55,11 @@ int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t l
     return launch_fwd<MODE_PAIR>(a, L, (hipStream_t)stream);
 }
 
+const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2) {
+    if (B <= 0 || check_model(D0, D1, D2) != NPLDA_OK) return "";
+    return pair_kernel_name(B, nplda_layout(D0, D1, D2));
+}
+
 int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1, int D2,
                     float* z, int64_t ldz, float* q, nplda_stream_t stream) {
     if (N < 0) return NPLDA_EINVAL;

@@ -5,6 +5,7 @@
 #include "nplda_fwd_v2.h"
 #include "nplda_fwd_v3.h"
 #include "nplda_fwd_v5.h"
+#include "nplda_fwd_mid.h"
 
 namespace nplda {
 
@@ -113,8 +114,31 @@ static inline int launch_fwd_small(FwdArgs a, const NpldaLayout& L, hipStream_t 
     return nplda_launch_status();
 }
 
+// pair scoring between the regimes (nplda_fwd_mid.h): balanced contiguous tile ranges, one block per CU
+static inline int mid_cus() {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    return cus;
+}
+static inline int launch_fwd_mid(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    const long long n16 = (a.n + 15) / 16;
+    const int cus = mid_cus();
+    const long long grid = n16 < cus ? n16 : cus;
+    const long long c = (n16 + grid - 1) / grid;
+    const long long r = n16 - grid * (c - 1);
+    if (c > 0x7fffffffLL) return NPLDA_EINVAL;
+    switch (L.NB) {
+        case 10: hipLaunchKernelGGL((nplda_fwd_mid_kernel<10>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
+        case 11: hipLaunchKernelGGL((nplda_fwd_mid_kernel<11>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+    return nplda_launch_status();
+}
+
 template <int MODE>
-static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
     const long long units = (MODE == MODE_EMBED ? (a.n + 1) / 2 : a.n);
@@ -126,6 +150,50 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         return launch_fwd_v5(a, L, st);
     }
     return launch_fwd_v2<MODE>(a, L, st);
+}
+
+// Which pair-scoring kernel a batch takes.  Three regimes (profiles/r03*_size_sweep.txt):
+//  * one 16-pair tile per CU or less (<= 16 * CUs pairs): the feature-split small-batch kernel;
+//  * the streaming kernels (v3 / v5) move 128-pair tiles through a persistent grid: ROUNDS = ceil(tiles128 / CUs) passes
+//    of ~100 us (NB = 10) / ~115 us (NB = 11) each, whatever share of the last pass is filled;
+//  * the mid kernel (nplda_fwd_mid.h; 512-d x-vectors, NB = 10 / 11) balances 16-pair tiles to within one tile per CU at
+//    ~13.3 / 16.8 us per tile — 6 to 25 % more per pair than a FULL streaming round, far less than a part-filled one.
+// The two are compared by these measured costs (tenths of a microsecond; both scale with the shader clock alike).
+enum { FWD_SMALL = 0, FWD_MID = 1, FWD_STREAM = 2 };
+static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus) {
+    if (n <= 16LL * cus) return FWD_SMALL;
+    const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
+    if (!mid_ok) return n <= 64LL * cus ? FWD_SMALL : FWD_STREAM;
+    const long long c = ((n + 15) / 16 + cus - 1) / cus;
+    const long long rounds = ((n + 127) / 128 + cus - 1) / cus;
+    const long long t_mid = 40 + c * (L.NB == 10 ? 133 : 168);
+    const long long t_stream = 50 + rounds * (L.NB == 10 ? 1000 : 1150);
+    return t_mid < t_stream ? FWD_MID : FWD_STREAM;
+}
+
+template <int MODE>
+static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    if constexpr (MODE == MODE_PAIR) {
+        const int cus = mid_cus();
+        const int k = pair_kernel_choice(a.n, L, cus);
+        a.D0 = L.D0; a.KS1 = L.KS1;
+        a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+        if (k == FWD_MID) return launch_fwd_mid(a, L, st);
+        if (k == FWD_SMALL) return launch_fwd_small<MODE>(a, L, st);
+        if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
+        return launch_fwd_v5(a, L, st);
+    }
+    return launch_fwd_old<MODE>(a, L, st);
+}
+
+// name of the kernel nplda_score_pairs_f32 launches for a batch of n pairs (bench.py labels its roofline object with it)
+static inline const char* pair_kernel_name(long long n, const NpldaLayout& L) {
+    switch (pair_kernel_choice(n, L, mid_cus())) {
+        case FWD_SMALL: return "nplda_fwd_small_kernel (4 waves share a 16-pair tile, feature-split)";
+        case FWD_MID: return "nplda_fwd_mid_kernel (balanced 16-pair tiles, K-split layer 1, groups of 2 tiles)";
+        default: return L.NB <= 10 ? "nplda_fwd_v3_kernel (persistent, 8 waves x 16 pairs, weights through LDS)"
+                                   : "nplda_fwd_v5_kernel (persistent, LDS-DMA weight chunks, layer 2 by output groups)";
+    }
 }
 
 static inline int check_model(int D0, int D1, int D2) {

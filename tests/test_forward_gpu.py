@@ -120,12 +120,77 @@ def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
     ref = orc.forward(x1, x2, p, np.float64)
     assert np.all(np.abs(s - ref) <= ATOL + RTOL * np.abs(ref)), np.abs(s - ref).max()
     st, saved = ops.forward_train(X1, X2, packed)
-    assert torch.equal(st.cpu(), torch.from_numpy(s))
+    # the train-mode forward runs the v2 schedule; pair scoring of this size may run the balanced-tile kernel
+    # (nplda_fwd_mid.h: 512-d, D = 145..176), whose layer-1 K sum associates differently: same bits only where the
+    # schedules share the association, the fp32 tolerance everywhere
+    if D0 == 512 and 145 <= D1 <= 176 and D1 == D2:
+        assert np.all(np.abs(st.cpu().numpy() - s) <= ATOL + RTOL * np.abs(ref))
+    else:
+        assert torch.equal(st.cpu(), torch.from_numpy(s))
     z, q = ops.embed(torch.cat([X1, X2]), packed)
     zr = orc.extract_plda_embeddings(np.concatenate([x1, x2]), p, np.float64)
     np.testing.assert_allclose(z.cpu().numpy()[:, :D2], zr, atol=2e-6, rtol=1e-5)
     assert torch.equal(saved[4][:, :D2].cpu(), z[:, :D2].cpu())          # train-mode z == embed-mode z, bit for bit
     np.testing.assert_allclose(q.cpu().numpy(), orc.self_term(zr, p, np.float64), atol=2e-6, rtol=1e-5)
+
+
+@pytest.mark.parametrize("D", [150, 160, 170])
+@pytest.mark.parametrize("B", [4097, 4112, 8192, 12289, 16384, 16385, 20480, 24577, 40000, 100001])
+def test_mid_regime_batches_match_oracle(hip_lib, D, B):
+    """The batch sizes between one 16-pair tile per CU and full streaming rounds — validate()'s 5 x batch_size = 20 480
+    pairs (xvector_NeuralPlda_pytorch.py:125), the 10 240-pair score-file chunks, any 8-way shard of a modest list — take
+    the balanced-tile kernel (nplda_fwd_mid.h): contiguous tile ranges per block, T = 2 groups with an odd T = 1 tail,
+    blocks with c and c - 1 tiles, a ragged last tile.  Every score against the fp64 oracle, determinism, and independence of
+    a pair's score from its position in the batch (to the last bits)."""
+    from neuralplda_amd import _lib, ops
+    rng = np.random.default_rng(31 * D + B)
+    p = rand_params(rng, 512, D, D)
+    x1 = rng.standard_normal((B, 512)).astype(np.float32)
+    x2 = rng.standard_normal((B, 512)).astype(np.float32)
+    packed = ops.pack_params(*to_dev(p))
+    X1, X2 = torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda()
+    s = ops.score_pairs(X1, X2, packed)
+    ref = orc.forward(x1, x2, p, np.float64)
+    got = s.cpu().numpy()
+    assert np.all(np.abs(got - ref) <= ATOL + RTOL * np.abs(ref)), np.abs(got - ref).max()
+    # deterministic (no atomics: the same batch gives the same bits), and a pair's score does not depend on where it sits
+    # in the batch beyond the association of the sums over features (which wave owns a left-over feature block follows
+    # the tile slot: last-bit differences, inside the tolerance; every tile slot of every wave is exercised)
+    assert torch.equal(ops.score_pairs(X1, X2, packed), s)
+    perm = torch.randperm(B, device="cuda", generator=torch.Generator(device="cuda").manual_seed(B))
+    sp = ops.score_pairs(X1[perm], X2[perm], packed).cpu().numpy()
+    assert np.all(np.abs(sp - ref[perm.cpu().numpy()]) <= ATOL + RTOL * np.abs(ref[perm.cpu().numpy()]))
+    assert np.abs(sp - got[perm.cpu().numpy()]).max() <= 4e-6 * max(1.0, np.abs(ref).max())
+    name = _lib.load().nplda_score_pairs_kernel_name(B, 512, D, D).decode()
+    assert name.startswith("nplda_fwd_") and "kernel" in name
+
+
+def test_no_cliff_between_the_forward_regimes(hip_lib):
+    """One pair more than a full set of tiles must not cost a whole extra streaming round: 16 385 pairs took 104 us against
+    72 us for 16 384 before the balanced-tile kernel (profiles/r02m_size_sweep.txt).  Loose bound (1.35x), on kernel time."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(5)
+    p = rand_params(rng, 512, 150, 150)
+    packed = ops.pack_params(*to_dev(p))
+    x1 = torch.randn(16385, 512, device="cuda")
+    x2 = torch.randn(16385, 512, device="cuda")
+
+    def t(n):
+        for _ in range(5):
+            ops.score_pairs(x1[:n], x2[:n], packed)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = 1e9
+        for _ in range(5):
+            e0.record()
+            for _ in range(20):
+                ops.score_pairs(x1[:n], x2[:n], packed)
+            e1.record()
+            torch.cuda.synchronize()
+            best = min(best, e0.elapsed_time(e1) / 20)
+        return best
+
+    t0, t1 = t(16384), t(16385)
+    assert t1 <= 1.35 * t0, (t0, t1)
 
 
 @pytest.mark.parametrize("D0,D,B", [(72, 40, 300), (72, 150, 20000 + 37), (512, 150, 70000), (100, 24, 5000)])
