@@ -7,6 +7,7 @@ tokens, `\\x04`+int32 sizes, little-endian payload) or Kaldi text (`[ ... ]`) â€
 installation is needed.  It is host-side file I/O only (SURVEY.md Â§8 f2).
 """
 import io
+import os
 import struct
 
 import numpy as np
@@ -236,6 +237,15 @@ def _split_rx(rx):
     return rx, None
 
 
+def _scp_file(f, scp_path):
+    """An archive named by an scp entry: as written (Kaldi resolves against the working directory), else â€” for a relative
+    name that is not there â€” next to the scp itself (an scp shipped in the same directory as its archive)."""
+    if os.path.isabs(f) or os.path.exists(f):
+        return f
+    alt = os.path.join(os.path.dirname(os.path.abspath(scp_path)), f)
+    return alt if os.path.exists(alt) else f
+
+
 def _vec_at(buf, off):
     """float32 view of the (binary or text) vector whose object starts at byte `off` of `buf`."""
     if bytes(buf[off:off + 2]) == b"\0B":
@@ -256,7 +266,7 @@ def read_vector_scp(path):
     for key, rx in read_scp(path):
         f, off = _split_rx(rx)
         if f not in maps:
-            maps[f] = np.memmap(f, dtype=np.uint8, mode="r")
+            maps[f] = np.memmap(_scp_file(f, path), dtype=np.uint8, mode="r")
         yield key, np.asarray(_vec_at(maps[f], off or 0), dtype=np.float32)
 
 
@@ -329,12 +339,12 @@ def load_vector_scp(path, out=None):
         f, off = _split_rx(rx)
         by_file.setdefault(f, []).append((i, off or 0))
     first_f, first_off = _split_rx(entries[0][1])
-    probe = np.memmap(first_f, dtype=np.uint8, mode="r")
+    probe = np.memmap(_scp_file(first_f, path), dtype=np.uint8, mode="r")
     dim = int(_vec_at(probe, first_off or 0).shape[0])
     mat = _out_buffer(out, len(entries), dim)
     m8 = mat.view(np.uint8).reshape(len(entries), 4 * dim)
     for f, lst in by_file.items():
-        buf = np.memmap(f, dtype=np.uint8, mode="r")
+        buf = np.memmap(_scp_file(f, path), dtype=np.uint8, mode="r")
         rows = np.asarray([i for i, _ in lst], dtype=np.int64)
         offs = np.asarray([o for _, o in lst], dtype=np.int64)
         hdr = buf[offs[:, None] + np.arange(10, dtype=np.int64)[None, :]]

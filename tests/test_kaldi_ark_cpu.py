@@ -76,3 +76,47 @@ def test_table_from_a_100k_vector_ark_replaces_the_mega_dict(tmp_path):
     kf.write_vector_ark(str(tmp_path / "dup.ark"), [keys[3]], M[10:11])
     tab3 = svl.XvectorTable.from_ark(a1, str(tmp_path / "dup.ark"))
     assert len(tab3) == half and np.array_equal(tab3[keys[3]], M[10])
+
+
+def _fixture_expected():
+    """The fixture's values recomputed from its closed formula (tests/golden/make_ark_fixture.py) — no reader involved."""
+    import struct
+    dim = 8
+    keys = ["id10001-utt_a", "id10001-utt_b", "sw_4021-B_0003", "x", "spk99-long.key-with.dots_and-dashes"]
+    special = {(1, 0): 0x80000000, (2, 3): 0x00000001, (3, 7): 0x7F7FFFFF, (4, 2): 0x3DFCD6EA}
+    bits = np.zeros((len(keys), dim), dtype=np.uint32)
+    for i in range(len(keys)):
+        for j in range(dim):
+            if (i, j) in special:
+                bits[i, j] = special[(i, j)]
+            else:
+                v = (i + 1) * 0.25 - j * 0.125 + (1 if (i + j) % 3 == 0 else -1) * 1e-3 * (i * dim + j)
+                bits[i, j] = struct.unpack("<I", struct.pack("<f", v))[0]
+    return keys, bits
+
+
+def test_archive_the_build_did_not_write():
+    """tests/golden/xvec_fixture.{ark,scp,txt.ark}: assembled byte by byte from Kaldi's documented layout with `struct`
+    alone (key, blank, \\0B, 'FV ', \\x04, int32 dim, little-endian floats; scp offsets at the \\0B marker) — the `FV ` path
+    meeting bytes from another producer than kaldi_format.write_vector_ark.  Every reader, bit for bit (negative zero, a
+    denormal and FLT_MAX included); the text archive to the last digit (repr round-trips float32 through float64)."""
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    ark, scp, txt = (os.path.join(here, "xvec_fixture" + e) for e in (".ark", ".scp", ".txt.ark"))
+    keys, bits = _fixture_expected()
+    raw = open(ark, "rb").read()
+    assert len(raw) == sum(len(k) + 1 + 10 + 32 for k in keys) and raw[:14] == b"id10001-utt_a " and raw[14:20] == b"\0BFV \x04"
+    for k, m in (kf.load_vector_ark(ark), kf.load_vector_scp(scp)):
+        assert k == keys and m.dtype == np.float32 and np.array_equal(m.view(np.uint32), bits)
+    for reader, path in ((kf.read_vector_ark, ark), (kf.read_vector_scp, scp)):
+        pairs = list(reader(path))
+        assert [k for k, _ in pairs] == keys
+        assert all(np.array_equal(np.asarray(v, np.float32).view(np.uint32), bits[i]) for i, (_, v) in enumerate(pairs))
+    kt, mt = kf.load_vector_ark(txt)
+    assert kt == keys and np.array_equal(mt.view(np.uint32), bits)
+    # scp offsets are the fixture's own: each points at the \\0B marker right after "<key> "
+    for (k, rx), key in zip(kf.read_scp(scp), keys):
+        name, _, off = rx.rpartition(":")
+        assert k == key and name == "xvec_fixture.ark" and raw[int(off):int(off) + 2] == b"\0B"
+        assert raw[int(off) - len(key) - 1:int(off)] == key.encode() + b" "
+    tab = svl.XvectorTable.from_scp(scp)
+    assert len(tab) == 5 and tab.dim == 8 and np.array_equal(tab.host.view(np.uint32), bits)

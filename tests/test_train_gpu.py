@@ -872,3 +872,40 @@ def test_reference_driver_train_and_validate_g12(hip_lib, tmp_path):
         minc1, th1 = train.validate(Conf, m, "cuda", mega, num_to_id, valid[str(g["val_key"])])
         assert abs(float(minc1) - float(g["minc1"])) <= 1e-3  # the north-star minDCF tolerance
         np.testing.assert_allclose([float(th1[99.0]), float(th1[199.0])], g["th1"], atol=2e-3)
+
+
+def test_table_from_a_100k_vector_archive_trains_on_the_device(hip_lib, tmp_path):
+    """SURVEY f2 end to end on the GPU box: 100 000 x-vectors in a binary Kaldi archive (the bytes assembled here with
+    struct: key, blank, \\0B 'FV ' \\x04 int32 dim, floats — not by kaldi_format's writer) -> XvectorTable.from_ark (one pinned
+    host matrix) -> .on('cuda') -> one FusedTrainStep.step_rows on pairs named by table rows.  The device copy must hold
+    the archive's bits, and the step must equal the same step fed gathered (B, 512) tensors."""
+    import struct
+    from neuralplda_amd import ops, train
+    from neuralplda_amd import sv_trials_loaders as svl
+    rng = np.random.default_rng(17)
+    N, D0, D, B = 100000, 512, 150, 2048
+    M = rng.standard_normal((N, D0), dtype=np.float32)
+    path = str(tmp_path / "xvector.1.ark")
+    hdr = b"\0BFV \x04" + struct.pack("<i", D0)
+    with open(path, "wb") as fh:
+        for lo in range(0, N, 10000):
+            fh.write(b"".join(b"utt%07d " % i + hdr + M[i].tobytes() for i in range(lo, min(N, lo + 10000))))
+    tab = svl.XvectorTable.from_ark(path)
+    assert len(tab) == N and tab.dim == D0 and tab.ids[12345] == "utt0012345"
+    dev = tab.on("cuda")
+    assert dev.is_cuda and dev.shape == (N, D0)
+    torch.cuda.synchronize()
+    assert torch.equal(dev[::997].cpu(), torch.from_numpy(M[::997])) and torch.equal(dev[-1].cpu(), torch.from_numpy(M[-1]))
+    p = rand_params(rng, D0, D, D)
+    nc = NC(D0, D, D)
+    m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    r1 = torch.from_numpy(rng.integers(0, N, B)).cuda()
+    r2 = torch.from_numpy(rng.integers(0, N, B)).cuda()
+    t = torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()
+    la = sa.step_rows(dev, r1, r2, t)
+    lb = sb(ops.gather_rows(dev, r1), ops.gather_rows(dev, r2), t)
+    assert la.item() == lb.item()
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        assert torch.equal(a, b), k
