@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """bench.py — throughput of the NPLDA hot path on MI355X (BASELINE.json metric: scored trial-pairs/s).
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3] [--scaling weak|strong] [--dim D]
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--workload cfg1|cfg2|cfg3|cfg5] [--scaling weak|strong] [--dim D]
+                    [--emulate-rank r/N]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
 
 Workloads (BASELINE.json `configs`):
@@ -16,7 +17,15 @@ Workloads (BASELINE.json `configs`):
         embed this rank's row shard and the cohort -> cohort score matrix + per-row statistics (nplda_cohort_stats_f32)
         -> the ONE collective of the path, an all-gather of the (R, 4) fp64 statistics over RCCL -> normalise this rank's
         trial shard (nplda_asnorm_apply_f64).  The collective is timed separately (`config.allgather_ms`).
+  cfg5  the head's share of the end-to-end fine-tune (BASELINE configs[4]; the x-vector extractor itself is out of scope):
+        bf16 x-vectors that carry a graph (stand-ins for the extractor's output) -> NeuralPlda.forward -> SoftCdet ->
+        backward incl. dL/dx1, dL/dx2 for the extractor -> Adam on the head; one step = one 4096-pair minibatch.
 `value` = units all ranks processed / max-over-ranks wall time of exactly K steps between barrier + synchronize pairs.
+
+--emulate-rank r/N (one process, one GPU): run exactly rank r's share of an N-rank job — its shard of the trial list /
+rows / minibatch, every replicated part included, the collectives replaced by their byte counts — and report that
+rank's time.  This is a SINGLE-GPU SHARD TIMING (the compute side of a scaling curve), never a scaling measurement: the
+line says so (`config.emulated_rank`, `n_gpus` 1).
 
 --gpus N without a torchrun environment re-launches this script under torch.distributed.run with N ranks (one per
 GPU, RCCL); it exits non-zero if the box has fewer than N devices.  NPLDA_BENCH_BACKEND=gloo is a plumbing dry run on a
@@ -281,7 +290,7 @@ def run_cfg1(args, ctx):
     # Untimed extra pass: the shader clock the chip holds under this kernel.  A one-wave probe (nplda_clock_probe) sits
     # on a side stream next to 12 more launches and compares the shader-cycle counter with the constant 100 MHz counter.
     sclk_mhz = None
-    if rank == 0 and not args.no_clock_probe:
+    if rank == 0 and not args.no_clock_probe and not ctx.emulated:
         try:
             lib = _lib.load()
             ticks = torch.zeros(2, dtype=torch.int64, device=dev)
@@ -303,7 +312,7 @@ def run_cfg1(args, ctx):
             sys.stderr.write(f"clock probe skipped: {e}\n")
 
     alt = alt170 = None
-    if rank == 0 and args.precision == "fp32" and not args.no_alt:
+    if rank == 0 and args.precision == "fp32" and not args.no_alt and not ctx.emulated:
         # the opt-in split-bf16 scoring kernel on the same inputs (reported beside, never as `value`)
         pk3 = ops.pack_params(*params, precision="bf16x3")
         ms3, s3 = kernel_ms_of(lambda: ops.score_pairs(x1, x2, pk3))
@@ -326,14 +335,14 @@ def run_cfg1(args, ctx):
                 pass
             alt170 = {"bound": "mfma", "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                       "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": t170,
-                      "kernel": "nplda_fwd_v5_kernel<11, 8 waves, 2 k16-steps/barrier, groups of 4> (persistent)", "kernel_ms": ms170,
+                      "kernel": _lib.load().nplda_score_pairs_kernel_name(B, D0, 170, 170).decode(), "kernel_ms": ms170,
                       "pairs_per_s_1gpu": B / (ms170 * 1e-3), "flop_per_pair_algorithmic": f170,
                       "workload": f"{B} trial pairs, 512->170->170 (conf/voices_config.cfg:14-16), scoring only",
                       "checksum_finite": bool(torch.isfinite(s170).all().item())}
 
-    if rank != 0:
+    if rank != 0 and not ctx.emulated:
         return None
-    total_pairs = (args.pairs if args.scaling == "strong" else B * world) * args.steps
+    total_pairs = (B if ctx.emulated else (args.pairs if args.scaling == "strong" else B * world)) * args.steps
     flops = algorithmic_flops_per_pair(D0, D, D)
     achieved = B * flops / (kern_ms * 1e-3) / 1e12
     traffic = None
@@ -364,7 +373,7 @@ def run_cfg1(args, ctx):
                    "backend": ctx.backend if world > 1 else "single process"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": traffic,
-                     "kernel": "nplda_fwd_v3_kernel<NB, PAIR, 8 waves, 2 k16-steps/barrier> (persistent)", "kernel_ms": kern_ms,
+                     "kernel": _lib.load().nplda_score_pairs_kernel_name(B, D0, D, D).decode(), "kernel_ms": kern_ms,
                      "flop_per_pair_algorithmic": flops,
                      "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
     }
@@ -408,6 +417,14 @@ def run_cfg3(args, ctx):
     ag_out = torch.empty((world * chunk, 4), dtype=torch.float64, device=dev)
     ev = {k: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for k in ("stats", "ag", "apply")}
     acc = {"stats": 0.0, "ag": 0.0, "apply": 0.0, "n": 0}
+    emu_stats = None
+    if ctx.emulated:
+        # the other ranks' rows of the (R, 4) statistics, computed once outside the timed region: what the all-gather
+        # would have delivered (its payload is counted, not moved)
+        zc0, qc0 = ops.embed(x_coh, packed)
+        zr0, qr0 = ops.embed(x_rows, packed)
+        emu_stats = ops.cohort_stats(zr0, qr0, zc0, qc0, packed, topn=topn).clone()
+        del zc0, qc0, zr0, qr0
 
     def step():
         zc, qc = ops.embed(x_coh, packed)
@@ -425,6 +442,9 @@ def run_cfg3(args, ctx):
                 o = torch.empty(ag_out.shape, dtype=torch.float64)
                 ctx.dist.all_gather_into_tensor(o, ag_in.cpu())
                 stats = o[:R].to(dev)
+        elif emu_stats is not None:
+            emu_stats[rlo:rhi] = local
+            stats = emu_stats
         else:
             stats = local
         ev["ag"][1].record()
@@ -443,7 +463,7 @@ def run_cfg3(args, ctx):
         acc["n"] += 1
     if not torch.isfinite(out).all():
         raise SystemExit("non-finite normalised scores")
-    if rank != 0:
+    if rank != 0 and not ctx.emulated:
         return None
     stats_ms, ag_ms, apply_ms = (acc[k] / acc["n"] for k in ("stats", "ag", "apply"))
     rows_local = rhi - rlo
@@ -451,7 +471,7 @@ def run_cfg3(args, ctx):
     achieved = flops / (stats_ms * 1e-3) / 1e12
     return {
         "metric": "AS-normalised trials/sec (10k-utterance cohort, top-500)",
-        "value": T * args.steps / elapsed,
+        "value": (thi - tlo if ctx.emulated else T) * args.steps / elapsed,
         "unit": "trials/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -466,10 +486,11 @@ def run_cfg3(args, ctx):
                                f"lowest, 512->{D}->{D}; rows and trials sharded x{world}, one all-gather of (R, 4) fp64",
                    "cohort": M, "rows": R, "trials": T, "rows_per_gpu": rows_local, "trials_per_gpu": thi - tlo,
                    "parallelism": f"row shard + trial shard x{world}", "backend": ctx.backend if world > 1 else "single process",
-                   "cohort_scores_per_s": R * M * args.steps / elapsed, "stats_ms": stats_ms, "allgather_ms": ag_ms,
+                   "cohort_scores_per_s": (rows_local if ctx.emulated else R) * M * args.steps / elapsed, "stats_ms": stats_ms,
+                   "allgather_ms": ag_ms,
                    "allgather_bytes": int(world * chunk * 32), "apply_ms": apply_ms, "params": psrc},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"cohort_stats_D{D}_R{rows_local}_M{M}"),
                      "kernel": "nplda_cohort_stats_f32 (cohort score GEMM + per-row statistics), whole call",
                      "kernel_ms": stats_ms, "flop_per_score_algorithmic": 2 * D},
     }
@@ -497,14 +518,19 @@ def run_cfg2(args, ctx):
     with torch.no_grad():
         for q, v in zip(model._params(), params):
             q.copy_(v)
-    if world > 1:
+    if world > 1 and ctx.emulated:
+        # the data-parallel form of the step (separate launches around the two exchange points) with the exchanges left
+        # out: the loss sums stay this shard's (so the loss VALUE is not the global one), the compute is rank r's exactly
+        model._reduce_sums = lambda sums: sums
+        model._reduce_flat = lambda flat: flat
+    elif world > 1:
         ndist.make_data_parallel(model)
     gen = torch.Generator(device=dev).manual_seed(777)  # the same table on every rank
     N = args.table
     table = torch.empty(N, D0, device=dev)
     for r0 in range(0, N, 1 << 18):
         table[r0:r0 + (1 << 18)].normal_(generator=gen)
-    graph = ctx.backend == "nccl" or world == 1  # (the gloo dry run cannot capture its collectives)
+    graph = ctx.backend == "nccl" or world == 1 or ctx.emulated  # (the gloo dry run cannot capture its collectives)
     step_fn = train.FusedTrainStep(model, 1e-4, weight_decay=1e-5, batch_size=Bl, graph=graph)
     gen_r = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank its own shard of every minibatch
     # one rank: the epoch's batches as packed records on the device, walked by the captured step through its cursor
@@ -532,7 +558,7 @@ def run_cfg2(args, ctx):
     elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False)
     if not torch.isfinite(loss).all():
         raise SystemExit("non-finite training loss")
-    if rank != 0:
+    if rank != 0 and not ctx.emulated:
         return None
     # forward + weight gradients (the same two GEMMs) + the data gradient through layer 2; SURVEY.md section 8d: ~3x Regime A
     fwd = 2 * (2 * D0 * D + 2 * D * D) + 8 * D
@@ -540,7 +566,7 @@ def run_cfg2(args, ctx):
     achieved = Bl * flops / (step_ms * 1e-3) / 1e12
     return {
         "metric": "trained trial-pairs/sec (4096-pair minibatches, SoftCdet + backward + Adam)",
-        "value": Bg * args.steps / elapsed,
+        "value": (Bl if ctx.emulated else Bg) * args.steps / elapsed,
         "unit": "pairs/s",
         "n_gpus": world,
         "steps": args.steps,
@@ -556,13 +582,88 @@ def run_cfg2(args, ctx):
                    "global_batch": Bg, "pairs_per_gpu_per_step": Bl, "table_utterances": N, "params": psrc,
                    "parallelism": f"data parallel x{world}", "backend": ctx.backend if world > 1 else "single process",
                    "graph_replay": bool(graph), "final_loss": float(loss),
+                   "collective_bytes_per_step": ({"loss_sums_allreduce": 8 * 18, "flat_gradient_allreduce":
+                                                  4 * int(step_fn.m.numel() - len(step_fn.thetas))} if world > 1 else None),
                    "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32)"
                                  if by_cursor else "one 20 B-byte record copy per step (nplda_train_step_rows_f32)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"train_step_D{D}_B{Bl}"),
                      "kernel": ("nplda_train_step_records_f32" if by_cursor else "nplda_train_step_rows_f32") +
                                " (forward + loss + data gradients, weight-gradient slabs, update), whole step", "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
     }
+
+
+def _traffic(key):
+    """Per-launch HBM bytes recorded from the PMC passes (profiles/traffic.json), None if that shape was not measured."""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", "traffic.json"))).get(key)
+    except Exception:
+        return None
+
+
+def run_cfg5(args, ctx):
+    """BASELINE configs[4], the head's share: bf16 x-vectors carrying a graph (what a jointly trained extractor hands over,
+    utils/models.py:251-268) -> NeuralPlda.forward -> SoftCdet -> backward with dL/dx1, dL/dx2 -> Adam on the head.
+    The E-TDNN extractor itself is SURVEY section 2 item 4: out of scope; its output is synthetic here."""
+    from neuralplda_amd import models, train
+    dev, rank, world = ctx.dev, ctx.rank, ctx.world
+    if world > 1 and not ctx.emulated:
+        raise SystemExit("cfg5 is a one-GPU workload here (the data-parallel head step is cfg2's)")
+    D0, D, B = 512, args.dim, args.batch
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = D0, D, D
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, str(dev), "SoftCdet"
+
+    torch.manual_seed(0)
+    model = models.NeuralPlda(NC()).to(dev)
+    params, psrc = make_params(D, dev)
+    with torch.no_grad():
+        for q, v in zip(model._params(), params):
+            q.copy_(v)
+    gen = torch.Generator(device=dev).manual_seed(55)
+    nb = 8
+    xs = [(torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16), torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16),
+           (torch.rand(B, device=dev, generator=gen) < 0.1).float()) for _ in range(nb)]
+    step_fn = train.HeadStepWithInputGrads(model, 1e-4, weight_decay=1e-5, batch_size=B)
+    state = {"k": 0}
+
+    def step():
+        x1, x2, t = xs[state["k"] % nb]
+        state["k"] += 1
+        return step_fn(x1, x2, t)
+
+    elapsed, step_ms, out = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False)
+    loss, dx1, dx2 = out
+    if not (torch.isfinite(loss).all() and torch.isfinite(dx1.float()).all() and torch.isfinite(dx2.float()).all()):
+        raise SystemExit("non-finite loss / input gradient")
+    if rank != 0 and not ctx.emulated:
+        return None
+    fwd = 2 * (2 * D0 * D + 2 * D * D) + 8 * D
+    flops = 2 * fwd + 2 * (2 * D * D) + 2 * (2 * D0 * D)  # cfg2's step + the dx = du . W1 GEMM of both sides
+    achieved = B * flops / (step_ms * 1e-3) / 1e12
+    return {
+        "metric": "fine-tuned trial-pairs/sec through the NPLDA head (bf16 x-vectors in, dL/dx out, SoftCdet + Adam)",
+        "value": B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "bf16 x-vectors and dL/dx, f32 head arithmetic", "data": "synthetic",
+        "config": {"workload": f"cfg5 (head only): {B}-pair minibatches of bf16 512-d x-vectors with a graph, 512->{D}->{D}, "
+                               f"SoftCdet, backward incl. dL/dx, Adam(1e-4, wd 1e-5); extractor out of scope (SURVEY 2 #4)",
+                   "global_batch": B, "params": psrc, "step": step_fn.describe(), "final_loss": float(loss)},
+        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"head_step_dx_D{D}_B{B}"),
+                     "kernel": step_fn.describe(), "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
+    }
+
+
+def _compact(r):
+    """The fields of a --workload line that travel on the default line as alt_cfg2 / alt_cfg3 / alt_cfg5."""
+    keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline")}
+    keep["workload"] = r["config"]["workload"]
+    for k in ("stats_ms", "apply_ms", "allgather_bytes", "batch_feed", "step"):
+        if k in r["config"]:
+            keep[k] = r["config"][k]
+    return keep
 
 
 def main():
@@ -570,12 +671,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3"], default="cfg1")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg5"], default="cfg1")
+    ap.add_argument("--emulate-rank", default=None, metavar="r/N",
+                    help="one process runs exactly rank r's share of an N-rank job (collectives replaced by their byte "
+                         "counts): single-GPU shard timing, not a scaling measurement")
     ap.add_argument("--scaling", choices=["weak", "strong"], default="weak",
                     help="cfg1: weak = --pairs per GPU (default), strong = --pairs in total split over the ranks")
     ap.add_argument("--pairs", type=int, default=1 << 20, help="cfg1: trial pairs per GPU (weak) / in total (strong) per step")
     ap.add_argument("--dim", type=int, default=150, help="layer1_LDA_dim = layer2_PLDA_spkfactor_dim")
-    ap.add_argument("--batch", type=int, default=4096, help="cfg2: minibatch pairs per GPU (weak) / in total (strong)")
+    ap.add_argument("--batch", type=int, default=4096, help="cfg2 / cfg5: minibatch pairs per GPU (weak) / in total (strong)")
     ap.add_argument("--table", type=int, default=1200000, help="cfg2: utterances in the resident x-vector table")
     ap.add_argument("--cohort", type=int, default=10000, help="cfg3: cohort utterances")
     ap.add_argument("--enroll", type=int, default=2000, help="cfg3: enroll ids")
@@ -592,6 +696,15 @@ def main():
     if args.gpus < 1:
         raise SystemExit("--gpus must be >= 1")
 
+    emu = None
+    if args.emulate_rank is not None:
+        try:
+            er, en = (int(v) for v in args.emulate_rank.split("/"))
+        except ValueError:
+            raise SystemExit("--emulate-rank takes r/N, e.g. 3/8")
+        if not (en >= 1 and 0 <= er < en) or args.gpus != 1 or "WORLD_SIZE" in os.environ:
+            raise SystemExit("--emulate-rank r/N needs 0 <= r < N and a plain one-process launch (--gpus 1)")
+        emu = (er, en)
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         self_spawn(args)
     rank = int(os.environ.get("RANK", "0"))
@@ -611,8 +724,10 @@ def main():
     torch.cuda.set_device(local_rank)
     ctx = Ctx()
     ctx.dev = torch.device("cuda", local_rank)
-    ctx.rank, ctx.world, ctx.backend, ctx.dist = rank, world, backend, None
-    if world > 1:
+    ctx.rank, ctx.world, ctx.backend, ctx.dist, ctx.emulated = rank, world, backend, None, emu is not None
+    if emu is not None:
+        ctx.rank, ctx.world = emu
+    elif world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -626,9 +741,33 @@ def main():
     from neuralplda_amd import _lib
     _lib.load()  # fail loudly if libnplda_hip.so is missing
 
-    out = {"cfg1": run_cfg1, "cfg2": run_cfg2, "cfg3": run_cfg3}[args.workload](args, ctx)
-    if rank == 0:
+    if emu is not None and args.workload == "cfg1":
+        args.scaling = "strong"  # rank r's slice of the one list
+    out = {"cfg1": run_cfg1, "cfg2": run_cfg2, "cfg3": run_cfg3, "cfg5": run_cfg5}[args.workload](args, ctx)
+    if emu is not None:
+        out["n_gpus"] = 1
+        out["config"]["emulated_rank"] = f"{emu[0]}/{emu[1]}"
+        out["config"]["note"] = ("single-GPU shard timing: this process ran rank %d's share of a %d-rank job, collectives "
+                                 "replaced by their byte counts; NOT a scaling measurement" % emu)
+        out.pop("cpu_baseline", None)
+    elif (rank == 0 and world == 1 and args.workload == "cfg1" and not args.no_alt and args.precision == "fp32"
+          and args.dim == 150 and args.pairs == 1 << 20):
+        # the other BASELINE configs on the driver's default line (a few hundred steps each, ~2 s in all)
+        torch.cuda.empty_cache()
+        for name, fn, kw in (("alt_cfg2", run_cfg2, {"steps": 300, "warmup": 30}), ("alt_cfg3", run_cfg3, {"steps": 20, "warmup": 3}),
+                             ("alt_cfg5", run_cfg5, {"steps": 300, "warmup": 30})):
+            a2 = argparse.Namespace(**vars(args))
+            for k, v in kw.items():
+                setattr(a2, k, v)
+            a2.scaling = "weak"
+            try:
+                out[name] = _compact(fn(a2, ctx))
+            except Exception as e:  # an alt object never takes the headline down with it
+                out[name] = {"error": f"{type(e).__name__}: {e}"}
+            torch.cuda.empty_cache()
+    if rank == 0 or emu is not None:
         out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
+        out["lib"] = _lib.build_info()
         print(json.dumps(out), flush=True)
     if ctx.dist is not None:
         ctx.dist.destroy_process_group()

@@ -25,7 +25,7 @@ from .NpldaConf import NpldaConf
 from .sv_trials_loaders import (TrialIndexDataset, TrialLoader, combine_trials_and_get_loader,
                                 get_trials_loaders_dict, load_xvec_trials_from_numbatch, xvector_table)
 
-__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "FusedDPldaStep", "main_kaldiplda", "main_dplda",
+__all__ = ["train", "validate", "GraphedTrainStep", "FusedTrainStep", "FusedDPldaStep", "HeadStepWithInputGrads", "main_kaldiplda", "main_dplda",
            "train_gaussian_backend"]
 
 
@@ -569,6 +569,63 @@ class FusedTrainStep:
         self._touched()
         self._account(self._loss, self.batch_size)
         return self._loss
+
+
+class HeadStepWithInputGrads(FusedTrainStep):
+    """The head's step of an end-to-end fine-tune (BASELINE configs[4]; the reference's Etdnn_Xvec_NeuralPlda chains an
+    extractor into this head, utils/models.py:251-268): x-vectors that an extractor produced (any float dtype, typically
+    bf16) go through NeuralPlda.forward and the loss, the head takes its Adam step, and dL/dx1, dL/dx2 come back in the
+    inputs' dtype for the extractor's own backward.  `step(x1, x2, target) -> (loss, dx1, dx2)`; direct C-ABI launches
+    replayed from a HIP graph (static input / output buffers), no autograd.  Same arithmetic as
+    loss = model.loss(model(x1.float(), x2.float()), t); loss.backward(); optimizer.step() with x requiring grad."""
+
+    def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True,
+                 dtype=torch.bfloat16):
+        super(HeadStepWithInputGrads, self).__init__(model, lr, weight_decay, betas, eps, batch_size=None, graph=False)
+        self.batch_size, self.io_dtype = batch_size, dtype
+        self.use_graph = bool(graph) and batch_size is not None
+        self._g = None
+        if self.use_graph:
+            D0 = self.dims[0]
+            self.x1 = torch.zeros(batch_size, D0, device=self.dev, dtype=dtype)
+            self.x2 = torch.zeros(batch_size, D0, device=self.dev, dtype=dtype)
+            self.t = torch.zeros(batch_size, device=self.dev)
+            self.t[::2] = 1
+
+    def describe(self):
+        return ("x.float() x2, pack, nplda_forward_train_f32, nplda_loss_fwd_bwd_f32, nplda_backward_ex_f32 (flat gradient + "
+                "dx1, dx2), nplda_adam_step_f32, dx.to(dtype) x2" + (", one HIP-graph replay" if self.use_graph else ""))
+
+    def _eager(self, x1, x2, t):
+        ops = self._ops
+        D0, D1, D2 = self.dims
+        with torch.no_grad():
+            prm = [q.detach() for q in self.params]
+            packed = ops.pack_params(*prm)
+            s, saved = ops.forward_train(x1.float(), x2.float(), packed)
+            ths = [th.detach() for th in self.thetas]
+            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
+            flat, dx1, dx2 = ops.backward(saved, g, packed, prm[4], want_dx=True)
+            grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
+            self._adam(prm + ths, grads)
+        return loss, dx1.to(x1.dtype), dx2.to(x2.dtype)
+
+    def __call__(self, x1, x2, target):
+        B = x1.shape[0]
+        if not self.use_graph or B != self.batch_size or x1.dtype != self.io_dtype:
+            out = self._eager(x1, x2, target)
+            self._touched()
+            self._account(out[0], B)
+            return out
+        if self._g is None:
+            self._g, self._out = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
+        self.x1.copy_(x1, non_blocking=True)
+        self.x2.copy_(x2, non_blocking=True)
+        self.t.copy_(target, non_blocking=True)
+        self._g.replay()
+        self._touched()
+        self._account(self._out[0], B)
+        return self._out
 
 
 class FusedDPldaStep(FusedTrainStep):

@@ -374,3 +374,34 @@ def test_fused_dplda_step_crossentropy(hip_lib):
                                    m_ref.logistic_regres.weight.detach().cpu().numpy(), rtol=2e-4, atol=2e-6)
         for b in m.beta:  # thresholds do not train under BCE
             assert float(m.threshold[b]) == 0.0
+
+
+def test_head_step_with_input_grads_follows_autograd(hip_lib):
+    """train.HeadStepWithInputGrads (BASELINE cfg 5, the head's share): bf16 x-vectors in, the head's Adam step, dL/dx back
+    in bf16 — against loss.backward() + torch.optim.Adam on the same model with x.float() requiring grad."""
+    from neuralplda_amd import train
+    from tests.test_train_gpu import NC, model_from, rand_params
+    rng = np.random.default_rng(77)
+    D, B = 150, 1024
+    p = rand_params(rng, 512, D, D)
+    batches = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().to(torch.bfloat16),
+                torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().to(torch.bfloat16),
+                torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    for graph in (False, True):
+        nc = NC(512, D, D)
+        m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+        step = train.HeadStepWithInputGrads(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+        opt = train.make_optimizer(m_b, 1e-3)
+        for x1, x2, t in batches:
+            loss, dx1, dx2 = step(x1, x2, t)
+            a1, a2 = x1.float().requires_grad_(True), x2.float().requires_grad_(True)
+            opt.zero_grad()
+            L = m_b.loss(m_b(a1, a2), t)
+            L.backward()
+            opt.step()
+            assert dx1.dtype == torch.bfloat16 and dx1.shape == (B, 512)
+            assert abs(loss.item() - L.item()) <= 1e-5 * abs(L.item())
+            for got, want in ((dx1, a1.grad), (dx2, a2.grad)):
+                assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
+        for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
