@@ -24,6 +24,7 @@
 #include "nplda_bwd_loss.h"
 #include "nplda_loss_tail.h"
 #include "nplda_train_fb_small.h"
+#include <cstdlib>
 #include "nplda_wgrad_fm.h"
 
 namespace nplda {  // nplda_matmul.hip
@@ -160,6 +161,171 @@ __global__ __launch_bounds__(WAVES * 64, 1) void bwd_data_kernel(const BwdArgs a
             const f32x4 yB = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
             if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA * dotA) * rnA;
             if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB * dotB) * rnB;
+        }
+    }
+}
+
+// Streaming form of K-A (B > 16 384 pairs; NB >= 8: the whole W2^T image fits the 160 KB of LDS).
+//
+// The first form above holds dz of both sides (8 NB registers) next to the dy accumulators (8 NB): 300+ registers, ONE
+// 4-wave block per CU, and every tile starts by waiting out the HBM latency of its z rows — 540 us at 262 144 pairs for
+// 1.3 GB of traffic and 150 us of MFMA work.  Here
+//  * W2^T (NB x NB KB) is loaded into LDS ONCE per block; the tile loop has no weight traffic and NO barrier, the 8 waves
+//    of the (one per CU, persistent) block run independently;
+//  * dz is formed one k-block at a time from a ring of z rows fetched four k-blocks ahead (and, past the tile's last
+//    k-block, for the NEXT tile): 16 live registers instead of 8 NB, two waves per SIMD fit;
+//  * y is read once (kept in registers between the dot product and du), issued under the last k-blocks' MFMAs;
+//  * the dQ / dP pair sums g (z1^2 + z2^2), g z1 z2 — which the weight-gradient kernel used to re-derive from three
+//    more loads per k4-step — are formed here from the z rows in registers: reduced over the tile's 16 pairs (DPP) and
+//    added into the wave's own LDS row; one row per block leaves in the end (fixed order: deterministic).
+template <int NB, bool GIVEN>
+__global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a) {
+    constexpr int WAVES = 8, PFZ = 4;
+    __shared__ f32x4 w2t[NB * NB * 64];
+    __shared__ f32x4 pqs[WAVES][2][NB * 4];  // per wave: [dQ | dP] partial sums over its tiles, 16 NB floats each
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g4 = lane >> 4;
+    {
+        const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
+        for (int i = tid; i < NB * NB * 64; i += WAVES * 64) w2t[i] = W2T[i];
+        for (int i = tid; i < WAVES * 2 * NB * 4; i += WAVES * 64) (&pqs[0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    const float* src = GIVEN ? a.dz : a.z;  // GIVEN: the upstream dL/dz rows are the B operand as they are
+    const long long nwt = (a.nA + 15) / 16;  // wave tiles
+    auto rows_of = [&](long long wt, long long& rA, long long& rB, bool& okA, bool& okB) {
+        const long long t0 = wt * 16;
+        okA = t0 + j < a.nA;
+        okB = t0 + j < a.nB;
+        rA = okA ? t0 + j : a.nA - 1;
+        rB = a.offB + (okB ? t0 + j : (a.nB > 0 ? a.nB - 1 : 0));
+    };
+    long long wt = (long long)blockIdx.x * WAVES + wave;
+    const long long stride = (long long)gridDim.x * WAVES;
+    long long rA, rB;
+    bool okA, okB;
+    rows_of(wt < nwt ? wt : nwt - 1, rA, rB, okA, okB);
+    f32x4 zrA[PFZ], zrB[PFZ];
+    auto fetchz = [&](int slot, long long ra, long long rb, int kb) {
+        zrA[slot] = *reinterpret_cast<const f32x4*>(src + ra * a.ldz + 16 * kb + 4 * g4);
+        zrB[slot] = *reinterpret_cast<const f32x4*>(src + rb * a.ldz + 16 * kb + 4 * g4);
+    };
+#pragma unroll
+    for (int s = 0; s < PFZ; ++s) fetchz(s, rA, rB, s);
+    __syncthreads();  // the weights are in LDS
+
+    for (; wt < nwt; wt += stride) {
+        long long rA_n, rB_n;
+        bool okA_n, okB_n;
+        rows_of(wt + stride < nwt ? wt + stride : wt, rA_n, rB_n, okA_n, okB_n);
+        const float tg = GIVEN ? 0.f : 2.0f * (okA ? a.g[rA] : 0.f);
+        f32x4 dyA[NB], dyB[NB], yA[NB], yB[NB];
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            dyA[nb] = f32x4{0.f, 0.f, 0.f, 0.f};
+            dyB[nb] = dyA[nb];
+        }
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int sl = kb % PFZ;
+            f32x4 dA, dB;
+            if (GIVEN) {
+                dA = zrA[sl];
+                dB = zrB[sl];
+            } else {
+                const f32x4 q = Qp[4 * kb + g4], p = Pp[4 * kb + g4];
+                dA = dz_of(tg, q, p, zrA[sl], zrB[sl]);
+                dB = dz_of(tg, q, p, zrB[sl], zrA[sl]);
+                if (okA) {
+                    *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * kb + 4 * g4) = dA;
+                    *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * kb + 4 * g4) = dB;
+                }
+                f32x4 eq, ep;
+                pair_sum_terms(0.5f * tg, zrA[sl], zrB[sl], eq, ep);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    eq[r] = row16_sum(eq[r]);
+                    ep[r] = row16_sum(ep[r]);
+                }
+                if (j == 0) {  // the wave's own row: a plain read-modify-write
+                    pqs[wave][0][4 * kb + g4] += eq;
+                    pqs[wave][1][4 * kb + g4] += ep;
+                }
+            }
+            // refill the slot: k-block kb + PFZ of this tile, or the first k-blocks of the wave's next tile
+            if (kb + PFZ < NB) fetchz(sl, rA, rB, kb + PFZ);
+            else fetchz(sl, rA_n, rB_n, kb + PFZ - NB);
+            if (kb >= NB - 2) {  // y under the last MFMAs: half of the blocks each
+#pragma unroll
+                for (int nb = (kb == NB - 2 ? 0 : NB / 2); nb < (kb == NB - 2 ? NB / 2 : NB); ++nb) {
+                    yA[nb] = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nb + 4 * g4);
+                    yB[nb] = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);  // (left free, the scheduler hoists the LDS reads of every k-block to the top: spills)
+#pragma unroll
+            for (int nb0 = 0; nb0 < NB; nb0 += 2) {
+                f32x4 av[2];
+#pragma unroll
+                for (int u = 0; u < 2; ++u)
+                    if (nb0 + u < NB) av[u] = w2t[(kb * NB + nb0 + u) * 64 + lane];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                    for (int u = 0; u < 2; ++u) {
+                        if (nb0 + u < NB) {
+                            dyA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], dA[r], dyA[nb0 + u], 0, 0, 0);
+                            dyB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], dB[r], dyB[nb0 + u], 0, 0, 0);
+                        }
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); clamp branch: du = dy / eps
+        const float rnA = a.rn[rA], rnB = a.rn[rB];
+        float dotA = 0.f, dotB = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                dotA = fmaf(yA[nb][r], dyA[nb][r], dotA);
+                dotB = fmaf(yB[nb][r], dyB[nb][r], dotB);
+            }
+        }
+        dotA = wave_xor_add(dotA, 16); dotA = wave_xor_add(dotA, 32);
+        dotB = wave_xor_add(dotB, 16); dotB = wave_xor_add(dotB, 32);
+        if (rnA >= 1e12f) dotA = 0.f;
+        if (rnB >= 1e12f) dotB = 0.f;
+#pragma unroll
+        for (int nb = 0; nb < NB; ++nb) {
+            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA[nb] * dotA) * rnA;
+            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB[nb] * dotB) * rnB;
+        }
+        rA = rA_n; rB = rB_n; okA = okA_n; okB = okB_n;
+        // the next tile's k-block i was fetched into slot (NB - PFZ + i) % PFZ (the slot that was free): back to slot i
+        if constexpr (NB % PFZ != 0) {
+            f32x4 tA[PFZ], tB[PFZ];
+#pragma unroll
+            for (int i = 0; i < PFZ; ++i) {
+                tA[i] = zrA[(NB - PFZ + i) % PFZ];
+                tB[i] = zrB[(NB - PFZ + i) % PFZ];
+            }
+#pragma unroll
+            for (int i = 0; i < PFZ; ++i) {
+                zrA[i] = tA[i];
+                zrB[i] = tB[i];
+            }
+        }
+    }
+    if (!GIVEN && a.pq != nullptr) {  // the block's pair sums: the 8 wave rows in wave order
+        __syncthreads();
+        for (int i = tid; i < 2 * NB * 4; i += WAVES * 64) {
+            const int row = i / (NB * 4), e = i % (NB * 4);
+            f32x4 v = pqs[0][row][e];
+#pragma unroll
+            for (int w = 1; w < WAVES; ++w) v += pqs[w][row][e];
+            *reinterpret_cast<f32x4*>(a.pq + ((size_t)blockIdx.x * 2 + row) * a.ldz + 4 * e) = v;
         }
     }
 }
@@ -562,9 +728,12 @@ __global__ __launch_bounds__(256, 2) void wgrad_kernel(const WgradArgs a) {
     else wgrad_body<4>(a, P, w, red, rede);
 }
 
-constexpr long long kFmMaxRows = 32 * 1024;  // minibatch-sized products (larger K: the 64 x 64 form's grid is already even)
+constexpr long long kFmMaxRows = 1LL << 40;  // (round 2 stopped at 32 768 rows; the full-M strips also win at streaming sizes:
+                                             // no padding of M, and the strips of one k-group share their A rows through L2)
 
 static inline bool wgrad_fm_rows(long long K, int NB) { return NB >= 10 && NB <= 12 && K >= 4 && K <= kFmMaxRows; }
+// streaming sizes: 64-column strips (NB = 12 keeps the 32-column form: 192 accumulator registers + the ring do not fit 256)
+static inline bool fm_wide(long long K, int NB) { return K > 32 * 1024 && NB <= 11; }
 
 // The weight-gradient launch: full-M form where it applies, the 64 x 64 form otherwise.  nprob: problems in use (1 or 2).
 // tail: the training step's loss tail, to ride along if the full-M form runs (*tail_done reports it).
@@ -581,10 +750,13 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
         return nplda_launch_status();
     }
+    // streaming sizes: 64-column strips (11 tiles x 23 k-groups at D0 = 512, NB = 10); minibatch sizes: 32-column strips
+    const bool wide = fm_wide(wa.K, NB);
+    const int sw = wide ? 64 : 32;
     WgradFmArgs fa = {};
     fa.w = wa;
-    fa.nt0 = (wa.p[0].N + 31) / 32;
-    fa.nt1 = nprob > 1 ? (wa.p[1].N + 31) / 32 : 0;
+    fa.nt0 = (wa.p[0].N + sw - 1) / sw;
+    fa.nt1 = nprob > 1 ? (wa.p[1].N + sw - 1) / sw : 0;
     const int tiles = fa.nt0 + fa.nt1;
     fa.ps_cols = wa.pq ? (2 * wa.Mp + tiles - 1) / tiles : 0;
     if (fa.ps_cols > kFmWaves * 64) return NPLDA_EUNSUPPORTED;
@@ -594,11 +766,15 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
         if (tail_done) *tail_done = true;
     }
     const dim3 grid((unsigned)(tiles * wa.ksplit + (tail ? 1 : 0))), block(kFmWaves * 64);
+#define NPLDA_FM(NBV)                                                                        \
+    if (wide) hipLaunchKernelGGL((wgrad_fm_kernel<NBV, (NBV <= 10 ? kFmPF : 3), 4>), grid, block, 0, st, fa);  \
+    else hipLaunchKernelGGL((wgrad_fm_kernel<NBV, kFmPF, 2>), grid, block, 0, st, fa)
     switch (NB) {
-        case 10: hipLaunchKernelGGL(wgrad_fm_kernel<10>, grid, block, 0, st, fa); break;
-        case 11: hipLaunchKernelGGL(wgrad_fm_kernel<11>, grid, block, 0, st, fa); break;
-        default: hipLaunchKernelGGL(wgrad_fm_kernel<12>, grid, block, 0, st, fa); break;
+        case 10: NPLDA_FM(10); break;
+        case 11: NPLDA_FM(11); break;
+        default: NPLDA_FM(12); break;
     }
+#undef NPLDA_FM
     return nplda_launch_status();
 }
 
@@ -785,6 +961,16 @@ struct WsLayout {
     int Mp, Np1;
 };
 
+// persistent grid of bwd_data_stream_kernel: one 8-wave block per CU (each wave walks 16-pair tiles)
+static inline long long stream_grid(long long nA) {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long need = (nA + 127) / 128;
+    return need < cus ? (need > 0 ? need : 1) : cus;
+}
+
 // K = rows of the A^T B products (2 B for pair scoring).  want_dx adds room for the W1 fragment image of dx = du W1.
 WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     WsLayout w;
@@ -799,9 +985,10 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     if (ks * tiles > 512) ks = 512 / tiles;
     if (wgrad_fm_rows(K, L.NB)) {
         // full-M form: (32-column tiles) x (k-groups) 8-wave blocks, ONE per CU; every wave at least one k4-step
-        const long long tiles32 = (L.D0 + 31) / 32 + (w.Mp + 31) / 32;
+        const int sw = fm_wide(K, L.NB) ? 64 : 32;
+        const long long tiles32 = (L.D0 + sw - 1) / sw + (w.Mp + sw - 1) / sw;
         ks = 256 / tiles32;
-        if (ks > 16) ks = 16;
+        if (ks > 16 && !fm_wide(K, L.NB)) ks = 16;
         if (ks > (K / 4 + kFmWaves - 1) / kFmWaves) ks = (K / 4 + kFmWaves - 1) / kFmWaves;
     }
     if (ks < 1) ks = 1;
@@ -845,7 +1032,10 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     }
     b.oW2T = L.oW2T; b.oQ = L.oQ; b.oP = L.oP; b.total = L.total;
     b.dz = wsf + W.dz; b.du = wsf + W.du;
-    const bool pair_sums = !given && b.nA <= 16 * 1024;  // K-A (small kernel) leaves the dQ / dP sums per block
+    // K-A leaves the dQ / dP pair sums per block: the small-batch kernel one row per 16-pair tile, the streaming kernel
+    // (NB >= 8) one row per persistent block
+    const long long stream_blocks = stream_grid(b.nA);
+    const bool pair_sums = !given && (b.nA <= 16 * 1024 || L.NB >= 8);
     b.pq = pair_sums ? wsf + W.pq : nullptr;
     const long long ntb = (b.nA + 16 * kBwdWaves - 1) / (16 * kBwdWaves);
     if (ntb > 0x7fffffffLL) return NPLDA_EINVAL;
@@ -853,9 +1043,12 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     if (!data_done) {  // (data_done: train_fb_small_kernel has already left dz, du, the pair sums and the loss partials)
         // small batches: 4 waves share a 16-pair tile (feature split), so a 4096-pair minibatch fills 256 CUs
         const bool small = b.nA <= 16 * 1024;
-        dim3 grid(small ? (unsigned)((b.nA + 15) / 16) : (unsigned)(ntb < 2048 ? ntb : 2048)), block(256);
+        const bool stream = !small && L.NB >= 8;
+        dim3 grid(small ? (unsigned)((b.nA + 15) / 16) : (stream ? (unsigned)stream_blocks : (unsigned)(ntb < 2048 ? ntb : 2048))),
+            block(stream ? 512 : 256);
 #define NPLDA_LAUNCH2(NBV, GV)                                                                  \
     if (small) hipLaunchKernelGGL((bwd_data_small_kernel<NBV, GV>), grid, block, 0, st, b);      \
+    else if (NBV >= 8) hipLaunchKernelGGL((bwd_data_stream_kernel<(NBV >= 8 ? NBV : 8), GV>), grid, block, 0, st, b);   \
     else hipLaunchKernelGGL((bwd_data_kernel<NBV, kBwdWaves, GV>), grid, block, 0, st, b)
 #define NPLDA_LAUNCH(NBV)                                                                        \
     if (ls) hipLaunchKernelGGL((bwd_data_small_kernel<NBV, false, true>), grid, block, 0, st, b); \
@@ -887,7 +1080,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
     wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
-    wa.pq = b.pq; wa.nblk = (int)((b.nA + 15) / 16);
+    wa.pq = b.pq; wa.nblk = b.nA <= 16 * 1024 ? (int)((b.nA + 15) / 16) : (int)stream_blocks;
     if (int rc = wgrad_launch(wa, L.NB, 2, st, tail, tail_done)) return rc;
     // K-C
     ReduceArgs ra = {};

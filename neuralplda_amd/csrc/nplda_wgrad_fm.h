@@ -82,19 +82,25 @@ template <> struct FmVec<2> { typedef float type __attribute__((ext_vector_type(
 template <> struct FmVec<3> { typedef float type __attribute__((ext_vector_type(3))); };
 template <> struct FmVec<4> { typedef float type __attribute__((ext_vector_type(4))); };
 
-template <int NB, bool EXT>
+// NSB: 16-column blocks of the strip a wave owns: 2 (32 columns, minibatch sizes: 21 tiles x 12 k-groups fill the chip) or 4
+// (64 columns, streaming sizes: 40 MFMAs per four loads instead of 20, and the A rows cross L2 -> CU 11 times instead of 21).
+template <int NSB> struct FmRounds { static constexpr int RB(int NB) { return NSB == 2 ? (NB + 1) / 2 : (NB + 3) / 4; } };
+
+template <int NB, bool EXT, int PF = kFmPF, int NSB = 2>
 __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const WgradProblem P, int tile_all, int nt, int ks,
-                                              f32x4 (*red)[((NB + 1) / 2) * 2][64], f32x4 (*rede)[3][16],
+                                              f32x4 (*red)[FmRounds<NSB>::RB(NB) * NSB][64], f32x4 (*rede)[3][16],
                                               float* psum) {
-    constexpr int NW = kFmWaves, PF = kFmPF;
+    static_assert(NSB == 2 || NSB == 4, "strips of 32 or 64 columns");
+    constexpr int NW = kFmWaves;
     constexpr int CL = NB - 8;
-    constexpr int RB = (NB + 1) / 2;
+    constexpr int RB = FmRounds<NSB>::RB(NB);
+    constexpr int NRND = (NB + RB - 1) / RB;
     const WgradArgs& a = fa.w;
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
     const long long lda = P.lda, ldb = P.ldb, nsplit = a.nsplit;
-    const int n0 = nt * 32;
-    const bool nval = n0 + 2 * i16 < P.N;
+    const int n0 = nt * (16 * NSB);
+    const bool nval = n0 + NSB * i16 < P.N;
 
     NPLDA_FM_STAMP(0);
     // ---- the block's share of the pair sums: one (column, block chunk) per thread, loaded now, summed at the end ----
@@ -131,12 +137,13 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     // explicit waits was measured too: 27.6 us instead of 24.9 for the plain register ring at B = 4096 — six DMA
     // instructions per step, four of them 4 bytes per lane, cost more in the vector memory pipe than they save.)
     typedef typename FmVec<CL>::type fvCL;
-    struct Ops { f32x4 a0, a1; fvCL a2; f32x2 b; };
+    typedef typename FmVec<NSB>::type fvB;
+    struct Ops { f32x4 a0, a1; fvCL a2; fvB b; };
     constexpr int NLD = 4;                                                 // loads per unit
-    static_assert((PF - 2) * NLD < 16, "vmcnt immediate");
+    static_assert((PF - 2) * NLD < 64, "vmcnt immediate (6 bits on gfx9+)");
     unsigned offA = (unsigned)((g4 * lda + 4 * i16) * 4);
     unsigned offA2 = (unsigned)((g4 * lda + 128 + CL * i16) * 4);
-    unsigned offB = (unsigned)((g4 * ldb + (nval ? n0 + 2 * i16 : 0)) * 4);
+    unsigned offB = (unsigned)((g4 * ldb + (nval ? n0 + NSB * i16 : 0)) * 4);
     const char* PA = reinterpret_cast<const char*>(P.A);
     const char* PB0 = reinterpret_cast<const char*>(P.B0);
     const char* PB1 = reinterpret_cast<const char*>(P.B1) - nsplit * ldb * 4;  // row r >= nsplit: PB1 + r ldb
@@ -153,7 +160,10 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
             else if constexpr (CL == 3) asm volatile("global_load_dwordx3 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
         }
-        if (piece == 3) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+        if (piece == 3) {
+            if constexpr (NSB == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+            else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+        }
     };
     auto load = [&](Ops& o, long long u) {
 #pragma unroll
@@ -163,20 +173,23 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
         asm volatile("s_waitcnt vmcnt(%4)" : "+v"(o.a0), "+v"(o.a1), "+v"(o.a2), "+v"(o.b) : "n"((PF - 2) * NLD) : "memory");
     };
 
-    f32x4 acc[NB][2];
+    f32x4 acc[NB][NSB];
 #pragma unroll
-    for (int mb = 0; mb < NB; ++mb) acc[mb][0] = acc[mb][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+        for (int cb = 0; cb < NSB; ++cb) acc[mb][cb] = f32x4{0.f, 0.f, 0.f, 0.f};
     f32x4 e0 = {0.f, 0.f, 0.f, 0.f}, e1 = e0;
     float e2[CL];
 #pragma unroll
     for (int c = 0; c < CL; ++c) e2[c] = 0.f;
-    auto mfmas = [&](const Ops& o, float b0, float b1, int mb0, int mb1) {
+    auto mfmas = [&](const Ops& o, const fvB& bv, int mb0, int mb1) {
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) {
             if (mb >= mb0 && mb < mb1) {
                 const float av = mb < 4 ? o.a0[mb & 3] : (mb < 8 ? o.a1[mb & 3] : o.a2[mb >= 8 ? mb - 8 : 0]);
-                acc[mb][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b0, acc[mb][0], 0, 0, 0);
-                acc[mb][1] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, b1, acc[mb][1], 0, 0, 0);
+#pragma unroll
+                for (int cb = 0; cb < NSB; ++cb)
+                    acc[mb][cb] = __builtin_amdgcn_mfma_f32_16x16x4f32(av, bv[cb], acc[mb][cb], 0, 0, 0);
             }
         }
     };
@@ -194,7 +207,9 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
                 if (u + s < u1) {
                     Ops& o = ring[s];
                     wait(o);
-                    const float b0 = nval ? o.b[0] : 0.f, b1 = nval ? o.b[1] : 0.f;
+                    fvB bv;
+#pragma unroll
+                    for (int cb = 0; cb < NSB; ++cb) bv[cb] = nval ? o.b[cb] : 0.f;
                     // the set of the previous step is refilled one load at a time between groups of MFMAs (all four in one
                     // place: 2-3 % slower)
                     Ops& n = ring[(s + PF - 1) % PF];
@@ -202,12 +217,12 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
                     constexpr int cut[5] = {0, 2, 5, 7, 9};
 #pragma unroll
                     for (int piece = 0; piece < 4; ++piece) {
-                        mfmas(o, b0, b1, cut[piece], cut[piece + 1]);
+                        mfmas(o, bv, cut[piece], cut[piece + 1]);
                         __builtin_amdgcn_sched_barrier(0);
                         load1(n, un, piece);
                         __builtin_amdgcn_sched_barrier(0);
                     }
-                    mfmas(o, b0, b1, cut[4], NB);
+                    mfmas(o, bv, cut[4], NB);
                     if (EXT) {
                         e0 += o.a0;
                         e1 += o.a1;
@@ -244,40 +259,43 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     if (ps_col >= 0) psum[(threadIdx.x / psc) * psc + ps_col] = psv;
     float* slab = P.slab + (size_t)ks * P.Mp * P.Np;
 #pragma unroll
-    for (int rnd = 0; rnd < 2; ++rnd) {
+    for (int rnd = 0; rnd < NRND; ++rnd) {
         const int mb0 = rnd * RB;
-        const int cnt = rnd == 0 ? RB : NB - RB;
-        if (rnd) __syncthreads();  // round 0's sums have been read
+        const int cnt = (NB - mb0) < RB ? (NB - mb0) : RB;
+        if (rnd) __syncthreads();  // the previous round's sums have been read
 #pragma unroll
         for (int mb = 0; mb < NB; ++mb) {
             if (mb >= mb0 && mb < mb0 + cnt) {
-                red[wave][(mb - mb0) * 2 + 0][lane] = acc[mb][0];
-                red[wave][(mb - mb0) * 2 + 1][lane] = acc[mb][1];
+#pragma unroll
+                for (int cb = 0; cb < NSB; ++cb) red[wave][(mb - mb0) * NSB + cb][lane] = acc[mb][cb];
             }
         }
         __syncthreads();
-        NPLDA_FM_STAMP(5 + 2 * rnd);
+        if (rnd < 2) NPLDA_FM_STAMP(5 + 2 * rnd);
         if (wave < cnt) {  // wave w finishes m-block mb0 + w of the round
             const int mb = mb0 + wave;
-            f32x4 sum[2];
+            f32x4 sum[NSB];
 #pragma unroll
-            for (int cb = 0; cb < 2; ++cb) {
-                const int idx = wave * 2 + cb;
+            for (int cb = 0; cb < NSB; ++cb) {
+                const int idx = wave * NSB + cb;
                 f32x4 v = red[0][idx][lane];
 #pragma unroll
                 for (int ww = 1; ww < NW; ++ww) v += red[ww][idx][lane];
                 sum[cb] = v;
             }
-            if (nval && n0 + 2 * i16 < P.Np) {
+            if (nval && n0 + NSB * i16 < P.Np) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     const int i = 4 * g4 + r;  // row of the MFMA block
                     const int m = mb < 8 ? 64 * (mb >> 2) + 4 * i + (mb & 3) : 128 + CL * i + (mb - 8);
-                    *reinterpret_cast<f32x2*>(slab + (size_t)m * P.Np + n0 + 2 * i16) = f32x2{sum[0][r], sum[1][r]};
+                    fvB v;
+#pragma unroll
+                    for (int cb = 0; cb < NSB; ++cb) v[cb] = sum[cb][r];
+                    *reinterpret_cast<fvB*>(slab + (size_t)m * P.Np + n0 + NSB * i16) = v;
                 }
             }
         }
-        NPLDA_FM_STAMP(6 + 2 * rnd);
+        if (rnd < 2) NPLDA_FM_STAMP(6 + 2 * rnd);
     }
     NPLDA_FM_STAMP(3);
     // ---- column sums of A (db1 / db2), pair sums -------------------------------------------------------------------------
@@ -311,9 +329,11 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     NPLDA_FM_STAMP(4);
 }
 
-template <int NB>
+// PF: operand register sets per wave.  4 at minibatch sizes (everything comes out of L2); streaming sizes (K > 32 768 rows: the
+// B rows come from HBM) take a deeper ring.
+template <int NB, int PF = kFmPF, int NSB = 2>
 __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradFmArgs fa) {
-    __shared__ f32x4 red[kFmWaves][((NB + 1) / 2) * 2][64];
+    __shared__ f32x4 red[kFmWaves][FmRounds<NSB>::RB(NB) * NSB][64];
     __shared__ f32x4 rede[kFmWaves][3][16];
     __shared__ float psum[kFmWaves * 64];
     const int w = blockIdx.x;
@@ -326,8 +346,8 @@ __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradF
     const int pi = tile >= fa.nt0 ? 1 : 0;
     const WgradProblem P = pi ? fa.w.p[1] : fa.w.p[0];
     const int nt = pi ? tile - fa.nt0 : tile;
-    if (nt == 0 && P.extras) wgrad_fm_body<NB, true>(fa, P, tile, nt, ks, red, rede, psum);
-    else wgrad_fm_body<NB, false>(fa, P, tile, nt, ks, red, rede, psum);
+    if (nt == 0 && P.extras) wgrad_fm_body<NB, true, PF, NSB>(fa, P, tile, nt, ks, red, rede, psum);
+    else wgrad_fm_body<NB, false, PF, NSB>(fa, P, tile, nt, ks, red, rede, psum);
 }
 
 }  // namespace nplda
