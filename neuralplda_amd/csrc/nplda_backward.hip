@@ -765,6 +765,7 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
         fa.tail = *tail;
         if (tail_done) *tail_done = true;
     }
+    fa.xcd_groups = (wide && !tail) ? 1 : 0;
     const dim3 grid((unsigned)(tiles * wa.ksplit + (tail ? 1 : 0))), block(kFmWaves * 64);
 #define NPLDA_FM(NBV)                                                                        \
     if (wide) hipLaunchKernelGGL((wgrad_fm_kernel<NBV, (NBV <= 10 ? kFmPF : 3), 4>), grid, block, 0, st, fa);  \

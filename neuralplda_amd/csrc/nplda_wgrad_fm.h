@@ -72,6 +72,7 @@ struct WgradFmArgs {
     WgradArgs w;
     int nt0, nt1;     // 32-column tiles of the two problems
     int ps_cols;      // pair-sum columns per block (of 2 Mp), 0 = none
+    int xcd_groups;   // 1: k-groups are laid out XCD by XCD (streaming sizes; no tail block)
     int has_tail;     // one more block after the GEMM blocks: the loss / threshold tail of the training step
     LossTail tail;
 };
@@ -342,7 +343,38 @@ __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradF
         loss_tail_block(fa.tail, red);
         return;
     }
-    const int ks = w % fa.w.ksplit, tile = w / fa.w.ksplit;
+    int ks, tile;
+    if (fa.xcd_groups) {
+        // Streaming sizes: the strips of one k-group read the same A rows (640 B each) and must share them through ONE L2.
+        // Workgroup w runs on XCD w % 8 (each with its own 4 MB L2): with k-groups laid out as w % ksplit the 11 strips of
+        // a k-group sat on 8 different XCDs and every A row crossed HBM -> L2 eleven times (TCC hit rate 0.3 %, 5.2 GB per
+        // launch at 262 144 pairs: the kernel ran at the HBM limit, not the MFMA one).  Here XCD x takes whole k-groups
+        // while its share of the grid lasts; what is left over of every XCD's share is strung together, XCD by XCD, into the
+        // remaining k-groups (each then spans two XCDs at most).
+        const int T = fa.nt0 + fa.nt1, G = T * fa.w.ksplit;
+        const int x = w & 7, slot = w >> 3;
+        int base = 0, lbase = 0, whole_all = 0;
+        for (int xx = 0; xx < 8; ++xx) {
+            const int n = (G - xx + 7) >> 3, wh = n / T;
+            if (xx < x) {
+                base += wh;
+                lbase += n - wh * T;
+            }
+            whole_all += wh;
+        }
+        const int n = (G - x + 7) >> 3, wh = n / T;
+        if (slot < wh * T) {
+            ks = base + slot / T;
+            tile = slot % T;
+        } else {
+            const int l = lbase + (slot - wh * T);
+            ks = whole_all + l / T;
+            tile = l % T;
+        }
+    } else {
+        ks = w % fa.w.ksplit;
+        tile = w / fa.w.ksplit;
+    }
     const int pi = tile >= fa.nt0 ? 1 : 0;
     const WgradProblem P = pi ? fa.w.p[1] : fa.w.p[0];
     const int nt = pi ? tile - fa.nt0 : tile;
