@@ -208,13 +208,20 @@ class Ctx:
     pass
 
 
-def timed_steps(ctx, step, steps, warmup, per_step_events=True):
+def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0):
     """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (elapsed max over ranks,
-    mean HIP-event duration of a step on the launch stream, last result)."""
+    mean HIP-event duration of a step on the launch stream, last result).  settle_s: the untimed warm-up lasts at least
+    this long (steps of tens of microseconds: W = 30 of them end before the clock has settled — the first ~50 ms after
+    idle run up to 1.8x slower)."""
     dist = ctx.dist
     out = None
-    for _ in range(warmup):
+    t_end = time.perf_counter() + settle_s
+    done = 0
+    while done < warmup or time.perf_counter() < t_end:
         out = step()
+        done += 1
+        if settle_s > 0.0 and done % 64 == 0:
+            torch.cuda.synchronize()
     torch.cuda.synchronize()
     # per_step_events=False (steps of tens of microseconds): ONE event pair around the K steps — two event records per step
     # are two more packets between the graph launches, 12 us on a 70 us training step
@@ -535,7 +542,7 @@ def run_cfg2(args, ctx):
     gen_r = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank its own shard of every minibatch
     # one rank: the epoch's batches as packed records on the device, walked by the captured step through its cursor
     # (FusedTrainStep.begin_epoch / step_record: the training loop's form, train.train); data parallel: step_rows
-    nbat = min(args.steps + args.warmup + 1, 4096) if world == 1 else 32
+    nbat = 4096 if world == 1 else 32  # (an epoch of 4096 records: the cursor path restarts it when it runs out)
     recs = []
     for _ in range(nbat):
         r1 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
@@ -555,7 +562,7 @@ def run_cfg2(args, ctx):
         state["k"] += 1
         return step_fn.step_rows(table, r1, r2, t, record=rec)
 
-    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False)
+    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.08)
     if not torch.isfinite(loss).all():
         raise SystemExit("non-finite training loss")
     if rank != 0 and not ctx.emulated:
@@ -633,7 +640,7 @@ def run_cfg5(args, ctx):
         state["k"] += 1
         return step_fn(x1, x2, t)
 
-    elapsed, step_ms, out = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False)
+    elapsed, step_ms, out = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.08)
     loss, dx1, dx2 = out
     if not (torch.isfinite(loss).all() and torch.isfinite(dx1.float()).all() and torch.isfinite(dx2.float()).all()):
         raise SystemExit("non-finite loss / input gradient")

@@ -438,6 +438,20 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          double* loss_sum, float* grad_out, nplda_stream_t stream);
 
+/* The head's step of an end-to-end fine-tune (BASELINE configs[4]; the reference chains an x-vector extractor into this head:
+ * Etdnn_Xvec_NeuralPlda, utils/models.py:251-268, and autograd hands dL/dx back to it): nplda_train_step_f32 that also returns
+ * dx1, dx2 (B, lddx) = dL/dx1, dL/dx2 = du . W1 with the weights the forward used — four launches: forward + loss + data
+ * gradients, weight-gradient slabs, the input-gradient product, update.  io_bf16 != 0: x1, x2 are bfloat16 rows (ldx in
+ * elements) and dx1, dx2 are written in bfloat16 (round to nearest even) — the dtype a bf16 extractor works in; the head's own
+ * arithmetic stays fp32 (the rows are widened exactly).  io_bf16 needs D0 == 512 and D1, D2 in 145..192.  B <= 16384.
+ * Workspace: nplda_train_step_dx_workspace_bytes. */
+size_t nplda_train_step_dx_workspace_bytes(int64_t B, int D0, int D1, int D2, int io_bf16);
+int nplda_train_step_dx_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, int io_bf16, const float* target,
+                            float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
+                            float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
+                            double* loss_sum, float* grad_out, void* dx1, void* dx2, int64_t lddx, nplda_stream_t stream);
+
 /* ---- split-bf16 scoring (opt-in) --------------------------------------------------------------------------- */
 
 /* Same functions as nplda_pack_params_f32 / nplda_score_pairs_f32 / nplda_embed_f32 computed on the bf16 matrix

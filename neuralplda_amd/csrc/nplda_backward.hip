@@ -29,7 +29,7 @@
 
 namespace nplda {  // nplda_matmul.hip
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
-                       float* frag, float* dx0, float* dx1, long long nsplit, long long lddx, hipStream_t st);
+                       float* frag, void* dx0, void* dx1, long long nsplit, long long lddx, hipStream_t st, bool out_bf16 = false);
 int pad_rows(const float* in, long long ldin, long long N, int D, float* out, long long ldo, hipStream_t st);
 }  // namespace nplda
 
@@ -890,6 +890,7 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
                 stride = (size_t)a.r.Mp * a.r.Np1;
                 pp = a.prm[0] + idx;
                 pk0 = a.L.oW1 + frag_pos(f, k, a.L.NB);
+                pk1 = a.L.oW1T + frag_pos(k, f, a.L.KS1);  // W1^T image (dx = du W1): rows and columns change places
             } else if (idx < nW1 + D1) {
                 const int f = (int)(idx - nW1);
                 src = a.r.ext + 3 * a.r.Mp + f;
@@ -1271,7 +1272,8 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                          float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
-                         double* loss_sum, float* grad_out, nplda_stream_t stream) {
+                         double* loss_sum, float* grad_out, nplda_stream_t stream, void* dxa = nullptr, void* dxb = nullptr,
+                         int64_t lddx = 0, bool io_bf16 = false) {
     if (cursor) {  // the batch sits in the staging record [rows1 | rows2 | labels]
         if (!stage || !nplda_aligned16(stage) || B < 1) return NPLDA_EINVAL;
         if ((B % 4) != 0) return NPLDA_EUNSUPPORTED;  // 16-byte pieces: the labels sit behind 16 B bytes of indices
@@ -1279,10 +1281,14 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         rows2 = rows1 + B;
         target = (const float*)(rows2 + B);
     }
-    const bool rows = rows1 != nullptr;
+    // staged form: the first kernel leaves fp32 copies of the x rows it read for the weight gradients — rows named by table
+    // indices, or (io_bf16) the batch's own bfloat16 rows
+    const bool rows = rows1 != nullptr || io_bf16;
     if (int rc = check_model(D0, D1, D2)) return rc;
-    if (rows && (!rows2 || ntab < 1)) return NPLDA_EINVAL;
+    if (rows1 && (!rows2 || ntab < 1)) return NPLDA_EINVAL;
     if (rows && (D0 % 16) != 0) return NPLDA_EUNSUPPORTED;  // the staged rows are written k16-step by k16-step
+    if (io_bf16 && (D0 != 512 || rows1)) return NPLDA_EUNSUPPORTED;
+    if ((dxa == nullptr) != (dxb == nullptr) || (dxa && lddx < D0)) return NPLDA_EINVAL;
     if (B < 1) return NPLDA_EINVAL;
     if (B > 16 * 1024) return NPLDA_EUNSUPPORTED;  // larger batches: the separate launches (two-pass loss)
     if (kind != 0 && kind != 1) return kind == 2 ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
@@ -1318,14 +1324,16 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         fb.out_s = wsf + S.s; fb.out_y = wsf + S.y; fb.dz = bws + W.dz; fb.du = bws + W.du; fb.ldz = S.ldz;
         fb.pq = bws + W.pq; fb.ls = ls; fb.step_bump = step;
         if (rows) {
-            fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = ntab;
+            fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = rows1 ? ntab : B;
             fb.rec_bump = cursor ? cursor + 1 : nullptr;
             fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs;
         }
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
         const bool k32 = L.KS1 == 32 && L.D0 == 512;
+        if (io_bf16 && !(k32 && L.NB >= 10)) return NPLDA_EUNSUPPORTED;
 #define NPLDA_LAUNCH(NBV)                                                                                   \
-    if (k32 && rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, true>), grid, block, 0, st, fb);      \
+    if (io_bf16) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, true, true>), grid, block, 0, st, fb); \
+    else if (k32 && rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, true>), grid, block, 0, st, fb);      \
     else if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, false>), grid, block, 0, st, fb);        \
     else if (rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, true>), grid, block, 0, st, fb);         \
     else hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, false>), grid, block, 0, st, fb)
@@ -1357,6 +1365,10 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
                                  st, &ls, &ua.r, true, &ua.tail, &tail_done))
         return rc;
+    if (dxa) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
+        if (int rc = input_grad_from_du(bws + W.du, 2 * B, S.ldz, (const float*)packed, L, nullptr, dxa, dxb, B, lddx, st, io_bf16))
+            return rc;
+    }
     for (int i = 0; i < 6; ++i) ua.prm[i] = params[i];
     ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;
     ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
@@ -1386,6 +1398,22 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
     return train_step_impl(x1, x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0, D1, D2, thetas, betas, K, alpha, kind,
                            exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps, weight_decay, packed, ws, ws_bytes, loss,
                            loss_sum, grad_out, stream);
+}
+
+int nplda_train_step_dx_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, int io_bf16, const float* target,
+                            float* const* params, int D0, int D1, int D2, float* const* thetas, const float* betas, int K,
+                            float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
+                            float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
+                            double* loss_sum, float* grad_out, void* dx1, void* dx2, int64_t lddx, nplda_stream_t stream) {
+    if (!dx1 || !dx2) return NPLDA_EINVAL;
+    return train_step_impl((const float*)x1, (const float*)x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0,
+                           D1, D2, thetas, betas, K, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
+                           weight_decay, packed, ws, ws_bytes, loss, loss_sum, grad_out, stream, dx1, dx2, lddx, io_bf16 != 0);
+}
+
+size_t nplda_train_step_dx_workspace_bytes(int64_t B, int D0, int D1, int D2, int io_bf16) {
+    if (B < 1 || check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return step_ws(B, nplda_layout(D0, D1, D2), io_bf16 != 0).total * sizeof(float);
 }
 
 int nplda_train_step_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,

@@ -7,7 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NPLDA_ABI_VERSION 2  // 2: cohort workspace starts with a 256-byte control block; Adam step buffer is two words
+#define NPLDA_ABI_VERSION 3  // 3: the parameter image carries a W1^T fragment copy (dx = du . W1); 2: cohort control block, two-word Adam step
 #define NPLDA_MAX_NB 12            // 12 x 16 = 192 features per layer
 #define NPLDA_MAX_DIM (NPLDA_MAX_NB * 16)
 
@@ -32,11 +32,13 @@ __host__ __device__ inline int nplda_kernel_nb(int D1, int D2) {
 //   W1p[ks][nb][lane][i] = W1[16 nb + (lane & 15)][16 ks + 4 (lane >> 4) + i]   (0 outside D1 x D0)
 //   W2p[kb][nb][lane][i] = W2[16 nb + (lane & 15)][16 kb + 4 (lane >> 4) + i]   (0 outside D2 x D1)
 //   W2Tp[kb][nb][lane][i] = W2[16 kb + 4 (lane >> 4) + i][16 nb + (lane & 15)]  (W2^T, backward dy = dz W2)
+//   W1Tp[kb][xb][lane][i] = W1[16 kb + 4 (lane >> 4) + i][16 xb + (lane & 15)]  (W1^T, input gradient dx = du W1;
+//                                                                               xb < KS1 column blocks of the x-vector)
 // followed by zero-padded b1, b2, Q, P = P_sqrt^2 (NB*16 each).
 struct NpldaLayout {
     int D0, D1, D2;
     int NB, KS1;  // 16-blocks per layer (square kernel), k16-steps over D0
-    size_t oW1, oW2, oW2T, ob1, ob2, oQ, oP, total;
+    size_t oW1, oW2, oW2T, oW1T, ob1, ob2, oQ, oP, total;
 };
 
 __host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
@@ -47,7 +49,8 @@ __host__ __device__ inline NpldaLayout nplda_layout(int D0, int D1, int D2) {
     L.oW1 = 0;
     L.oW2 = L.oW1 + (size_t)L.KS1 * L.NB * 256;
     L.oW2T = L.oW2 + (size_t)L.NB * L.NB * 256;
-    L.ob1 = L.oW2T + (size_t)L.NB * L.NB * 256;
+    L.oW1T = L.oW2T + (size_t)L.NB * L.NB * 256;
+    L.ob1 = L.oW1T + (size_t)L.NB * L.KS1 * 256;
     L.ob2 = L.ob1 + (size_t)L.NB * 16;
     L.oQ = L.ob2 + (size_t)L.NB * 16;
     L.oP = L.oQ + (size_t)L.NB * 16;

@@ -415,7 +415,14 @@ static __global__ void nplda_pack_kernel(const float* __restrict__ W1, const flo
     const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= L.total) return;
     float v = 0.f;
-    if (idx < L.ob1) {
+    if (idx >= L.oW1T && idx < L.ob1) {  // W1^T image [kb][xb][lane][i] (dx = du W1: nplda_matmul.hip)
+        const size_t rel = idx - L.oW1T;
+        const int i = (int)(rel & 3), lane = (int)((rel >> 2) & 63);
+        const size_t blk = rel >> 8;
+        const int xb = (int)(blk % L.KS1), kb = (int)(blk / L.KS1);
+        const int f = 16 * kb + 4 * (lane >> 4) + i, k = 16 * xb + (lane & 15);
+        if (f < L.D1 && k < L.D0) v = W1[(size_t)f * L.D0 + k];
+    } else if (idx < L.ob1) {
         const int region = idx >= L.oW2T ? 2 : (idx >= L.oW2 ? 1 : 0);
         const size_t rel = region == 2 ? idx - L.oW2T : (region == 1 ? idx - L.oW2 : idx);
         const int i = (int)(rel & 3);

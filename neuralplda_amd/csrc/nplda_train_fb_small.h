@@ -49,8 +49,12 @@ struct TrainFbArgs {
                           // the update kernel of this step, which stages the next record (a launch later: no race)
 };
 
-template <int NB, int KS1C, bool ROWS>  // ROWS: the indexed form (pairs named by table rows, x rows staged for K-B)
+// ROWS: the indexed form (pairs named by table rows — or, ia == nullptr, the batch's own rows — with the x rows staged in
+// fp32 for K-B); XBF: the x rows are bfloat16 (ldx in elements): what a jointly trained extractor hands over (cfg 5) —
+// widened in registers (one shift / mask per value), staged in fp32 like gathered rows
+template <int NB, int KS1C, bool ROWS, bool XBF = false>
 __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArgs a) {
+    static_assert(!XBF || (ROWS && KS1C > 0), "bf16 rows: the staged 512-d form only");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;  // feature-block slots per wave
     // NB = 10: blocks 0 .. 7 go two to a wave, and the two left-over blocks are split by SIDE — wave w takes block
@@ -94,13 +98,17 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     long long xrA = rA, xrB = rA;
     const BwdLoss& ls = a.ls;
     if constexpr (ROWS) {
-        xrA = a.ia[rA];
-        xrB = a.ib[rA];
-        xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
-        xrB = xrB < 0 ? 0 : (xrB < a.ntab ? xrB : a.ntab - 1);
+        if (a.ia != nullptr) {
+            xrA = a.ia[rA];
+            xrB = a.ib[rA];
+            xrA = xrA < 0 ? 0 : (xrA < a.ntab ? xrA : a.ntab - 1);
+            xrB = xrB < 0 ? 0 : (xrB < a.ntab ? xrB : a.ntab - 1);
+        }
     }
-    const float* sa = a.xa + xrA * a.ldx;
-    const float* sb = a.xb + xrB * a.ldx;
+    const float* sa = XBF ? nullptr : a.xa + xrA * a.ldx;
+    const float* sb = XBF ? nullptr : a.xb + xrB * a.ldx;
+    const unsigned short* sah4 = reinterpret_cast<const unsigned short*>(a.xa) + xrA * a.ldx + 4 * (lane >> 4);
+    const unsigned short* sbh4 = reinterpret_cast<const unsigned short*>(a.xb) + xrB * a.ldx + 4 * (lane >> 4);
 
     const f32x4* W1p = reinterpret_cast<const f32x4*>(a.packed);
     const f32x4* W2p = reinterpret_cast<const f32x4*>(a.packed + a.oW2);
@@ -132,7 +140,16 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     const float* sa4 = sa + 4 * g;
     const float* sb4 = sb + 4 * g;
     auto fetchx = [&](int slot, int ks) {
-        if constexpr (KS1C > 0) {  // D0 = 16 KS1C: whole k16-steps only, the column offset is an immediate of the load
+        if constexpr (XBF) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const int kc = ks < KS1C ? ks : KS1C - 1;
+            const u32x2 ra = *reinterpret_cast<const u32x2*>(sah4 + 16 * kc);
+            const u32x2 rb = *reinterpret_cast<const u32x2*>(sbh4 + 16 * kc);
+            xa[slot] = f32x4{__uint_as_float(ra[0] << 16), __uint_as_float(ra[0] & 0xffff0000u),
+                             __uint_as_float(ra[1] << 16), __uint_as_float(ra[1] & 0xffff0000u)};
+            xb[slot] = f32x4{__uint_as_float(rb[0] << 16), __uint_as_float(rb[0] & 0xffff0000u),
+                             __uint_as_float(rb[1] << 16), __uint_as_float(rb[1] & 0xffff0000u)};
+        } else if constexpr (KS1C > 0) {  // D0 = 16 KS1C: whole k16-steps only, the column offset is an immediate of the load
             const int kc = ks < KS1C ? ks : KS1C - 1;
             xa[slot] = *reinterpret_cast<const f32x4*>(sa4 + 16 * kc);
             xb[slot] = *reinterpret_cast<const f32x4*>(sb4 + 16 * kc);

@@ -474,6 +474,54 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
     return loss
 
 
+def train_step_dx(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
+                  weight_decay, packed, ws, loss, dx1, dx2, loss_sum=None):
+    """nplda_train_step_dx_f32: train_step that also writes dL/dx1, dL/dx2 into `dx1`, `dx2` (B, D0).  x1 / x2 and dx1 / dx2
+    are all float32 or all bfloat16 (the head's arithmetic is fp32 either way).  Four launches.  `ws`: a float32 tensor of
+    nplda_train_step_dx_workspace_bytes (train_step_dx_workspace)."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_dx")
+    bf = x1.dtype == torch.bfloat16
+    for t in (x1, x2, dx1, dx2):
+        if t.dtype != x1.dtype or t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda:
+            raise ValueError("train_step_dx: x1, x2, dx1, dx2 must be device tensors, all float32 or all bfloat16")
+        if t.dim() != 2 or t.shape[1] != packed.D0 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            raise ValueError("train_step_dx: (B, D0) rows with unit inner stride, 16-byte aligned")
+    B = x1.shape[0]
+    if x2.shape[0] != B or target.shape[0] != B or dx1.shape[0] != B or dx2.shape[0] != B:
+        raise ValueError("x1, x2, target, dx1, dx2 must have the same number of rows")
+    if x1.stride(0) != x2.stride(0) or dx1.stride(0) != dx2.stride(0):
+        raise ValueError("train_step_dx: x1 / x2 (and dx1 / dx2) must share their row stride")
+    _require_dev_f32(target, "target")
+    if not target.is_contiguous() or target.data_ptr() % 16:
+        raise ValueError("train_step_dx: target must be contiguous and 16-byte aligned")
+    for q in list(params) + list(thetas):
+        _require_dev_f32(q, "parameter")
+        if not q.is_contiguous():
+            raise ValueError("train_step_dx updates the parameter tensors in place: they must be contiguous")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(x1.device):
+        code = lib.nplda_train_step_dx_f32(_lib.ptr(x1), _lib.ptr(x2), B, x1.stride(0), 1 if bf else 0, _lib.ptr(target), parr,
+                                           packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha), kind,
+                                           _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step), float(lr), float(beta1),
+                                           float(beta2), float(eps), float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(ws),
+                                           ws.numel() * 4, _lib.ptr(loss), _lib.ptr(loss_sum) if loss_sum is not None else None,
+                                           None, _lib.ptr(dx1), _lib.ptr(dx2), dx1.stride(0), _lib.current_stream())
+    _lib.check(code, "nplda_train_step_dx_f32")
+    return loss
+
+
+def train_step_dx_workspace(B, packed, bf16):
+    """Workspace tensor for train_step_dx (None when the fused step does not cover this size / shape)."""
+    n = _lib.load().nplda_train_step_dx_workspace_bytes(B, packed.D0, packed.D1, packed.D2, 1 if bf16 else 0)
+    if n == 0:
+        return None
+    return torch.empty(n // 4, dtype=torch.float32, device=packed.buf.device)
+
+
 def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1,
                     beta2, eps, weight_decay, packed, ws, loss, grad_out=None, loss_sum=None):
     """nplda_train_step_rows_f32: train_step on the pairs (table[rows1], table[rows2]) of a resident x-vector matrix; the

@@ -592,13 +592,43 @@ class HeadStepWithInputGrads(FusedTrainStep):
             self.t = torch.zeros(batch_size, device=self.dev)
             self.t[::2] = 1
 
+    def _fused_ok(self, x1):
+        D0, D1, D2 = self.dims
+        return (self.kind in (self._ops.LOSS_SOFTCDET, self._ops.LOSS_BCE) and self.reduce_sums is None
+                and self.reduce_flat is None and 0 < x1.shape[0] <= 16384
+                and (x1.dtype == torch.float32 or (x1.dtype == torch.bfloat16 and D0 == 512 and max(D1, D2) > 144)))
+
     def describe(self):
+        if self._fused_ok(self.x1 if self.use_graph else torch.empty(1, self.dims[0], dtype=self.io_dtype)):
+            return ("nplda_train_step_dx_f32: forward + loss + data gradients (bf16 rows widened in registers) | weight-gradient "
+                    "slabs | dx = du . W1 (bf16 out) | slab sums + Adam + image" + (", one HIP-graph replay" if self.use_graph else ""))
         return ("x.float() x2, pack, nplda_forward_train_f32, nplda_loss_fwd_bwd_f32, nplda_backward_ex_f32 (flat gradient + "
                 "dx1, dx2), nplda_adam_step_f32, dx.to(dtype) x2" + (", one HIP-graph replay" if self.use_graph else ""))
 
     def _eager(self, x1, x2, t):
         ops = self._ops
         D0, D1, D2 = self.dims
+        if self._fused_ok(x1):
+            B = x1.shape[0]
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            key = ("dx", B, x1.dtype)
+            st = self._ws.get(key)
+            if st is None:
+                st = self._ws[key] = (ops.train_step_dx_workspace(B, self._packed, x1.dtype == torch.bfloat16),
+                                      torch.empty_like(x1), torch.empty_like(x2))
+            ws, dx1, dx2 = st
+            x1c = x1 if x1.is_contiguous() else x1.contiguous()
+            x2c = x2 if x2.is_contiguous() else x2.contiguous()
+            tc = t.float().contiguous()
+            with torch.no_grad():
+                ops.train_step_dx(x1c, x2c, tc, [q.detach() for q in self.params], [th.detach() for th in self.thetas],
+                                  self.betas_loss, self.alpha, self.kind, self.m, self.v, self.step_count, self.lr,
+                                  self.betas[0], self.betas[1], self.eps, self.wd, self._packed, ws, self._loss_buf,
+                                  dx1, dx2, loss_sum=self._acc())
+            if torch.cuda.is_current_stream_capturing():
+                return self._loss_buf, dx1, dx2
+            return self._loss_buf.clone(), dx1.clone(), dx2.clone()
         with torch.no_grad():
             prm = [q.detach() for q in self.params]
             packed = ops.pack_params(*prm)
@@ -610,21 +640,30 @@ class HeadStepWithInputGrads(FusedTrainStep):
             self._adam(prm + ths, grads)
         return loss, dx1.to(x1.dtype), dx2.to(x2.dtype)
 
+    def _account_step(self, x1, loss):
+        self._acc_n += 1
+        if not self._fused_ok(x1):  # (the fused call adds its loss to the device-side sum itself)
+            self._acc().add_(loss.detach().reshape(1))
+
     def __call__(self, x1, x2, target):
         B = x1.shape[0]
         if not self.use_graph or B != self.batch_size or x1.dtype != self.io_dtype:
             out = self._eager(x1, x2, target)
             self._touched()
-            self._account(out[0], B)
+            self._account_step(x1, out[0])
             return out
         if self._g is None:
+            if self._fused_ok(self.x1):
+                self._sync_packed()
             self._g, self._out = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
+        if self._fused_ok(self.x1):
+            self._sync_packed()
         self.x1.copy_(x1, non_blocking=True)
         self.x2.copy_(x2, non_blocking=True)
         self.t.copy_(target, non_blocking=True)
         self._g.replay()
         self._touched()
-        self._account(self._out[0], B)
+        self._account_step(self.x1, self._out[0])
         return self._out
 
 
