@@ -215,6 +215,8 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0):
     idle run up to 1.8x slower)."""
     dist = ctx.dist
     out = None
+    if dist is not None:
+        settle_s = 0.0  # ranks must take the SAME number of steps (their collectives pair up): W steps exactly
     t_end = time.perf_counter() + settle_s
     done = 0
     while done < warmup or time.perf_counter() < t_end:

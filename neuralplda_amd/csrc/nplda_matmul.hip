@@ -291,8 +291,8 @@ namespace nplda {
 struct DxSmallArgs {
     const float* du;
     long long ldz, rows, nsplit;
-    const float* packed;
-    size_t oW1T, total;
+    const float* frag;    // [NB][32][64][4]: W1^T fragments (the parameter image's oW1T region, or a frag_pack_kernel image)
+    size_t frag_bytes;
     void* dx0;
     void* dx1;
     long long lddx;
@@ -312,14 +312,14 @@ __global__ __launch_bounds__(256, 1) void dx_small_kernel(const DxSmallArgs a) {
         ok[rg] = row[rg] < a.rows;
         if (!ok[rg]) row[rg] = a.rows - 1;
     }
-    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, (int)(a.total * 4), 0x00020000);
+    const __amdgpu_buffer_rsrc_t img = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.frag), 0, (int)a.frag_bytes, 0x00020000);
     unsigned voff[XBW];
 #pragma unroll
     for (int u = 0; u < XBW; ++u) voff[u] = (unsigned)(((XBW * wave + u) * 64 + lane) * 16);
     f32x4 wf[PF1][XBW];
     auto fetchw = [&](int slot, int kb) {
         const int kbc = kb < NB ? kb : NB - 1;
-        const int soff = (int)(a.oW1T * 4) + kbc * (KS1 * 1024);
+        const int soff = kbc * (KS1 * 1024);
 #pragma unroll
         for (int u = 0; u < XBW; ++u)
             wf[slot][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(img, (int)voff[u], soff, 0));
@@ -374,25 +374,32 @@ __global__ __launch_bounds__(256, 1) void dx_small_kernel(const DxSmallArgs a) {
     }
 }
 
+static int launch_dx_small(const float* du, long long ldz, long long rows, long long nsplit, const float* frag, int NB, void* dx0,
+                           void* dx1, long long lddx, bool out_bf16, hipStream_t st) {
+    DxSmallArgs a = {du, ldz, rows, nsplit, frag, (size_t)NB * 32 * 1024, dx0, dx1, lddx};
+    const dim3 grid((unsigned)((rows + 31) / 32)), block(256);
+#define NPLDA_DX(NBV)                                                                              \
+    if (out_bf16) hipLaunchKernelGGL((dx_small_kernel<NBV, true>), grid, block, 0, st, a);          \
+    else hipLaunchKernelGGL((dx_small_kernel<NBV, false>), grid, block, 0, st, a)
+    switch (NB) {
+        case 8: NPLDA_DX(8); break;
+        case 9: NPLDA_DX(9); break;
+        case 10: NPLDA_DX(10); break;
+        case 11: NPLDA_DX(11); break;
+        case 12: NPLDA_DX(12); break;
+        default: return NPLDA_EUNSUPPORTED;
+    }
+#undef NPLDA_DX
+    return nplda_launch_status();
+}
+
 // dx0 / dx1: fp32 (lddx in floats) or, out_bf16, bfloat16 (lddx in elements) — the bf16 form exists for the minibatch kernel only
 int input_grad_from_du(const float* du, long long rows, long long ldz, const float* packed, const NpldaLayout& L,
                        float* /*frag: the W1^T image now rides in the parameter image*/, void* dx0, void* dx1, long long nsplit,
                        long long lddx, hipStream_t st, bool out_bf16) {
     if (rows <= 0) return NPLDA_OK;
     if (rows <= 32 * 1024 && L.D0 == 512 && L.KS1 == 32 && L.NB >= 8) {
-        DxSmallArgs a = {du, ldz, rows, nsplit, packed, L.oW1T, L.total, dx0, dx1, lddx};
-        const dim3 grid((unsigned)((rows + 31) / 32)), block(256);
-#define NPLDA_DX(NBV)                                                                              \
-    if (out_bf16) hipLaunchKernelGGL((dx_small_kernel<NBV, true>), grid, block, 0, st, a);          \
-    else hipLaunchKernelGGL((dx_small_kernel<NBV, false>), grid, block, 0, st, a)
-        switch (L.NB) {
-            case 8: NPLDA_DX(8); break;
-            case 10: NPLDA_DX(10); break;
-            case 11: NPLDA_DX(11); break;
-            default: NPLDA_DX(12); break;
-        }
-#undef NPLDA_DX
-        return nplda_launch_status();
+        return launch_dx_small(du, ldz, rows, nsplit, packed + L.oW1T, L.NB, dx0, dx1, lddx, out_bf16, st);
     }
     if (out_bf16) return NPLDA_EUNSUPPORTED;
     MatmulArgs a = {};
@@ -520,6 +527,8 @@ int nplda_lda_dgrad_f32(const float* du, int64_t ldz, int64_t B, const float* W1
     hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((need / 4 + 255) / 256)), dim3(256), 0, st, W1, (long long)D0,
                        D1, D0, 0, KB, XB, (float*)ws);
     if (int rc = nplda_launch_status()) return rc;
+    if (2 * B <= 32 * 1024 && D0 == 512 && KB >= 8 && KB <= 12)  // minibatch sizes: fragments straight from L2, no LDS slice
+        return nplda::launch_dx_small(du, ldz, 2 * B, B, (const float*)ws, KB, dx1, dx2, lddx, false, st);
     MatmulArgs a = {};
     a.in = du; a.ldin = ldz; a.R = 2 * B; a.K = Kp; a.KB = KB; a.XB = XB; a.N = D0;
     a.frag = reinterpret_cast<const f32x4*>(ws);

@@ -307,6 +307,8 @@ class FusedTrainStep:
         nplda_train_step_f32), the separate-launch forms here.  A replayed step hands out ONE loss tensor, rewritten by
         every replay, so the losses of a logging interval cannot be collected as a list of tensors."""
         self._acc_n += 1
+        if isinstance(loss, tuple):  # (loss, dx1, dx2) of a step that also returns input gradients
+            loss = loss[0]
         if not (self._one_call and 0 < B <= 16384):
             self._acc().add_(loss.detach().reshape(1))
 
@@ -674,16 +676,24 @@ class FusedDPldaStep(FusedTrainStep):
     Same interface as FusedTrainStep (call, step_rows, graph replay); follows the autograd + torch.optim.Adam
     trajectory of models.DPlda (tests/test_dplda_gpu.py)."""
 
-    def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True):
+    def __init__(self, model, lr, weight_decay=1e-5, betas=(0.9, 0.999), eps=1e-8, batch_size=None, graph=True,
+                 train_lda=False, want_dx=False):
+        """train_lda: the LDA layer trains too (a joint fine-tune; the recipe itself freezes it); want_dx: the step also
+        returns dL/dx1, dL/dx2 — `step(x1, x2, t) -> (loss, dx1, dx2)` — for an extractor upstream.  Either adds the input
+        side of the backward to the captured step (dL/d[y1; y2] = g ((M + M^T) x + v) as one resident-matrix GEMM on the
+        paired rows, the F.normalize backward, the LDA wgrad / dgrad GEMMs: the launches autograd makes one by one)."""
         from . import _lib, ops
         from .models import _loss_kind
         self._lib, self._ops = _lib, ops
         p = model.logistic_regres.weight
         if not p.is_cuda:
             raise ValueError("FusedDPldaStep needs the model on a HIP device")
-        if model.centering_and_LDA.weight.requires_grad or model.centering_and_LDA.bias.requires_grad:
+        self.train_lda, self.want_dx = bool(train_lda), bool(want_dx)
+        if not self.train_lda and (model.centering_and_LDA.weight.requires_grad or model.centering_and_LDA.bias.requires_grad):
             raise ValueError("DPlda trains with centering_and_LDA frozen (xvector_DPlda_pytorch.py:140-147): "
-                             "set requires_grad = False on its weight and bias")
+                             "set requires_grad = False on its weight and bias, or pass train_lda=True")
+        if (self.train_lda or self.want_dx) and model.centering_and_LDA.out_features % 2:
+            raise ValueError("a backward through DPlda's LDA needs an even layer1_LDA_dim (16-byte paired rows)")
         self.model, self.dev = model, p.device
         self.lr, self.wd, self.betas, self.eps = float(lr), float(weight_decay), betas, float(eps)
         self.kind = _loss_kind(model.lossfn)
@@ -693,6 +703,8 @@ class FusedDPldaStep(FusedTrainStep):
         self.betas_loss = [float(b) for b in model.beta] if self.kind == ops.LOSS_SOFTCDET else []
         self.alpha = float(model.alpha) if self.kind == ops.LOSS_SOFTCDET else 0.0
         self.params = [model.logistic_regres.weight, model.logistic_regres.bias]
+        if self.train_lda:
+            self.params += [model.centering_and_LDA.weight, model.centering_and_LDA.bias]
         D0, self.D1 = model.centering_and_LDA.in_features, model.centering_and_LDA.out_features
         n = sum(q.numel() for q in self.params) + len(self.thetas)
         self.m = torch.zeros(n, device=self.dev)
@@ -714,9 +726,14 @@ class FusedDPldaStep(FusedTrainStep):
     def _eager(self, x1, x2, t):
         ops, mdl = self._ops, self.model
         with torch.no_grad():
-            wlr, blr = (q.detach() for q in self.params)
-            packed = ops.dplda_pack(mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach(), wlr, blr)
-            s, paired = ops._gb_call(x1, x2, packed, True, True)
+            wlr, blr = (q.detach() for q in self.params[:2])
+            W1, b1 = mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach()
+            packed = ops.dplda_pack(W1, b1, wlr, blr)
+            input_side = self.train_lda or self.want_dx
+            if input_side:
+                s, paired, rn = ops._gb_call(x1, x2, packed, True, True, want_rn=True)
+            else:
+                s, paired = ops._gb_call(x1, x2, packed, True, True)
             ths = [th.detach() for th in self.thetas]
             lths = ths if self.kind == ops.LOSS_SOFTCDET else [self._zero]
             if self.reduce_sums is None:
@@ -725,8 +742,21 @@ class FusedDPldaStep(FusedTrainStep):
                 sums = self.reduce_sums(ops.loss_sums(s, t, lths, self.alpha, self.kind))
                 loss, g, dth = ops.loss_finish(s, t, lths, self.betas_loss, self.alpha, self.kind, sums)
             dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1, reduce=self.reduce_flat)
-            self._adam([wlr, blr] + ths, [dw.contiguous(), db.contiguous()] + [dth[k:k + 1] for k in range(len(ths))])
-        return loss
+            tensors, grads = [wlr, blr], [dw.contiguous(), db.contiguous()]
+            dx1 = dx2 = None
+            if input_side:
+                M, v, _ = ops.dplda_quadform(wlr, None, self.D1)
+                dpaired = ops.rows_matmul(paired, ops.pack_matrix(M, mode=2), bias=v, rowscale=g)
+                dW1, db1, dx1, dx2 = ops.lda_backward(x1, x2, paired, rn, dpaired, W1, want_w=self.train_lda,
+                                                      want_dx=self.want_dx)
+                if self.train_lda:
+                    if self.reduce_flat is not None:
+                        both = self.reduce_flat(torch.cat([dW1.reshape(-1), db1]))
+                        dW1, db1 = both[:dW1.numel()].view_as(dW1), both[dW1.numel():]
+                    tensors += [W1, b1]
+                    grads += [dW1.contiguous(), db1.contiguous()]
+            self._adam(tensors + ths, grads + [dth[k:k + 1] for k in range(len(ths))])
+        return (loss, dx1, dx2) if self.want_dx else loss
 
 
 def train_gaussian_backend(nc, model, train_loader, mega_xvec_dict, num_to_id_dict, device=None):

@@ -405,3 +405,34 @@ def test_head_step_with_input_grads_follows_autograd(hip_lib):
                 assert float((got.float() - want).abs().max()) <= 2.0 ** -7 * float(want.abs().max())
         for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_fused_dplda_step_with_lda_and_input_grads(hip_lib):
+    """FusedDPldaStep(train_lda=True, want_dx=True): the joint fine-tune step of the DPlda head (linear unit + LDA + dL/dx)
+    as one captured set of direct launches, against loss.backward() + torch.optim.Adam on the same model."""
+    from neuralplda_amd import models, train
+    from tests.test_train_gpu import NC
+    rng = np.random.default_rng(5)
+    D, B = 150, 512
+    batches = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+                torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+                torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    for graph in (False, True):
+        torch.manual_seed(3)
+        m_a = models.DPlda(NC(512, D, D)).cuda()
+        m_b = models.DPlda(NC(512, D, D)).cuda()
+        m_b.load_state_dict(m_a.state_dict())
+        step = train.FusedDPldaStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph, train_lda=True, want_dx=True)
+        opt = train.make_optimizer(m_b, 1e-3)
+        for x1, x2, t in batches:
+            loss, dx1, dx2 = step(x1, x2, t)
+            a1, a2 = x1.clone().requires_grad_(True), x2.clone().requires_grad_(True)
+            opt.zero_grad()
+            L = m_b.loss(m_b(a1, a2), t)
+            L.backward()
+            opt.step()
+            assert abs(loss.item() - L.item()) <= 1e-5 * abs(L.item())
+            for got, want in ((dx1, a1.grad), (dx2, a2.grad)):
+                assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
+        for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+            np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)

@@ -50,3 +50,9 @@ for D in (150, 170):
         d.zero_grad()
         d.loss(d(x1, x2), t).backward()
     print(f"D={D} DPlda B={B} autograd step with LDA + x gradients: {ms(step, 10)*1e3:.1f} us")
+    from neuralplda_amd import train
+    fs = train.FusedDPldaStep(d, 1e-4, batch_size=B, graph=True, train_lda=True, want_dx=True)
+    xx1, xx2 = x1.detach(), x2.detach()
+    for _ in range(20):
+        fs(xx1, xx2, t)
+    print(f"D={D} DPlda B={B} FusedDPldaStep(train_lda, want_dx), graph replay incl. Adam: {ms(lambda: fs(xx1, xx2, t), 50)*1e3:.1f} us")
