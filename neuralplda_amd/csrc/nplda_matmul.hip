@@ -76,14 +76,17 @@ struct MatmulArgs {
     int ntiles;             // tiles of 128 rows
 };
 
-template <int NS>
-__global__ __launch_bounds__(256) void rows_matmul_kernel(const MatmulArgs a) {
+// WAVES: 4, or 8 when the resident slice is so large (> 53 KB: dx at D1 >= 112) that only ONE block fits a CU — four
+// waves would then be one per SIMD with every load latency exposed (dx at 262 144 pairs: 0.60 of the peak at D = 150,
+// 0.47 at 170); eight waves share the same slice, two per SIMD.
+template <int NS, int WAVES = 4>
+__global__ __launch_bounds__(WAVES * 64) void rows_matmul_kernel(const MatmulArgs a) {
     extern __shared__ f32x4 wl[];  // [KB][NS][64]
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     const int xb0 = blockIdx.y * NS;
     const int KB = a.KB;
-    for (int idx = tid; idx < KB * NS * 64; idx += 256) {
+    for (int idx = tid; idx < KB * NS * 64; idx += WAVES * 64) {
         const int kb = idx / (NS * 64), rem = idx - kb * (NS * 64), u = rem >> 6, l = rem & 63;
         const int xb = xb0 + u;
         const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void rows_matmul_kernel(const MatmulArgs a) {
     __syncthreads();
     const int kmax = a.K - 4;
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long long r0 = ((long long)tile * 4 + wave) * 32;
+        const long long r0 = ((long long)tile * WAVES + wave) * 32;
         long long row[2];
         bool ok[2];
         const float* src[2];
@@ -153,15 +156,17 @@ __global__ __launch_bounds__(256) void rows_matmul_kernel(const MatmulArgs a) {
 
 int launch_rows_matmul(MatmulArgs a, hipStream_t st) {
     if (a.R <= 0) return NPLDA_OK;
-    const long long nt = (a.R + 127) / 128;
-    if (nt > 0x7fffffffLL) return NPLDA_EINVAL;
-    a.ntiles = (int)nt;
     // column blocks per LDS-resident slice: 8 while KB * 8 KiB fits comfortably (dx: KB <= 12 -> <= 96 KiB), else 4
     // ... and 4 as well when 8-wide slices would leave the last slice mostly empty (N = 176: 8 + 3 blocks -> 4 + 4 + 3,
     // and 44 KiB of LDS instead of 88: three resident blocks per CU)
     const int NS = (a.KB * 8 <= 96 && (a.XB % 8 == 0 || a.XB >= 24)) ? 8 : 4;
     const size_t lds = (size_t)a.KB * NS * 1024;
     if (lds > 160 * 1024) return NPLDA_EUNSUPPORTED;
+    const bool wide = NS == 8 && lds > 53 * 1024 && a.R >= 4096;  // one block per CU: give it eight waves
+    const int rows_per_tile = wide ? 256 : 128;
+    const long long nt = (a.R + rows_per_tile - 1) / rows_per_tile;
+    if (nt > 0x7fffffffLL) return NPLDA_EINVAL;
+    a.ntiles = (int)nt;
     const int slices = (a.XB + NS - 1) / NS;
     int dev = 0, cus = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
@@ -170,9 +175,16 @@ int launch_rows_matmul(MatmulArgs a, hipStream_t st) {
     long long gx = (2LL * cus + slices - 1) / slices;  // persistent: about two resident blocks per CU in total
     if (gx > nt) gx = nt;
     if (gx < 1) gx = 1;
-    dim3 grid((unsigned)gx, (unsigned)slices), block(256);
+    dim3 grid((unsigned)gx, (unsigned)slices), block(wide ? 512 : 256);
     hipError_t e;
-    if (NS == 8) {
+    if (wide) {
+        if (gx > (cus + slices - 1) / slices) gx = (cus + slices - 1) / slices;  // one resident block per CU
+        if (gx < 1) gx = 1;
+        grid.x = (unsigned)gx;
+        e = hipFuncSetAttribute((const void*)rows_matmul_kernel<8, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        hipLaunchKernelGGL((rows_matmul_kernel<8, 8>), grid, block, lds, st, a);
+    } else if (NS == 8) {
         e = hipFuncSetAttribute((const void*)rows_matmul_kernel<8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         hipLaunchKernelGGL(rows_matmul_kernel<8>, grid, block, lds, st, a);
