@@ -660,9 +660,14 @@ class HeadStepWithInputGrads(FusedTrainStep):
             self._g, self._out = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
         if self._fused_ok(self.x1):
             self._sync_packed()
-        self.x1.copy_(x1, non_blocking=True)
-        self.x2.copy_(x2, non_blocking=True)
-        self.t.copy_(target, non_blocking=True)
+        # a producer that writes into the step's own input buffers (step.x1 / .x2 / .t — e.g. the extractor's last layer
+        # with out=step.x1) skips the staging copies: 3 x ~4 us on a 0.08 ms step
+        if x1 is not self.x1:
+            self.x1.copy_(x1, non_blocking=True)
+        if x2 is not self.x2:
+            self.x2.copy_(x2, non_blocking=True)
+        if target is not self.t:
+            self.t.copy_(target, non_blocking=True)
         self._g.replay()
         self._touched()
         self._account_step(self.x1, self._out[0])
