@@ -1,5 +1,6 @@
 // nplda_fwd_dispatch.h — host-side selection of the forward kernel variant (shared by the .hip files).
 #pragma once
+#include <cstdlib>
 #include "nplda_fwd_kernel.h"
 #include "nplda_fwd_small.h"
 #include "nplda_fwd_v2.h"
@@ -162,7 +163,9 @@ static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st
 enum { FWD_SMALL = 0, FWD_MID = 1, FWD_STREAM = 2 };
 static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus) {
     if (n <= 16LL * cus) return FWD_SMALL;
-    const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
+    // NPLDA_FWD_NO_MID=1: the round-2 dispatch (A/B measurements only: tools/validate_e2e.py)
+    static const bool no_mid = getenv("NPLDA_FWD_NO_MID") != nullptr && getenv("NPLDA_FWD_NO_MID")[0] == '1';
+    const bool mid_ok = !no_mid && (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
     if (!mid_ok) return n <= 64LL * cus ? FWD_SMALL : FWD_STREAM;
     const long long c = ((n + 15) / 16 + cus - 1) / cus;
     const long long rounds = ((n + 127) / 128 + cus - 1) / cus;

@@ -97,13 +97,16 @@ class _PairScoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, opts, W1, b1, W2, b2, P_sqrt, Q):
-        reduce_flat, precision, cache = opts
+        reduce_flat, precision, cache, grad_on = opts
         dev = _compute_device(x1, W1)
         params = (W1, b1, W2, b2, P_sqrt, Q)
         on_dev = all(t.device == dev and t.dtype == torch.float32 for t in params)
         prm = [_to_dev(t, dev) for t in params]
-        need_x = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
-        need = need_x or any(ctx.needs_input_grad[3:])  # Function.forward runs with grad mode off: ask the ctx
+        # Function.forward runs with grad mode off, and ctx.needs_input_grad only says which inputs REQUIRE grad — it is
+        # True for the parameters under torch.no_grad() too: `grad_on` is the caller's grad mode (validate() and the score
+        # generators run under no_grad: they must take the scoring kernels, not the activation-saving training forward)
+        need_x = grad_on and (ctx.needs_input_grad[0] or ctx.needs_input_grad[1])
+        need = grad_on and (need_x or any(ctx.needs_input_grad[3:]))
         # training always runs the exact-fp32 kernels; `precision` only selects the inference kernel
         packed = _packed_for(cache if on_dev else None, prm, "fp32" if need else precision)
         X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
@@ -141,12 +144,12 @@ class _EmbedFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, opts, W1, b1, W2, b2, P_sqrt, Q):
-        reduce_flat, cache = opts
+        reduce_flat, cache, grad_on = opts
         dev = _compute_device(x, W1)
         params = (W1, b1, W2, b2, P_sqrt, Q)
         on_dev = all(t.device == dev and t.dtype == torch.float32 for t in params)
         packed = _packed_for(cache if on_dev else None, [_to_dev(t, dev) for t in params], "fp32")
-        need = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:6])
+        need = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[2:6]))
         ctx.need, ctx.reduce_flat = need, reduce_flat
         X = _to_dev(x, dev)
         if need:
@@ -179,11 +182,12 @@ class _EmbScoreFn(torch.autograd.Function):
     """s = forward_from_plda_embeddings(z1, z2) (utils/models.py:372-376) with its backward (dz1, dz2, dP_sqrt, dQ)."""
 
     @staticmethod
-    def forward(ctx, z1, z2, reduce_flat, P_sqrt, Q):
+    def forward(ctx, z1, z2, opts, P_sqrt, Q):
+        reduce_flat, grad_on = opts
         dev = _compute_device(z1, Q)
         Z1, Z2, ps, q = _to_dev(z1, dev), _to_dev(z2, dev), _to_dev(P_sqrt, dev), _to_dev(Q, dev)
         s = ops.score_embeddings(Z1, Z2, ps, q)
-        ctx.need = any(ctx.needs_input_grad)
+        ctx.need = grad_on and any(ctx.needs_input_grad)
         ctx.reduce_flat = reduce_flat
         if ctx.need:
             ctx.save_for_backward(Z1, Z2, ps, q, z1, z2, P_sqrt, Q)
@@ -212,13 +216,13 @@ class _DPldaScoreFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x1, x2, opts, W1, b1, wlr, blr):
-        reduce_sums64, = opts
+        reduce_sums64, grad_on = opts
         dev = _compute_device(x1, W1)
         D1 = W1.shape[0]
         W1d, b1d = _to_dev(W1, dev), _to_dev(b1, dev)
         packed = ops.dplda_pack(W1d, b1d, _to_dev(wlr, dev), _to_dev(blr, dev))
-        need_unit = ctx.needs_input_grad[5] or ctx.needs_input_grad[6]
-        need_lda = any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
+        need_unit = grad_on and (ctx.needs_input_grad[5] or ctx.needs_input_grad[6])
+        need_lda = grad_on and any(ctx.needs_input_grad[i] for i in (0, 1, 3, 4))
         X1, X2 = _to_dev(x1, dev), _to_dev(x2, dev)
         ctx.need_unit, ctx.need_lda, ctx.D1 = need_unit, need_lda, D1
         ctx.reduce = reduce_sums64
@@ -271,14 +275,15 @@ class _LossFn(torch.autograd.Function):
     all-reduces the fp64 batch sums across data-parallel ranks before the gradient is formed."""
 
     @staticmethod
-    def forward(ctx, output, target, kind, alpha, betas, reduce_sums, *thetas):
+    def forward(ctx, output, target, kind, alpha, betas, opts, *thetas):
+        reduce_sums, grad_on = opts
         dev = _compute_device(output, target)
         s, t = _to_dev(output, dev), _to_dev(target, dev)
         ths = [_to_dev(th, dev) for th in thetas]
         sums = ops.loss_sums(s, t, ths, alpha, kind)
         if reduce_sums is not None:
             sums = reduce_sums(sums)
-        need = ctx.needs_input_grad[0] or any(ctx.needs_input_grad[6:])
+        need = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[6:]))
         loss, g, dth = ops.loss_finish(s, t, ths, betas, alpha, kind, sums, want_grad=need)
         ctx.need = need
         ctx.nth = len(thetas)
@@ -364,11 +369,11 @@ class NeuralPlda(nn.Module):
     def extract_plda_embeddings(self, x):
         """utils/models.py:366-370 -> (B, D2)."""
         x = x.reshape(-1, self.centering_and_LDA.in_features) if x.dim() != 2 else x
-        return _EmbedFn.apply(x, (self._reduce_flat, self.__dict__.get("_pack_cache")), *self._params())
+        return _EmbedFn.apply(x, (self._reduce_flat, self.__dict__.get("_pack_cache"), torch.is_grad_enabled()), *self._params())
 
     def forward_from_plda_embeddings(self, x1, x2):
         """utils/models.py:372-376."""
-        return _EmbScoreFn.apply(x1, x2, self._reduce_flat, self.P_sqrt, self.Q)
+        return _EmbScoreFn.apply(x1, x2, (self._reduce_flat, torch.is_grad_enabled()), self.P_sqrt, self.Q)
 
     def forward(self, x1, x2):
         """utils/models.py:378-382: (B, D0), (B, D0) -> (B,).  B == 0 returns an empty tensor (the
@@ -377,7 +382,7 @@ class NeuralPlda(nn.Module):
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
         return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32"),
-                                           self.__dict__.get("_pack_cache")), *self._params())
+                                           self.__dict__.get("_pack_cache"), torch.is_grad_enabled()), *self._params())
 
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):
@@ -387,11 +392,11 @@ class NeuralPlda(nn.Module):
         """utils/models.py:384-388."""
         thetas = [self.threshold[b] for b in self.beta]
         return _LossFn.apply(output, target, ops.LOSS_SOFTCDET, self._alpha(), [float(b) for b in self.beta],
-                             self._reduce_sums, *thetas)
+                             (self._reduce_sums, torch.is_grad_enabled()), *thetas)
 
     def crossentropy(self, output, target):
         """utils/models.py:390-393."""
-        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, self.threshold_Xent)
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], (self._reduce_sums, torch.is_grad_enabled()), self.threshold_Xent)
 
     def loss(self, output, target):
         """utils/models.py:395-399; accepts the config spelling 'softCdet' as well (conf/voices_config.cfg:25
@@ -497,13 +502,13 @@ class DPlda(NeuralPlda):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
-        return _DPldaScoreFn.apply(x1, x2, (self.__dict__.get("_reduce_sums64"),), self.centering_and_LDA.weight,
+        return _DPldaScoreFn.apply(x1, x2, (self.__dict__.get("_reduce_sums64"), torch.is_grad_enabled()), self.centering_and_LDA.weight,
                                    self.centering_and_LDA.bias, self.logistic_regres.weight, self.logistic_regres.bias)
 
     def crossentropy(self, output, target):
         """utils/models.py:503-506: BCE(sigmoid(output), target) — no threshold."""
         zero = torch.zeros(1, dtype=torch.float32, device=output.device)
-        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, zero)
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], (self._reduce_sums, torch.is_grad_enabled()), zero)
 
     def LoadParamsFromKaldi(self, mean_vec_file, transform_mat_file):
         """utils/models.py:551-564."""
@@ -552,7 +557,7 @@ class GaussianBackend(nn.Module):
     def crossentropy(self, output, target):
         """utils/models.py:609-612: BCE(sigmoid(output), target)."""
         zero = torch.zeros(1, dtype=torch.float32, device=output.device)
-        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], self._reduce_sums, zero)
+        return _LossFn.apply(output, target, ops.LOSS_BCE, 0.0, [], (self._reduce_sums, torch.is_grad_enabled()), zero)
 
     def minc(self, output, target, update_thresholds=False, showplots=False, exact=False):
         """utils/models.py:625-651 (thresholds live in self.threshold, not in the state dict)."""

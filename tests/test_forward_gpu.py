@@ -255,3 +255,43 @@ def test_full_size_batch_properties(hip_lib):
     # (5) checksum of checksums: 16 block sums add up to the total (fp64)
     parts = s.double().reshape(16, -1).sum(1)
     assert abs(float(parts.sum()) - float(s.double().sum())) <= 1e-6 * max(1.0, abs(float(s.double().sum())))
+
+
+def test_module_forward_under_no_grad_takes_the_scoring_kernels(hip_lib):
+    """validate() and the score generators call model(x1, x2) under torch.no_grad() (xvector_NeuralPlda_pytorch.py:60-66).
+    ctx.needs_input_grad is True for the parameters there too, so the autograd bridge must be told the caller's grad mode:
+    under no_grad the module runs nplda_score_pairs_f32 (same bits as the C-ABI call, no saved activations), with grad
+    enabled the training forward (and a working backward)."""
+    from neuralplda_amd import models, ops
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
+
+    torch.manual_seed(1)
+    m = models.NeuralPlda(NC()).cuda()
+    B = 20480
+    x1 = torch.randn(B, 512, device="cuda")
+    x2 = torch.randn(B, 512, device="cuda")
+    packed = ops.pack_params(*[p.detach() for p in m._params()])
+    want = ops.score_pairs(x1, x2, packed)
+    calls = {"train": 0}
+    real = ops.forward_train
+
+    def spy(*a, **k):
+        calls["train"] += 1
+        return real(*a, **k)
+
+    ops.forward_train = spy
+    try:
+        with torch.no_grad():
+            got = m(x1, x2)
+            t = (torch.rand(B, device="cuda") < 0.1).float()
+            loss_ng = m.loss(got, t)
+        assert calls["train"] == 0 and torch.equal(got, want) and not got.requires_grad and not loss_ng.requires_grad
+        s = m(x1[:256], x2[:256])
+        assert calls["train"] == 1 and s.requires_grad
+        m.loss(s, t[:256]).backward()
+        assert m.centering_and_LDA.weight.grad is not None and torch.isfinite(m.centering_and_LDA.weight.grad).all()
+    finally:
+        ops.forward_train = real
