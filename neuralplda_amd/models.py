@@ -381,6 +381,16 @@ class NeuralPlda(nn.Module):
         D0 = self.centering_and_LDA.in_features
         if x1.numel() == 0 and x2.numel() == 0:
             x1, x2 = x1.reshape(0, D0), x2.reshape(0, D0)
+        if not torch.is_grad_enabled():
+            # inference (validate(), the score generators): straight to the scoring call — no autograd node to build; the
+            # bridge below costs ~40 us of host time per call, more than the kernel below ~8 000 pairs
+            prm = self._params()
+            w = prm[0]
+            if (w.is_cuda and x1.device == w.device and x2.device == w.device and x1.dtype == torch.float32
+                    and x2.dtype == torch.float32 and all(t.dtype == torch.float32 for t in prm)):
+                packed = _packed_for(self.__dict__.get("_pack_cache"), prm,
+                                     getattr(self, "scoring_precision", "fp32"))
+                return ops.score_pairs(x1, x2, packed)
         return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32"),
                                            self.__dict__.get("_pack_cache"), torch.is_grad_enabled()), *self._params())
 
