@@ -67,6 +67,16 @@ int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t l
                           const void* packed, int D0, int D1, int D2, float* s,
                           nplda_stream_t stream);
 
+/* nplda_score_pairs_f32 on the pairs (table[rows1[i]], table[rows2[i]]) of a resident (N, ldt) x-vector table: the gather of
+ * load_xvec_trials_from_numbatch (utils/sv_trials_loaders.py:418-426) — two passes over 2 B x 2 KB in validate()'s loop,
+ * xvector_NeuralPlda_pytorch.py:60-66 — folded into the scoring kernel (the balanced-tile kernel reads its x fragments
+ * through the indices).  rows1 / rows2: int64 device arrays, values clamped into [0, N).  Covers the batches
+ * nplda_score_pairs_f32 itself gives to that kernel (D0 == 512, D1 and D2 in 145..176, B between the small-batch and the full
+ * streaming sizes: same bits as gather + score); otherwise NPLDA_EUNSUPPORTED: gather with nplda_gather_rows_f32 and call
+ * nplda_score_pairs_f32. */
+int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                               int64_t B, const void* packed, int D0, int D1, int D2, float* s, nplda_stream_t stream);
+
 /* Name of the kernel nplda_score_pairs_f32 launches for a batch of B pairs of a D0 -> D1 -> D2 model on the current
  * device (the batch decides between the small-batch, the balanced-tile and the streaming schedule); "" for B <= 0 or an
  * unsupported model.  Reporting only (bench.py labels its roofline object with it); static storage. */

@@ -27,6 +27,8 @@ SIGNATURES = {
     "nplda_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int] * 3 + [_c_vp, _c_sz, _c_vp]),
     "nplda_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,
                                        _c_f32p, _c_vp]),
+    "nplda_score_pairs_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_int,
+                                            _c_f32p, _c_vp]),
     "nplda_embed_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
                                  _c_f32p, _c_vp]),
     "nplda_forward_train_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,

@@ -55,6 +55,24 @@ int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t l
     return launch_fwd<MODE_PAIR>(a, L, (hipStream_t)stream);
 }
 
+int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                               int64_t B, const void* packed, int D0, int D1, int D2, float* s, nplda_stream_t stream) {
+    if (B < 0 || N < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (B == 0) return NPLDA_OK;
+    if (!packed || !s || !rows1 || !rows2 || N < 1 || !nplda_aligned16(packed) || !rows_ok(table, ldt, D0)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    // only where nplda_score_pairs_f32 would run the balanced-tile kernel itself: the fused form then gives the same bits as
+    // gather + score (validate()'s device-resident pass equals its generic loop); elsewhere: gather + nplda_score_pairs_f32
+    if (pair_kernel_choice(B, L, mid_cus()) != FWD_MID) return NPLDA_EUNSUPPORTED;
+    FwdArgs a = {};
+    a.xa = table; a.xb = table; a.n = B; a.ldx = ldt; a.packed = (const float*)packed; a.out_s = s;
+    a.ia = (const long long*)rows1; a.ib = (const long long*)rows2; a.ntab = N;
+    a.D0 = L.D0; a.KS1 = L.KS1;
+    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+    return launch_fwd_mid(a, L, (hipStream_t)stream);
+}
+
 const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2) {
     if (B <= 0 || check_model(D0, D1, D2) != NPLDA_OK) return "";
     return pair_kernel_name(B, nplda_layout(D0, D1, D2));

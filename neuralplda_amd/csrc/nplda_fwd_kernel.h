@@ -98,6 +98,12 @@ struct FwdArgs {
     float* out_y;         // train: (2n, ldz) normalised layer-1 outputs, x1 rows then x2 rows
     float* out_rn;        // train: (2n) 1/max(||u||, eps)
     int no_norm;          // MODE_GB only: skip F.normalize (rows are already the paired embeddings)
+    // Indexed pairs (nplda_fwd_mid.h only: nplda_score_pairs_rows_f32): pair i reads rows ia[i] of xa and ib[i] of xb
+    // (both the resident x-vector table; indices clamped into [0, ntab)) — the gather of
+    // load_xvec_trials_from_numbatch (utils/sv_trials_loaders.py:418-426) folded into the scoring kernel.
+    const long long* ia;
+    const long long* ib;
+    long long ntab;
 };
 
 // WAVES waves per block, each owning 16 pairs (or 32 rows); KPB k16-steps of weights per barrier.

@@ -86,6 +86,10 @@ __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int 
         const int rg = (rho & (2 * T - 1)) ^ swz;  // T = 1: slots 2, 3 repeat 0, 1 (loaded, never used)
         long long row = (tile0 + (rg >> 1)) * 16 + (lane & 15);
         if (row >= a.n) row = a.n - 1;
+        if (a.ia != nullptr) {  // indexed pairs: the pair's row of the x-vector table (one dependent load per group, a group ahead)
+            row = ((rg & 1) ? a.ib : a.ia)[row];
+            row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
+        }
         A.xr[rho] = ((rg & 1) ? a.xb : a.xa) + row * a.ldx + 4 * (lane >> 4) + 32 * wave;  // k16-steps 2 w, 2 w + 1 (+ 8 m)
     }
 #pragma unroll

@@ -394,6 +394,14 @@ class NeuralPlda(nn.Module):
         return _PairScoreFn.apply(x1, x2, (self._reduce_flat, getattr(self, "scoring_precision", "fp32"),
                                            self.__dict__.get("_pack_cache"), torch.is_grad_enabled()), *self._params())
 
+    def forward_rows(self, table, rows1, rows2):
+        """Inference on pairs named by rows of a resident x-vector table (validate()'s device-resident loop): forward(
+        table[rows1], table[rows2]) without materialising the gathered batches.  No graph is built (call under no_grad)."""
+        prm = self._params()
+        packed = _packed_for(self.__dict__.get("_pack_cache"), prm, getattr(self, "scoring_precision", "fp32"))
+        with torch.no_grad():
+            return ops.score_pairs_rows(table, rows1, rows2, packed)
+
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):
         return float(self.alpha.item()) if isinstance(self.alpha, torch.Tensor) else float(self.alpha)
@@ -493,6 +501,10 @@ class DPlda(NeuralPlda):
             xd = _to_dev(x, dev)
             y = ops.gb_paired(xd, xd, *self._lda(dev))[:, :D1]
         return y if y.device == x.device else y.to(x.device)
+
+    def forward_rows(self, table, rows1, rows2):
+        """(NeuralPlda's fused gather + score does not apply to the quadratic-form head: gather, then forward.)"""
+        return self.forward(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2))
 
     def forward_from_plda_embeddings(self, x1, x2):
         """utils/models.py:484-490 on (B, D1) embeddings (used as they are, not re-normalised)."""

@@ -97,6 +97,30 @@ def score_pairs(x1, x2, packed):
     return s
 
 
+def score_pairs_rows(table, rows1, rows2, packed):
+    """nplda_score_pairs_rows_f32: scores of the pairs (table[rows1], table[rows2]) of a resident (N, D0) x-vector matrix,
+    the gather folded into the kernel; falls back to gather_rows + score_pairs where the fused form does not apply."""
+    lib = _lib.load()
+    if packed.precision != "fp32" or rows1.dtype != torch.int64 or rows2.dtype != torch.int64:
+        return score_pairs(gather_rows(table, rows1), gather_rows(table, rows2), packed)
+    table, ldt = _rows(table, "table", packed.D0)
+    rows1, rows2 = rows1.contiguous(), rows2.contiguous()
+    B = rows1.shape[0]
+    if rows2.shape[0] != B:
+        raise ValueError("rows1 and rows2 must have the same length")
+    s = torch.empty(B, dtype=torch.float32, device=table.device)
+    if B == 0:
+        return s
+    with torch.cuda.device(table.device):
+        code = lib.nplda_score_pairs_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
+                                              _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2, _lib.ptr(s),
+                                              _lib.current_stream())
+    if code == -95:  # NPLDA_EUNSUPPORTED: a shape the balanced-tile kernel does not cover
+        return score_pairs(gather_rows(table, rows1), gather_rows(table, rows2), packed)
+    _lib.check(code, "nplda_score_pairs_rows_f32")
+    return s
+
+
 def embed(x, packed, want_q=True):
     """nplda_embed_f32: (N, D0) -> z table (N, ldz) [columns >= D2 are zero] and q (N,)."""
     lib = _lib.load()

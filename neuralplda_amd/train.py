@@ -138,9 +138,13 @@ def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, upd
             # device-resident pass (see train()): same batches, same forward launches, no per-batch host copies
             from . import ops
             table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
+            fused = hasattr(model, "forward_rows")  # NeuralPlda: the gather folded into the scoring kernel
             for rows1, rows2, target in data_loader.device_batches(device, row_map):
                 targets.append(target)
-                scores.append(model.forward(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2)))
+                if fused:
+                    scores.append(model.forward_rows(table, rows1, rows2))
+                else:
+                    scores.append(model.forward(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2)))
         else:
             for data1, data2, target in data_loader:
                 data1, data2, target = data1.to(device), data2.to(device), target.to(device)

@@ -295,3 +295,29 @@ def test_module_forward_under_no_grad_takes_the_scoring_kernels(hip_lib):
         assert m.centering_and_LDA.weight.grad is not None and torch.isfinite(m.centering_and_LDA.weight.grad).all()
     finally:
         ops.forward_train = real
+
+
+@pytest.mark.parametrize("D", [150, 170, 128])
+@pytest.mark.parametrize("B", [1, 300, 4096, 20480, 70001])
+def test_score_pairs_rows_equals_gather_then_score(hip_lib, D, B):
+    """nplda_score_pairs_rows_f32: the gather of load_xvec_trials_from_numbatch (utils/sv_trials_loaders.py:418-426) folded
+    into the scoring kernel — against gather_rows + score_pairs (bit-equal) and the fp64 oracle; indices with repeats, the
+    first and the last table row; shapes / sizes the fused form does not cover (D = 128, one tile per CU or less, full
+    streaming rounds) fall back to gather + score."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(B + D)
+    N = 5000
+    p = rand_params(rng, 512, D, D)
+    tab = rng.standard_normal((N, 512)).astype(np.float32)
+    r1 = rng.integers(0, N, B)
+    r2 = rng.integers(0, N, B)
+    r1[0], r2[0] = 0, N - 1
+    packed = ops.pack_params(*to_dev(p))
+    T = torch.from_numpy(tab).cuda()
+    R1, R2 = torch.from_numpy(r1).cuda(), torch.from_numpy(r2).cuda()
+    s = ops.score_pairs_rows(T, R1, R2, packed).cpu().numpy()
+    sel = rng.choice(B, min(B, 2000), replace=False)
+    ref = orc.forward(tab[r1[sel]], tab[r2[sel]], p, np.float64)
+    assert np.all(np.abs(s[sel] - ref) <= ATOL + RTOL * np.abs(ref)), np.abs(s[sel] - ref).max()
+    g = ops.score_pairs(ops.gather_rows(T, R1), ops.gather_rows(T, R2), packed).cpu().numpy()
+    assert np.array_equal(s, g)  # the fused form runs only where score_pairs takes the same kernel: same bits
