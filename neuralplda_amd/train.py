@@ -139,7 +139,9 @@ def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, upd
             from . import ops
             table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
             fused = hasattr(model, "forward_rows")  # NeuralPlda: the gather folded into the scoring kernel
-            for rows1, rows2, target in data_loader.device_batches(device, row_map):
+            # (file order: every metric below is a function of the set of (score, label) pairs, and the host-side
+            # permutation of the epoch costs more than the whole pass; the global RNG moves on as an iteration moves it)
+            for rows1, rows2, target in data_loader.device_batches(device, row_map, permute=False):
                 targets.append(target)
                 if fused:
                     scores.append(model.forward_rows(table, rows1, rows2))

@@ -398,3 +398,26 @@ def test_mode_switch_drops_the_packed_image_cache():
         m._pack_cache["key"] = "stale"
         switch()
         assert m._pack_cache == {}
+
+
+def test_order_free_device_epoch_keeps_the_rng_protocol():
+    """device_batches(permute=False) — validate()'s form: the trials in file order, and the global generator left exactly
+    where an ordinary (permuted) iteration leaves it, so everything drawn afterwards (the training shuffles) is unchanged."""
+    from neuralplda_amd import sv_trials_loaders as svl
+    n, bs = 1000, 128
+    ds = svl.TrialIndexDataset(torch.arange(n), torch.arange(n) * 7 % n, (torch.arange(n) % 4 == 0).float())
+    row_map = torch.arange(n, dtype=torch.int64) + 5
+    torch.manual_seed(11)
+    list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate))
+    state_iter = torch.get_rng_state()
+    torch.manual_seed(11)
+    b_perm = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", row_map))
+    state_perm = torch.get_rng_state()
+    torch.manual_seed(11)
+    b_free = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", row_map, permute=False))
+    state_free = torch.get_rng_state()
+    assert torch.equal(state_iter, state_perm) and torch.equal(state_iter, state_free)
+    r1 = torch.cat([b[0] for b in b_free]); r2 = torch.cat([b[1] for b in b_free]); t = torch.cat([b[2] for b in b_free])
+    assert torch.equal(r1, row_map[ds.x1.long()]) and torch.equal(r2, row_map[ds.x2.long()]) and torch.equal(t, ds.l)
+    p1 = torch.cat([b[0] for b in b_perm])
+    assert not torch.equal(p1, r1) and torch.equal(torch.sort(p1).values, torch.sort(r1).values)

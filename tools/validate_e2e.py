@@ -58,6 +58,23 @@ def main():
             m(x1, x2)
         torch.cuda.synchronize()
     t_fwd = (time.perf_counter() - t0) / 200
+    # gather + score against the fused form (what validate()'s device-resident loop runs per batch)
+    table = svl.xvector_table(mega).on("cuda")
+    r1 = torch.randint(0, n_utt, (B,), device="cuda"); r2 = torch.randint(0, n_utt, (B,), device="cuda")
+
+    def tm(fn, n=200):
+        for _ in range(30):
+            fn()
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / n * 1e6
+    with torch.no_grad():
+        t_gs = tm(lambda: m(ops.gather_rows(table, r1), ops.gather_rows(table, r2)))
+        t_fu = tm(lambda: m.forward_rows(table, r1, r2))
+    print(f"D={D} one validate() batch of {B} pairs by table rows: gather x2 + forward {t_gs:.1f} us, fused {t_fu:.1f} us")
     name = ops._lib.load().nplda_score_pairs_kernel_name(B, 512, D, D).decode().split(" ")[0]
     mode = "round-2 dispatch (NPLDA_FWD_NO_MID=1)" if os.environ.get("NPLDA_FWD_NO_MID") == "1" else "round-3 dispatch"
     print(f"D={D} {mode}: validate() over {len(loader.dataset)} trials in batches of {B}: {t_val * 1e3:.1f} ms "
