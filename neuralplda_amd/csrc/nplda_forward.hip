@@ -70,7 +70,7 @@ int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const
     a.ia = (const long long*)rows1; a.ib = (const long long*)rows2; a.ntab = N;
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
-    return launch_fwd_mid(a, L, (hipStream_t)stream);
+    return launch_fwd_mid<false>(a, L, (hipStream_t)stream);
 }
 
 const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2) {

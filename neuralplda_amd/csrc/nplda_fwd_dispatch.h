@@ -123,16 +123,17 @@ static inline int mid_cus() {
         cus = 256;
     return cus;
 }
+template <bool EMBED = false>
 static inline int launch_fwd_mid(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
-    const long long n16 = (a.n + 15) / 16;
+    const long long n16 = EMBED ? (a.n + 31) / 32 : (a.n + 15) / 16;  // tiles: 16 pairs, or 32 embedding rows
     const int cus = mid_cus();
     const long long grid = n16 < cus ? n16 : cus;
     const long long c = (n16 + grid - 1) / grid;
     const long long r = n16 - grid * (c - 1);
     if (c > 0x7fffffffLL) return NPLDA_EINVAL;
     switch (L.NB) {
-        case 10: hipLaunchKernelGGL((nplda_fwd_mid_kernel<10>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
-        case 11: hipLaunchKernelGGL((nplda_fwd_mid_kernel<11>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
+        case 10: hipLaunchKernelGGL((nplda_fwd_mid_kernel<10, EMBED>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
+        case 11: hipLaunchKernelGGL((nplda_fwd_mid_kernel<11, EMBED>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
         default: return NPLDA_EUNSUPPORTED;
     }
     return nplda_launch_status();
@@ -181,10 +182,19 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         const int k = pair_kernel_choice(a.n, L, cus);
         a.D0 = L.D0; a.KS1 = L.KS1;
         a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
-        if (k == FWD_MID) return launch_fwd_mid(a, L, st);
+        if (k == FWD_MID) return launch_fwd_mid<false>(a, L, st);
         if (k == FWD_SMALL) return launch_fwd_small<MODE>(a, L, st);
         if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
         return launch_fwd_v5(a, L, st);
+    }
+    if constexpr (MODE == MODE_EMBED) {
+        // embedding rows (inference: no saved activations): 32 rows are one tile's worth of work; the balanced-tile kernel
+        // between one tile per CU and the streaming sizes (10 000 cohort + 22 000 enroll / test rows of cfg3: 116 -> 60 us)
+        if (a.out_y == nullptr && pair_kernel_choice((a.n + 1) / 2, L, mid_cus()) == FWD_MID) {
+            a.D0 = L.D0; a.KS1 = L.KS1;
+            a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+            return launch_fwd_mid<true>(a, L, st);
+        }
     }
     return launch_fwd_old<MODE>(a, L, st);
 }

@@ -78,14 +78,19 @@ struct MidAddr {
     const float* xr[4];
     unsigned voff[NB];  // byte offset of this lane's 16 bytes of slot a's fragment inside a k16-step of the image
 };
-template <int NB>
+// EMBED: the rows are single rows of ONE table (a.xa); a "tile" is 32 consecutive rows, its two "sides" the two halves
+template <int NB, bool EMBED = false>
 __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int T, int wave, int lane, MidAddr<NB>& A) {
     const int swz = mid_swz<NB>(T, wave);
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) {
         const int rg = (rho & (2 * T - 1)) ^ swz;  // T = 1: slots 2, 3 repeat 0, 1 (loaded, never used)
-        long long row = (tile0 + (rg >> 1)) * 16 + (lane & 15);
+        long long row = EMBED ? (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + (lane & 15) : (tile0 + (rg >> 1)) * 16 + (lane & 15);
         if (row >= a.n) row = a.n - 1;
+        if (EMBED) {
+            A.xr[rho] = a.xa + row * a.ldx + 4 * (lane >> 4) + 32 * wave;
+            continue;
+        }
         if (a.ia != nullptr) {  // indexed pairs: the pair's row of the x-vector table (one dependent load per group, a group ahead)
             row = ((rg & 1) ? a.ib : a.ia)[row];
             row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
@@ -119,7 +124,7 @@ __device__ __forceinline__ void mid_fetchx(const MidAddr<NB>& A, MidRing<NB>& R,
 // One group of T tiles starting at 16-pair tile `tile0`; the next group (TN tiles from tile_n; the block's last group names
 // itself) gets its first loads from here.  LDS: red (the exchange of the layer-1 partial sums; reused as the y tiles of
 // layer 2), ssb / scb (row norms, scores), zx (left-over z of the other side), cv (b1, b2, Q, P).
-template <int NB, int T>
+template <int NB, int T, bool EMBED = false>
 __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int TN, long long tile_n, MidRing<NB>& R,
                                           int wave, int lane, f32x4* red, float (*ssb)[4][16], float (*scb)[2][16],
                                           f32x4 (*zx)[3][64], const f32x4* cv) {
@@ -138,8 +143,8 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
 
     NPLDA_MSTAMP(0);
     MidAddr<NB> A, AN;
-    mid_addr<NB>(a, tile0, T, wave, lane, A);
-    mid_addr<NB>(a, tile_n, TN, wave, lane, AN);
+    mid_addr<NB, EMBED>(a, tile0, T, wave, lane, A);
+    mid_addr<NB, EMBED>(a, tile_n, TN, wave, lane, AN);
     bool lo_valid = true;  // NB = 11, T = 1: wave 3 owns no left-over block
     if constexpr (NB == 11 && T == 1) lo_valid = wave < 3;
     // where unit (slot s, row group rho) of this wave's partial sums goes: wave v, index u, red[v][(src - v - 1) & 3][u]
@@ -353,6 +358,46 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
     }
 
     NPLDA_MSTAMP(9);
+    if constexpr (EMBED) {
+        // ---- extract_plda_embeddings (utils/models.py:366-370): z rows out, q = sum_f Q z^2 per row (the indexed scorer's
+        // self term) reduced over the waves through LDS --------------------------------------------------------------------
+        float qp[RG];
+#pragma unroll
+        for (int rho = 0; rho < RG; ++rho) qp[rho] = 0.f;
+        auto out_unit = [&](const f32x4& z, int b, int rho, bool valid) {
+            const int rg = rho ^ swz;
+            const long long row = (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + j;
+            if (valid && row < a.n) *reinterpret_cast<f32x4*>(a.out_z + row * a.ldz + 16 * b + 4 * g) = z;
+            if (valid) {
+                const f32x4 q = Qp[4 * b + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) qp[rho] = fmaf(q[r] * z[r], z[r], qp[rho]);
+            }
+        };
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int rho = 0; rho < RG; ++rho) out_unit(zF[i][rho], blk(4 * i), rho, true);
+#pragma unroll
+        for (int i = 0; i < LS; ++i)
+#pragma unroll
+            for (int rho = 0; rho < LR; ++rho) out_unit(zL[i][rho], blk(8 + i), rho, lo_valid);
+        if (a.out_q != nullptr) {
+#pragma unroll
+            for (int rho = 0; rho < RG; ++rho) {
+                float v = wave_xor_add(qp[rho], 16);
+                v = wave_xor_add(v, 32);
+                if (g == 0) ssb[wave][rho ^ swz][j] = v;  // (the row-norm buffer is free since the y tiles were published)
+            }
+            __syncthreads();
+            if (wave < RG && g == 0) {
+                const long long row = (tile0 + (wave >> 1)) * 32 + 16 * (wave & 1) + j;
+                if (row < a.n) a.out_q[row] = ((ssb[0][wave][j] + ssb[1][wave][j]) + ssb[2][wave][j]) + ssb[3][wave][j];
+            }
+        }
+        NPLDA_MSTAMP(10);
+        return;
+    }
     // ---- score: s = sum_f Q (z1^2 + z2^2) + 2 P z1 z2 (utils/models.py:372-376) ------------------------------------------
     auto term = [&](const f32x4& z1, const f32x4& z2, int b) {  // one block's share: an 8-fma chain of its own
         const f32x4 q = Qp[4 * b + g];
@@ -401,7 +446,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
 
 // Block b works on the contiguous tile range [start, start + k): k = c for the first r blocks, c - 1 for the rest
 // (c = ceil(n16 / grid), r = n16 - grid (c - 1)) — pairs of tiles as T = 2 groups, an odd last tile as a T = 1 group.
-template <int NB>
+template <int NB, bool EMBED = false>
 __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, int c, int r) {
     constexpr int UWM = MidCfg<NB, 2>::UW > MidCfg<NB, 1>::UW ? MidCfg<NB, 2>::UW : MidCfg<NB, 1>::UW;
     __shared__ f32x4 red[4 * 3 * UWM * 64];
@@ -418,7 +463,7 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
     MidRing<NB> R;
     {
         MidAddr<NB> A0;
-        mid_addr<NB>(a, tile, k >= 2 ? 2 : 1, wave, lane, A0);
+        mid_addr<NB, EMBED>(a, tile, k >= 2 ? 2 : 1, wave, lane, A0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -434,9 +479,9 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
     }
     for (; k >= 2; k -= 2, tile += 2) {
         const int TN = k >= 4 ? 2 : (k == 3 ? 1 : 2);  // the last group names itself: a harmless re-read of its own first rows
-        mid_group<NB, 2>(a, tile, TN, k >= 3 ? tile + 2 : tile, R, wave, lane, red, ssb, scb, zx, cv);
+        mid_group<NB, 2, EMBED>(a, tile, TN, k >= 3 ? tile + 2 : tile, R, wave, lane, red, ssb, scb, zx, cv);
     }
-    if (k == 1) mid_group<NB, 1>(a, tile, 1, tile, R, wave, lane, red, ssb, scb, zx, cv);
+    if (k == 1) mid_group<NB, 1, EMBED>(a, tile, 1, tile, R, wave, lane, red, ssb, scb, zx, cv);
 }
 
 }  // namespace nplda

@@ -47,7 +47,7 @@ int main(int argc, char** argv) {
         m.xa = x1; m.xb = x2; m.n = B; m.ldx = D0; m.packed = packed; m.out_s = s2;
         m.D0 = L.D0; m.KS1 = L.KS1; m.oW2 = L.oW2; m.ob1 = L.ob1; m.ob2 = L.ob2; m.oQ = L.oQ; m.oP = L.oP; m.total = L.total;
         for (int rep = 0; rep < 4; ++rep) {
-            for (int k = 0; k < 10; ++k) launch_fwd_mid(m, L, 0);
+            for (int k = 0; k < 10; ++k) launch_fwd_mid<false>(m, L, 0);
             CK(hipDeviceSynchronize());
             unsigned long long st[32];
             CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mid_stamps), sizeof(st)));
@@ -73,7 +73,7 @@ int main(int argc, char** argv) {
             m.D0 = L.D0; m.KS1 = L.KS1; m.oW2 = L.oW2; m.ob1 = L.ob1; m.ob2 = L.ob2; m.oQ = L.oQ; m.oP = L.oP; m.total = L.total;
             float t[3] = {0, 0, 0};
             for (int v = 0; v < 2; ++v) {
-                auto go = [&]() { return v == 0 ? launch_fwd_old<MODE_PAIR>(a, L, 0) : launch_fwd_mid(m, L, 0); };
+                auto go = [&]() { return v == 0 ? launch_fwd_old<MODE_PAIR>(a, L, 0) : launch_fwd_mid<false>(m, L, 0); };
                 CK(hipMemset(v == 0 ? s : s2, 0xff, B * 4));
                 int rc = go(); rc |= go();
                 if (rc) { printf("launch rc %d\n", rc); return 1; }
