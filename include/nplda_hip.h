@@ -182,6 +182,11 @@ int nplda_score_embeddings_bwd_f32(const float* z1, int64_t ld1, const float* z2
 size_t nplda_matrix_frag_bytes(int K, int N);
 int nplda_pack_matrix_f32(const float* src, int64_t ldw, int K, int N, int mode, void* frag, size_t frag_bytes,
                           nplda_stream_t stream);
+/* DPlda's quadratic form for the input-side backward, straight from logistic_regres.weight = [Wb | Ww | ws]
+ * (utils/models.py:484-490): the fragment image of M + M^T, M = [[Ww, Wb], [Wb, Ww]] (2 D1 x 2 D1,
+ * nplda_matrix_frag_bytes(2 D1, 2 D1) bytes) and v = [ws; ws] (2 D1 floats) in one launch — what
+ * torch.cat x 3 + nplda_pack_matrix_f32(mode 2) produced. */
+int nplda_dplda_quadform_f32(const float* wlr, int D1, void* frag, size_t frag_bytes, float* v, nplda_stream_t stream);
 /* out[r, :] = rowscale[r] * (in[r, :K] . Wm + bias) for R rows; bias (N) and rowscale (R) may be NULL.  With
  * Wm = M + M^T, bias = v, rowscale = dL/ds this is the gradient of DPlda's quadratic form x^T M x + x^T v + c
  * (utils/models.py:484-495) w.r.t. the paired rows x = [y1; y2]. */
@@ -318,6 +323,12 @@ size_t nplda_moments_workspace_bytes(int64_t B, int n);
 int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, const float* w0, const float* w1,
                                double* cnt, double* sum, double* sq, int accumulate, void* workspace,
                                size_t workspace_bytes, nplda_stream_t stream);
+/* Gradient of DPlda's linear unit from the paired rows x_k = [y1 | y2] (B, ld >= 2 D1) and g = dL/ds:
+ * dw (2 D1^2 + D1) = [G12 + G21 | G11 + G22 | s1 + s2], db (1) = sum g, G = sum_k g_k x_k x_k^T  (utils/models.py:484-490;
+ * xvector_DPlda_pytorch.py:140-152 trains exactly these).  Same bits as nplda_weighted_moments_f32 followed by the fold in
+ * fp64 and one rounding; workspace: nplda_moments_workspace_bytes(B, 2 D1). */
+int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* dw, float* db,
+                         void* workspace, size_t workspace_bytes, nplda_stream_t stream);
 
 /* ---- detection-cost sweep (validation metrics) -------------------------------------------------------------------- */
 

@@ -127,6 +127,8 @@ SIGNATURES = {
                                                 _c_sz, _c_vp]),
     "nplda_matrix_frag_bytes": (_c_sz, [_c_int, _c_int]),
     "nplda_pack_matrix_f32": (_c_int, [_c_f32p, _c_i64, _c_int, _c_int, _c_int, _c_vp, _c_sz, _c_vp]),
+    "nplda_dplda_quadform_f32": (_c_int, [_c_f32p, _c_int, _c_vp, _c_sz, _c_f32p, _c_vp]),
+    "nplda_dplda_grad_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_vp, _c_sz, _c_vp]),
     "nplda_rows_matmul_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_vp, _c_int, _c_f32p, _c_f32p, _c_f32p,
                                        _c_i64, _c_vp]),
     "nplda_normalize_bwd_paired_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_f32p, _c_i64, _c_int, _c_f32p,

@@ -28,10 +28,17 @@ using namespace nplda;
 // ------------------------------------------------------------------------------------------------------------------
 // fragment images:  frag[kb][xb][lane][i] = Wm[16 kb + 4 (lane >> 4) + i][16 xb + (lane & 15)],  0 outside K x N
 // ------------------------------------------------------------------------------------------------------------------
+// mode 3: src = DPlda's logistic_regres.weight [Wb | Ww | ws] (utils/models.py:484-490), ld = D1, K = N = 2 D1:
+// Wm = M + M^T for M = [[Ww, Wb], [Wb, Ww]], and vout (2 D1) = [ws; ws] — the gradient of the quadratic form w.r.t. the
+// paired rows is g ((M + M^T) x + v)
 __global__ void frag_pack_kernel(const float* __restrict__ src, long long ld, int K, int N, int mode, int KB, int XB,
-                                 float* __restrict__ out) {
+                                 float* __restrict__ out, float* __restrict__ vout) {
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)KB * XB * 256) return;
+    if (idx >= (size_t)KB * XB * 256) {
+        const size_t t = idx - (size_t)KB * XB * 256;
+        if (mode == 3 && vout != nullptr && t < (size_t)K) vout[t] = src[2 * ld * ld + (long long)(t % (size_t)ld)];
+        return;
+    }
     const int i = (int)(idx & 3), lane = (int)((idx >> 2) & 63);
     const size_t blk = idx >> 8;
     const int xb = (int)(blk % XB), kb = (int)(blk / XB);
@@ -40,7 +47,15 @@ __global__ void frag_pack_kernel(const float* __restrict__ src, long long ld, in
     if (k < K && n < N) {
         if (mode == 0) v = src[(size_t)k * ld + n];
         else if (mode == 1) v = src[(size_t)n * ld + k];
-        else v = src[(size_t)k * ld + n] + src[(size_t)n * ld + k];  // Wm = src + src^T (K == N)
+        else if (mode == 2) v = src[(size_t)k * ld + n] + src[(size_t)n * ld + k];  // Wm = src + src^T (K == N)
+        else {
+            const int D1 = (int)ld;
+            auto M = [&](int r, int c) {
+                const float* blk = ((r < D1) == (c < D1)) ? src + (size_t)D1 * D1 : src;
+                return blk[(size_t)(r % D1) * D1 + (c % D1)];
+            };
+            v = M(k, n) + M(n, k);
+        }
     }
     out[idx] = v;
 }
@@ -457,7 +472,19 @@ int nplda_pack_matrix_f32(const float* Wm, int64_t ldw, int K, int N, int mode, 
     if (frag_bytes < need) return NPLDA_ENOSPC;
     const int KB = (K + 15) / 16, XB = (N + 15) / 16;
     hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((need / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, Wm,
-                       (long long)ldw, K, N, mode, KB, XB, (float*)frag);
+                       (long long)ldw, K, N, mode, KB, XB, (float*)frag, (float*)nullptr);
+    return nplda_launch_status();
+}
+
+int nplda_dplda_quadform_f32(const float* wlr, int D1, void* frag, size_t frag_bytes, float* v, nplda_stream_t stream) {
+    if (!wlr || !frag || !v || D1 <= 0 || !nplda_aligned16(frag)) return NPLDA_EINVAL;
+    const int K = 2 * D1;
+    const size_t need = nplda_matrix_frag_bytes(K, K);
+    if (need == 0) return NPLDA_EUNSUPPORTED;
+    if (frag_bytes < need) return NPLDA_ENOSPC;
+    const int KB = (K + 15) / 16;
+    hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((need / 4 + K + 255) / 256)), dim3(256), 0, (hipStream_t)stream, wlr,
+                       (long long)D1, K, K, 3, KB, KB, (float*)frag, v);
     return nplda_launch_status();
 }
 
@@ -537,7 +564,7 @@ int nplda_lda_dgrad_f32(const float* du, int64_t ldz, int64_t B, const float* W1
     hipStream_t st = (hipStream_t)stream;
     const int XB = (D0 + 15) / 16;
     hipLaunchKernelGGL(frag_pack_kernel, dim3((unsigned)((need / 4 + 255) / 256)), dim3(256), 0, st, W1, (long long)D0,
-                       D1, D0, 0, KB, XB, (float*)ws);
+                       D1, D0, 0, KB, XB, (float*)ws, (float*)nullptr);
     if (int rc = nplda_launch_status()) return rc;
     if (2 * B <= 32 * 1024 && D0 == 512 && KB >= 8 && KB <= 12)  // minibatch sizes: fragments straight from L2, no LDS slice
         return nplda::launch_dx_small(du, ldz, 2 * B, B, (const float*)ws, KB, dx1, dx2, lddx, false, st);

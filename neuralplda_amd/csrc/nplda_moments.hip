@@ -183,6 +183,22 @@ struct MomReduceArgs {
     double* sq;    // [nc][n][n]
 };
 
+// fp64 sum of one slab entry over the k-groups, in k order; the loads of 40 k-groups are in flight together (the kernel
+// is latency-bound: one output per thread, about one block per CU)
+__device__ __forceinline__ double slab_sum1(const float* p, size_t stride, int kgroups) {
+    constexpr int KB = 40;
+    double s = 0.0;
+    for (int k0 = 0; k0 < kgroups; k0 += KB) {
+        float v[KB];
+#pragma unroll
+        for (int u = 0; u < KB; ++u) v[u] = p[(size_t)(k0 + u < kgroups ? k0 + u : kgroups - 1) * stride];
+#pragma unroll
+        for (int u = 0; u < KB; ++u)
+            if (k0 + u < kgroups) s += (double)v[u];
+    }
+    return s;
+}
+
 __global__ __launch_bounds__(256) void moments_reduce_kernel(const MomReduceArgs a) {
     const size_t per = (size_t)a.n * a.n + a.n + 1;
     const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -197,14 +213,75 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const MomReduceArgs
         if (i > j) { const int t = i; i = j; j = t; }  // upper triangle only (lower tiles are not computed; inside
                                                       // diagonal tiles (w x_i) x_j and (w x_j) x_i round differently)
         const float* p = a.slab + (size_t)c * a.kgroups * a.Np * a.Np + (size_t)i * a.Np + j;
-        for (int k = 0; k < a.kgroups; ++k) s += (double)p[(size_t)k * a.Np * a.Np];
+        s = slab_sum1(p, (size_t)a.Np * a.Np, a.kgroups);
     } else {
         const int col = (int)(e - (size_t)a.n * a.n);  // n columns, then the weight sum
         dst = col < a.n ? a.sum + (size_t)c * a.n + col : a.cnt + c;
         const float* p = a.ext + (size_t)c * a.kgroups * (a.Np + 4) + (col < a.n ? col : a.Np);
-        for (int k = 0; k < a.kgroups; ++k) s += (double)p[(size_t)k * (a.Np + 4)];
+        s = slab_sum1(p, (size_t)a.Np + 4, a.kgroups);
     }
     *dst = a.accumulate ? *dst + s : s;
+}
+
+// DPlda's gradient straight from the slabs (utils/models.py:484-490: one linear unit over [y1 y2^T + y2 y1^T,
+// y1 y1^T + y2 y2^T, y1 + y2]): with G = sum_k g_k x_k x_k^T of the paired rows x = [y1 | y2] in blocks G11 G12 / G21 G22,
+//   d wlr = [G12 + G21 | G11 + G22 | s1 + s2],  d bias = sum g.
+// Every G element is the fp64 sum of its slab entries in k-group order — the value moments_reduce_kernel leaves in `sq` —
+// and the two are added in fp64 before the one rounding to fp32: the bits of ops.dplda_fold_grad on that kernel's output,
+// without the 0.7 MB fp64 matrix, its reduction launch (22 us at B = 2048: 34 dependent strided loads per thread) and
+// the five torch kernels of the fold.
+struct DpldaFoldArgs {
+    const float* slab;
+    const float* ext;
+    int kgroups, Np, D1;
+    float* dw;   // 2 D1^2 + D1
+    float* db;   // 1
+};
+
+// One block per 16 x 16 tile of an output block.  Half of the entries a tile needs sit mirrored in the slabs (G21 = G12^T;
+// the lower triangle of G11 / G22 is not computed): read element-wise they are 64 different cache lines per wave-load and
+// the kernel took 21 us.  Here a thread sums ONE entry of the tile as it lies in memory (16 consecutive floats per row)
+// and the mirror is taken through LDS.
+__global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) {
+    const int D1 = a.D1, TB = (D1 + 15) / 16;
+    const size_t n2 = (size_t)D1 * D1, sst = (size_t)a.Np * a.Np;
+    const int tid = threadIdx.x;
+    const int b = (int)blockIdx.x;
+    if (b >= 2 * TB * TB) {  // s1 + s2 and sum g: one output per thread, consecutive columns
+        const size_t c = (size_t)(b - 2 * TB * TB) * 256 + tid;
+        const size_t est = (size_t)a.Np + 4;
+        if (c < (size_t)D1) a.dw[2 * n2 + c] = (float)(slab_sum1(a.ext + c, est, a.kgroups) + slab_sum1(a.ext + D1 + c, est, a.kgroups));
+        else if (c == (size_t)D1) a.db[0] = (float)slab_sum1(a.ext + a.Np, est, a.kgroups);
+        return;
+    }
+    __shared__ double t1[16][17], t2[16][17];
+    const int which = b / (TB * TB);  // 0: G12 + G21, 1: G11 + G22
+    const int I = (b % (TB * TB)) / TB, J = b % TB;
+    const int r = tid >> 4, c = tid & 15;
+    // source tiles (row block, column block in units of 16 inside a D1 x D1 block; row / column offsets of that block)
+    const bool tr1 = which == 1 && I > J;        // G11 tile below the diagonal: its mirror image, transposed
+    const int rb1 = tr1 ? J : I, cb1 = tr1 ? I : J;
+    const int ro1 = 0, co1 = which == 0 ? D1 : 0;
+    const bool tr2 = which == 0 || I > J;        // G21 = G12^T always; G22 like G11
+    const int rb2 = tr2 ? J : I, cb2 = tr2 ? I : J;
+    const int ro2 = which == 0 ? 0 : D1, co2 = D1;
+    {
+        const int rr = 16 * rb1 + r, cc = 16 * cb1 + c;
+        t1[r][c] = (rr < D1 && cc < D1) ? slab_sum1(a.slab + (size_t)(ro1 + rr) * a.Np + co1 + cc, sst, a.kgroups) : 0.0;
+    }
+    {
+        const int rr = 16 * rb2 + r, cc = 16 * cb2 + c;
+        t2[r][c] = (rr < D1 && cc < D1) ? slab_sum1(a.slab + (size_t)(ro2 + rr) * a.Np + co2 + cc, sst, a.kgroups) : 0.0;
+    }
+    __syncthreads();
+    const int i = 16 * I + r, j = 16 * J + c;
+    if (i < D1 && j < D1) {
+        // a diagonal tile of G11 / G22 holds both triangles; the upper one is the value (moments_reduce_kernel)
+        const bool diag = which == 1 && I == J;
+        const double v1 = (tr1 || (diag && r > c)) ? t1[c][r] : t1[r][c];
+        const double v2 = (tr2 || (diag && r > c)) ? t2[c][r] : t2[r][c];
+        a.dw[(size_t)which * n2 + (size_t)i * D1 + j] = (float)(v1 + v2);
+    }
 }
 
 struct MomPlan {
@@ -277,6 +354,30 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
     r.cnt = cnt; r.sum = sum; r.sq = sq;
     const size_t total = ((size_t)n * n + n + 1) * nc;
     hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    return nplda_launch_status();
+}
+
+int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* dw, float* db,
+                         void* workspace, size_t workspace_bytes, nplda_stream_t stream) {
+    const int n = 2 * D1;
+    if (B <= 0 || D1 <= 0) return NPLDA_EINVAL;
+    if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
+    if (!paired || !g || !dw || !db || !workspace) return NPLDA_EINVAL;
+    if (ld < n || (ld & 3) || !nplda_aligned16(paired) || !nplda_aligned16(workspace)) return NPLDA_EINVAL;
+    const MomPlan p = mom_plan(B, n);
+    if (workspace_bytes < (p.slab_floats + p.ext_floats) * sizeof(float)) return NPLDA_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    MomArgs a;
+    a.x = paired; a.ldx = ld; a.B = B; a.n = n; a.w0 = g; a.w1 = nullptr;
+    a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
+    a.slab = (float*)workspace;
+    a.ext = a.slab + p.slab_floats;
+    hipLaunchKernelGGL(moments_kernel<1>, dim3((unsigned)(p.ntile * p.kgroups)), dim3(256), 0, st, a);
+    if (int rc = nplda_launch_status()) return rc;
+    DpldaFoldArgs f;
+    f.slab = a.slab; f.ext = a.ext; f.kgroups = p.kgroups; f.Np = p.Np; f.D1 = D1; f.dw = dw; f.db = db;
+    const int TB = (D1 + 15) / 16;
+    hipLaunchKernelGGL(dplda_fold_kernel, dim3((unsigned)(2 * TB * TB + (D1 + 1 + 255) / 256)), dim3(256), 0, st, f);
     return nplda_launch_status();
 }
 

@@ -931,6 +931,51 @@ def dplda_quadform(wlr, blr, D1):
     return M, torch.cat([ws, ws]).contiguous(), (float(blr.detach().reshape(-1)[0]) if blr is not None else 0.0)
 
 
+def dplda_quadform_image(wlr, D1):
+    """nplda_dplda_quadform_f32: ((frag, K, N) of M + M^T, v) for rows_matmul — dplda_quadform + pack_matrix(mode=2)
+    in one launch (the input-side backward of DPlda's quadratic form)."""
+    lib = _lib.load()
+    _require_dev_f32(wlr, "wlr")
+    w = wlr.detach().reshape(-1)
+    if w.numel() != 2 * D1 * D1 + D1:
+        raise ValueError("logistic_regres.weight must have 2 D1^2 + D1 inputs")
+    w = w.contiguous()
+    K = 2 * D1
+    nbytes = lib.nplda_matrix_frag_bytes(K, K)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"a {K} x {K} matrix is outside the resident-matrix GEMM (K <= 512, N % 4 == 0)")
+    frag = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
+    v = torch.empty(K, dtype=torch.float32, device=w.device)
+    with torch.cuda.device(w.device):
+        code = lib.nplda_dplda_quadform_f32(_lib.ptr(w), D1, _lib.ptr(frag), nbytes, _lib.ptr(v), _lib.current_stream())
+    _lib.check(code, "nplda_dplda_quadform_f32")
+    return (frag, K, K), v
+
+
+def dplda_grad(paired, g, D1):
+    """nplda_dplda_grad_f32: (d logistic_regres.weight (1, 2 D1^2 + D1), d bias (1,)) from the paired rows and g = dL/ds —
+    weighted_moments + dplda_fold_grad (same bits) without the fp64 moment matrix in between."""
+    lib = _lib.load()
+    _require_dev_f32(paired, "paired")
+    _require_dev_f32(g, "g")
+    B, n = paired.shape
+    if n != 2 * D1 or g.numel() != B:
+        raise ValueError("paired must be (B, 2 D1) and g (B,)")
+    if paired.stride(1) != 1 or paired.stride(0) % 4 != 0 or paired.data_ptr() % 16 != 0:
+        paired = paired.contiguous()
+    nbytes = lib.nplda_moments_workspace_bytes(B, n)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"paired rows of length {n} are outside the moments kernel")
+    ws = torch.empty(nbytes // 4, dtype=torch.float32, device=paired.device)
+    out = torch.empty(2 * D1 * D1 + D1 + 1, dtype=torch.float32, device=paired.device)
+    gg = g.detach().contiguous()
+    with torch.cuda.device(paired.device):
+        code = lib.nplda_dplda_grad_f32(_lib.ptr(paired), B, paired.stride(0), D1, _lib.ptr(gg), _lib.ptr(out),
+                                        out.data_ptr() + 4 * (out.numel() - 1), _lib.ptr(ws), nbytes, _lib.current_stream())
+    _lib.check(code, "nplda_dplda_grad_f32")
+    return out[:-1].view(1, -1), out[-1:]
+
+
 def weighted_moments(x, w0, w1=None, out=None):
     """nplda_weighted_moments_f32: x (B, n) fp32, w0/w1 (B,) fp32 -> (cnt (nc,), sum (nc, n), sq (nc, n, n)) doubles,
     nc = 2 if w1 is given else 1.  `out` = a previous result to accumulate into (streamed batches)."""

@@ -752,12 +752,15 @@ class FusedDPldaStep(FusedTrainStep):
             else:
                 sums = self.reduce_sums(ops.loss_sums(s, t, lths, self.alpha, self.kind))
                 loss, g, dth = ops.loss_finish(s, t, lths, self.betas_loss, self.alpha, self.kind, sums)
-            dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1, reduce=self.reduce_flat)
+            if self.reduce_flat is None:
+                dw, db = ops.dplda_grad(paired, g, self.D1)  # moments + fold, one call (same bits)
+            else:
+                dw, db = ops.dplda_fold_grad(*ops.weighted_moments(paired, g), self.D1, reduce=self.reduce_flat)
             tensors, grads = [wlr, blr], [dw.contiguous(), db.contiguous()]
             dx1 = dx2 = None
             if input_side:
-                M, v, _ = ops.dplda_quadform(wlr, None, self.D1)
-                dpaired = ops.rows_matmul(paired, ops.pack_matrix(M, mode=2), bias=v, rowscale=g)
+                qimg, v = ops.dplda_quadform_image(wlr, self.D1)
+                dpaired = ops.rows_matmul(paired, qimg, bias=v, rowscale=g)
                 dW1, db1, dx1, dx2 = ops.lda_backward(x1, x2, paired, rn, dpaired, W1, want_w=self.train_lda,
                                                       want_dx=self.want_dx)
                 if self.train_lda:

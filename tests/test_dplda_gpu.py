@@ -284,3 +284,40 @@ def test_dplda_device_resident_epoch_equals_the_generic_loop(hip_lib, tmp_path):
     assert log_fast == log_gen
     for k in sd_gen:
         assert np.array_equal(sd_fast[k], sd_gen[k]), k
+
+
+@pytest.mark.parametrize("D1,B", [(24, 1), (24, 100), (150, 2048), (170, 777), (96, 4099)])
+def test_dplda_grad_one_call_equals_moments_then_fold(hip_lib, D1, B):
+    """nplda_dplda_grad_f32 (moments + fold in one call) gives the bits of weighted_moments -> dplda_fold_grad; against
+    numpy fp64 as well (d wlr = [G12 + G21 | G11 + G22 | s1 + s2], d bias = sum g: utils/models.py:484-490)."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(5 * D1 + B)
+    x = rng.standard_normal((B, 2 * D1)).astype(np.float32)
+    g = (rng.standard_normal(B) / B).astype(np.float32)
+    X, G = torch.from_numpy(x).cuda(), torch.from_numpy(g).cuda()
+    dw, db = ops.dplda_grad(X, G, D1)
+    dw0, db0 = ops.dplda_fold_grad(*ops.weighted_moments(X, G), D1)
+    assert torch.equal(dw, dw0) and torch.equal(db, db0)
+    M = np.einsum("k,ki,kj->ij", g.astype(np.float64), x.astype(np.float64), x.astype(np.float64))
+    ref = np.concatenate([(M[:D1, D1:] + M[D1:, :D1]).ravel(), (M[:D1, :D1] + M[D1:, D1:]).ravel(),
+                          (g[:, None].astype(np.float64) * x).sum(0)[:D1] + (g[:, None].astype(np.float64) * x).sum(0)[D1:]])
+    np.testing.assert_allclose(dw.cpu().numpy().ravel(), ref, atol=2e-6 * max(1.0, np.abs(ref).max()), rtol=2e-5)
+    np.testing.assert_allclose(db.cpu().numpy(), [g.astype(np.float64).sum()], atol=1e-6)
+
+
+@pytest.mark.parametrize("D1", [24, 150, 170])
+def test_dplda_quadform_image_one_launch(hip_lib, D1):
+    """nplda_dplda_quadform_f32 = dplda_quadform (three torch.cat) + pack_matrix(mode 2), bit for bit; the product with it
+    is the gradient of x^T M x + x^T v w.r.t. x."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D1)
+    w = torch.from_numpy(rng.standard_normal((1, 2 * D1 * D1 + D1)).astype(np.float32)).cuda()
+    (frag, K, N), v = ops.dplda_quadform_image(w, D1)
+    M, v0, _ = ops.dplda_quadform(w, None, D1)
+    frag0, K0, N0 = ops.pack_matrix(M, mode=2)
+    assert (K, N) == (K0, N0) == (2 * D1, 2 * D1)
+    assert torch.equal(frag, frag0) and torch.equal(v, v0)
+    x = torch.from_numpy(rng.standard_normal((37, 2 * D1)).astype(np.float32)).cuda()
+    out = ops.rows_matmul(x, (frag, K, N), bias=v)
+    ref = x.double() @ (M + M.T).double() + v0.double()
+    np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-4, rtol=1e-5)
