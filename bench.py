@@ -546,11 +546,22 @@ def run_cfg2(args, ctx):
     # (FusedTrainStep.begin_epoch / step_record: the training loop's form, train.train); data parallel: step_rows
     nbat = 4096 if world == 1 else 32  # (an epoch of 4096 records: the cursor path restarts it when it runs out)
     recs = []
+    # data parallel: every rank draws the labels of ALL shards (same per-rank generators), so that it knows the global
+    # minibatch's target / non-target counts without asking — what a loader that cuts its shard out of the global batch
+    # knows anyway; they are all the one-collective step needs from the other ranks before its backward
+    gens_t = [torch.Generator(device=dev).manual_seed(5000 + r) for r in range(world)] if world > 1 else None
     for _ in range(nbat):
         r1 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
         r2 = torch.randint(0, N, (Bl,), device=dev, generator=gen_r)
-        t = (torch.rand(Bl, device=dev, generator=gen_r) < 0.1).float()
-        recs.append((r1, r2, t, torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)])))
+        if world > 1:
+            ts = [(torch.rand(Bl, device=dev, generator=g) < 0.1).float() for g in gens_t]
+            t = ts[rank]
+            nt = torch.stack([x.sum() for x in ts]).sum().double()
+            gc = torch.stack([nt, float(Bl * world) - nt])
+        else:
+            t = (torch.rand(Bl, device=dev, generator=gen_r) < 0.1).float()
+            gc = None
+        recs.append((r1, r2, t, torch.cat([r1.view(torch.uint8), r2.view(torch.uint8), t.view(torch.uint8)]), gc))
     state = {"k": 0}
     records = torch.stack([r[3] for r in recs]) if world == 1 else None
     by_cursor = world == 1 and step_fn.records_ok(table, records)
@@ -560,9 +571,9 @@ def run_cfg2(args, ctx):
             if step_fn._records_left == 0:
                 step_fn.begin_epoch(table, records)
             return step_fn.step_record()
-        r1, r2, t, rec = recs[state["k"] % nbat]
+        r1, r2, t, rec, gc = recs[state["k"] % nbat]
         state["k"] += 1
-        return step_fn.step_rows(table, r1, r2, t, record=rec)
+        return step_fn.step_rows(table, r1, r2, t, record=rec, global_counts=gc)
 
     elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.08)
     if not torch.isfinite(loss).all():
@@ -591,8 +602,10 @@ def run_cfg2(args, ctx):
                    "global_batch": Bg, "pairs_per_gpu_per_step": Bl, "table_utterances": N, "params": psrc,
                    "parallelism": f"data parallel x{world}", "backend": ctx.backend if world > 1 else "single process",
                    "graph_replay": bool(graph), "final_loss": float(loss),
-                   "collective_bytes_per_step": ({"loss_sums_allreduce": 8 * 18, "flat_gradient_allreduce":
-                                                  4 * int(step_fn.m.numel() - len(step_fn.thetas))} if world > 1 else None),
+                   "collective_bytes_per_step": ({"one_allreduce_flat_gradient_and_loss_sums":
+                                                  4 * int(step_fn._flat.numel())} if world > 1 and step_fn._flat is not None
+                                                 else ({"loss_sums_allreduce": 8 * 18, "flat_gradient_allreduce":
+                                                        4 * int(step_fn.m.numel() - len(step_fn.thetas))} if world > 1 else None)),
                    "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32)"
                                  if by_cursor else "one 20 B-byte record copy per step (nplda_train_step_rows_f32)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",

@@ -459,6 +459,36 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          double* loss_sum, float* grad_out, nplda_stream_t stream);
 
+/* The data-parallel form of nplda_train_step_f32: ONE collective per step.  dL/ds_i of SoftCdet / BCE needs the pair's own
+ * score and target and the GLOBAL batch's counts N_t, N_n only (utils/models.py:384-399), and a rank that slices its shard
+ * out of the global minibatch knows those from the labels — so no collective has to precede the backward:
+ *   nplda_train_step_grad_f32   forward + loss terms + data gradients + weight-gradient slabs of this rank's B pairs (the
+ *                               same three launches), stopping at flat[0 .. nplda_train_step_flat_floats): the flat
+ *                               gradient (nplda_grad_floats order) followed by the rank's loss sums as 2 x 18 floats (hi
+ *                               then lo halves of the fp64 sums).  global_counts: device [N_t, N_n] doubles of the global
+ *                               batch (NULL: this rank's own counts, i.e. a single rank).  Counts Adam's step; updates nothing
+ *                               else.  Workspace: nplda_train_step_workspace_bytes(B, ...).
+ *   -- SUM all-reduce of flat (fp32) across the ranks --
+ *   nplda_train_step_apply_f32  one launch: Adam on the parameters from flat, the refreshed parameter image, loss and
+ *                               dL/dtheta from the summed loss sums, Adam on the thresholds, loss_sum[0] += loss.
+ * On one rank the two calls give nplda_train_step_f32's parameters (the same slab sums and update arithmetic; the loss
+ * sums pass through the hi/lo split, ~2^-46 relative).  B <= 16384 per rank. */
+size_t nplda_train_step_flat_floats(int D0, int D1, int D2);
+int nplda_train_step_grad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+                              const double* global_counts, float* const* params, int D0, int D1, int D2,
+                              float* const* thetas, const float* betas, int K, float alpha, int kind, float* step,
+                              void* packed, void* ws, size_t ws_bytes, float* flat, nplda_stream_t stream);
+/* (the gradient phase on the pairs (table[rows1], table[rows2]) of a resident x-vector matrix, as nplda_train_step_rows_f32;
+ * workspace: nplda_train_step_rows_workspace_bytes) */
+int nplda_train_step_grad_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                                   int64_t B, const float* target, const double* global_counts, float* const* params, int D0,
+                                   int D1, int D2, float* const* thetas, const float* betas, int K, float alpha, int kind,
+                                   float* step, void* packed, void* ws, size_t ws_bytes, float* flat, nplda_stream_t stream);
+int nplda_train_step_apply_f32(const float* flat, float* const* params, int D0, int D1, int D2, float* const* thetas,
+                               const float* betas, int K, float alpha, int kind, float* exp_avg, float* exp_avg_sq,
+                               float* step, float lr, float beta1, float beta2, float eps, float weight_decay, void* packed,
+                               float* loss, double* loss_sum, nplda_stream_t stream);
+
 /* The head's step of an end-to-end fine-tune (BASELINE configs[4]; the reference chains an x-vector extractor into this head:
  * Etdnn_Xvec_NeuralPlda, utils/models.py:251-268, and autograd hands dL/dx back to it): nplda_train_step_f32 that also returns
  * dx1, dx2 (B, lddx) = dL/dx1, dL/dx2 = du . W1 with the weights the forward used — four launches: forward + loss + data

@@ -87,6 +87,19 @@ SIGNATURES = {
                                       _c_int, _c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float),
                                       _c_int, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp] + [ctypes.c_float] * 5 +
                              [_c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp, _c_vp]),
+    "nplda_train_step_flat_floats": (_c_sz, [_c_int, _c_int, _c_int]),
+    "nplda_train_step_grad_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_f32p, _c_vp, ctypes.POINTER(ctypes.c_void_p),
+                                           _c_int, _c_int, _c_int, ctypes.POINTER(ctypes.c_void_p),
+                                           ctypes.POINTER(ctypes.c_float), _c_int, ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp,
+                                           _c_sz, _c_vp, _c_vp]),
+    "nplda_train_step_grad_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_vp, _c_i64, _c_f32p, _c_vp,
+                                                ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
+                                                ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
+                                                ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp]),
+    "nplda_train_step_apply_f32": (_c_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
+                                            ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
+                                            ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp] + [ctypes.c_float] * 5 +
+                                   [_c_vp, _c_vp, _c_vp, _c_vp]),
     "nplda_train_step_dx_workspace_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int, _c_int]),
     "nplda_train_step_dx_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_f32p, ctypes.POINTER(ctypes.c_void_p), _c_int,
                                          _c_int, _c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float),

@@ -848,6 +848,9 @@ struct UpdateArgs {
     long long rec_bytes;
     unsigned ncopy;
     unsigned ngrad_blocks;
+    // data parallel (nplda_train_step_grad_f32 / nplda_train_step_apply_f32)
+    int grad_only;            // write the flat gradient to r.out and stop: no Adam, no parameter or image store
+    const float* flat;        // take the gradient from here (the all-reduced flat gradient) instead of the slabs
 };
 
 // position of W[f][k] in a fragment image [k / 16][f / 16][lane = 16 ((k % 16) / 4) + f % 16][k % 4]
@@ -918,18 +921,24 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
             }
             // at most 16 slabs (ws_layout): all 16 loads in flight at once — together with the element's parameter and
             // moments (loaded here, ahead of the stores below that they might alias) — summed in slab order like K-C
-            float part[16];
-#pragma unroll
-            for (int k = 0; k < 16; ++k) part[k] = src[(k < a.r.ksplit ? k : 0) * stride];
+            float g;
             const float p = *pp;
-            float m = a.m[idx], v = a.v[idx];
-            float sum = 0.f;
+            if (a.flat) {
+                g = a.flat[idx];
+            } else {
+                float part[16];
 #pragma unroll
-            for (int k = 0; k < 16; ++k) sum += k < a.r.ksplit ? part[k] : 0.f;
-            // the product is rounded on its own, as K-C stores it: left to the compiler it is contracted into Adam's g + wd p
-            float g = which ? sum * (4.0f * p) : sum;
-            asm volatile("" : "+v"(g));
+                for (int k = 0; k < 16; ++k) part[k] = src[(k < a.r.ksplit ? k : 0) * stride];
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 16; ++k) sum += k < a.r.ksplit ? part[k] : 0.f;
+                // the product is rounded on its own, as K-C stores it: left to the compiler it is contracted into Adam's g + wd p
+                g = which ? sum * (4.0f * p) : sum;
+                asm volatile("" : "+v"(g));
+            }
             if (a.r.out) a.r.out[idx] = g;
+            if (a.grad_only) continue;
+            float m = a.m[idx], v = a.v[idx];
             const float pn = nplda_adam::update(p, g, m, v, c);
             a.m[idx] = m;
             a.v[idx] = v;
@@ -1273,7 +1282,13 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                          float alpha, int kind, float* exp_avg, float* exp_avg_sq, float* step, float lr, float beta1,
                          float beta2, float eps, float weight_decay, void* packed, void* ws, size_t ws_bytes, float* loss,
                          double* loss_sum, float* grad_out, nplda_stream_t stream, void* dxa = nullptr, void* dxb = nullptr,
-                         int64_t lddx = 0, bool io_bf16 = false) {
+                         int64_t lddx = 0, bool io_bf16 = false, const double* gcount = nullptr, float* dp_flat = nullptr) {
+    // dp_flat: the data-parallel gradient phase (nplda_train_step_grad_f32) — same three launches, but the last two stop at
+    // this rank's flat gradient [ngrad | loss sums as 2 x kLossNS floats] and nothing is updated
+    if (dp_flat) {
+        if (cursor || grad_out) return NPLDA_EINVAL;
+        grad_out = dp_flat;
+    }
     if (cursor) {  // the batch sits in the staging record [rows1 | rows2 | labels]
         if (!stage || !nplda_aligned16(stage) || B < 1) return NPLDA_EINVAL;
         if ((B % 4) != 0) return NPLDA_EUNSUPPORTED;  // 16-byte pieces: the labels sit behind 16 B bytes of indices
@@ -1308,6 +1323,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     BwdLoss ls = {};
     ls.s = wsf + S.s; ls.t = target; ls.K = nth; ls.kind = kind; ls.alpha = alpha; ls.B = B;
     ls.g_out = wsf + S.g; ls.partial = reinterpret_cast<double*>(wsf + S.partial);
+    ls.gcount = gcount;
     UpdateArgs ua = {};
     for (int k = 0; k < nth; ++k) {
         if (!thetas[k]) return NPLDA_EINVAL;
@@ -1356,7 +1372,9 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         t.loss = loss; t.loss_sum = loss_sum; t.m = exp_avg + ngrad0; t.v = exp_avg_sq + ngrad0;
         t.gout = grad_out ? grad_out + ngrad0 : nullptr; t.step = step; t.bumped = 1;
         t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
+        if (dp_flat) { t.sums_out = dp_flat + ngrad0; t.gout = nullptr; t.loss_sum = nullptr; }
     }
+    ua.grad_only = dp_flat ? 1 : 0;
     bool tail_done = false;
     // the weight gradients read the x rows: the caller's, or the ones the first kernel gathered
     const float* wx1 = rows ? wsf + S.xs : x1;
@@ -1409,6 +1427,73 @@ int nplda_train_step_dx_f32(const void* x1, const void* x2, int64_t B, int64_t l
     return train_step_impl((const float*)x1, (const float*)x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0,
                            D1, D2, thetas, betas, K, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
                            weight_decay, packed, ws, ws_bytes, loss, loss_sum, grad_out, stream, dx1, dx2, lddx, io_bf16 != 0);
+}
+
+int nplda_train_step_grad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
+                              const double* global_counts, float* const* params, int D0, int D1, int D2,
+                              float* const* thetas, const float* betas, int K, float alpha, int kind, float* step,
+                              void* packed, void* ws, size_t ws_bytes, float* flat, nplda_stream_t stream) {
+    if (!flat) return NPLDA_EINVAL;
+    float dummy_loss = 0.f;  // (never written: the tail stops at the sums)
+    // the optimiser state is not touched in this phase; the moments' pointers only have to be non-null
+    return train_step_impl(x1, x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0, D1, D2, thetas, betas, K,
+                           alpha, kind, flat, flat, step, 0.f, 0.f, 0.f, 0.f, 0.f, packed, ws, ws_bytes, &dummy_loss, nullptr,
+                           nullptr, stream, nullptr, nullptr, 0, false, global_counts, flat);
+}
+
+int nplda_train_step_grad_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
+                                   int64_t B, const float* target, const double* global_counts, float* const* params, int D0,
+                                   int D1, int D2, float* const* thetas, const float* betas, int K, float alpha, int kind,
+                                   float* step, void* packed, void* ws, size_t ws_bytes, float* flat, nplda_stream_t stream) {
+    if (!flat || !rows1 || !rows2 || N < 1) return NPLDA_EINVAL;
+    float dummy_loss = 0.f;
+    return train_step_impl(table, table, rows1, rows2, N, nullptr, nullptr, B, ldt, target, params, D0, D1, D2, thetas, betas, K,
+                           alpha, kind, flat, flat, step, 0.f, 0.f, 0.f, 0.f, 0.f, packed, ws, ws_bytes, &dummy_loss, nullptr,
+                           nullptr, stream, nullptr, nullptr, 0, false, global_counts, flat);
+}
+
+size_t nplda_train_step_flat_floats(int D0, int D1, int D2) {
+    if (check_model(D0, D1, D2) != NPLDA_OK) return 0;
+    return nplda_grad_floats(D0, D1, D2) + 2 * (size_t)kLossNS;
+}
+
+int nplda_train_step_apply_f32(const float* flat, float* const* params, int D0, int D1, int D2, float* const* thetas,
+                               const float* betas, int K, float alpha, int kind, float* exp_avg, float* exp_avg_sq,
+                               float* step, float lr, float beta1, float beta2, float eps, float weight_decay, void* packed,
+                               float* loss, double* loss_sum, nplda_stream_t stream) {
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (kind != 0 && kind != 1) return kind == 2 ? NPLDA_EUNSUPPORTED : NPLDA_EINVAL;
+    const int nth = kind == 1 ? 1 : K;
+    if (nth < 1 || nth > nplda_loss::kMaxK || !thetas || !params || (kind == 0 && !betas)) return NPLDA_EINVAL;
+    if (!flat || !exp_avg || !exp_avg_sq || !step || !packed || !loss || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    const size_t ngrad = nplda_grad_floats(D0, D1, D2);
+    UpdateArgs ua = {};
+    ua.r.D0 = D0; ua.r.D1 = D1; ua.r.D2 = D2;
+    for (int i = 0; i < 6; ++i) {
+        if (!params[i]) return NPLDA_EINVAL;
+        ua.prm[i] = params[i];
+    }
+    LossTail& t = ua.tail;
+    for (int k = 0; k < nth; ++k) {
+        if (!thetas[k]) return NPLDA_EINVAL;
+        t.theta[k] = thetas[k];
+        if (kind == 0) t.beta.b[k] = betas[k];
+    }
+    t.nblk = 0; t.K = nth; t.kind = kind; t.alpha = alpha; t.loss = loss; t.loss_sum = loss_sum;
+    t.m = exp_avg + ngrad; t.v = exp_avg_sq + ngrad; t.step = step; t.bumped = 1;
+    t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
+    t.sums_in = flat + ngrad;
+    ua.m = exp_avg; ua.v = exp_avg_sq; ua.step = step;
+    ua.lr = lr; ua.beta1 = beta1; ua.beta2 = beta2; ua.eps = eps; ua.wd = weight_decay;
+    ua.L = L; ua.packed = (float*)packed;
+    ua.bumped = 1;  // nplda_train_step_grad_f32's first kernel has counted the step
+    ua.tail_here = 1;
+    ua.flat = flat;
+    constexpr int E = 2;
+    ua.ngrad_blocks = (unsigned)((ngrad + 256 * E - 1) / (256 * E));
+    hipLaunchKernelGGL(train_update_kernel<E>, dim3(ua.ngrad_blocks + 1), dim3(256), 0, (hipStream_t)stream, ua);
+    return nplda_launch_status();
 }
 
 size_t nplda_train_step_dx_workspace_bytes(int64_t B, int D0, int D1, int D2, int io_bf16) {

@@ -18,6 +18,9 @@ struct BwdLoss {
     long long B;
     float* g_out;         // (B) dL/ds, for the weight-gradient kernel's dQ / dP sums
     double* partial;      // [blocks][kLossNS] loss sums of the block's 16 pairs
+    const double* gcount; // optional: the GLOBAL batch's [N_t, N_n] (data parallel: dL/ds_i needs the pair's own score and
+                          // target and these two counts only, so a rank given them forms its shard's gradient with no
+                          // collective in front — train_fb_small_kernel; null: counted from `t`)
 };
 
 

@@ -23,6 +23,11 @@ struct LossTail {
     const float* step;        // Adam's step counter
     int bumped;               // step[0] already counts this step (train_fb_small_kernel)
     float lr, beta1, beta2, eps, wd;
+    // data parallel (nplda_train_step_grad_f32 / _apply_f32): the loss sums cross the ranks inside the ONE fp32 all-reduce
+    // of the flat gradient, as (hi, lo) float pairs — hi = (float)d, lo = (float)(d - hi): the fp32 sums of the his and of
+    // the los give the fp64 sum to ~2^-46 relative.
+    float* sums_out;          // grad phase: write the block-summed loss sums here [kLossNS his | kLossNS los] and stop
+    const float* sums_in;     // apply phase: take the (all-reduced) sums from here instead of `partial`
 };
 
 constexpr int kLossTailSmem = (256 * (kLossNS + 1) + kLossNS * 8 + kLossNS) * 8 + nplda_loss::kMaxK * 4;  // bytes
@@ -39,7 +44,7 @@ __device__ __forceinline__ void loss_tail_block(const LossTail& a, void* smem) {
     const int ns = nplda_loss::nsums(a.K, a.kind);
     const int i = tid >> 3, cc = tid & 7;
     double vv = 0.0;
-    for (int base = 0; base < a.nblk; base += 256) {
+    for (int base = 0; base < (a.sums_in ? 0 : a.nblk); base += 256) {
         const int b = base + tid;
         if (on) {
 #pragma unroll
@@ -56,7 +61,17 @@ __device__ __forceinline__ void loss_tail_block(const LossTail& a, void* smem) {
         double w = 0.0;
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) w += chain[tid][c8];
+        if (a.sums_in) w = (double)a.sums_in[tid] + (double)a.sums_in[kLossNS + tid];
         sums[tid] = w;
+        if (a.sums_out) {
+            const float hi = (float)w;
+            a.sums_out[tid] = hi;
+            a.sums_out[kLossNS + tid] = (float)(w - (double)hi);
+        }
+    }
+    if (a.sums_out) {  // (unused slots stay zero for the all-reduce)
+        if (tid >= ns && tid < kLossNS) a.sums_out[tid] = a.sums_out[kLossNS + tid] = 0.f;
+        return;
     }
     __syncthreads();
     if (tid == 0) {

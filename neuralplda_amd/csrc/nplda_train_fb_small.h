@@ -242,8 +242,9 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         if (lane == 0) cnt_s[wave] = cw;
     }
     __syncthreads();
-    const double Nt = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // as block_target_count
-    const double Nn = (double)ls.B - Nt;
+    const double Ntl = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));  // as block_target_count
+    const double Nt = ls.gcount ? ls.gcount[0] : Ntl;                            // data parallel: the global batch's counts
+    const double Nn = ls.gcount ? ls.gcount[1] : (double)ls.B - Ntl;
     const float invA = 1.0f / fmaxf(sqrtf(((red[0][0][j] + red[1][0][j]) + red[2][0][j]) + red[3][0][j]), 1e-12f);
     const float invB = 1.0f / fmaxf(sqrtf(((red[0][1][j] + red[1][1][j]) + red[2][1][j]) + red[3][1][j]), 1e-12f);
     const long long rH = hside ? rB : rA;  // HALF: the row of the half slot's side

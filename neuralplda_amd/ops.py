@@ -498,6 +498,103 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
     return loss
 
 
+def train_step_flat_floats(packed):
+    """Length of the data-parallel step's flat buffer: the flat gradient + 2 x 18 floats of loss sums."""
+    return int(_lib.load().nplda_train_step_flat_floats(packed.D0, packed.D1, packed.D2))
+
+
+def train_step_grad(x1, x2, target, params, thetas, betas, alpha, kind, step, packed, ws, flat, global_counts=None):
+    """nplda_train_step_grad_f32: this rank's share of a data-parallel step up to the flat gradient (+ loss sums) in
+    `flat`; `global_counts` = device float64 [N_t, N_n] of the GLOBAL minibatch (None: one rank).  Follow with a SUM
+    all-reduce of `flat` and train_step_apply."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_grad")
+    x1, ld1 = _rows(x1, "x1", packed.D0)
+    x2, ld2 = _rows(x2, "x2", packed.D0)
+    if x1.shape[0] != x2.shape[0] or target.shape[0] != x1.shape[0]:
+        raise ValueError("x1, x2 and target must have the same number of rows")
+    if ld1 != ld2:
+        x1, x2 = x1.contiguous(), x2.contiguous()
+        ld1 = ld2 = packed.D0
+    _require_dev_f32(target, "target")
+    target = target.contiguous()
+    if target.data_ptr() % 16:
+        target = target.clone()
+    if global_counts is not None and (global_counts.dtype != torch.float64 or not global_counts.is_cuda
+                                      or global_counts.numel() != 2 or not global_counts.is_contiguous()):
+        raise ValueError("global_counts must be a contiguous device float64 tensor [N_t, N_n]")
+    if flat.dtype != torch.float32 or not flat.is_cuda or flat.numel() < train_step_flat_floats(packed) or not flat.is_contiguous():
+        raise ValueError("flat must be a contiguous device float32 tensor of train_step_flat_floats(packed) elements")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(x1.device):
+        code = lib.nplda_train_step_grad_f32(_lib.ptr(x1), _lib.ptr(x2), x1.shape[0], ld1, _lib.ptr(target),
+                                             _lib.ptr(global_counts) if global_counts is not None else None, parr,
+                                             packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha),
+                                             kind, _lib.ptr(step), _lib.ptr(packed.buf), _lib.ptr(ws), ws.numel() * 4,
+                                             _lib.ptr(flat), _lib.current_stream())
+    _lib.check(code, "nplda_train_step_grad_f32")
+    return flat
+
+
+def train_step_grad_rows(table, rows1, rows2, target, params, thetas, betas, alpha, kind, step, packed, ws, flat,
+                         global_counts=None):
+    """nplda_train_step_grad_rows_f32: train_step_grad on the pairs (table[rows1], table[rows2]); the first kernel gathers
+    the rows itself.  `ws`: train_step_workspace(B, packed, rows=True)."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_grad_rows")
+    table, ldt = _rows(table, "table", packed.D0)
+    dev = table.device
+    if rows1.dtype != torch.int64 or rows2.dtype != torch.int64 or rows1.device != dev or rows2.device != dev:
+        raise TypeError("rows must be int64 tensors on the table's device")
+    rows1, rows2 = rows1.contiguous(), rows2.contiguous()
+    B = rows1.shape[0]
+    if rows2.shape[0] != B or target.shape[0] != B:
+        raise ValueError("rows1, rows2 and target must have the same length")
+    _require_dev_f32(target, "target")
+    target = target.contiguous()
+    if target.data_ptr() % 16:
+        target = target.clone()
+    if global_counts is not None and (global_counts.dtype != torch.float64 or not global_counts.is_cuda
+                                      or global_counts.numel() != 2 or not global_counts.is_contiguous()):
+        raise ValueError("global_counts must be a contiguous device float64 tensor [N_t, N_n]")
+    if flat.dtype != torch.float32 or not flat.is_cuda or flat.numel() < train_step_flat_floats(packed) or not flat.is_contiguous():
+        raise ValueError("flat must be a contiguous device float32 tensor of train_step_flat_floats(packed) elements")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(dev):
+        code = lib.nplda_train_step_grad_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
+                                                  _lib.ptr(target), _lib.ptr(global_counts) if global_counts is not None else None,
+                                                  parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K,
+                                                  float(alpha), kind, _lib.ptr(step), _lib.ptr(packed.buf), _lib.ptr(ws),
+                                                  ws.numel() * 4, _lib.ptr(flat), _lib.current_stream())
+    _lib.check(code, "nplda_train_step_grad_rows_f32")
+    return flat
+
+
+def train_step_apply(flat, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
+                     weight_decay, packed, loss, loss_sum=None):
+    """nplda_train_step_apply_f32: the update half of the data-parallel step from the all-reduced `flat`."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_apply")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(flat.device):
+        code = lib.nplda_train_step_apply_f32(_lib.ptr(flat), parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas),
+                                              barr, K, float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
+                                              _lib.ptr(step), float(lr), float(beta1), float(beta2), float(eps),
+                                              float(weight_decay), _lib.ptr(packed.buf), _lib.ptr(loss),
+                                              _lib.ptr(loss_sum) if loss_sum is not None else None, _lib.current_stream())
+    _lib.check(code, "nplda_train_step_apply_f32")
+    return loss
+
+
 def train_step_dx(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
                   weight_decay, packed, ws, loss, dx1, dx2, loss_sum=None):
     """nplda_train_step_dx_f32: train_step that also writes dL/dx1, dL/dx2 into `dx1`, `dx2` (B, D0).  x1 / x2 and dx1 / dx2

@@ -251,6 +251,7 @@ class FusedTrainStep:
     are stream operations), so the replayed step stays one graph launch per rank."""
 
     _one_call = False  # subclasses with their own kernels (FusedDPldaStep) keep the separate calls
+    _dp_call = False
     _packed = _packed_key = None
     _loss_acc, _acc_n = None, 0  # fp64 device sum of the losses since pop_loss_mean(), number of steps in it
     _cursor = _stage = _graph_rec = _loss_rec = _graph_rec_table = _records_ref = None
@@ -293,6 +294,13 @@ class FusedTrainStep:
         # parameters from step to step (re-packed only when something else has touched them: version counters)
         self._one_call = (type(self) is FusedTrainStep and self.reduce_sums is None and self.reduce_flat is None
                           and self.kind in (ops.LOSS_SOFTCDET, ops.LOSS_BCE))
+        # data-parallel one-collective step (nplda_train_step_grad_f32 -> ONE all-reduce -> nplda_train_step_apply_f32): the
+        # same kernels as the one-call step; dL/ds needs only the GLOBAL batch's counts, which the caller passes (or a
+        # 16-byte all-reduce in front finds)
+        self._dp_call = (type(self) is FusedTrainStep and self.reduce_flat is not None
+                         and self.kind in (ops.LOSS_SOFTCDET, ops.LOSS_BCE))
+        self.gcount = torch.zeros(2, dtype=torch.float64, device=self.dev) if self._dp_call else None
+        self._flat = None
         self._packed = None
         self._packed_key = None
         self._ws = {}
@@ -315,7 +323,7 @@ class FusedTrainStep:
         self._acc_n += 1
         if isinstance(loss, tuple):  # (loss, dx1, dx2) of a step that also returns input gradients
             loss = loss[0]
-        if not (self._one_call and 0 < B <= 16384):
+        if not ((self._one_call or self._dp_call) and 0 < B <= 16384):
             self._acc().add_(loss.detach().reshape(1))
 
     def pop_loss_mean(self):
@@ -356,6 +364,46 @@ class FusedTrainStep:
         # the captured step hands out its static output; an eager step a tensor of its own (callers keep losses around)
         return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
 
+    def _dp_step(self, x1, x2, t, table=None):
+        """This rank's shard of the global minibatch: gradient phase -> ONE SUM all-reduce of [flat gradient | loss sums]
+        (captured with the kernels when the step is a graph) -> update phase.  self.gcount holds the global [N_t, N_n].
+        With `table`, x1 / x2 are row indices into it and the first kernel gathers the rows itself."""
+        ops = self._ops
+        B = x1.shape[0]
+        key = ("rows", B) if table is not None else B
+        ws = self._ws.get(key)
+        if ws is None:
+            ws = self._ws[key] = ops.train_step_workspace(B, self._packed, rows=table is not None)
+        if self._flat is None:
+            self._flat = torch.zeros(ops.train_step_flat_floats(self._packed), device=self.dev)
+        with torch.no_grad():
+            prm, ths = [q.detach() for q in self.params], [th.detach() for th in self.thetas]
+            if table is not None:
+                ops.train_step_grad_rows(table, x1, x2, t, prm, ths, self.betas_loss, self.alpha, self.kind, self.step_count,
+                                         self._packed, ws, self._flat, self.gcount)
+            else:
+                ops.train_step_grad(x1, x2, t, prm, ths, self.betas_loss, self.alpha, self.kind, self.step_count,
+                                    self._packed, ws, self._flat, self.gcount)
+            self.reduce_flat(self._flat)
+            ops.train_step_apply(self._flat, prm, ths, self.betas_loss, self.alpha, self.kind, self.m, self.v, self.step_count,
+                                 self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self._packed, self._loss_buf,
+                                 loss_sum=self._acc())
+        return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
+
+    def set_global_counts(self, target=None, counts=None):
+        """Data parallel: the GLOBAL minibatch's [N_t, N_n] for the next step.  `counts` (two numbers or a tensor) when the
+        caller knows them — a loader that slices its shard out of the global batch does; else they are found from this
+        rank's `target` with a 16-byte all-reduce."""
+        if not self._dp_call:
+            return
+        if counts is not None:
+            c = counts if torch.is_tensor(counts) else torch.tensor([float(counts[0]), float(counts[1])], dtype=torch.float64)
+            self.gcount.copy_(c.to(torch.float64).reshape(2), non_blocking=True)
+        else:
+            nt = target.detach().double().sum().reshape(1)
+            c = torch.cat([nt, float(target.shape[0]) - nt])
+            self.gcount.copy_(self.reduce_sums(c) if self.reduce_sums is not None else c)
+
     def _eager(self, x1, x2, t):
         ops = self._ops
         D0, D1, D2 = self.dims
@@ -363,6 +411,10 @@ class FusedTrainStep:
             if self._packed is None or not torch.cuda.is_current_stream_capturing():
                 self._sync_packed()
             return self._one_call_step(x1, x2, t)
+        if self._dp_call and 0 < x1.shape[0] <= 16384:
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            return self._dp_step(x1, x2, t)
         with torch.no_grad():
             prm = [q.detach() for q in self.params]
             packed = ops.pack_params(*prm)
@@ -416,7 +468,7 @@ class FusedTrainStep:
             self.v.copy_(v0)
             self.step_count.copy_(s0)
             self._loss_acc.copy_(a0)
-        if self._one_call:
+        if self._one_call or self._dp_call:
             self._sync_packed()  # the warm-up moved the image along with the parameters: back to the restored values
         graph = torch.cuda.CUDAGraph()
         # with collectives in the step the RCCL watchdog thread polls events while we capture: only this thread's calls
@@ -429,7 +481,7 @@ class FusedTrainStep:
     def _capture(self):
         self._graph, self._loss = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
 
-    def step_rows(self, table, rows1, rows2, target, record=None):
+    def step_rows(self, table, rows1, rows2, target, record=None, global_counts=None):
         """One step on the pairs (table[rows1], table[rows2]): `table` is the resident (N, D0) x-vector matrix, rows
         int64 device tensors.  With graph replay the gather is part of the captured step (its first kernel reads the rows
         through the indices) and the indices sit in static buffers, so a step costs three small device copies — ONE when
@@ -437,6 +489,8 @@ class FusedTrainStep:
         graph launch on the host."""
         ops = self._ops
         B = rows1.shape[0]
+        if self._dp_call and 0 < B <= 16384:
+            self.set_global_counts(target, global_counts)
         if not self.use_graph or B != self.batch_size:
             loss = self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
             self._touched()
@@ -444,7 +498,7 @@ class FusedTrainStep:
             return loss
         if self._graph_rows is None or self._graph_table != (table.data_ptr(), table.shape, table.stride(0)):
             self._capture_rows(table)
-        if self._one_call:
+        if self._one_call or self._dp_call:
             self._sync_packed()
         if record is not None:
             self._rec.copy_(record, non_blocking=True)
@@ -539,6 +593,10 @@ class FusedTrainStep:
                                     self.v, self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd,
                                     self._packed, ws, self._loss_buf, loss_sum=self._acc())
             return self._loss_buf if torch.cuda.is_current_stream_capturing() else self._loss_buf.clone()
+        if self._dp_call and 0 < self.batch_size <= 16384 and self.dims[0] % 16 == 0:
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            return self._dp_step(self.i1, self.i2, self._t_rows, table=table)
         ops.gather_rows(table, self.i1, out=self.x1)
         ops.gather_rows(table, self.i2, out=self.x2)
         return self._eager(self.x1, self.x2, self._t_rows)
@@ -555,7 +613,11 @@ class FusedTrainStep:
         self._graph_table = (table.data_ptr(), table.shape, table.stride(0))
         self._table_ref = table  # keeps the captured pointer alive
 
-    def __call__(self, x1, x2, target):
+    def __call__(self, x1, x2, target, global_counts=None):
+        """global_counts (data parallel only): [N_t, N_n] of the GLOBAL minibatch this rank's shard was cut from; without
+        it a 16-byte all-reduce of the shard's counts comes first (see set_global_counts)."""
+        if self._dp_call and 0 < x1.shape[0] <= 16384:
+            self.set_global_counts(target, global_counts)
         if not self.use_graph or x1.shape[0] != self.batch_size:
             loss = self._eager(x1, x2, target)
             self._touched()
@@ -563,7 +625,7 @@ class FusedTrainStep:
             return loss
         if self._graph is None:
             self._capture()
-        if self._one_call:
+        if self._one_call or self._dp_call:
             self._sync_packed()
         # a caller that fills the step's own input buffers (step.x1 / .x2 / .t, e.g. gather_rows(..., out=step.x1)) skips
         # the staging copies: at 4096 x 512 they are 2 x 8 MB, 16 us of a 70 us step

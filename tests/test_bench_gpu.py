@@ -170,7 +170,8 @@ def test_bench_emulate_rank_lines(hip_lib):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["config"]["pairs_per_gpu_per_step"] == 512 and d["config"]["global_batch"] == 4096
-    assert d["config"]["collective_bytes_per_step"]["flat_gradient_allreduce"] > 390000
+    cb = d["config"]["collective_bytes_per_step"]  # ONE all-reduce per step: flat gradient + 2 x 18 floats of loss sums
+    assert list(cb) == ["one_allreduce_flat_gradient_and_loss_sums"] and 390000 < cb["one_allreduce_flat_gradient_and_loss_sums"] < 410000
     assert _run(["--emulate-rank", "8/8"])[0].returncode != 0 and _run(["--emulate-rank", "1/2", "--gpus", "2"])[0].returncode != 0
 
 

@@ -909,3 +909,82 @@ def test_table_from_a_100k_vector_archive_trains_on_the_device(hip_lib, tmp_path
     assert la.item() == lb.item()
     for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
         assert torch.equal(a, b), k
+
+
+@pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("crossentropy", 1000, 170), ("SoftCdet", 250, 40)])
+def test_one_collective_dp_step_on_one_rank_equals_the_one_call_step(hip_lib, lossname, B, D):
+    """nplda_train_step_grad_f32 -> (all-reduce) -> nplda_train_step_apply_f32 with identity reductions = one rank: the SAME
+    parameter bits as nplda_train_step_f32 (same slabs, same update arithmetic); loss and thresholds go through the hi/lo
+    float split of the fp64 loss sums (2^-46)."""
+    from neuralplda_amd import ops, train
+    rng = np.random.default_rng(99)
+    p = rand_params(rng, 512, D, D)
+    xs = [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda(),
+           torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    nc = NC(512, D, D, loss=lossname)
+    m_a = model_from(p, nc, thetas=[-0.5, -0.3], theta_xent=0.1)
+    m_b = model_from(p, nc, thetas=[-0.5, -0.3], theta_xent=0.1)
+    calls = []
+    m_b._reduce_sums = lambda t: t
+    m_b._reduce_flat = lambda t: (calls.append(t.numel()), t)[1]
+    for graph in (False, True):
+        sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+        sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+        assert sa._one_call and sb._dp_call and not sb._one_call
+        for i, (x1, x2, t) in enumerate(xs):
+            nt = float(t.sum().item())
+            la = sa(x1, x2, t)
+            lb = sb(x1, x2, t, global_counts=(nt, B - nt)) if i != 1 else sb(x1, x2, t)  # (i == 1: counts by the fallback)
+            assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+            for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+                if k.startswith("Th") or k.startswith("threshold"):
+                    assert torch.allclose(a, b, rtol=1e-6, atol=1e-9), (graph, i, k)
+                else:
+                    assert torch.equal(a, b), (graph, i, k)
+            fresh = ops.pack_params(*[q.detach() for q in sb.params])
+            assert torch.equal(sb._packed.buf, fresh.buf), (graph, i)
+        assert abs(sa.pop_loss_mean() - sb.pop_loss_mean()) < 1e-6
+    assert calls and all(n == ops.train_step_flat_floats(sb._packed) for n in calls)  # ONE reduction per step, of this size
+
+
+def test_one_collective_dp_step_two_shards_sum_to_the_global_step(hip_lib):
+    """Two ranks' shards of a 4096-pair minibatch, emulated on one GPU: each shard's gradient phase with the GLOBAL counts,
+    the two flat buffers added (what the all-reduce does), one update phase — against nplda_train_step_f32 on the whole
+    minibatch.  (dL/ds needs only the global counts: no collective in front of the backward.)"""
+    from neuralplda_amd import ops, train
+    rng = np.random.default_rng(5)
+    B, D = 4096, 150
+    p = rand_params(rng, 512, D, D)
+    x1 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(B) < 0.15).astype(np.float32)).cuda()
+    nc = NC(512, D, D)
+    m_a = model_from(p, nc, thetas=[-0.5, -0.3])
+    m_b = model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    la = sa(x1, x2, t)
+    # the two "ranks": same parameters, shards [0, 1500) and [1500, 4096) (unequal on purpose)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+    sb._sync_packed()
+    prm, ths = [q.detach() for q in sb.params], [th.detach() for th in sb.thetas]
+    nt = float(t.sum().item())
+    gc = torch.tensor([nt, B - nt], dtype=torch.float64, device="cuda")
+    nflat = ops.train_step_flat_floats(sb._packed)
+    flats = []
+    for lo, hi in ((0, 1500), (1500, B)):
+        step_r = sb.step_count.clone()  # every rank counts its own step
+        ws = ops.train_step_workspace(hi - lo, sb._packed)
+        f = torch.zeros(nflat, device="cuda")
+        ops.train_step_grad(x1[lo:hi], x2[lo:hi], t[lo:hi].contiguous(), prm, ths, sb.betas_loss, sb.alpha, sb.kind, step_r,
+                            sb._packed, ws, f, gc)
+        flats.append(f)
+    sb.step_count.copy_(step_r)
+    flat = flats[0] + flats[1]
+    loss = torch.zeros((), device="cuda")
+    ops.train_step_apply(flat, prm, ths, sb.betas_loss, sb.alpha, sb.kind, sb.m, sb.v, sb.step_count, sb.lr, sb.betas[0],
+                         sb.betas[1], sb.eps, sb.wd, sb._packed, loss)
+    assert abs(la.item() - loss.item()) <= 1e-6 * abs(la.item())
+    for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        # Adam's first step is lr * sign-like: compare the applied update, not just the parameter
+        assert torch.allclose(a, b, rtol=1e-5, atol=2e-6), k
