@@ -464,15 +464,16 @@ int nplda_train_step_f32(const float* x1, const float* x2, int64_t B, int64_t ld
  * out of the global minibatch knows those from the labels — so no collective has to precede the backward:
  *   nplda_train_step_grad_f32   forward + loss terms + data gradients + weight-gradient slabs of this rank's B pairs (the
  *                               same three launches), stopping at flat[0 .. nplda_train_step_flat_floats): the flat
- *                               gradient (nplda_grad_floats order) followed by the rank's loss sums as 2 x 18 floats (hi
- *                               then lo halves of the fp64 sums).  global_counts: device [N_t, N_n] doubles of the global
+ *                               gradient (nplda_grad_floats order) followed by the rank's fp64 loss sums as 4 x 18 floats
+ *                               (four 16-bit fixed-point limbs each: integer-valued floats whose fp32 sum over <= 256
+ *                               ranks is exact, so the summed loss sums come back to 2^-41 absolute).  global_counts: device [N_t, N_n] doubles of the global
  *                               batch (NULL: this rank's own counts, i.e. a single rank).  Counts Adam's step; updates nothing
  *                               else.  Workspace: nplda_train_step_workspace_bytes(B, ...).
  *   -- SUM all-reduce of flat (fp32) across the ranks --
  *   nplda_train_step_apply_f32  one launch: Adam on the parameters from flat, the refreshed parameter image, loss and
  *                               dL/dtheta from the summed loss sums, Adam on the thresholds, loss_sum[0] += loss.
  * On one rank the two calls give nplda_train_step_f32's parameters (the same slab sums and update arithmetic; the loss
- * sums pass through the hi/lo split, ~2^-46 relative).  B <= 16384 per rank. */
+ * sums pass through the limbs, 2^-41 absolute).  B <= 16384 per rank, <= 256 ranks. */
 size_t nplda_train_step_flat_floats(int D0, int D1, int D2);
 int nplda_train_step_grad_f32(const float* x1, const float* x2, int64_t B, int64_t ldx, const float* target,
                               const double* global_counts, float* const* params, int D0, int D1, int D2,

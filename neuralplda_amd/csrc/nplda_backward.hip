@@ -1284,7 +1284,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                          double* loss_sum, float* grad_out, nplda_stream_t stream, void* dxa = nullptr, void* dxb = nullptr,
                          int64_t lddx = 0, bool io_bf16 = false, const double* gcount = nullptr, float* dp_flat = nullptr) {
     // dp_flat: the data-parallel gradient phase (nplda_train_step_grad_f32) — same three launches, but the last two stop at
-    // this rank's flat gradient [ngrad | loss sums as 2 x kLossNS floats] and nothing is updated
+    // this rank's flat gradient [ngrad | loss sums as kLossLimbs x kLossNS floats] and nothing is updated
     if (dp_flat) {
         if (cursor || grad_out) return NPLDA_EINVAL;
         grad_out = dp_flat;
@@ -1454,7 +1454,7 @@ int nplda_train_step_grad_rows_f32(const float* table, int64_t N, int64_t ldt, c
 
 size_t nplda_train_step_flat_floats(int D0, int D1, int D2) {
     if (check_model(D0, D1, D2) != NPLDA_OK) return 0;
-    return nplda_grad_floats(D0, D1, D2) + 2 * (size_t)kLossNS;
+    return nplda_grad_floats(D0, D1, D2) + (size_t)kLossLimbs * kLossNS;
 }
 
 int nplda_train_step_apply_f32(const float* flat, float* const* params, int D0, int D1, int D2, float* const* thetas,

@@ -23,12 +23,28 @@ struct LossTail {
     const float* step;        // Adam's step counter
     int bumped;               // step[0] already counts this step (train_fb_small_kernel)
     float lr, beta1, beta2, eps, wd;
-    // data parallel (nplda_train_step_grad_f32 / _apply_f32): the loss sums cross the ranks inside the ONE fp32 all-reduce
-    // of the flat gradient, as (hi, lo) float pairs — hi = (float)d, lo = (float)(d - hi): the fp32 sums of the his and of
-    // the los give the fp64 sum to ~2^-46 relative.
-    float* sums_out;          // grad phase: write the block-summed loss sums here [kLossNS his | kLossNS los] and stop
+    // data parallel (nplda_train_step_grad_f32 / _apply_f32): the fp64 loss sums cross the ranks inside the ONE fp32
+    // all-reduce of the flat gradient, as kLossLimbs fixed-point limbs of 16 bits each (loss_limbs_of): a limb is an
+    // integer below 2^16, so the fp32 sum of up to 256 ranks' limbs is EXACT, and the limbs of the sum put the fp64 sum
+    // back together to 2^-41 absolute (|sum| < 2^24: the sums are counts and sums of sigmoids / log terms over the batch).
+    // (A (hi, lo) float pair does not do it: the ranks' `hi`s are rounded to 24 bits again when fp32 adds them.)
+    float* sums_out;          // grad phase: write the block-summed loss sums here [kLossLimbs][kLossNS] and stop
     const float* sums_in;     // apply phase: take the (all-reduced) sums from here instead of `partial`
 };
+
+constexpr int kLossLimbs = 4;
+__device__ __forceinline__ void loss_limbs_of(double x, float (&l)[kLossLimbs]) {
+    const double sg = x < 0.0 ? -1.0 : 1.0;
+    double r = fabs(x);
+    const double a = floor(r * 0x1p-8);  r -= a * 0x1p8;
+    const double b = floor(r * 0x1p8);   r -= b * 0x1p-8;
+    const double c = floor(r * 0x1p24);  r -= c * 0x1p-24;
+    const double d = rint(r * 0x1p40);
+    l[0] = (float)(sg * a); l[1] = (float)(sg * b); l[2] = (float)(sg * c); l[3] = (float)(sg * d);
+}
+__device__ __forceinline__ double loss_limbs_sum(const float* p, int stride) {
+    return (double)p[0] * 0x1p8 + (double)p[stride] * 0x1p-8 + (double)p[2 * stride] * 0x1p-24 + (double)p[3 * stride] * 0x1p-40;
+}
 
 constexpr int kLossTailSmem = (256 * (kLossNS + 1) + kLossNS * 8 + kLossNS) * 8 + nplda_loss::kMaxK * 4;  // bytes
 
@@ -61,16 +77,20 @@ __device__ __forceinline__ void loss_tail_block(const LossTail& a, void* smem) {
         double w = 0.0;
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) w += chain[tid][c8];
-        if (a.sums_in) w = (double)a.sums_in[tid] + (double)a.sums_in[kLossNS + tid];
+        if (a.sums_in) w = loss_limbs_sum(a.sums_in + tid, kLossNS);
         sums[tid] = w;
         if (a.sums_out) {
-            const float hi = (float)w;
-            a.sums_out[tid] = hi;
-            a.sums_out[kLossNS + tid] = (float)(w - (double)hi);
+            float l[kLossLimbs];
+            loss_limbs_of(w, l);
+#pragma unroll
+            for (int q = 0; q < kLossLimbs; ++q) a.sums_out[q * kLossNS + tid] = l[q];
         }
     }
     if (a.sums_out) {  // (unused slots stay zero for the all-reduce)
-        if (tid >= ns && tid < kLossNS) a.sums_out[tid] = a.sums_out[kLossNS + tid] = 0.f;
+        if (tid >= ns && tid < kLossNS) {
+#pragma unroll
+            for (int q = 0; q < kLossLimbs; ++q) a.sums_out[q * kLossNS + tid] = 0.f;
+        }
         return;
     }
     __syncthreads();

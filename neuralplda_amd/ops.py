@@ -499,7 +499,7 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
 
 
 def train_step_flat_floats(packed):
-    """Length of the data-parallel step's flat buffer: the flat gradient + 2 x 18 floats of loss sums."""
+    """Length of the data-parallel step's flat buffer: the flat gradient + 4 x 18 floats of loss sums (16-bit limbs)."""
     return int(_lib.load().nplda_train_step_flat_floats(packed.D0, packed.D1, packed.D2))
 
 

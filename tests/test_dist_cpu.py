@@ -104,6 +104,34 @@ def _worker(rank, world, port, tmp):
         np.testing.assert_allclose(flat.numpy(), ref, rtol=1e-9, atol=1e-14)
         dth = [(alpha * sums[4 + 4 * k] / sums[0] - beta[k] * alpha * sums[5 + 4 * k] / sums[1]) / 2 for k in range(2)]
         np.testing.assert_allclose(dth, dth_full, rtol=1e-10)
+        # ---- 3b. the ONE-collective form (nplda_train_step_grad_f32 -> all-reduce -> nplda_train_step_apply_f32): the
+        #          counts come from the global label vector (no collective before the backward), and the fp64 loss sums
+        #          ride in the gradient's fp32 all-reduce as four 16-bit limbs each -------------------------------------------
+        nt_g, nn_g = float(t.sum()), float(B - t.sum())
+        g1, _ = orc.softcdet_grad(s_loc, st, theta, beta, alpha, nt=nt_g, nn=nn_g)
+        np.testing.assert_allclose(g1, g_full[blo:bhi], rtol=1e-12)
+        gl1 = orc.backward(sx1, sx2, g1, p)
+        own = _softcdet_sums(s_loc, st, theta, alpha)
+
+        def limbs(v):  # csrc/nplda_loss_tail.h: loss_limbs_of — four 16-bit fixed-point limbs, exact under fp32 addition
+            sg, r = np.where(v < 0, -1.0, 1.0), np.abs(v)
+            a = np.floor(r * 2.0 ** -8); r = r - a * 2.0 ** 8
+            b = np.floor(r * 2.0 ** 8); r = r - b * 2.0 ** -8
+            c = np.floor(r * 2.0 ** 24); r = r - c * 2.0 ** -24
+            d = np.rint(r * 2.0 ** 40)
+            return np.concatenate([sg * a, sg * b, sg * c, sg * d]).astype(np.float32)
+
+        one = torch.from_numpy(np.concatenate([np.concatenate([gl1[k].ravel() for k in ("W1", "b1", "W2", "b2", "P_sqrt", "Q")])
+                                               .astype(np.float32), limbs(own)]))
+        nd.allreduce_sum_(one)  # the step's only exchange
+        one = one.numpy()
+        ng, ns_ = ref.size, own.size
+        np.testing.assert_allclose(one[:ng], ref, rtol=2e-5, atol=1e-7)
+        L4 = one[ng:].astype(np.float64).reshape(4, ns_)
+        sums1 = L4[0] * 2.0 ** 8 + L4[1] * 2.0 ** -8 + L4[2] * 2.0 ** -24 + L4[3] * 2.0 ** -40
+        np.testing.assert_allclose(sums1, _softcdet_sums(s_full, t, theta, alpha), rtol=0, atol=2.0 ** -39)
+        L1 = np.mean([sums1[2 + 4 * k] / sums1[0] + beta[k] * sums1[3 + 4 * k] / sums1[1] for k in range(2)])
+        assert abs(L1 - L_full) <= 1e-11 * abs(L_full) and sums1[0] == nt_g and sums1[1] == nn_g
         # ---- 4. make_data_parallel wires the two reductions into the module ----------------------------
         from neuralplda_amd import models
 

@@ -914,8 +914,8 @@ def test_table_from_a_100k_vector_archive_trains_on_the_device(hip_lib, tmp_path
 @pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("crossentropy", 1000, 170), ("SoftCdet", 250, 40)])
 def test_one_collective_dp_step_on_one_rank_equals_the_one_call_step(hip_lib, lossname, B, D):
     """nplda_train_step_grad_f32 -> (all-reduce) -> nplda_train_step_apply_f32 with identity reductions = one rank: the SAME
-    parameter bits as nplda_train_step_f32 (same slabs, same update arithmetic); loss and thresholds go through the hi/lo
-    float split of the fp64 loss sums (2^-46)."""
+    parameter bits as nplda_train_step_f32 (same slabs, same update arithmetic); loss and thresholds go through the 16-bit
+    limbs of the fp64 loss sums (2^-41 absolute)."""
     from neuralplda_amd import ops, train
     rng = np.random.default_rng(99)
     p = rand_params(rng, 512, D, D)
