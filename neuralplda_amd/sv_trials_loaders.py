@@ -172,15 +172,35 @@ class TrialLoader(DataLoader):
         tail = (e1[lo:], e2[lo:], el[lo:]) if lo < n else None
         return self._pack_records(n, e1, e2, el, device), tail
 
-    def device_batches(self, device, num_to_row=None, pack=False, permute=True):
+    def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None):
         """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
         batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
         `num_to_row`: optional int64 device map applied to both index columns (trial number -> x-vector table row);
         a negative entry (unknown utterance) raises KeyError like load_xvec_trials_from_numbatch.
         pack=True also yields, per full batch, the batch as one contiguous uint8 record (None for a last partial batch).
-        permute=False: file order (see _device_epoch_arrays) for order-free consumers."""
+        permute=False: file order (see _device_epoch_arrays) for order-free consumers.
+        shard=(rank, world) (data parallel; every rank must draw the same epoch, i.e. share the RNG state): yields this
+        rank's contiguous slice of every GLOBAL batch and, fourth, the global batch's [N_t, N_n] as a device float64
+        tensor — all the one-collective training step needs to know about the other ranks' shards (the counts of the
+        whole epoch are formed in one pass)."""
         n, e1, e2, el = self._device_epoch_arrays(device, num_to_row, permute)
         bs = self.batch_size
+        if shard is not None:
+            if pack:
+                raise ValueError("device_batches: packed records describe whole batches; shard=(rank, world) yields views")
+            rank, world = shard
+            nb = (n + bs - 1) // bs
+            csum = torch.cat([torch.zeros(1, dtype=torch.float64, device=el.device), el.double().cumsum(0)])
+            edges = torch.clamp(torch.arange(nb + 1, device=el.device) * bs, max=n)
+            nt = csum[edges[1:]] - csum[edges[:-1]]
+            counts = torch.stack([nt, (edges[1:] - edges[:-1]).double() - nt], 1).contiguous()
+            for k, lo in enumerate(range(0, n, bs)):
+                B = min(bs, n - lo)
+                chunk = (B + world - 1) // world  # dist.shard_bounds: chunks of ceil(B / world), the last short or empty
+                a = lo + min(rank * chunk, B)
+                b = lo + min(rank * chunk + chunk, B)
+                yield e1[a:b], e2[a:b], el[a:b], counts[k]
+            return
         if pack and bs % 2:
             pack = None  # no aligned record layout for an odd batch size: the consumer gets record=None and copies the views
         if pack is None:

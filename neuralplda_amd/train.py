@@ -43,10 +43,16 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
     fast = (isinstance(step_fn, FusedTrainStep) and isinstance(train_loader, TrialLoader) and device.type == "cuda"
             and isinstance(train_loader.dataset, TrialIndexDataset) and train_loader.num_workers == 0
             and not train_loader.drop_last)
+    dp = None
+    if fast and step_fn._dp_call:
+        # data parallel: every rank walks the SAME epoch (same RNG state on every rank) and takes its slice of each global
+        # batch; the loader hands over the global label counts with it, so the step needs ONE collective (its all-reduce)
+        from . import dist as ndist
+        dp = ndist.world()
     if fast:
         table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
         bs = train_loader.batch_size
-        same = step_fn.batch_size == bs
+        same = step_fn.batch_size == bs and dp is None
         # decide the path BEFORE building anything: packed records are only made when something will consume them
         if same and step_fn.cursor_ok(table):
             # the whole epoch as packed records on the device; the captured step walks them through a device-side cursor
@@ -69,7 +75,9 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
         # graph replay from static index buffers: one record copy per step instead of three (records need an even batch
         # size: int64 fields at 20 * bs * k bytes); the eager step gathers from the views and never looks at a record
         pack = same and step_fn.use_graph and bs % 2 == 0
-        if pack:
+        if dp is not None:
+            batches = ((r1, r2, t, None, gc) for r1, r2, t, gc in train_loader.device_batches(device, row_map, shard=dp))
+        elif pack:
             batches = ((r1, r2, t, None, rec)
                        for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
         else:
@@ -79,7 +87,10 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
     for batch_idx, (rows1, rows2, target, data1, data2) in enumerate(batches):
         if fast:
             rec, data1 = data2, rows1  # (data2 carries the packed record here; len(data1) below)
-            step_fn.step_rows(table, rows1, rows2, target, record=rec)
+            if dp is not None:  # (data2 carries the global batch's counts)
+                step_fn.step_rows(table, rows1, rows2, target, global_counts=rec)
+            else:
+                step_fn.step_rows(table, rows1, rows2, target, record=rec)
             if batch_idx % nc.log_interval == 0:  # (the step keeps the interval's loss sum on the device)
                 _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean())
             continue

@@ -421,3 +421,30 @@ def test_order_free_device_epoch_keeps_the_rng_protocol():
     assert torch.equal(r1, row_map[ds.x1.long()]) and torch.equal(r2, row_map[ds.x2.long()]) and torch.equal(t, ds.l)
     p1 = torch.cat([b[0] for b in b_perm])
     assert not torch.equal(p1, r1) and torch.equal(torch.sort(p1).values, torch.sort(r1).values)
+
+
+def test_device_batches_sharded_for_data_parallel():
+    """device_batches(shard=(rank, world)): every rank draws the same epoch and gets its dist.shard_bounds slice of each
+    global batch plus the GLOBAL batch's [N_t, N_n] — what FusedTrainStep's one-collective step takes as global_counts."""
+    from neuralplda_amd import dist as nd
+    from neuralplda_amd import sv_trials_loaders as svl
+    n, bs, world = 1003, 64, 3
+    ds = svl.TrialIndexDataset(torch.arange(n), torch.arange(n) * 2 % n, (torch.arange(n) % 5 == 0).float())
+    torch.manual_seed(11)
+    plain = list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", None))
+    per_rank = []
+    for r in range(world):
+        torch.manual_seed(11)
+        per_rank.append(list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate)
+                             .device_batches("cpu", None, shard=(r, world))))
+    assert all(len(pr) == len(plain) for pr in per_rank)
+    for k, (r1, r2, t) in enumerate(plain):
+        B = len(r1)
+        for r in range(world):
+            lo, hi = nd.shard_bounds(B, world, r)
+            s1, s2, st, gc = per_rank[r][k]
+            assert torch.equal(s1, r1[lo:hi]) and torch.equal(s2, r2[lo:hi]) and torch.equal(st, t[lo:hi])
+            assert gc.dtype == torch.float64 and gc.tolist() == [float(t.sum()), float(B - t.sum())]
+        assert sum(len(per_rank[r][k][0]) for r in range(world)) == B
+    with pytest.raises(ValueError):
+        list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", None, pack=True, shard=(0, 2)))

@@ -988,3 +988,41 @@ def test_one_collective_dp_step_two_shards_sum_to_the_global_step(hip_lib):
     for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
         # Adam's first step is lr * sign-like: compare the applied update, not just the parameter
         assert torch.allclose(a, b, rtol=1e-5, atol=2e-6), k
+
+
+def test_train_loop_data_parallel_form_on_one_rank(hip_lib, tmp_path):
+    """train() with a data-parallel model: the loader hands each rank its slice of every global batch and the global
+    label counts (TrialLoader.device_batches(shard=...)), the step runs its one-collective form.  With one rank (identity
+    reductions) the epoch must leave the parameters of the plain run, bit for bit, and print the same progress lines."""
+    import contextlib
+    import io
+    from neuralplda_amd import train
+    rng = np.random.default_rng(6)
+    B = 128
+    mega, num_to_id, loader = _tiny_trial_set(tmp_path, rng, B)
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    nc.log_interval = 3
+
+    def run(dp):
+        m = model_from(p, nc, thetas=[-0.5, -0.3])
+        if dp:
+            m._reduce_sums = lambda t: t
+            m._reduce_flat = lambda t: t
+        step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+        assert step._dp_call == dp
+        torch.manual_seed(11)
+        out = io.StringIO()
+        with contextlib.redirect_stdout(out):
+            train.train(nc, m, torch.device("cuda"), loader, mega, num_to_id, None, 1, step_fn=step)
+        return {k: v.detach().cpu().numpy().copy() for k, v in m.state_dict().items()}, out.getvalue(), step
+
+    sd_plain, log_plain, _ = run(False)
+    sd_dp, log_dp, step_dp = run(True)
+    assert step_dp._graph_rows is not None and step_dp.step_count[0].item() == 8
+    assert log_dp == log_plain
+    for k in sd_plain:
+        if k.startswith("Th"):
+            np.testing.assert_allclose(sd_dp[k], sd_plain[k], rtol=1e-6, atol=1e-9)
+        else:
+            assert np.array_equal(sd_dp[k], sd_plain[k]), k
