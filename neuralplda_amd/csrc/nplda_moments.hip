@@ -199,28 +199,44 @@ __device__ __forceinline__ double slab_sum1(const float* p, size_t stride, int k
     return s;
 }
 
+// One block per 16 x 16 tile of sq (per class): a tile on or above the diagonal is summed as it lies in the slabs, a
+// tile below it from its mirror image (the lower triangle is not computed) — 16 consecutive floats per row either way, the
+// transposition taken through LDS.  (One output per thread with the mirror read element-wise made half of the loads one
+// cache line per lane: 22 us at n = 300, now 8.)  The last blocks do the n column sums and the weight sum.
 __global__ __launch_bounds__(256) void moments_reduce_kernel(const MomReduceArgs a) {
-    const size_t per = (size_t)a.n * a.n + a.n + 1;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= per * a.nc) return;
-    const int c = (int)(idx / per);
-    const size_t e = idx % per;
-    double s = 0.0;
-    double* dst;
-    if (e < (size_t)a.n * a.n) {
-        int i = (int)(e / a.n), j = (int)(e % a.n);
-        dst = a.sq + (size_t)c * a.n * a.n + e;
-        if (i > j) { const int t = i; i = j; j = t; }  // upper triangle only (lower tiles are not computed; inside
-                                                      // diagonal tiles (w x_i) x_j and (w x_j) x_i round differently)
-        const float* p = a.slab + (size_t)c * a.kgroups * a.Np * a.Np + (size_t)i * a.Np + j;
-        s = slab_sum1(p, (size_t)a.Np * a.Np, a.kgroups);
-    } else {
-        const int col = (int)(e - (size_t)a.n * a.n);  // n columns, then the weight sum
-        dst = col < a.n ? a.sum + (size_t)c * a.n + col : a.cnt + c;
+    const int TB = (a.n + 15) / 16;
+    const int tid = threadIdx.x;
+    const int ntile = TB * TB;
+    const int b = (int)blockIdx.x;
+    if (b >= a.nc * ntile) {
+        const size_t e = (size_t)(b - a.nc * ntile) * 256 + tid;  // (class, column): n columns, then the weight sum
+        if (e >= (size_t)a.nc * (a.n + 1)) return;
+        const int c = (int)(e / (a.n + 1)), col = (int)(e % (a.n + 1));
+        double* dst = col < a.n ? a.sum + (size_t)c * a.n + col : a.cnt + c;
         const float* p = a.ext + (size_t)c * a.kgroups * (a.Np + 4) + (col < a.n ? col : a.Np);
-        s = slab_sum1(p, (size_t)a.Np + 4, a.kgroups);
+        const double s = slab_sum1(p, (size_t)a.Np + 4, a.kgroups);
+        *dst = a.accumulate ? *dst + s : s;
+        return;
     }
-    *dst = a.accumulate ? *dst + s : s;
+    __shared__ double tl[16][17];
+    const int c = b / ntile, I = (b % ntile) / TB, J = b % TB;
+    const int r = tid >> 4, cc = tid & 15;
+    const bool tr = I > J;  // below the diagonal: the mirror tile, transposed
+    const int rb = tr ? J : I, cb = tr ? I : J;
+    {
+        const int rr = 16 * rb + r, col = 16 * cb + cc;
+        const float* p = a.slab + (size_t)c * a.kgroups * a.Np * a.Np + (size_t)rr * a.Np + col;
+        tl[r][cc] = (rr < a.n && col < a.n) ? slab_sum1(p, (size_t)a.Np * a.Np, a.kgroups) : 0.0;
+    }
+    __syncthreads();
+    const int i = 16 * I + r, j = 16 * J + cc;
+    if (i < a.n && j < a.n) {
+        // inside a diagonal tile both triangles exist in the slabs ((w x_i) x_j and (w x_j) x_i round differently): the
+        // upper one is the value, so that sq is exactly symmetric
+        const double s = (tr || (I == J && r > cc)) ? tl[cc][r] : tl[r][cc];
+        double* dst = a.sq + (size_t)c * a.n * a.n + (size_t)i * a.n + j;
+        *dst = a.accumulate ? *dst + s : s;
+    }
 }
 
 // DPlda's gradient straight from the slabs (utils/models.py:484-490: one linear unit over [y1 y2^T + y2 y1^T,
@@ -228,8 +244,7 @@ __global__ __launch_bounds__(256) void moments_reduce_kernel(const MomReduceArgs
 //   d wlr = [G12 + G21 | G11 + G22 | s1 + s2],  d bias = sum g.
 // Every G element is the fp64 sum of its slab entries in k-group order — the value moments_reduce_kernel leaves in `sq` —
 // and the two are added in fp64 before the one rounding to fp32: the bits of ops.dplda_fold_grad on that kernel's output,
-// without the 0.7 MB fp64 matrix, its reduction launch (22 us at B = 2048: 34 dependent strided loads per thread) and
-// the five torch kernels of the fold.
+// without the 0.7 MB fp64 matrix, its reduction launch and the five torch kernels of the fold.
 struct DpldaFoldArgs {
     const float* slab;
     const float* ext;
@@ -352,8 +367,8 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
     MomReduceArgs r;
     r.slab = a.slab; r.ext = a.ext; r.nc = nc; r.n = n; r.Np = p.Np; r.kgroups = p.kgroups; r.accumulate = accumulate;
     r.cnt = cnt; r.sum = sum; r.sq = sq;
-    const size_t total = ((size_t)n * n + n + 1) * nc;
-    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, r);
+    const int TBr = (n + 15) / 16;
+    hipLaunchKernelGGL(moments_reduce_kernel, dim3((unsigned)(nc * TBr * TBr + (nc * (n + 1) + 255) / 256)), dim3(256), 0, st, r);
     return nplda_launch_status();
 }
 
