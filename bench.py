@@ -208,7 +208,7 @@ class Ctx:
     pass
 
 
-def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0):
+def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0, step_many=None):
     """W untimed steps, then exactly K steps between barrier + synchronize pairs; returns (elapsed max over ranks,
     mean HIP-event duration of a step on the launch stream, last result).  settle_s: the untimed warm-up lasts at least
     this long (steps of tens of microseconds: W = 30 of them end before the clock has settled — the first ~50 ms after
@@ -227,6 +227,9 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0):
     torch.cuda.synchronize()
     # per_step_events=False (steps of tens of microseconds): ONE event pair around the K steps — two event records per step
     # are two more packets between the graph launches, 12 us on a 70 us training step
+    # step_many(n): n steps in as few launches as the workload has (several steps per captured graph); still EXACTLY K steps
+    if step_many is not None:
+        per_step_events = False
     nev = steps if per_step_events else 1
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(nev)]
     if dist is not None:
@@ -235,7 +238,9 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0):
     t0 = time.perf_counter()
     if not per_step_events:
         evs[0][0].record()
-    for k in range(steps):
+    if step_many is not None:
+        out = step_many(steps)
+    for k in range(0 if step_many is not None else steps):
         if per_step_events:
             evs[k][0].record()
         out = step()
@@ -575,7 +580,18 @@ def run_cfg2(args, ctx):
         state["k"] += 1
         return step_fn.step_rows(table, r1, r2, t, record=rec, global_counts=gc)
 
-    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.08)
+    def step_many(n):  # the cursor path: FusedTrainStep.step_records (8 steps per graph launch), epochs restarted as needed
+        out = None
+        while n > 0:
+            if step_fn._records_left == 0:
+                step_fn.begin_epoch(table, records)
+            k = min(n, step_fn._records_left)
+            out = step_fn.step_records(k)
+            n -= k
+        return out
+
+    elapsed, step_ms, loss = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.08,
+                                         step_many=step_many if by_cursor else None)
     if not torch.isfinite(loss).all():
         raise SystemExit("non-finite training loss")
     if rank != 0 and not ctx.emulated:
@@ -606,7 +622,8 @@ def run_cfg2(args, ctx):
                                                   4 * int(step_fn._flat.numel())} if world > 1 and step_fn._flat is not None
                                                  else ({"loss_sums_allreduce": 8 * 18, "flat_gradient_allreduce":
                                                         4 * int(step_fn.m.numel() - len(step_fn.thetas))} if world > 1 else None)),
-                   "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32)"
+                   "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32), "
+                                 f"{step_fn.records_per_replay} steps per graph launch"
                                  if by_cursor else "one 20 B-byte record copy per step (nplda_train_step_rows_f32)"},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"train_step_D{D}_B{Bl}"),

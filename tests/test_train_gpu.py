@@ -1026,3 +1026,38 @@ def test_train_loop_data_parallel_form_on_one_rank(hip_lib, tmp_path):
             np.testing.assert_allclose(sd_dp[k], sd_plain[k], rtol=1e-6, atol=1e-9)
         else:
             assert np.array_equal(sd_dp[k], sd_plain[k]), k
+
+
+def test_step_records_several_steps_per_graph_launch(hip_lib):
+    """step_records(n): records_per_replay steps in one captured graph (each step's last kernel stages the next record, so
+    they chain on the device) + single steps for the rest — the same parameter bits and loss mean as n x step_record()."""
+    from neuralplda_amd import train
+    rng = np.random.default_rng(17)
+    B, nb, N = 256, 21, 3000
+    p = rand_params(rng, 512, 150, 150)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    table = torch.from_numpy(rng.standard_normal((N, 512)).astype(np.float32)).cuda()
+    records = torch.empty((nb, 20 * B), dtype=torch.uint8, device="cuda")
+    records[:, :8 * B].view(torch.int64).copy_(torch.from_numpy(rng.integers(0, N, (nb, B))).cuda())
+    records[:, 8 * B:16 * B].view(torch.int64).copy_(torch.from_numpy(rng.integers(0, N, (nb, B))).cuda())
+    records[:, 16 * B:].view(torch.float32).copy_(torch.from_numpy((rng.random((nb, B)) < 0.2).astype(np.float32)).cuda())
+    m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.FusedTrainStep(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+    sb = train.FusedTrainStep(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=True)
+    assert sa.records_per_replay == 8
+    sa.begin_epoch(table, records)
+    sb.begin_epoch(table, records)
+    assert sa._graph_rec_multi is not None
+    la = sa.step_records(19)  # 8 + 8 + 3 singles
+    for _ in range(19):
+        lb = sb.step_record()
+    assert la.item() == lb.item() and sa._records_left == sb._records_left == 2
+    assert sa._cursor[1].item() == sb._cursor[1].item() and sa.step_count[0].item() == 19
+    for (key, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+        assert torch.equal(a, b), key
+    assert abs(sa.pop_loss_mean() - sb.pop_loss_mean()) < 1e-12
+    with pytest.raises(RuntimeError):
+        sa.step_records(3)
+    sa.step_records(2)
+    sb.step_record(); sb.step_record()
+    assert torch.equal(next(iter(m_a.state_dict().values())), next(iter(m_b.state_dict().values())))
