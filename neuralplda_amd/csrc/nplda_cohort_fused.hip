@@ -25,6 +25,7 @@
 // with 2 P into a fragment image; (z_rows . C'') by the resident-matrix GEMM (nplda_matmul.hip); one wave per row forms
 // the row's mean and t_r.
 
+#include <cstdlib>
 #include <type_traits>
 
 #include "nplda_cohort_common.h"
@@ -720,7 +721,11 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     if (M < 4096 || topn < 1 || Mp < 16 || Mp > NPLDA_MAX_DIM) return p;
     // candidates proposed per row: about twice the wanted count, and relatively more when N is small — the proposal
     // sits far out in the tail there, where a row's distribution agrees least with the normal model
-    const double want = 2.0 * topn + 16.0 + 300.0 * exp(-(double)topn / 300.0);
+    // NPLDA_COHORT_WANT: the factor on N (default 2).  On the bench's Gaussian rows 1.4 is 22 us faster (select 104 -> 88 us,
+    // fused kernel 645 -> 634 us, fallback 2 -> 4.5 us: profiles/r03e, DESIGN K8/K9); the default stays at 2 because a row
+    // whose scores are far from normal pays the fallback path, and real cohorts have such rows
+    static const double want_f = getenv("NPLDA_COHORT_WANT") ? atof(getenv("NPLDA_COHORT_WANT")) : 2.0;
+    const double want = want_f * topn + 16.0 + 300.0 * exp(-(double)topn / 300.0);
     const double f = want / (double)M;
     if (f > 0.25 || want > 0.8 * kCandMax) return p;
     const long long nx = (M + 127) / 128;
