@@ -22,11 +22,17 @@ def one_rank_group():
     from neuralplda_amd import dist as ndist
     if td.is_initialized():
         pytest.skip("a process group already exists")
-    os.environ.update({"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1",
-                       "MASTER_PORT": "29533"})
+    env = {"RANK": "0", "WORLD_SIZE": "1", "LOCAL_RANK": "0", "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": "29533"}
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update(env)
     ndist.init("nccl")
     yield ndist
     td.destroy_process_group()
+    for k, v in saved.items():  # (bench.py's launcher checks in later tests read these)
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v
 
 
 def test_rccl_single_rank_paths(hip_lib, one_rank_group):
