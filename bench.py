@@ -645,10 +645,9 @@ def run_cfg5(args, ctx):
     utils/models.py:251-268) -> NeuralPlda.forward -> SoftCdet -> backward with dL/dx1, dL/dx2 -> Adam on the head.
     The E-TDNN extractor itself is SURVEY section 2 item 4: out of scope; its output is synthetic here."""
     from neuralplda_amd import models, train
+    from neuralplda_amd import dist as ndist
     dev, rank, world = ctx.dev, ctx.rank, ctx.world
-    if world > 1 and not ctx.emulated:
-        raise SystemExit("cfg5 is a one-GPU workload here (the data-parallel head step is cfg2's)")
-    D0, D, B = 512, args.dim, args.batch
+    D0, D, B = 512, args.dim, args.batch  # per rank (weak scaling: the extractor's data-parallel batch is B x world)
 
     class NC:
         xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = D0, D, D
@@ -660,22 +659,36 @@ def run_cfg5(args, ctx):
     with torch.no_grad():
         for q, v in zip(model._params(), params):
             q.copy_(v)
-    gen = torch.Generator(device=dev).manual_seed(55)
+    if world > 1 and ctx.emulated:
+        model._reduce_sums = lambda v: v   # rank r's compute with the exchange left out (payload listed below)
+        model._reduce_flat = lambda v: v
+    elif world > 1:
+        ndist.make_data_parallel(model)
+    gen = torch.Generator(device=dev).manual_seed(55 + rank)
+    gens_t = [torch.Generator(device=dev).manual_seed(7000 + r) for r in range(world)]
     nb = 8
-    xs = [(torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16), torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16),
-           (torch.rand(B, device=dev, generator=gen) < 0.1).float()) for _ in range(nb)]
-    step_fn = train.HeadStepWithInputGrads(model, 1e-4, weight_decay=1e-5, batch_size=B)
+    xs = []
+    for _ in range(nb):
+        ts = [(torch.rand(B, device=dev, generator=g) < 0.1).float() for g in gens_t]  # every rank's labels: the global counts
+        nt = torch.stack([x.sum() for x in ts]).sum().double()
+        xs.append((torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16),
+                   torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16), ts[rank],
+                   torch.stack([nt, float(B * world) - nt]) if world > 1 else None))
+    graph = ctx.backend == "nccl" or world == 1 or ctx.emulated
+    step_fn = train.HeadStepWithInputGrads(model, 1e-4, weight_decay=1e-5, batch_size=B, graph=graph)
     state = {"k": 0}
 
     def step_copy():  # a fresh minibatch handed over as new tensors every step: three staging copies into the graph's buffers
-        x1, x2, t = xs[state["k"] % nb]
+        x1, x2, t, gc = xs[state["k"] % nb]
         state["k"] += 1
-        return step_fn(x1, x2, t)
+        return step_fn(x1, x2, t, global_counts=gc)
 
     def step():       # the minibatch already sits in the step's input buffers (the producer wrote it there): the timed form,
-        return step_fn(step_fn.x1, step_fn.x2, step_fn.t)  # inputs resident in HBM when the step starts, as for cfg1
+        if not graph:
+            return step_fn(*xs[0][:3], global_counts=xs[0][3])
+        return step_fn(step_fn.x1, step_fn.x2, step_fn.t, global_counts=xs[0][3])  # inputs resident in HBM, as for cfg1
 
-    step_fn(*xs[0])  # (captures the graph and leaves batch 0 in the step's buffers)
+    step_fn(*xs[0][:3], global_counts=xs[0][3])  # (captures the graph and leaves batch 0 in the step's buffers)
     _, copy_ms, _ = timed_steps(ctx, step_copy, max(args.steps // 2, 10), args.warmup, per_step_events=False, settle_s=0.08)
     elapsed, step_ms, out = timed_steps(ctx, step, args.steps, args.warmup, per_step_events=False, settle_s=0.02)
     loss, dx1, dx2 = out
@@ -688,12 +701,19 @@ def run_cfg5(args, ctx):
     achieved = B * flops / (step_ms * 1e-3) / 1e12
     return {
         "metric": "fine-tuned trial-pairs/sec through the NPLDA head (bf16 x-vectors in, dL/dx out, SoftCdet + Adam)",
-        "value": B * args.steps / elapsed, "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "value": (B if ctx.emulated else B * world) * args.steps / elapsed, "unit": "pairs/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "bf16 x-vectors and dL/dx, f32 head arithmetic", "data": "synthetic",
         "config": {"workload": f"cfg5 (head only): {B}-pair minibatches of bf16 512-d x-vectors with a graph, 512->{D}->{D}, "
                                f"SoftCdet, backward incl. dL/dx, Adam(1e-4, wd 1e-5); extractor out of scope (SURVEY 2 #4)",
-                   "global_batch": B, "params": psrc, "step": step_fn.describe(), "final_loss": float(loss),
+                   "global_batch": B * world, "pairs_per_gpu_per_step": B, "params": psrc,
+                   "step": (step_fn.describe() if world == 1 else
+                            "nplda_train_step_grad_dx_f32 (forward + loss + data gradients with the global label counts | weight-"
+                            "gradient slabs | dx = du . W1 | flat gradient) -> ONE all-reduce -> nplda_train_step_apply_f32"),
+                   "parallelism": f"data parallel x{world}", "final_loss": float(loss),
+                   "collective_bytes_per_step": ({"one_allreduce_flat_gradient_and_loss_sums": 4 * int(step_fn._flat.numel())}
+                                                 if world > 1 and step_fn._flat is not None else None),
                    "ms_per_step_with_input_copies": copy_ms,
                    "inputs": "resident in the step's own buffers (a producer writing elsewhere adds three staging copies: "
                              "ms_per_step_with_input_copies)"},

@@ -485,6 +485,14 @@ int nplda_train_step_grad_rows_f32(const float* table, int64_t N, int64_t ldt, c
                                    int64_t B, const float* target, const double* global_counts, float* const* params, int D0,
                                    int D1, int D2, float* const* thetas, const float* betas, int K, float alpha, int kind,
                                    float* step, void* packed, void* ws, size_t ws_bytes, float* flat, nplda_stream_t stream);
+/* (the gradient phase of the head's end-to-end step, as nplda_train_step_dx_f32: x1 / x2 and dx1 / dx2 float32 or, with
+ * io_bf16, bfloat16; dL/dx of this rank's rows is complete after this call — it depends on the other ranks through the global
+ * counts only; workspace: nplda_train_step_dx_workspace_bytes) */
+int nplda_train_step_grad_dx_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, int io_bf16, const float* target,
+                                 const double* global_counts, float* const* params, int D0, int D1, int D2,
+                                 float* const* thetas, const float* betas, int K, float alpha, int kind, float* step,
+                                 void* packed, void* ws, size_t ws_bytes, float* flat, void* dx1, void* dx2, int64_t lddx,
+                                 nplda_stream_t stream);
 int nplda_train_step_apply_f32(const float* flat, float* const* params, int D0, int D1, int D2, float* const* thetas,
                                const float* betas, int K, float alpha, int kind, float* exp_avg, float* exp_avg_sq,
                                float* step, float lr, float beta1, float beta2, float eps, float weight_decay, void* packed,

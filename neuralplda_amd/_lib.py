@@ -96,6 +96,11 @@ SIGNATURES = {
                                                 ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
                                                 ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
                                                 ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp]),
+    "nplda_train_step_grad_dx_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_int, _c_f32p, _c_vp,
+                                              ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
+                                              ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
+                                              ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp, _c_sz, _c_vp, _c_vp, _c_vp, _c_i64,
+                                              _c_vp]),
     "nplda_train_step_apply_f32": (_c_int, [_c_f32p, ctypes.POINTER(ctypes.c_void_p), _c_int, _c_int, _c_int,
                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int,
                                             ctypes.c_float, _c_int, _c_vp, _c_vp, _c_vp] + [ctypes.c_float] * 5 +

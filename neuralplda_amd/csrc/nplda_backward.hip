@@ -1452,6 +1452,18 @@ int nplda_train_step_grad_rows_f32(const float* table, int64_t N, int64_t ldt, c
                            nullptr, stream, nullptr, nullptr, 0, false, global_counts, flat);
 }
 
+int nplda_train_step_grad_dx_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, int io_bf16, const float* target,
+                                 const double* global_counts, float* const* params, int D0, int D1, int D2,
+                                 float* const* thetas, const float* betas, int K, float alpha, int kind, float* step,
+                                 void* packed, void* ws, size_t ws_bytes, float* flat, void* dx1, void* dx2, int64_t lddx,
+                                 nplda_stream_t stream) {
+    if (!flat || !dx1 || !dx2) return NPLDA_EINVAL;
+    float dummy_loss = 0.f;
+    return train_step_impl((const float*)x1, (const float*)x2, nullptr, nullptr, 0, nullptr, nullptr, B, ldx, target, params, D0,
+                           D1, D2, thetas, betas, K, alpha, kind, flat, flat, step, 0.f, 0.f, 0.f, 0.f, 0.f, packed, ws,
+                           ws_bytes, &dummy_loss, nullptr, nullptr, stream, dx1, dx2, lddx, io_bf16 != 0, global_counts, flat);
+}
+
 size_t nplda_train_step_flat_floats(int D0, int D1, int D2) {
     if (check_model(D0, D1, D2) != NPLDA_OK) return 0;
     return nplda_grad_floats(D0, D1, D2) + (size_t)kLossLimbs * kLossNS;

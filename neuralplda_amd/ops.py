@@ -576,6 +576,46 @@ def train_step_grad_rows(table, rows1, rows2, target, params, thetas, betas, alp
     return flat
 
 
+def train_step_grad_dx(x1, x2, target, params, thetas, betas, alpha, kind, step, packed, ws, flat, dx1, dx2,
+                       global_counts=None):
+    """nplda_train_step_grad_dx_f32: train_step_grad that also writes dL/dx1, dL/dx2 (float32 or bfloat16, as x1 / x2) — the
+    data-parallel form of train_step_dx's first half.  `ws`: train_step_dx_workspace."""
+    import ctypes
+    lib = _lib.load()
+    _need_fp32(packed, "train_step_grad_dx")
+    bf = x1.dtype == torch.bfloat16
+    for t in (x1, x2, dx1, dx2):
+        if t.dtype != x1.dtype or t.dtype not in (torch.float32, torch.bfloat16) or not t.is_cuda:
+            raise ValueError("train_step_grad_dx: x1, x2, dx1, dx2 must be device tensors, all float32 or all bfloat16")
+        if t.dim() != 2 or t.shape[1] != packed.D0 or t.stride(1) != 1 or t.stride(0) % 4 or t.data_ptr() % 16:
+            raise ValueError("train_step_grad_dx: (B, D0) rows with unit inner stride, 16-byte aligned")
+    B = x1.shape[0]
+    if x2.shape[0] != B or target.shape[0] != B or dx1.shape[0] != B or dx2.shape[0] != B:
+        raise ValueError("x1, x2, target, dx1, dx2 must have the same number of rows")
+    if x1.stride(0) != x2.stride(0) or dx1.stride(0) != dx2.stride(0):
+        raise ValueError("train_step_grad_dx: x1 / x2 (and dx1 / dx2) must share their row stride")
+    _require_dev_f32(target, "target")
+    if not target.is_contiguous() or target.data_ptr() % 16:
+        raise ValueError("train_step_grad_dx: target must be contiguous and 16-byte aligned")
+    if global_counts is not None and (global_counts.dtype != torch.float64 or not global_counts.is_cuda
+                                      or global_counts.numel() != 2 or not global_counts.is_contiguous()):
+        raise ValueError("global_counts must be a contiguous device float64 tensor [N_t, N_n]")
+    if flat.dtype != torch.float32 or not flat.is_cuda or flat.numel() < train_step_flat_floats(packed) or not flat.is_contiguous():
+        raise ValueError("flat must be a contiguous device float32 tensor of train_step_flat_floats(packed) elements")
+    K = len(thetas)
+    parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
+    barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    with torch.cuda.device(x1.device):
+        code = lib.nplda_train_step_grad_dx_f32(x1.data_ptr(), x2.data_ptr(), B, x1.stride(0), 1 if bf else 0, _lib.ptr(target),
+                                                _lib.ptr(global_counts) if global_counts is not None else None, parr,
+                                                packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha),
+                                                kind, _lib.ptr(step), _lib.ptr(packed.buf), _lib.ptr(ws), ws.numel() * 4,
+                                                _lib.ptr(flat), dx1.data_ptr(), dx2.data_ptr(), dx1.stride(0),
+                                                _lib.current_stream())
+    _lib.check(code, "nplda_train_step_grad_dx_f32")
+    return flat
+
+
 def train_step_apply(flat, params, thetas, betas, alpha, kind, exp_avg, exp_avg_sq, step, lr, beta1, beta2, eps,
                      weight_decay, packed, loss, loss_sum=None):
     """nplda_train_step_apply_f32: the update half of the data-parallel step from the all-reduced `flat`."""

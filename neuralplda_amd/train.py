@@ -700,6 +700,11 @@ class HeadStepWithInputGrads(FusedTrainStep):
         self.batch_size, self.io_dtype = batch_size, dtype
         self.use_graph = bool(graph) and batch_size is not None
         self._g = None
+        # data parallel (the head under an extractor's DDP): the one-collective form of the step — gradient phase with the
+        # global label counts (dL/dx of this rank's rows is complete there), all-reduce of [flat gradient | loss sums], update
+        self._dp_head = self.reduce_flat is not None and self.kind in (self._ops.LOSS_SOFTCDET, self._ops.LOSS_BCE)
+        if self._dp_head:
+            self.gcount = torch.zeros(2, dtype=torch.float64, device=self.dev)
         if self.use_graph:
             D0 = self.dims[0]
             self.x1 = torch.zeros(batch_size, D0, device=self.dev, dtype=dtype)
@@ -707,11 +712,28 @@ class HeadStepWithInputGrads(FusedTrainStep):
             self.t = torch.zeros(batch_size, device=self.dev)
             self.t[::2] = 1
 
-    def _fused_ok(self, x1):
+    def _shape_ok(self, x1):
         D0, D1, D2 = self.dims
-        return (self.kind in (self._ops.LOSS_SOFTCDET, self._ops.LOSS_BCE) and self.reduce_sums is None
-                and self.reduce_flat is None and 0 < x1.shape[0] <= 16384
+        return (self.kind in (self._ops.LOSS_SOFTCDET, self._ops.LOSS_BCE) and 0 < x1.shape[0] <= 16384
                 and (x1.dtype == torch.float32 or (x1.dtype == torch.bfloat16 and D0 == 512 and max(D1, D2) > 144)))
+
+    def _fused_ok(self, x1):
+        return self.reduce_sums is None and self.reduce_flat is None and self._shape_ok(x1)
+
+    def _dp_ok(self, x1):
+        return self._dp_head and self._shape_ok(x1)
+
+    def set_global_counts(self, target=None, counts=None):
+        """As FusedTrainStep.set_global_counts: the GLOBAL minibatch's [N_t, N_n] for the next step."""
+        if not self._dp_head:
+            return
+        if counts is not None:
+            c = counts if torch.is_tensor(counts) else torch.tensor([float(counts[0]), float(counts[1])], dtype=torch.float64)
+            self.gcount.copy_(c.to(torch.float64).reshape(2), non_blocking=True)
+        else:
+            nt = target.detach().double().sum().reshape(1)
+            c = torch.cat([nt, float(target.shape[0]) - nt])
+            self.gcount.copy_(self.reduce_sums(c) if self.reduce_sums is not None else c)
 
     def describe(self):
         if self._fused_ok(self.x1 if self.use_graph else torch.empty(1, self.dims[0], dtype=self.io_dtype)):
@@ -744,34 +766,70 @@ class HeadStepWithInputGrads(FusedTrainStep):
             if torch.cuda.is_current_stream_capturing():
                 return self._loss_buf, dx1, dx2
             return self._loss_buf.clone(), dx1.clone(), dx2.clone()
+        if self._dp_ok(x1):
+            B = x1.shape[0]
+            if self._packed is None or not torch.cuda.is_current_stream_capturing():
+                self._sync_packed()
+            key = ("dx", B, x1.dtype)
+            st = self._ws.get(key)
+            if st is None:
+                st = self._ws[key] = (ops.train_step_dx_workspace(B, self._packed, x1.dtype == torch.bfloat16),
+                                      torch.empty_like(x1), torch.empty_like(x2))
+            ws, dx1, dx2 = st
+            if self._flat is None:
+                self._flat = torch.zeros(ops.train_step_flat_floats(self._packed), device=self.dev)
+            x1c = x1 if x1.is_contiguous() else x1.contiguous()
+            x2c = x2 if x2.is_contiguous() else x2.contiguous()
+            tc = t.float().contiguous()
+            with torch.no_grad():
+                prm, ths = [q.detach() for q in self.params], [th.detach() for th in self.thetas]
+                ops.train_step_grad_dx(x1c, x2c, tc, prm, ths, self.betas_loss, self.alpha, self.kind, self.step_count,
+                                       self._packed, ws, self._flat, dx1, dx2, self.gcount)
+                self.reduce_flat(self._flat)
+                ops.train_step_apply(self._flat, prm, ths, self.betas_loss, self.alpha, self.kind, self.m, self.v,
+                                     self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, self._packed,
+                                     self._loss_buf, loss_sum=self._acc())
+            if torch.cuda.is_current_stream_capturing():
+                return self._loss_buf, dx1, dx2
+            return self._loss_buf.clone(), dx1.clone(), dx2.clone()
         with torch.no_grad():
             prm = [q.detach() for q in self.params]
             packed = ops.pack_params(*prm)
             s, saved = ops.forward_train(x1.float(), x2.float(), packed)
             ths = [th.detach() for th in self.thetas]
-            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
+            if self.reduce_sums is None:
+                loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, self.betas_loss, self.alpha, self.kind)
+            else:  # data parallel, outside the fused forms: global loss sums, then the summed flat gradient
+                sums = self.reduce_sums(ops.loss_sums(s, t, ths, self.alpha, self.kind))
+                loss, g, dth = ops.loss_finish(s, t, ths, self.betas_loss, self.alpha, self.kind, sums)
             flat, dx1, dx2 = ops.backward(saved, g, packed, prm[4], want_dx=True)
+            if self.reduce_flat is not None:
+                flat = self.reduce_flat(flat)
             grads = list(ops.split_flat_grad(flat, D0, D1, D2)) + [dth[k:k + 1] for k in range(len(ths))]
             self._adam(prm + ths, grads)
         return loss, dx1.to(x1.dtype), dx2.to(x2.dtype)
 
     def _account_step(self, x1, loss):
         self._acc_n += 1
-        if not self._fused_ok(x1):  # (the fused call adds its loss to the device-side sum itself)
+        if not (self._fused_ok(x1) or self._dp_ok(x1)):  # (the fused calls add their loss to the device-side sum themselves)
             self._acc().add_(loss.detach().reshape(1))
 
-    def __call__(self, x1, x2, target):
+    def __call__(self, x1, x2, target, global_counts=None):
+        """global_counts (data parallel): [N_t, N_n] of the GLOBAL minibatch (else a 16-byte all-reduce finds them)."""
         B = x1.shape[0]
+        if self._dp_ok(x1):
+            self.set_global_counts(target, global_counts)
         if not self.use_graph or B != self.batch_size or x1.dtype != self.io_dtype:
             out = self._eager(x1, x2, target)
             self._touched()
             self._account_step(x1, out[0])
             return out
+        fused = self._fused_ok(self.x1) or self._dp_ok(self.x1)
         if self._g is None:
-            if self._fused_ok(self.x1):
+            if fused:
                 self._sync_packed()
             self._g, self._out = self._capture_fn(lambda: self._eager(self.x1, self.x2, self.t))
-        if self._fused_ok(self.x1):
+        if fused:
             self._sync_packed()
         # a producer that writes into the step's own input buffers (step.x1 / .x2 / .t — e.g. the extractor's last layer
         # with out=step.x1) skips the staging copies: 3 x ~4 us on a 0.08 ms step

@@ -172,6 +172,12 @@ def test_bench_emulate_rank_lines(hip_lib):
     assert d["config"]["pairs_per_gpu_per_step"] == 512 and d["config"]["global_batch"] == 4096
     cb = d["config"]["collective_bytes_per_step"]  # ONE all-reduce per step: flat gradient + 2 x 18 floats of loss sums
     assert list(cb) == ["one_allreduce_flat_gradient_and_loss_sums"] and 390000 < cb["one_allreduce_flat_gradient_and_loss_sums"] < 410000
+    out, lines = _run(["--workload", "cfg5", "--emulate-rank", "3/8", "--steps", "20", "--warmup", "5"])
+    assert out.returncode == 0, out.stderr[-2000:]
+    d = json.loads(lines[0])  # the head step under an extractor's data parallelism: ONE all-reduce, dL/dx local
+    assert d["config"]["emulated_rank"] == "3/8" and d["config"]["global_batch"] == 8 * d["config"]["pairs_per_gpu_per_step"]
+    assert list(d["config"]["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]
+    assert "nplda_train_step_grad_dx_f32" in d["config"]["step"] and 0 < d["ms_per_step"] < 1.0
     assert _run(["--emulate-rank", "8/8"])[0].returncode != 0 and _run(["--emulate-rank", "1/2", "--gpus", "2"])[0].returncode != 0
 
 

@@ -439,3 +439,72 @@ def test_fused_dplda_step_with_lda_and_input_grads(hip_lib):
                 assert float((got - want).abs().max()) <= 1e-4 * float(want.abs().max())
         for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
             np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=2e-4, atol=2e-6, err_msg=k)
+
+
+def test_head_step_data_parallel_form(hip_lib):
+    """HeadStepWithInputGrads on a data-parallel model (the head under an extractor's DDP, BASELINE configs[4]): one rank
+    with identity reductions = the plain fused head step, bit for bit in parameters and dL/dx (eager and graph replay, bf16
+    and fp32 rows, incl. the separate-launch fall-back for an unsupported shape); two unequal shards of one minibatch with
+    the GLOBAL counts give the dL/dx rows of the whole-batch step."""
+    from neuralplda_amd import ops, train
+    from tests.test_train_gpu import NC, model_from, rand_params
+    rng = np.random.default_rng(123)
+    D, B = 150, 1024
+    p = rand_params(rng, 512, D, D)
+    mk = lambda dt: [(torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().to(dt),
+                      torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().to(dt),
+                      torch.from_numpy((rng.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(3)]
+    for dt in (torch.bfloat16, torch.float32):
+        batches = mk(dt)
+        for graph in (False, True):
+            nc = NC(512, D, D)
+            m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+            calls = []
+            m_b._reduce_sums = lambda t: t
+            m_b._reduce_flat = lambda t: (calls.append(t.numel()), t)[1]
+            sa = train.HeadStepWithInputGrads(m_a, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph, dtype=dt)
+            sb = train.HeadStepWithInputGrads(m_b, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph, dtype=dt)
+            assert sb._dp_head and not sb._fused_ok(batches[0][0]) and sb._dp_ok(batches[0][0])
+            for i, (x1, x2, t) in enumerate(batches):
+                nt = float(t.sum().item())
+                la, da1, da2 = sa(x1, x2, t)
+                lb, db1, db2 = sb(x1, x2, t, global_counts=(nt, B - nt)) if i else sb(x1, x2, t)
+                assert abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+                assert torch.equal(da1, db1) and torch.equal(da2, db2)
+                for (k, a), (_, b) in zip(m_a.state_dict().items(), m_b.state_dict().items()):
+                    if k.startswith("Th"):
+                        assert torch.allclose(a, b, rtol=1e-6, atol=1e-9), (dt, graph, i, k)
+                    else:
+                        assert torch.equal(a, b), (dt, graph, i, k)
+            assert calls and all(n == ops.train_step_flat_floats(sb._packed) for n in calls)
+    # the fall-back (40-dimensional head: no fused form for bf16 rows) also goes through the two reductions
+    nc = NC(512, 40, 40)
+    p40 = rand_params(rng, 512, 40, 40)
+    m_a, m_b = model_from(p40, nc, thetas=[-0.5, -0.3]), model_from(p40, nc, thetas=[-0.5, -0.3])
+    seen = []
+    m_b._reduce_sums = lambda t: (seen.append("sums"), t)[1]
+    m_b._reduce_flat = lambda t: (seen.append("flat"), t)[1]
+    x1, x2, t = mk(torch.bfloat16)[0]
+    sa = train.HeadStepWithInputGrads(m_a, 1e-3, batch_size=B, graph=False)
+    sb = train.HeadStepWithInputGrads(m_b, 1e-3, batch_size=B, graph=False)
+    assert not sb._dp_ok(x1)
+    la, da1, _ = sa(x1, x2, t)
+    lb, db1, _ = sb(x1, x2, t)
+    assert seen == ["sums", "flat"] and abs(la.item() - lb.item()) <= 1e-6 * abs(la.item())
+    assert float((da1.float() - db1.float()).abs().max()) <= 2.0 ** -7 * float(da1.float().abs().max())
+    # two shards, global counts: each shard's dL/dx = its rows of the whole-batch dL/dx
+    nc = NC(512, D, D)
+    x1, x2, t = mk(torch.float32)[0]
+    m_a, m_b = model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3])
+    sa = train.HeadStepWithInputGrads(m_a, 1e-3, batch_size=B, graph=False, dtype=torch.float32)
+    _, da1, da2 = sa(x1, x2, t)
+    m_b._reduce_sums = lambda v: v
+    m_b._reduce_flat = lambda v: v
+    nt = float(t.sum().item())
+    for lo, hi in ((0, 300), (300, B)):
+        m_c = model_from(p, nc, thetas=[-0.5, -0.3])
+        m_c._reduce_sums, m_c._reduce_flat = m_b._reduce_sums, m_b._reduce_flat
+        sc = train.HeadStepWithInputGrads(m_c, 1e-3, batch_size=hi - lo, graph=False, dtype=torch.float32)
+        _, dc1, dc2 = sc(x1[lo:hi].contiguous(), x2[lo:hi].contiguous(), t[lo:hi].contiguous(), global_counts=(nt, B - nt))
+        for got, want in ((dc1, da1[lo:hi]), (dc2, da2[lo:hi])):
+            assert float((got - want).abs().max()) <= 2e-6 * float(want.abs().max()) + 1e-12

@@ -26,7 +26,8 @@ def main():
     jobs = [("cfg1 strong (1 048 576 pairs / N)", ["--workload", "cfg1", "--steps", "30", "--warmup", "5", "--no-clock-probe"], "pairs"),
             ("cfg2 strong (4096-pair batch / N)", ["--workload", "cfg2", "--scaling", "strong", "--steps", "300", "--warmup", "30"], "pairs"),
             ("cfg2 weak (4096 pairs per rank)", ["--workload", "cfg2", "--scaling", "weak", "--steps", "300", "--warmup", "30"], "pairs"),
-            ("cfg3 (22 000 rows, 2 M trials / N; cohort 10 000 replicated)", ["--workload", "cfg3", "--steps", "20", "--warmup", "3"], "trials")]
+            ("cfg3 (22 000 rows, 2 M trials / N; cohort 10 000 replicated)", ["--workload", "cfg3", "--steps", "20", "--warmup", "3"], "trials"),
+            ("cfg5 weak (head step with dL/dx, 4096 bf16 pairs per rank)", ["--workload", "cfg5", "--steps", "300", "--warmup", "30"], "pairs")]
     for title, argv, unit in jobs:
         base = None
         for n in (1, 2, 4, 8):
