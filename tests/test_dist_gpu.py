@@ -108,6 +108,21 @@ def test_data_parallel_fused_steps_replay_from_a_graph(hip_lib, one_rank_group):
     for (k, p1), (_, p2) in zip(m_plain.state_dict().items(), m_dp.state_dict().items()):
         assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-8), k
 
+    # the head's end-to-end step (bf16 rows in, dL/dx out) in its one-collective data-parallel form, graph-replayed
+    h_plain = models.NeuralPlda(NC()).cuda()
+    h_dp = models.NeuralPlda(NC()).cuda()
+    h_dp.load_state_dict(h_plain.state_dict())
+    ndist.make_data_parallel(h_dp)
+    hs_plain = train.HeadStepWithInputGrads(h_plain, 1e-3, batch_size=B, graph=True)
+    hs_dp = train.HeadStepWithInputGrads(h_dp, 1e-3, batch_size=B, graph=True)
+    assert hs_dp._dp_head
+    for x1, x2, t in batches:
+        (a, da1, da2), (b, db1, db2) = hs_plain(x1.bfloat16(), x2.bfloat16(), t), hs_dp(x1.bfloat16(), x2.bfloat16(), t)
+        assert abs(float(a) - float(b)) <= 1e-6 * abs(float(a)) and torch.equal(da1, db1) and torch.equal(da2, db2)
+    assert hs_dp._g is not None
+    for (k, p1), (_, p2) in zip(h_plain.state_dict().items(), h_dp.state_dict().items()):
+        assert torch.allclose(p1, p2, rtol=1e-6, atol=1e-8), k
+
     class NCD:
         xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 170, 170
         beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
