@@ -76,6 +76,12 @@ int nplda_score_pairs_f32(const float* x1, const float* x2, int64_t B, int64_t l
  * nplda_score_pairs_f32. */
 int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows1, const int64_t* rows2,
                                int64_t B, const void* packed, int D0, int D1, int D2, float* s, nplda_stream_t stream);
+/* nplda_score_pairs_f32 on BFLOAT16 rows (x-vectors straight from an extractor that runs in bf16, BASELINE configs[4]):
+ * ldx in elements, rows 8-byte aligned.  The rows are widened in registers by the streaming kernels — no fp32 copy of
+ * the batch is made (2 x 1 M x 512: 4 GB of writes and reads) and the scores are those of nplda_score_pairs_f32 on the
+ * widened rows, bit for bit.  NPLDA_EUNSUPPORTED below the streaming sizes (convert and call nplda_score_pairs_f32). */
+int nplda_score_pairs_bf16rows_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, const void* packed, int D0,
+                                   int D1, int D2, float* s, nplda_stream_t stream);
 
 /* Name of the kernel nplda_score_pairs_f32 launches for a batch of B pairs of a D0 -> D1 -> D2 model on the current
  * device (the batch decides between the small-batch, the balanced-tile and the streaming schedule); "" for B <= 0 or an

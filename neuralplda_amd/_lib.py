@@ -27,6 +27,7 @@ SIGNATURES = {
     "nplda_pack_params_f32": (_c_int, [_c_f32p] * 6 + [_c_int] * 3 + [_c_vp, _c_sz, _c_vp]),
     "nplda_score_pairs_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,
                                        _c_f32p, _c_vp]),
+    "nplda_score_pairs_bf16rows_f32": (_c_int, [_c_vp, _c_vp, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_vp]),
     "nplda_score_pairs_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_int,
                                             _c_f32p, _c_vp]),
     "nplda_embed_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
@@ -201,6 +202,9 @@ def build_info():
     tree = nbuild.source_sha()
     return {"abi_version": int(lib.nplda_abi_version()), "csrc_sha": sha, "tree_sha": tree,
             "stale": bool(tree is not None and tree != sha)}
+
+
+NPLDA_EUNSUPPORTED = -95  # include/nplda_hip.h
 
 
 def check(code, what):

@@ -1,4 +1,5 @@
 // nplda_forward.hip — C-ABI entry points of the fused Neural-PLDA forward (kernel: nplda_fwd_kernel.h).
+#include <cstdint>
 #include "nplda_fwd_dispatch.h"
 
 namespace {
@@ -71,6 +72,20 @@ int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
     return launch_fwd_mid<false>(a, L, (hipStream_t)stream);
+}
+
+int nplda_score_pairs_bf16rows_f32(const void* x1, const void* x2, int64_t B, int64_t ldx, const void* packed, int D0,
+                                   int D1, int D2, float* s, nplda_stream_t stream) {
+    if (B < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (B == 0) return NPLDA_OK;
+    if (!packed || !s || !x1 || !x2 || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    // rows of 2-byte elements: 8-byte loads of four columns
+    if (ldx < D0 || (ldx % 4) != 0 || ((uintptr_t)x1 & 7) != 0 || ((uintptr_t)x2 & 7) != 0) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    FwdArgs a = {};
+    a.xa = (const float*)x1; a.xb = (const float*)x2; a.n = B; a.ldx = ldx; a.packed = (const float*)packed; a.out_s = s;
+    return launch_fwd_pairs_bf16rows(a, L, (hipStream_t)stream);
 }
 
 const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2) {

@@ -47,7 +47,7 @@ static inline int launch_fwd_v2(FwdArgs a, const NpldaLayout& L, hipStream_t st)
 }
 
 // persistent grid: one 8-wave block per CU walks the tiles blockIdx.x, + gridDim.x, ...
-template <int MODE>
+template <int MODE, int XM = 0>
 static inline int launch_fwd_v3(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     constexpr int WAVES = 8;
     const long long per_block = (MODE == MODE_EMBED ? 32 : 16) * WAVES;
@@ -60,7 +60,7 @@ static inline int launch_fwd_v3(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     const long long blocks = ntiles < cus ? ntiles : cus;
     dim3 grid((unsigned)blocks), block(WAVES * 64);
 #define NPLDA_LAUNCH(NBV) \
-    hipLaunchKernelGGL((nplda_fwd_v3_kernel<NBV, MODE, WAVES, false, (NBV == 2 ? 4 : 2)>), grid, block, 0, st, a, (int)ntiles)
+    hipLaunchKernelGGL((nplda_fwd_v3_kernel<NBV, MODE, WAVES, XM, (NBV == 2 ? 4 : 2)>), grid, block, 0, st, a, (int)ntiles)
     switch (L.NB) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
@@ -73,6 +73,7 @@ static inline int launch_fwd_v3(FwdArgs a, const NpldaLayout& L, hipStream_t st)
 }
 
 // pair scoring at NB = 11 / 12: persistent grid, weight chunks by LDS-DMA, layer 2 by output groups (nplda_fwd_v5.h)
+template <int XM = 0>
 static inline int launch_fwd_v5(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     constexpr int WAVES = 8;
     const long long ntiles = (a.n + 16 * WAVES - 1) / (16 * WAVES);
@@ -84,8 +85,8 @@ static inline int launch_fwd_v5(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     const long long blocks = ntiles < cus ? ntiles : cus;
     dim3 grid((unsigned)blocks), block(WAVES * 64);
     switch (L.NB) {
-        case 11: hipLaunchKernelGGL((nplda_fwd_v5_kernel<11, WAVES, 2, 4, 1>), grid, block, 0, st, a, (int)ntiles); break;
-        case 12: hipLaunchKernelGGL((nplda_fwd_v5_kernel<12, WAVES, 4, 4, 1>), grid, block, 0, st, a, (int)ntiles); break;
+        case 11: hipLaunchKernelGGL((nplda_fwd_v5_kernel<11, WAVES, 2, 4, 1, XM>), grid, block, 0, st, a, (int)ntiles); break;
+        case 12: hipLaunchKernelGGL((nplda_fwd_v5_kernel<12, WAVES, 4, 4, 1, XM>), grid, block, 0, st, a, (int)ntiles); break;
         default: return NPLDA_EUNSUPPORTED;
     }
     return nplda_launch_status();
@@ -149,7 +150,7 @@ static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st
     // (1.2 M rows: 0.72 of the peak either way; the mode is paced by its 0.77 GB of output)
     if constexpr (MODE == MODE_PAIR) {
         if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
-        return launch_fwd_v5(a, L, st);
+        return launch_fwd_v5<0>(a, L, st);
     }
     return launch_fwd_v2<MODE>(a, L, st);
 }
@@ -185,7 +186,7 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         if (k == FWD_MID) return launch_fwd_mid<false>(a, L, st);
         if (k == FWD_SMALL) return launch_fwd_small<MODE>(a, L, st);
         if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
-        return launch_fwd_v5(a, L, st);
+        return launch_fwd_v5<0>(a, L, st);
     }
     if constexpr (MODE == MODE_EMBED) {
         // embedding rows (inference: no saved activations): 32 rows are one tile's worth of work; the balanced-tile kernel
@@ -197,6 +198,15 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         }
     }
     return launch_fwd_old<MODE>(a, L, st);
+}
+
+// bf16 rows (load_xrow, XM = 2): the streaming kernels only — below their sizes a conversion pass costs next to nothing
+static inline int launch_fwd_pairs_bf16rows(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    if (pair_kernel_choice(a.n, L, mid_cus()) != FWD_STREAM) return NPLDA_EUNSUPPORTED;
+    a.D0 = L.D0; a.KS1 = L.KS1;
+    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+    if (L.NB <= 10) return launch_fwd_v3<MODE_PAIR, 2>(a, L, st);
+    return launch_fwd_v5<2>(a, L, st);
 }
 
 // name of the kernel nplda_score_pairs_f32 launches for a batch of n pairs (bench.py labels its roofline object with it)

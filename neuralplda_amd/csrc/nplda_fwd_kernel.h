@@ -83,6 +83,25 @@ __device__ __forceinline__ f32x4 load_x4c(const float* row, int koff, int D0) {
     return *q;
 }
 
+// The streaming pair kernels also take BFLOAT16 rows (XM = 2: what an extractor running in bf16 hands over — BASELINE
+// configs[4]): FwdArgs.xa / xb then point at 2-byte elements (ldx counted in elements), a lane's four columns are one
+// 8-byte load and are widened in registers; everything behind the load is the fp32 arithmetic of the fp32-row kernel on
+// the widened values, bit for bit.  XM: 0 fp32 rows, 1 fp32 rows with non-temporal loads, 2 bf16 rows.
+template <int XM>
+__device__ __forceinline__ const float* x_row(const float* base, long long row, long long ldx) {
+    if (XM == 2) return reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(base) + row * ldx);
+    return base + row * ldx;
+}
+template <int XM>
+__device__ __forceinline__ f32x4 load_xrow(const float* row, int koff, int D0) {
+    if (XM != 2) return load_x4c<XM == 1>(row, koff, D0);
+    const int o = koff < D0 - 4 ? koff : D0 - 4;
+    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+    const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(row) + o);
+    return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                 __uint_as_float(r[1] & 0xffff0000u)};
+}
+
 struct FwdArgs {
     const float* xa;      // group-A rows (x1, or x in embed mode)
     const float* xb;      // group-B rows (x2, or x in embed mode)

@@ -14,7 +14,7 @@
 
 namespace nplda {
 
-template <int NB, int MODE, int WAVES, bool NT, int KPB, int G = 4>
+template <int NB, int MODE, int WAVES, int NT, int KPB, int G = 4>  // NT: the x-row mode XM of load_xrow
 __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdArgs a, int ntiles) {
     static_assert(MODE == MODE_PAIR || MODE == MODE_EMBED || MODE == MODE_TRAIN, "v2 kernel modes");
     constexpr int THREADS = WAVES * 64;
@@ -54,8 +54,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
     bool okA = rowA < a.n, okB = rowB < a.n;
     if (!okA) rowA = a.n - 1;
     if (!okB) rowB = a.n - 1;
-    const float* sa = a.xa + rowA * a.ldx;
-    const float* sb = a.xb + rowB * a.ldx;
+    const float* sa = x_row<NT>(a.xa, rowA, a.ldx);
+    const float* sb = x_row<NT>(a.xb, rowB, a.ldx);
 
     const f32x4* Wall = reinterpret_cast<const f32x4*>(a.packed);
     // b1, b2, Q, P (NB * 16 floats each) are needed once per tile: a persistent block keeps them in LDS instead of
@@ -105,8 +105,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
     f32x4 xa[KPB], xb[KPB];
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
-        xa[s] = load_x4c<NT>(sa, 16 * s + 4 * g, D0);
-        xb[s] = load_x4c<NT>(sb, 16 * s + 4 * g, D0);
+        xa[s] = load_xrow<NT>(sa, 16 * s + 4 * g, D0);
+        xb[s] = load_xrow<NT>(sb, 16 * s + 4 * g, D0);
     }
     store1(wbuf[0]);
     load2(0);
@@ -122,8 +122,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
     const bool okA_n = rowA_n < a.n, okB_n = rowB_n < a.n;
     if (!okA_n) rowA_n = a.n - 1;
     if (!okB_n) rowB_n = a.n - 1;
-    const float* sa_n = a.xa + rowA_n * a.ldx;
-    const float* sb_n = a.xb + rowB_n * a.ldx;
+    const float* sa_n = x_row<NT>(a.xa, rowA_n, a.ldx);
+    const float* sb_n = x_row<NT>(a.xb, rowB_n, a.ldx);
 
     f32x4 accA[NB], accB[NB];
 #pragma unroll
@@ -168,8 +168,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v3_kernel(const FwdAr
                 const int ks = more ? KPB * (c + 1) + s : s;
                 const float* ra = more ? sa : sa_n;
                 const float* rb = more ? sb : sb_n;
-                xa[s] = load_x4c<NT>(ra, 16 * ks + 4 * g, D0);
-                xb[s] = load_x4c<NT>(rb, 16 * ks + 4 * g, D0);
+                xa[s] = load_xrow<NT>(ra, 16 * ks + 4 * g, D0);
+                xb[s] = load_xrow<NT>(rb, 16 * ks + 4 * g, D0);
             }
             if (s == SMID - 1) {
                 store1(wbuf[cur ^ 1]);

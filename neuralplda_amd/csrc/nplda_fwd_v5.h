@@ -18,7 +18,7 @@
 
 namespace nplda {
 
-template <int NB, int WAVES, int KPB = 2, int G = 4, int H = 2>
+template <int NB, int WAVES, int KPB = 2, int G = 4, int H = 2, int XM = 0>  // XM: the x-row mode of load_xrow
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(const FwdArgs a, int ntiles) {
     constexpr int STEP4 = NB * 64;                   // float4 per k16-step of weights
     constexpr int CH1 = STEP4 * KPB;                 // layer-1 chunk
@@ -98,16 +98,16 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
     tile_rows(tile, t0, row);
     bool ok = row < a.n;
     if (!ok) row = a.n - 1;
-    const float* sa = a.xa + row * a.ldx;
-    const float* sb = a.xb + row * a.ldx;
+    const float* sa = x_row<XM>(a.xa, row, a.ldx);
+    const float* sb = x_row<XM>(a.xb, row, a.ldx);
 
     // ---- prologue: chunk 0 of layer 1 and the first x rows -------------------------------------------------
     dma_l1(0, wbuf[0]);
     f32x4 xa[KPB], xb[KPB];
 #pragma unroll
     for (int s = 0; s < KPB; ++s) {
-        xa[s] = load_x4c<false>(sa, 16 * s + 4 * g, D0);
-        xb[s] = load_x4c<false>(sb, 16 * s + 4 * g, D0);
+        xa[s] = load_xrow<XM>(sa, 16 * s + 4 * g, D0);
+        xb[s] = load_xrow<XM>(sb, 16 * s + 4 * g, D0);
     }
     __syncthreads();  // cvec
     chunk_fence();
@@ -119,8 +119,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
         tile_rows(tile_n, t0_n, row_n);
         const bool ok_n = row_n < a.n;
         if (!ok_n) row_n = a.n - 1;
-        const float* sa_n = a.xa + row_n * a.ldx;
-        const float* sb_n = a.xb + row_n * a.ldx;
+        const float* sa_n = x_row<XM>(a.xa, row_n, a.ldx);
+        const float* sb_n = x_row<XM>(a.xb, row_n, a.ldx);
 
         f32x4 accA[NB], accB[NB];
 #pragma unroll
@@ -141,8 +141,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
                 const int ks = more ? KPB * (c + 1) + s : KPB * c + s;
-                xan[s] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
-                xbn[s] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
+                xan[s] = load_xrow<XM>(sa, 16 * ks + 4 * g, D0);
+                xbn[s] = load_xrow<XM>(sb, 16 * ks + 4 * g, D0);
             }
             const f32x4* w = wbuf[par];
 #pragma unroll
@@ -228,8 +228,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
                     dma_l1(0, nxt);  // chunk 0 of the next tile, and its first x rows
 #pragma unroll
                     for (int s = 0; s < KPB; ++s) {
-                        xa[s] = load_x4c<false>(sa_n, 16 * s + 4 * g, D0);
-                        xb[s] = load_x4c<false>(sb_n, 16 * s + 4 * g, D0);
+                        xa[s] = load_xrow<XM>(sa_n, 16 * s + 4 * g, D0);
+                        xb[s] = load_xrow<XM>(sb_n, 16 * s + 4 * g, D0);
                     }
                 }
                 const f32x4* w = wbuf[par];

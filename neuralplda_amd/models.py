@@ -386,8 +386,9 @@ class NeuralPlda(nn.Module):
             # bridge below costs ~40 us of host time per call, more than the kernel below ~8 000 pairs
             prm = self._params()
             w = prm[0]
-            if (w.is_cuda and x1.device == w.device and x2.device == w.device and x1.dtype == torch.float32
-                    and x2.dtype == torch.float32 and all(t.dtype == torch.float32 for t in prm)):
+            if (w.is_cuda and x1.device == w.device and x2.device == w.device and x1.dtype == x2.dtype
+                    and x1.dtype in (torch.float32, torch.bfloat16)  # (bf16 rows: scored without an fp32 copy, ops.score_pairs)
+                    and all(t.dtype == torch.float32 for t in prm)):
                 packed = _packed_for(self.__dict__.get("_pack_cache"), prm,
                                      getattr(self, "scoring_precision", "fp32"))
                 return ops.score_pairs(x1, x2, packed)

@@ -76,8 +76,24 @@ def pack_params(W1, b1, W2, b2, P_sqrt, Q, precision="fp32"):
 
 
 def score_pairs(x1, x2, packed):
-    """nplda_score_pairs_f32: (B, D0), (B, D0) -> (B,) scores."""
+    """nplda_score_pairs_f32: (B, D0), (B, D0) -> (B,) scores.  Two bfloat16 row batches (an extractor's output) go to
+    nplda_score_pairs_bf16rows_f32 where the streaming kernels apply — no fp32 copy of the batch — and are widened otherwise;
+    the scores are those of the widened rows either way."""
     lib = _lib.load()
+    if (x1.dtype == torch.bfloat16 and x2.dtype == torch.bfloat16 and packed.precision == "fp32" and x1.is_cuda and x2.is_cuda
+            and x1.dim() == 2 and x1.shape == x2.shape and x1.shape[1] == packed.D0):
+        B = x1.shape[0]
+        ok = all(t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 8 == 0 for t in (x1, x2)) and x1.stride(0) == x2.stride(0)
+        if ok and B > 0:
+            s = torch.empty(B, dtype=torch.float32, device=x1.device)
+            with torch.cuda.device(x1.device):
+                code = lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr(), x2.data_ptr(), B, x1.stride(0), _lib.ptr(packed.buf),
+                                                          packed.D0, packed.D1, packed.D2, _lib.ptr(s), _lib.current_stream())
+            if code == 0:
+                return s
+            if code != _lib.NPLDA_EUNSUPPORTED:
+                _lib.check(code, "nplda_score_pairs_bf16rows_f32")
+        x1, x2 = x1.float(), x2.float()
     x1, ld1 = _rows(x1, "x1", packed.D0)
     x2, ld2 = _rows(x2, "x2", packed.D0)
     if x1.shape[0] != x2.shape[0]:

@@ -347,3 +347,42 @@ def test_mid_regime_embedding_rows_match_oracle(hip_lib, D, N):
     np.testing.assert_allclose(q[sel], orc.self_term(zr, p, np.float64), atol=2e-6, rtol=1e-5)
     z2, _ = ops.embed(torch.from_numpy(x).cuda(), packed, want_q=False)
     assert np.array_equal(z2.cpu().numpy(), z)  # deterministic, and q is optional
+
+
+@pytest.mark.parametrize("D1", [150, 170])
+def test_bf16_rows_are_scored_without_an_fp32_copy(hip_lib, D1):
+    """nplda_score_pairs_bf16rows_f32 (streaming kernels, bf16 rows widened in registers): the scores of
+    nplda_score_pairs_f32 on the widened rows, bit for bit; below the streaming sizes ops.score_pairs widens the batch
+    itself; the module's no_grad forward takes bf16 x-vectors (BASELINE configs[4]: an extractor running in bf16)."""
+    from neuralplda_amd import _lib, models, ops
+    rng = np.random.default_rng(9 + D1)
+    p = rand_params(rng, 512, D1, D1)
+    packed = ops.pack_params(*to_dev(p))
+    lib = _lib.load()
+    for B in (262144, 131072 + 77, 4096, 1):
+        x1 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().bfloat16()
+        x2 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().bfloat16()
+        s_b = ops.score_pairs(x1, x2, packed)
+        s_f = ops.score_pairs(x1.float(), x2.float(), packed)
+        assert torch.equal(s_b, s_f), B
+        name = lib.nplda_score_pairs_kernel_name(B, 512, D1, D1).decode()
+        out = torch.empty(B, device="cuda")
+        code = lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr(), x2.data_ptr(), B, 512, _lib.ptr(packed.buf), 512, D1, D1,
+                                                  _lib.ptr(out), _lib.current_stream())
+        assert (code == 0) == ("persistent" in name), (B, name, code)  # the entry point itself: streaming sizes only
+        if code == 0:
+            assert torch.equal(out, s_f)
+    # a strided view (every other row of a wider buffer) and the module's inference path
+    big = torch.from_numpy(rng.standard_normal((2 * 140000, 512)).astype(np.float32)).cuda().bfloat16()
+    v1, v2 = big[0::2], big[1::2]
+    assert torch.equal(ops.score_pairs(v1, v2, packed), ops.score_pairs(v1.float(), v2.float(), packed))
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D1, D1
+        beta, alpha, device, loss = [99.0], 15.0, "cuda", "SoftCdet"
+    m = models.NeuralPlda(NC()).cuda()
+    with torch.no_grad():
+        assert torch.equal(m(v1, v2), m(v1.float(), v2.float()))
+    # misaligned rows are refused by the entry point (the wrapper widens instead)
+    assert lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr() + 2, x2.data_ptr(), 1, 512, _lib.ptr(packed.buf), 512, D1, D1,
+                                              _lib.ptr(out), _lib.current_stream()) != 0
