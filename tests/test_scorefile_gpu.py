@@ -61,6 +61,35 @@ def test_score_files_match_reference_output(hip_lib, tmp_path):
     assert m.training is False or True
 
 
+def test_binary_score_file_round_trip(hip_lib, tmp_path):
+    """generate_scores_binary / load_scores_binary: the scores of the TSV writers (same rows, same float32
+    values) in a binary file tied to its trials file by size and MD5; a different trials file, a truncated file and a text
+    file are refused."""
+    from neuralplda_amd import scorefile_generator as sg
+    g = np.load(os.path.join(G, "g8_loaders.npz"))
+    m, _ = kaldi_model()
+    utt = [str(u) for u in g["utt_ids"]]
+    mega = {u: g["xvec"][i] for i, u in enumerate(utt)}
+    for kind, skip, fn in (("voices", 0, sg.generate_voices_scores), ("sre", 1, sg.generate_sre_scores)):
+        trials = tmp_path / f"{kind}_trials"
+        trials.write_text(str(g[f"{kind}_trials_text"]))
+        fn(str(tmp_path / "tsv"), str(trials), mega, m, torch.device("cuda"))
+        want = np.asarray([np.float32(ln.split("\t")[-1]) for ln in (tmp_path / "tsv").read_text().splitlines()[skip:]])
+        S = sg.generate_scores_binary(str(tmp_path / "bin"), str(trials), mega, m, torch.device("cuda"), skip_rows=skip)
+        assert S.dtype == np.float32 and np.array_equal(S, want)
+        assert np.array_equal(sg.load_scores_binary(str(tmp_path / "bin"), str(trials)), want)
+        assert (tmp_path / "bin").stat().st_size == 48 + 4 * len(want)
+        other = tmp_path / "other"
+        other.write_text(str(g[f"{kind}_trials_text"]) + "x")
+        with pytest.raises(ValueError):
+            sg.load_scores_binary(str(tmp_path / "bin"), str(other))
+        (tmp_path / "cut").write_bytes((tmp_path / "bin").read_bytes()[:-4])
+        with pytest.raises(ValueError):
+            sg.load_scores_binary(str(tmp_path / "cut"))
+        with pytest.raises(ValueError):
+            sg.load_scores_binary(str(tmp_path / "tsv"))
+
+
 def test_device_loaders_equal_reference_gather(hip_lib):
     from neuralplda_amd import sv_trials_loaders as L
     g = np.load(os.path.join(G, "g8_loaders.npz"))
