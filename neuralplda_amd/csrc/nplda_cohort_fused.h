@@ -10,6 +10,7 @@ struct FusedPlan {
     int nbands, nx, nsub;             // column bands (a multiple of 8), column tiles, candidate sub-lists per row
     int q, ksub;                      // list bands per column band (a band's columns in q parts, each with its own
                                       // sub-lists), slots per sub-list
+    int cap;                          // candidate keys one row may bring to the select kernel (its LDS run)
     float zhi, fhi;                   // proposed candidate fraction fhi and its normal quantile zhi = Phi^-1(fhi)
     size_t fixed_bytes, row_bytes;    // workspace: fixed part and per row (rows are planned in multiples of 128)
     long long max_rows;               // rows one launch may cover (32-bit list offsets)

@@ -497,17 +497,20 @@ struct FinishArgs {
     const float* trow;
     float zhi, fhi;                       // the proposal: t_r = c_r + sgn zhi sd_r, fhi = Phi(zhi) = proposed fraction
     int nsub, nsub_valid, topn, lowest;   // sub-lists [nsub_valid, nsub) belong to bands past the last column tile: never written
-    int ksub;
+    int ksub, cap;                        // cap: keys one row may bring (<= kCandMax); more -> the fail list
     unsigned* nfail; unsigned* fail_rows;
     double* stats;
 };
 
 __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) {
-    __shared__ unsigned keys[4][kCandMax];
+    // this wave's run of candidate keys: a.cap of them (dynamic LDS, 4 a.cap words per block).  The run is sized by the plan
+    // (what the proposal expects + a wide margin, at most kCandMax) instead of always kCandMax: the kernel lives on the number
+    // of rows in flight, and 32 KiB per block kept a CU at 20 waves
+    extern __shared__ unsigned keys_dyn[];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const long long row = (long long)blockIdx.x * 4 + wave;
     if (row >= a.R) return;
-    unsigned* kl = keys[wave];
+    unsigned* kl = keys_dyn + (size_t)wave * a.cap;
     const unsigned* cnt = a.counts + (size_t)row * a.nsub;
     // everything else the row needs from memory is asked for now, next to the counts: at their places of use (the
     // bracket, the very end) each of these loads was a memory round trip of its own at the tail of the wave's life
@@ -539,7 +542,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     long long N = a.topn;
     if (N > a.M) N = a.M;
     if (N < 1) N = 1;
-    if (ovf != 0 || total < (unsigned)N || total > (unsigned)kCandMax) {
+    if (ovf != 0 || total < (unsigned)N || total > (unsigned)a.cap) {
         if (lane == 0) a.fail_rows[atomicAdd(a.nfail, 1u)] = (unsigned)row;
         return;
     }
@@ -728,6 +731,14 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     const double want = want_f * topn + 16.0 + 300.0 * exp(-(double)topn / 300.0);
     const double f = want / (double)M;
     if (f > 0.25 || want > 0.8 * kCandMax) return p;
+    {   // keys one row may bring to the select kernel: 1.4 x the proposal (NPLDA_COHORT_CAP), rounded up to 64, at most kCandMax.
+        // A row with more goes to the fail list (exact, slower path) — on Gaussian rows the count is want +- ~3 %, and a row
+        // 40 % over the proposal is far enough from the model to be there anyway.  cfg3: 1536 keys = 24 KiB per block, 6 blocks
+        // per CU instead of 5 at kCandMax: select kernel 99.7 -> 84.5 us (1.3: 82.5, 1.2: 80.3)
+        static const double cap_f = getenv("NPLDA_COHORT_CAP") ? atof(getenv("NPLDA_COHORT_CAP")) : 1.4;
+        long long cap = ((long long)(cap_f * want) + 63) / 64 * 64;
+        p.cap = (int)(cap < kCandMax ? cap : kCandMax);
+    }
     const long long nx = (M + 127) / 128;
     p.nx = (int)nx;
     // Column bands: a multiple of 8 (band b belongs to XCD b % 8), widths equal to within one tile; a work item is (tile of
@@ -865,9 +876,9 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
 #undef NPLDA_LAUNCH
     if (int rc = nplda_launch_status()) return rc;
-    FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, ctl + 8,
+    FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, p.cap, ctl + 8,
                      fail_rows, stats};
-    hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, fi);
+    hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), (size_t)p.cap * 16, st, fi);
     return nplda_launch_status();
 }
 
