@@ -796,22 +796,48 @@ __global__ __launch_bounds__(256) void asnorm_apply_kernel(const double* __restr
                                                            const long long* __restrict__ it, long long T,
                                                            const double* __restrict__ stats, long long R,
                                                            double* __restrict__ out) {
-    const long long stride = (long long)gridDim.x * 256;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < T; i += stride) {
-        const long long e = ie[i], t = it[i];
-        double4 o;
-        if (e < 0 || e >= R || t < 0 || t >= R) {
-            const double nan = __builtin_nan("");
-            o = make_double4(nan, nan, nan, nan);
-        } else {
-            const double r = raw[i];
-            const double4 se = *reinterpret_cast<const double4*>(stats + 4 * e);
-            const double4 st = *reinterpret_cast<const double4*>(stats + 4 * t);
-            const double zn = (r - se.x) / se.y;
-            const double tn = (r - st.x) / st.y;
-            o = make_double4(zn, tn, (zn + tn) / 2, ((r - se.z) / se.w + (r - st.z) / st.w) / 2);
+    // Four trials per thread and round (a block's four runs of 256): the trial's three streams are loaded for all four before the
+    // first statistics row is asked for, the gathers before the first division — the kernel is a chain of dependent memory
+    // round trips (index -> statistics row -> store), and one trial per thread left the memory system at 2.2 TB/s.
+    const long long stride = (long long)gridDim.x * 1024;
+    for (long long i0 = (long long)blockIdx.x * 1024 + threadIdx.x; i0 < T; i0 += stride) {
+        long long idx[4], e[4], t[4];
+        double r[4];
+        bool live[4], ok[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            idx[u] = i0 + 256 * u;
+            live[u] = idx[u] < T;
+            const long long ic = live[u] ? idx[u] : T - 1;
+            e[u] = ie[ic];
+            t[u] = it[ic];
+            r[u] = raw[ic];
         }
-        *reinterpret_cast<double4*>(out + 4 * i) = o;
+        double4 se[4], st[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            ok[u] = !(e[u] < 0 || e[u] >= R || t[u] < 0 || t[u] >= R);
+            // (unconditional loads: an index outside the table reads row 0 and is answered with NaN below; R = 0 -> ok is false
+            // everywhere and the table is not touched)
+            se[u] = st[u] = make_double4(0.0, 1.0, 0.0, 1.0);
+            if (R > 0) {
+                se[u] = *reinterpret_cast<const double4*>(stats + 4 * (ok[u] ? e[u] : 0));
+                st[u] = *reinterpret_cast<const double4*>(stats + 4 * (ok[u] ? t[u] : 0));
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            double4 o;
+            if (!ok[u]) {
+                const double nan = __builtin_nan("");
+                o = make_double4(nan, nan, nan, nan);
+            } else {
+                const double zn = (r[u] - se[u].x) / se[u].y;
+                const double tn = (r[u] - st[u].x) / st[u].y;
+                o = make_double4(zn, tn, (zn + tn) / 2, ((r[u] - se[u].z) / se[u].w + (r[u] - st[u].z) / st[u].w) / 2);
+            }
+            if (live[u]) *reinterpret_cast<double4*>(out + 4 * idx[u]) = o;
+        }
     }
 }
 
@@ -1001,7 +1027,7 @@ int nplda_asnorm_apply_f64(const double* raw, const int64_t* ie, const int64_t* 
     if (T == 0) return NPLDA_OK;
     if (!raw || !ie || !it || !stats || !out) return NPLDA_EINVAL;
     if ((((uintptr_t)stats) & 31u) || (((uintptr_t)out) & 31u)) return NPLDA_EINVAL;
-    long long blocks = (T + 255) / 256;
+    long long blocks = (T + 1023) / 1024;
     if (blocks > 8192) blocks = 8192;
     hipLaunchKernelGGL(asnorm_apply_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, raw,
                        (const long long*)ie, (const long long*)it, (long long)T, stats, (long long)R, out);
