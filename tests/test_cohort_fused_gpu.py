@@ -95,3 +95,26 @@ def test_ineligible_shapes_keep_the_spilling_path(hip_lib):
     ops, packed, zr, qr, zc, qc, C = setup(150, 64, 8000, 9)
     got = ops.cohort_stats(zr, qr, zc, qc, packed, topn=3000).cpu().numpy()                # 3000 of 8000: spilling path
     np.testing.assert_allclose(got, orc.cohort_stats(C, 3000), atol=2e-5, rtol=2e-5)
+
+
+def test_rows_with_more_candidates_than_the_key_run_take_the_exact_path(hip_lib):
+    """The select kernel's LDS run holds NPLDA_COHORT_CAP x the proposal (1.4 by default); a row that brings more goes to the
+    fail list and through the general path.  With the factor forced to 0.9 (read once per process, hence the child) a good
+    part of the rows overflow — and every row still equals the spilling path."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import numpy as np, torch
+        from tests.test_cohort_fused_gpu import setup
+        ops, packed, zr, qr, zc, qc, C = setup(150, 600, 10000, 77)
+        got, nfb = ops.cohort_stats(zr, qr, zc, qc, packed, topn=500, return_fallback_rows=True)
+        spill = ops.cohort_stats(zr, qr, zc, qc, packed, topn=500, force_spill=True)
+        assert 50 <= nfb <= 600, nfb
+        np.testing.assert_allclose(got.cpu().numpy(), spill.cpu().numpy(), rtol=2e-6, atol=2e-7)
+        np.testing.assert_allclose(got[:, 2].cpu().numpy(), spill[:, 2].cpu().numpy(), rtol=1e-12, atol=1e-12)
+        print("overflow rows", nfb)
+    """)
+    env = dict(os.environ, NPLDA_COHORT_CAP="0.9")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "overflow rows" in r.stdout
