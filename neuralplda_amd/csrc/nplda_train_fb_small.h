@@ -85,10 +85,17 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     auto blk = [&](int i) { return HALF && i == HS ? hb : wave + NW * i; };
     // one 64-lane weight fragment at a wave-uniform address: uniform base + 32-bit lane offset (the SGPR-base form of the
     // load; the offset is made opaque at every use, or hipcc folds it into one 64-bit vector add per load)
+    // (round 3: as a BUFFER load — descriptor of the packed image in SGPRs, the fragment's byte offset as the scalar offset,
+    // the lane's 16 bytes as the vector offset: no vector instruction per load at all.  The global-load form cost four
+    // (v_mov, v_lshl_add_u64, v_add_co, v_addc for the 64-bit address), and every VALU instruction between the MFMAs of a
+    // wave alone on its SIMD costs the matrix pipe 6 - 13 cycles: tools/exp_issue_cost.hip)
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
     auto frag = [&](const f32x4* base) {
-        unsigned lo = (unsigned)lane * 16u;
-        asm volatile("" : "+v"(lo));
-        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(base) + lo);
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int soff = __builtin_amdgcn_readfirstlane((int)(reinterpret_cast<const char*>(base) - reinterpret_cast<const char*>(a.packed)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(prsrc, lane16, soff, 0);
+        return __builtin_bit_cast(f32x4, v);
     };
 
     const long long t0 = (long long)blockIdx.x * 16;
