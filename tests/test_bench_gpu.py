@@ -126,7 +126,7 @@ def test_bench_cfg3_single_and_two_rank_dry_run(hip_lib):
 
 def test_bench_cfg3_full_size_line(hip_lib):
     """BASELINE configs[3] at full size on one GPU: the line the driver would get from `--workload cfg3`."""
-    out, lines = _run(["--workload", "cfg3", "--steps", "3", "--warmup", "1"])
+    out, lines = _run(["--workload", "cfg3", "--steps", "10", "--warmup", "3"])  # (3 steps after 1 warm-up once read 6 ms: one slow step)
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["config"]["cohort"] == 10000 and d["config"]["rows"] == 22000 and d["config"]["trials"] == 2000000

@@ -57,7 +57,8 @@ def test_table_from_a_100k_vector_ark_replaces_the_mega_dict(tmp_path):
     tab = svl.XvectorTable.from_scp(s1, s2)
     dt = time.perf_counter() - t0
     assert len(tab) == n and tab.dim == D and np.array_equal(tab.host, M)
-    assert dt < 30.0  # one strided gather per archive, no per-utterance Python objects (kaldi_io: ~1e4 vectors/s)
+    assert dt < 90.0  # one strided gather per archive, no per-utterance Python objects; a few seconds on an idle box (the bound
+                      # is wide because this runs on shared CPU boxes: 30 s was once exceeded under load)
     tab2 = svl.XvectorTable.from_ark(a1, a2)
     assert tab2.ids == keys and np.array_equal(tab2.host, M)
     # dict protocol of the reference's scripts: list(mega) / mega[utt] / len / in
