@@ -82,6 +82,19 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
     const int KS1 = KS1C ? KS1C : a.KS1;
     const int D0 = a.D0;
+    // a 64-lane weight fragment as a BUFFER load: descriptor of the packed image in SGPRs, the fragment's byte offset as the
+    // scalar offset, the lane's 16 bytes as the vector offset — no vector instruction per load.  (As a global load each one
+    // took a 64-bit vector address: v_lshl_add_u64 + v_add_co + v_addc, 273 of the 677 VALU instructions between this
+    // kernel's 840 MFMAs at NB = 10, and a VALU instruction there costs the matrix pipe 6 - 13 cycles: tools/exp_issue_cost.hip)
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto fragb = [&](const f32x4* base, size_t fragidx) {
+        typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+        const int soff = __builtin_amdgcn_readfirstlane(
+            (int)(reinterpret_cast<const char*>(base + fragidx * 64) - reinterpret_cast<const char*>(a.packed)));
+        const u32x4 v = __builtin_amdgcn_raw_buffer_load_b128(prsrc, lane16, soff, 0);
+        return __builtin_bit_cast(f32x4, v);
+    };
 
     // ---- layer 1 --------------------------------------------------------------------------------------------
     f32x4 accA[NBW], accB[NBW];
@@ -102,7 +115,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     auto fetchw = [&](int slot, int ks, int i) {
         const int ksc = ks < KS1 ? ks : KS1 - 1;
         const int nb = blk(i);
-        wf[slot][i] = W1p[((size_t)ksc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+        wf[slot][i] = fragb(W1p, (size_t)ksc * NB + (nb < NB ? nb : NB - 1));
     };
     auto fetchx = [&](int slot, int ks) {
         xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
@@ -250,7 +263,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
 #pragma unroll
             for (int i = 0; i < NBW; ++i) {
                 const int nb = wave + NW * i;
-                wf[slot][i] = Gp[((size_t)qc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+                wf[slot][i] = fragb(Gp, (size_t)qc * NB + (nb < NB ? nb : NB - 1));
             }
         };
 #pragma unroll
@@ -309,7 +322,7 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
 #pragma unroll
         for (int i = 0; i < NBW; ++i) {
             const int nb = blk(i);
-            wf[slot][i] = W2p[((size_t)kbc * NB + (nb < NB ? nb : NB - 1)) * 64 + lane];
+            wf[slot][i] = fragb(W2p, (size_t)kbc * NB + (nb < NB ? nb : NB - 1));
         }
     };
 #pragma unroll
