@@ -477,9 +477,14 @@ def run_cfg3(args, ctx):
         acc["n"] += 1
     if not torch.isfinite(out).all():
         raise SystemExit("non-finite normalised scores")
+    phases = torch.tensor([acc[k] / acc["n"] for k in ("stats", "ag", "apply")], dtype=torch.float64)
+    if ctx.dist is not None:  # the slowest rank's phases (the step's time is already the max over ranks)
+        phases = phases.to(dev) if ctx.backend == "nccl" else phases
+        ctx.dist.all_reduce(phases, op=ctx.dist.ReduceOp.MAX)
+        phases = phases.cpu()
     if rank != 0 and not ctx.emulated:
         return None
-    stats_ms, ag_ms, apply_ms = (acc[k] / acc["n"] for k in ("stats", "ag", "apply"))
+    stats_ms, ag_ms, apply_ms = (float(v) for v in phases)
     rows_local = rhi - rlo
     flops = 2.0 * D * rows_local * M  # 2 D2 FLOP per cohort score
     achieved = flops / (stats_ms * 1e-3) / 1e12
@@ -501,7 +506,10 @@ def run_cfg3(args, ctx):
                    "cohort": M, "rows": R, "trials": T, "rows_per_gpu": rows_local, "trials_per_gpu": thi - tlo,
                    "parallelism": f"row shard + trial shard x{world}", "backend": ctx.backend if world > 1 else "single process",
                    "cohort_scores_per_s": (rows_local if ctx.emulated else R) * M * args.steps / elapsed, "stats_ms": stats_ms,
-                   "allgather_ms": ag_ms,
+                   "allgather_ms": ag_ms, "ranks_in_group": world,
+                   "collective": (None if world == 1 or ctx.emulated else
+                                  f"ONE all_gather_into_tensor of the (R, 4) fp64 row statistics per step ({ctx.backend}), eager"),
+                   "phase_times": "max over ranks" if ctx.dist is not None else "this process",
                    "allgather_bytes": int(world * chunk * 32), "apply_ms": apply_ms, "params": psrc},
         "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                      "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"cohort_stats_D{D}_R{rows_local}_M{M}"),
@@ -545,6 +553,8 @@ def run_cfg2(args, ctx):
     for r0 in range(0, N, 1 << 18):
         table[r0:r0 + (1 << 18)].normal_(generator=gen)
     graph = ctx.backend == "nccl" or world == 1 or ctx.emulated  # (the gloo dry run cannot capture its collectives)
+    if world > 1 and not ctx.emulated and getattr(args, "dp_graph", "auto") == "off":
+        graph = False  # eager collectives: every step is the three kernels, torch.distributed.all_reduce, the update kernel
     step_fn = train.FusedTrainStep(model, 1e-4, weight_decay=1e-5, batch_size=Bl, graph=graph)
     gen_r = torch.Generator(device=dev).manual_seed(1000 + rank)  # each rank its own shard of every minibatch
     # one rank: the epoch's batches as packed records on the device, walked by the captured step through its cursor
@@ -617,7 +627,10 @@ def run_cfg2(args, ctx):
                                f"512->{D}->{D}, SoftCdet (beta 99, 199; alpha 15), Adam(1e-4, wd 1e-5); batch sharded x{world}",
                    "global_batch": Bg, "pairs_per_gpu_per_step": Bl, "table_utterances": N, "params": psrc,
                    "parallelism": f"data parallel x{world}", "backend": ctx.backend if world > 1 else "single process",
-                   "graph_replay": bool(graph), "final_loss": float(loss),
+                   "graph_replay": bool(graph), "final_loss": float(loss), "ranks_in_group": world,
+                   "collective": (None if world == 1 or ctx.emulated else
+                                  ("RCCL all-reduce captured INSIDE the step's HIP graph" if graph and ctx.backend == "nccl"
+                                   else f"eager torch.distributed.all_reduce ({ctx.backend}) between the step's launches")),
                    "collective_bytes_per_step": ({"one_allreduce_flat_gradient_and_loss_sums":
                                                   4 * int(step_fn._flat.numel())} if world > 1 and step_fn._flat is not None
                                                  else ({"loss_sums_allreduce": 8 * 18, "flat_gradient_allreduce":
@@ -675,6 +688,8 @@ def run_cfg5(args, ctx):
                    torch.randn(B, D0, device=dev, generator=gen).to(torch.bfloat16), ts[rank],
                    torch.stack([nt, float(B * world) - nt]) if world > 1 else None))
     graph = ctx.backend == "nccl" or world == 1 or ctx.emulated
+    if world > 1 and not ctx.emulated and getattr(args, "dp_graph", "auto") == "off":
+        graph = False
     step_fn = train.HeadStepWithInputGrads(model, 1e-4, weight_decay=1e-5, batch_size=B, graph=graph)
     state = {"k": 0}
 
@@ -711,7 +726,11 @@ def run_cfg5(args, ctx):
                    "step": (step_fn.describe() if world == 1 else
                             "nplda_train_step_grad_dx_f32 (forward + loss + data gradients with the global label counts | weight-"
                             "gradient slabs | dx = du . W1 | flat gradient) -> ONE all-reduce -> nplda_train_step_apply_f32"),
-                   "parallelism": f"data parallel x{world}", "final_loss": float(loss),
+                   "parallelism": f"data parallel x{world}", "final_loss": float(loss), "ranks_in_group": world,
+                   "graph_replay": bool(graph),
+                   "collective": (None if world == 1 or ctx.emulated else
+                                  ("RCCL all-reduce captured INSIDE the step's HIP graph" if graph and ctx.backend == "nccl"
+                                   else f"eager torch.distributed.all_reduce ({ctx.backend}) between the step's launches")),
                    "collective_bytes_per_step": ({"one_allreduce_flat_gradient_and_loss_sums": 4 * int(step_fn._flat.numel())}
                                                  if world > 1 and step_fn._flat is not None else None),
                    "ms_per_step_with_input_copies": copy_ms,
@@ -727,10 +746,98 @@ def _compact(r):
     """The fields of a --workload line that travel on the default line as alt_cfg2 / alt_cfg3 / alt_cfg5."""
     keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline")}
     keep["workload"] = r["config"]["workload"]
-    for k in ("stats_ms", "apply_ms", "allgather_bytes", "batch_feed", "step", "ms_per_step_with_input_copies"):
+    keep["n_gpus"], keep["scaling"] = r["n_gpus"], r["scaling"]
+    for k in ("stats_ms", "apply_ms", "allgather_ms", "allgather_bytes", "batch_feed", "step", "ms_per_step_with_input_copies",
+              "ranks_in_group", "collective", "collective_bytes_per_step", "graph_replay", "phase_times", "global_batch",
+              "pairs_per_gpu_per_step", "rows_per_gpu", "trials_per_gpu", "backend"):
         if k in r["config"]:
             keep[k] = r["config"][k]
     return keep
+
+
+def multi_rank_alts(args, ctx, out):
+    """N > 1 ranks (the driver's SCALE command): the collective-bearing workloads on the SAME line as the weak cfg1 value.
+    cfg1 has no data-path collective, so alone it would prove nothing about RCCL; every rank therefore also runs
+      alt_cfg1_strong  BASELINE's 1 M pairs split N ways (no collective: the compute side of strong scaling),
+      alt_cfg3         row-sharded cohort statistics -> ONE RCCL all-gather of (R, 4) fp64 -> trial-sharded apply,
+      alt_cfg2         the one-collective data-parallel training step, 4096 pairs per rank (weak), all-reduce of
+                       [flat gradient | loss sums]: first with EAGER collectives, then with the all-reduce captured inside
+                       the step's HIP graph (the default of train.FusedTrainStep); if the capture fails on this stack the
+                       eager figure stays and the line says so (`graph_capture_error`),
+      alt_cfg5         the head's end-to-end step in the same data-parallel form.
+    Each object carries ranks_in_group, the collective's bytes and times that are the MAX over ranks.  A watchdog prints the
+    line assembled so far and ends the process if a collective hangs (a stuck capture must not cost the driver its line)."""
+    import threading
+    rank, world = ctx.rank, ctx.world
+    state = {"phase": "start"}
+    budget = float(os.environ.get("NPLDA_BENCH_ALT_SECONDS", "300"))
+
+    def fire():
+        if rank == 0:
+            out["alts_aborted"] = f"watchdog: no progress {budget:.0f} s into the multi-rank alt workloads (phase {state['phase']})"
+            out["config"]["ranks_in_group"] = world
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    # (rank 0 fires first and prints; the others give it ten seconds before they go: a launcher that sees a worker leave may
+    # stop the rest)
+    dog = threading.Timer(budget if rank == 0 else budget + 10.0, fire)
+    dog.daemon = True
+    dog.start()
+
+    def sub(**kw):
+        a2 = argparse.Namespace(**vars(args))
+        a2.no_alt, a2.no_clock_probe, a2.no_cpu_baseline, a2.scaling = True, True, True, "weak"
+        for k, v in kw.items():
+            setattr(a2, k, v)
+        return a2
+
+    def run(name, fn, a2, compact=True):
+        state["phase"] = name
+        torch.cuda.empty_cache()
+        r = fn(a2, ctx)  # (rank != 0 gets None; an exception on one rank leaves the others to the watchdog)
+        if rank == 0:
+            out[name] = _compact(r) if compact else r
+        return r
+
+    r = run("alt_cfg1_strong", run_cfg1, sub(scaling="strong", steps=max(args.steps, 20)))
+    run("alt_cfg3", run_cfg3, sub(steps=20, warmup=3))
+    run("alt_cfg2", run_cfg2, sub(steps=300, warmup=30, dp_graph="off"))
+    if rank == 0:
+        out["alt_cfg2"]["mode"] = "eager collectives"
+    if ctx.backend == "nccl":
+        # the risky part last: RCCL collectives captured in a HIP graph with more than one rank
+        for name, fn in (("alt_cfg2", run_cfg2), ("alt_cfg5", run_cfg5)):
+            state["phase"] = name + " (graph capture)"
+            torch.cuda.empty_cache()
+            err = None
+            try:
+                r = fn(sub(steps=300, warmup=30, dp_graph="auto"), ctx)
+            except Exception as e:
+                r, err = None, f"{type(e).__name__}: {e}"
+            ok = torch.tensor([0.0 if err else 1.0], device=ctx.dev)
+            ctx.dist.all_reduce(ok, op=ctx.dist.ReduceOp.MIN)  # every rank must have captured, or none uses the figure
+            if rank == 0:
+                if ok.item() == 1.0 and r is not None:
+                    g = _compact(r)
+                    g["mode"] = "all-reduce captured inside the step's HIP graph"
+                    if name == "alt_cfg2":
+                        g["eager_collectives_ms_per_step"] = out["alt_cfg2"]["ms_per_step"]
+                    out[name] = g
+                elif name == "alt_cfg2":
+                    out[name]["graph_capture_error"] = err or "capture failed on another rank"
+                else:
+                    out[name] = {"error": err or "capture failed on another rank"}
+            if ok.item() != 1.0 and name == "alt_cfg5":
+                run("alt_cfg5", run_cfg5, sub(steps=300, warmup=30, dp_graph="off"))
+                if rank == 0:
+                    out["alt_cfg5"]["mode"] = "eager collectives"
+                    out["alt_cfg5"]["graph_capture_error"] = err or "capture failed on another rank"
+    else:
+        run("alt_cfg5", run_cfg5, sub(steps=100, warmup=10, dp_graph="off"))
+        if rank == 0:
+            out["alt_cfg5"]["mode"] = f"eager collectives ({ctx.backend} dry run: nothing to capture)"
+    dog.cancel()
 
 
 def main():
@@ -752,6 +859,9 @@ def main():
     ap.add_argument("--enroll", type=int, default=2000, help="cfg3: enroll ids")
     ap.add_argument("--test", type=int, default=20000, help="cfg3: test ids")
     ap.add_argument("--trials", type=int, default=2000000, help="cfg3: trials")
+    ap.add_argument("--dp-graph", choices=["auto", "off"], default="auto",
+                    help="cfg2 / cfg5 with N > 1: auto = the step's all-reduce captured inside its HIP graph (RCCL), off = eager "
+                         "collectives between the step's launches")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")
@@ -832,6 +942,10 @@ def main():
             except Exception as e:  # an alt object never takes the headline down with it
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+    elif (world > 1 and args.workload == "cfg1" and not args.no_alt and args.precision == "fp32" and args.scaling == "weak"):
+        if rank != 0:
+            out = {"config": {}}
+        multi_rank_alts(args, ctx, out)
     if rank == 0 or emu is not None:
         out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
         out["lib"] = _lib.build_info()

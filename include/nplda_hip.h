@@ -29,6 +29,12 @@
 extern "C" {
 #endif
 
+/* The library is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of
+ * the header are its whole dynamic symbol table (tests/test_abi_cpu.py checks `nm -D`). */
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)
+#endif
+
 #define NPLDA_OK            0
 #define NPLDA_EINVAL      (-22)  /* null pointer, negative size, misaligned row, bad ld      */
 #define NPLDA_EUNSUPPORTED (-95) /* dimension outside the compiled kernel set (see _max_dim) */
@@ -541,6 +547,9 @@ int nplda_embed_bf16x3(const float* x, int64_t N, int64_t ldx, const void* packe
  * test it reports the clock the chip actually holds under that kernel (the roofline peak assumes 2.4 GHz). */
 int nplda_clock_probe(uint64_t* out2, unsigned window_us, nplda_stream_t stream);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

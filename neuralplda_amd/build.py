@@ -15,6 +15,7 @@ PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(PKG_DIR, "csrc")
 LIB_PATH = os.path.join(PKG_DIR, "libnplda_hip.so")
 ARCH = "gfx950"
+VERSION_SCRIPT = os.path.join(CSRC, "libnplda_hip.map")  # exports nplda_* / gb_* only
 
 
 def _hipcc():
@@ -72,7 +73,7 @@ def build(force=False, verbose=False):
         else:
             need = _stale(obj, [src] + hdrs)
         if force or need:
-            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-c", src, "-o", obj]
+            cmd = [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-c", src, "-o", obj]
             if is_id:
                 cmd.insert(1, f'-DNPLDA_SRC_SHA="{sha}"')
                 with open(stamp, "w") as fh:
@@ -84,8 +85,9 @@ def build(force=False, verbose=False):
         out, _ = p.communicate()
         if p.returncode != 0:
             raise RuntimeError(f"hipcc failed on {src}:\n{out.decode(errors='replace')}")
-    if force or procs or _stale(LIB_PATH, objs):
-        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", LIB_PATH] + objs
+    if force or procs or _stale(LIB_PATH, objs + [VERSION_SCRIPT]):
+        cmd = [hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", f"-Wl,--version-script={VERSION_SCRIPT}",
+               "-o", LIB_PATH] + objs
         if verbose:
             print(" ".join(cmd), file=sys.stderr)
         r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)

@@ -1247,7 +1247,7 @@ int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void*
 // ---- the fused training step --------------------------------------------------------------------------------
 namespace {
 struct StepWs { size_t y, z, rn, s, g, partial, xs, bwd, total; long long ldz, ldxs; int nblk; };  // float offsets
-StepWs step_ws(long long B, const NpldaLayout& L, bool rows) {
+static StepWs step_ws(long long B, const NpldaLayout& L, bool rows) {
     StepWs w;
     w.ldz = 16 * L.NB;
     w.nblk = (int)((B + 15) / 16);

@@ -114,6 +114,7 @@ def make_data_parallel(model, group=None):
     to model(x1, x2) / model.loss(...) / loss.backward() exactly as on one GPU; the loss value and every
     parameter gradient then equal the single-process result on the whole minibatch.  Parameters must be
     identical on all ranks at entry (same seed or a broadcast)."""
+    model.__dict__["_dp_group"] = group  # train.train() takes rank / world size from here, not from the default group
     model._reduce_sums = lambda sums: allreduce_sum_(sums, group)
     model._reduce_flat = lambda flat: allreduce_sum_(flat, group)
     # DPlda: the folded fp64 gradient of the linear unit (and of the LDA when it trains) is summed before it is rounded

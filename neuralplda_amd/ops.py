@@ -93,7 +93,12 @@ def score_pairs(x1, x2, packed):
                 return s
             if code != _lib.NPLDA_EUNSUPPORTED:
                 _lib.check(code, "nplda_score_pairs_bf16rows_f32")
-        x1, x2 = x1.float(), x2.float()
+    # any remaining non-fp32 floating input (bf16 rows the streaming form did not take — a 'bf16x3' image, short or
+    # strided batches —, fp16, fp64) is widened / narrowed here: the kernels below read fp32 rows
+    if torch.is_tensor(x1) and x1.is_floating_point() and x1.dtype != torch.float32:
+        x1 = x1.float()
+    if torch.is_tensor(x2) and x2.is_floating_point() and x2.dtype != torch.float32:
+        x2 = x2.float()
     x1, ld1 = _rows(x1, "x1", packed.D0)
     x2, ld2 = _rows(x2, "x2", packed.D0)
     if x1.shape[0] != x2.shape[0]:

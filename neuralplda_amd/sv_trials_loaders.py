@@ -74,6 +74,20 @@ def _read_trials(f, id_to_num_dict, strip_ext_col2):
     return (torch.from_numpy(x1.copy()), torch.from_numpy(x2.copy()), torch.from_numpy(l.copy()), rows - len(x1))
 
 
+def _seed_broadcaster(device, group=None):
+    """seed -> rank 0's seed (one 8-byte broadcast on `group`); None when there is nothing to synchronise with."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) < 2:
+        return None
+
+    def sync(seed):
+        on_dev = dist.get_backend(group) == "nccl"
+        t = torch.tensor([seed], dtype=torch.int64, device=device if on_dev else "cpu")
+        dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        return int(t.item())
+    return sync
+
+
 class TrialLoader(DataLoader):
     """DataLoader(dataset, batch_size, shuffle=True) over a TrialIndexDataset with a vectorised iterator: the batches are
     slices of ONE permutation instead of 2048 Python ints per batch going through sampler -> list -> collate (0.4 ms per
@@ -100,7 +114,7 @@ class TrialLoader(DataLoader):
             ii = perm[lo:lo + bs]
             yield ds.x1[ii], ds.x2[ii], ds.l[ii]
 
-    def _device_epoch_arrays(self, device, num_to_row, permute=True):
+    def _device_epoch_arrays(self, device, num_to_row, permute=True, seed_sync=None):
         """One epoch's permuted index / label arrays on `device` (the draws of __iter__: same permutation).
         permute=False: the same two draws from the global generator (its state moves on exactly as an iteration would move
         it) but the trials in file order — for a consumer to whom the order means nothing (validate(): every metric is a
@@ -112,17 +126,20 @@ class TrialLoader(DataLoader):
         n = len(ds)
         torch.empty((), dtype=torch.int64).random_()
         seed = int(torch.empty((), dtype=torch.int64).random_().item())
+        if seed_sync is not None:  # data parallel: every rank walks rank 0's epoch whatever its own generator's state
+            seed = int(seed_sync(seed))
         gen = torch.Generator()
         gen.manual_seed(seed)
         device = torch.device(device)
         if not permute:
-            e1, e2, el = ds.x1.to(device, non_blocking=True), ds.x2.to(device, non_blocking=True), ds.l.to(device, non_blocking=True)
-            if device.type == "cuda":
+            if device.type == "cuda":  # the columns stay on the device across calls: copied on a cache miss only
                 key = (str(device), ds.x1.data_ptr(), ds.x2.data_ptr(), ds.l.data_ptr(), n)
                 cache = getattr(self, "_dev_columns", None)
                 if cache is None or cache[0] != key:
-                    cache = self._dev_columns = (key, e1, e2, el)
+                    cache = self._dev_columns = (key, ds.x1.to(device), ds.x2.to(device), ds.l.to(device))
                 e1, e2, el = cache[1], cache[2], cache[3]
+            else:
+                e1, e2, el = ds.x1.to(device), ds.x2.to(device), ds.l.to(device)
             if num_to_row is not None:
                 e1, e2 = num_to_row[e1.long()], num_to_row[e2.long()]
                 if n and (int(e1.min()) < 0 or int(e2.min()) < 0):
@@ -172,7 +189,7 @@ class TrialLoader(DataLoader):
         tail = (e1[lo:], e2[lo:], el[lo:]) if lo < n else None
         return self._pack_records(n, e1, e2, el, device), tail
 
-    def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None):
+    def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None, group=None):
         """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
         batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
         `num_to_row`: optional int64 device map applied to both index columns (trial number -> x-vector table row);
@@ -182,8 +199,11 @@ class TrialLoader(DataLoader):
         shard=(rank, world) (data parallel; every rank must draw the same epoch, i.e. share the RNG state): yields this
         rank's contiguous slice of every GLOBAL batch and, fourth, the global batch's [N_t, N_n] as a device float64
         tensor — all the one-collective training step needs to know about the other ranks' shards (the counts of the
-        whole epoch are formed in one pass)."""
-        n, e1, e2, el = self._device_epoch_arrays(device, num_to_row, permute)
+        whole epoch are formed in one pass).  The loader must be the GLOBAL, unsharded one (the slicing happens here);
+        when torch.distributed is initialised the epoch's permutation seed is broadcast from rank 0 of `group`, so a rank
+        whose generator has drifted (a rank-0-only validate(), say) still walks the same epoch as the others."""
+        n, e1, e2, el = self._device_epoch_arrays(device, num_to_row, permute,
+                                                  seed_sync=_seed_broadcaster(device, group) if shard is not None else None)
         bs = self.batch_size
         if shard is not None:
             if pack:

@@ -47,8 +47,11 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
     if fast and step_fn._dp_call:
         # data parallel: every rank walks the SAME epoch (same RNG state on every rank) and takes its slice of each global
         # batch; the loader hands over the global label counts with it, so the step needs ONE collective (its all-reduce)
+        # (the loader is the GLOBAL, unsharded one — the slicing happens in device_batches; rank and size are those of the
+        # group the model was made data parallel on, and the epoch's seed is rank 0's)
         from . import dist as ndist
-        dp = ndist.world()
+        dp_group = getattr(model, "_dp_group", None)
+        dp = ndist.world(dp_group)
     if fast:
         table, row_map = _device_table(mega_xvec_dict, num_to_id_dict, device)
         bs = train_loader.batch_size
@@ -81,7 +84,7 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
         # size: int64 fields at 20 * bs * k bytes); the eager step gathers from the views and never looks at a record
         pack = same and step_fn.use_graph and bs % 2 == 0
         if dp is not None:
-            batches = ((r1, r2, t, None, gc) for r1, r2, t, gc in train_loader.device_batches(device, row_map, shard=dp))
+            batches = ((r1, r2, t, None, gc) for r1, r2, t, gc in train_loader.device_batches(device, row_map, shard=dp, group=dp_group))
         elif pack:
             batches = ((r1, r2, t, None, rec)
                        for r1, r2, t, rec in train_loader.device_batches(device, row_map, pack=True))
@@ -341,7 +344,7 @@ class FusedTrainStep:
         self._acc_n += 1
         if isinstance(loss, tuple):  # (loss, dx1, dx2) of a step that also returns input gradients
             loss = loss[0]
-        if not ((self._one_call or self._dp_call) and 0 < B <= 16384):
+        if not ((self._one_call and 0 < B <= 16384) or (self._dp_call and B <= 16384)):
             self._acc().add_(loss.detach().reshape(1))
 
     def pop_loss_mean(self):
@@ -390,13 +393,19 @@ class FusedTrainStep:
         B = x1.shape[0]
         key = ("rows", B) if table is not None else B
         ws = self._ws.get(key)
-        if ws is None:
+        if ws is None and B > 0:
             ws = self._ws[key] = ops.train_step_workspace(B, self._packed, rows=table is not None)
         if self._flat is None:
             self._flat = torch.zeros(ops.train_step_flat_floats(self._packed), device=self.dev)
         with torch.no_grad():
             prm, ths = [q.detach() for q in self.params], [th.detach() for th in self.thetas]
-            if table is not None:
+            if B == 0:
+                # an empty shard (the ragged last batch cut over more ranks than it has rows): this rank contributes a zero
+                # gradient and zero loss sums but issues the SAME single all-reduce as every other rank, and counts the
+                # step the gradient kernel would have counted (Adam's bias correction must agree on every rank)
+                self._flat.zero_()
+                self.step_count[0] += 1
+            elif table is not None:
                 ops.train_step_grad_rows(table, x1, x2, t, prm, ths, self.betas_loss, self.alpha, self.kind, self.step_count,
                                          self._packed, ws, self._flat, self.gcount)
             else:
@@ -429,7 +438,7 @@ class FusedTrainStep:
             if self._packed is None or not torch.cuda.is_current_stream_capturing():
                 self._sync_packed()
             return self._one_call_step(x1, x2, t)
-        if self._dp_call and 0 < x1.shape[0] <= 16384:
+        if self._dp_call and x1.shape[0] <= 16384:  # (0 rows included: every rank makes the step's one collective)
             if self._packed is None or not torch.cuda.is_current_stream_capturing():
                 self._sync_packed()
             return self._dp_step(x1, x2, t)
@@ -507,7 +516,7 @@ class FusedTrainStep:
         graph launch on the host."""
         ops = self._ops
         B = rows1.shape[0]
-        if self._dp_call and 0 < B <= 16384:
+        if self._dp_call and B <= 16384:
             self.set_global_counts(target, global_counts)
         if not self.use_graph or B != self.batch_size:
             loss = self._eager(ops.gather_rows(table, rows1), ops.gather_rows(table, rows2), target)
@@ -1025,9 +1034,11 @@ def main_kaldiplda(configfile='conf/voices_config.cfg', use_graph=True):
         all_losses.append(float(val_losses[nc.heldout_set_for_lr_decay]))
         model.SaveModel("models/NPLDA_{}_{}.pt".format(epoch, timestamp))
         for trial_file in nc.test_trials_list:
-            nc.generate_scorefile("scores/scores_kaldipldanet_CUDA_Random{}_{}.txt".format(
-                epoch, os.path.splitext(os.path.basename(trial_file))[0]), trial_file, mega_xvec_dict, model,
-                device, 5 * nc.batch_size)
+            print("Generating scores for Epoch {} with trial file {}".format(epoch, trial_file))
+            # the reference's file name, timestamp included (xvector_NeuralPlda_pytorch.py:172)
+            nc.generate_scorefile("scores/kaldipldanet_epoch{}_{}_{}.txt".format(
+                epoch, os.path.splitext(os.path.basename(trial_file))[0], timestamp), trial_file, mega_xvec_dict,
+                model, device, 5 * nc.batch_size)
         # LR halving: three strictly increasing held-out minC values, optimiser re-created (:174-179)
         if len(all_losses) >= 3 and all_losses[-1] > all_losses[-2] > all_losses[-3]:
             lr = lr / 2

@@ -189,3 +189,38 @@ def test_bench_cfg5_line(hip_lib):
     assert d["unit"] == "pairs/s" and d["config"]["global_batch"] == 4096 and d["dtype"].startswith("bf16")
     assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["ms_per_step"] < 0.3
     assert d["roofline"]["flop_per_pair_algorithmic"] == 2 * 398400 + 2 * 2 * 150 * 150 + 2 * 2 * 512 * 150
+
+
+def test_driver_scale_command_carries_the_collective_workloads(hip_lib):
+    """The driver's SCALE command, unchanged (`python -m torch.distributed.run ... bench.py --gpus N --steps K --warmup W`),
+    with two gloo ranks sharing this box's GPU: the ONE line must carry, beside the weak cfg1 value (which has no data-path
+    collective), the strong cfg1 figure, the row-sharded AS-norm step with its all-gather, the one-collective data-parallel
+    training step and the head step — each with ranks_in_group, the collective's bytes and max-over-ranks times.  (With RCCL
+    the training steps are also timed with the all-reduce captured inside the HIP graph; gloo cannot be captured, so this dry
+    run reports the eager form — exactly what the RCCL run falls back to if the capture fails.)"""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NPLDA_BENCH_BACKEND="gloo")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29541", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["config"]["ranks_in_group"] == 2 and "alts_aborted" not in d
+    assert d["config"]["pairs_per_gpu_per_step"] == 1 << 20 and "cpu_baseline" not in d
+    s = d["alt_cfg1_strong"]
+    assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["pairs_per_gpu_per_step"] == 1 << 19
+    assert abs(s["value"] - (1 << 20) / (s["ms_per_step"] * 1e-3)) <= 1e-6 * s["value"]
+    a3 = d["alt_cfg3"]
+    assert a3["ranks_in_group"] == 2 and a3["rows_per_gpu"] == 11000 and a3["trials_per_gpu"] == 1000000
+    assert a3["allgather_bytes"] == 2 * 11000 * 32 and "all_gather_into_tensor" in a3["collective"]
+    assert a3["phase_times"] == "max over ranks" and a3["stats_ms"] > 0 and a3["allgather_ms"] > 0 and a3["apply_ms"] > 0
+    a2 = d["alt_cfg2"]
+    assert a2["ranks_in_group"] == 2 and a2["global_batch"] == 8192 and a2["pairs_per_gpu_per_step"] == 4096
+    assert a2["scaling"] == "weak" and a2["mode"] == "eager collectives" and a2["graph_replay"] is False
+    assert list(a2["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]
+    assert abs(a2["value"] - 8192 / (a2["ms_per_step"] * 1e-3)) <= 1e-6 * a2["value"]
+    a5 = d["alt_cfg5"]
+    assert a5["ranks_in_group"] == 2 and a5["global_batch"] == 8192 and "eager collectives" in a5["mode"]
+    assert list(a5["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]

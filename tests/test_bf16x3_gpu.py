@@ -76,3 +76,24 @@ def test_bf16x3_image_is_scoring_only(hip_lib):
     x = torch.randn(8, 512, device="cuda")
     with pytest.raises(ValueError):
         ops.forward_train(x, x, pk3)
+
+
+def test_bf16_rows_through_a_bf16x3_model_are_widened(hip_lib):
+    """NeuralPlda.forward under no_grad takes bfloat16 rows straight to ops.score_pairs; with scoring_precision = 'bf16x3'
+    the streaming bf16-rows kernel does not apply, so the rows must be widened there (they used to reach the fp32 check
+    and raise TypeError): same scores as the explicit .float() call."""
+    from neuralplda_amd import models
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
+
+    torch.manual_seed(0)
+    m = models.NeuralPlda(NC()).cuda()
+    m.scoring_precision = "bf16x3"
+    x1 = torch.randn(300, 512, device="cuda").bfloat16()
+    x2 = torch.randn(300, 512, device="cuda").bfloat16()
+    with torch.no_grad():
+        a = m(x1, x2)
+        b = m(x1.float(), x2.float())
+    assert a.dtype == torch.float32 and torch.equal(a, b)

@@ -23,3 +23,18 @@ def test_plain_c_program_links_and_runs(tmp_path, hip_lib):
     out = subprocess.run([exe], capture_output=True, text=True)
     assert out.returncode == 0, (out.returncode, out.stdout, out.stderr)
     assert out.stdout.startswith("abi ")
+
+
+def test_dynamic_symbol_table_is_the_declared_abi_only(hip_lib):
+    """The library is built -fvisibility=hidden with a linker version script: `nm -D` must list the entry points
+    include/nplda_hip.h declares and nothing else (no C++ kernel stubs, no helper such as the former `step_ws`)."""
+    import re
+    nm = shutil.which("nm")
+    if nm is None:
+        pytest.skip("no nm")
+    so = os.path.join(ROOT, "neuralplda_amd", "libnplda_hip.so")
+    out = subprocess.run([nm, "-D", "--defined-only", so], check=True, capture_output=True, text=True).stdout
+    exported = {ln.split()[-1] for ln in out.splitlines() if ln.strip()}
+    hdr = open(os.path.join(ROOT, "include", "nplda_hip.h")).read()
+    declared = set(re.findall(r"\b((?:nplda|gb)_[a-z0-9_]+)\s*\(", hdr))
+    assert exported == declared, sorted(exported ^ declared)

@@ -149,3 +149,84 @@ def test_data_parallel_fused_steps_replay_from_a_graph(hip_lib, one_rank_group):
         d.zero_grad()
         d.loss(d(x1, x2), t).backward()
     assert torch.allclose(d_plain.logistic_regres.weight.grad, d_dp.logistic_regres.weight.grad, rtol=1e-6, atol=1e-9)
+
+
+# ---- two ranks on ONE device (gloo carries the collectives; the compute is the HIP library's) ---------------------------------
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _two_rank_train_worker(rank, world, port, tmp):
+    """train.train() in its data-parallel form on `world` gloo ranks sharing cuda:0: 129 trials at batch size 64 leave a
+    tail batch of ONE pair, i.e. an EMPTY shard on rank 1 — every rank must still issue the step's single all-reduce and
+    count the step.  Rank 1's generator is deliberately out of step (the epoch's seed is broadcast from rank 0).  The
+    parameters after the epoch must be the same on both ranks and follow the single-process run on the global batches."""
+    import contextlib
+    import io
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK="0")
+    import torch.distributed as td
+    from neuralplda_amd import dist as ndist, models, sv_trials_loaders as svl, train
+    torch.cuda.set_device(0)
+    ndist.init("gloo")
+    try:
+        rng = np.random.default_rng(21)
+        n_utt, n_trials, B = 200, 129, 64
+        ids = [f"u{u:04d}" for u in range(n_utt)]
+        xv = rng.standard_normal((n_utt, 512)).astype(np.float32)
+        mega = {u: xv[i] for i, u in enumerate(ids)}
+        num_to_id = dict(enumerate(ids))
+        a, b = rng.integers(0, n_utt, n_trials), rng.integers(0, n_utt, n_trials)
+        lab = (rng.random(n_trials) < 0.3).astype(np.float32)
+        ds = svl.TrialIndexDataset(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab))
+        loader = svl._loader(ds, B)
+
+        class Conf:
+            xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+            beta, alpha, device, loss, log_interval = [99.0, 199.0], 15.0, "cuda", "SoftCdet", 1
+
+        def fresh():
+            torch.manual_seed(0)
+            return models.NeuralPlda(Conf()).cuda()
+
+        def run(m, seed):
+            step = train.FusedTrainStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=False)
+            torch.manual_seed(seed)
+            out = io.StringIO()
+            with contextlib.redirect_stdout(out):
+                train.train(Conf, m, torch.device("cuda"), loader, mega, num_to_id, None, 1, step_fn=step)
+            return step, out.getvalue()
+
+        m_dp = ndist.make_data_parallel(fresh())
+        step, log_dp = run(m_dp, 11 if rank == 0 else 12345)  # rank 1's own seed would give another permutation
+        assert step._dp_call and int(step.step_count[0].item()) == 3
+        sd = {k: v.detach().cpu() for k, v in m_dp.state_dict().items()}
+        others = [None] * world
+        td.all_gather_object(others, sd)
+        for k in sd:
+            assert torch.equal(others[0][k], others[1][k]), k  # the ranks stay in step, bit for bit
+        if rank == 0:
+            m_one = fresh()
+            _, log_one = run(m_one, 11)
+            for (k, p1), (_, p2) in zip(m_one.state_dict().items(), m_dp.state_dict().items()):
+                assert torch.allclose(p1, p2, rtol=2e-5, atol=2e-7), k
+            l_one = [float(ln.rsplit(" ", 1)[-1]) for ln in log_one.strip().splitlines()]
+            l_dp = [float(ln.rsplit(" ", 1)[-1]) for ln in log_dp.strip().splitlines()]
+            assert len(l_one) == len(l_dp) == 3 and np.allclose(l_one, l_dp, rtol=1e-5)
+        td.barrier()
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        td.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_two_gloo_ranks_on_one_device_train_with_an_empty_tail_shard(hip_lib, tmp_path):
+    import torch.multiprocessing as mp
+    world = 2
+    mp.spawn(_two_rank_train_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
