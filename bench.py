@@ -325,6 +325,21 @@ def run_cfg1(args, ctx):
         except Exception as e:  # the probe is reporting only
             sys.stderr.write(f"clock probe skipped: {e}\n")
 
+    # Untimed: the cold start.  After one second of idle the clock has ramped down; the first launches run at about half
+    # speed (a single 1 M-pair scoring call from an idle GPU takes roughly twice the steady-state time).  Ten back-to-back
+    # launches, each bracketed by its own events.
+    after_idle = None
+    if rank == 0 and world == 1 and not ctx.emulated and not args.no_alt:
+        torch.cuda.synchronize()
+        time.sleep(1.0)
+        evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(10)]
+        for a, b in evs:
+            a.record()
+            s = step()
+            b.record()
+        torch.cuda.synchronize()
+        after_idle = [round(a.elapsed_time(b), 4) for a, b in evs]
+
     alt = alt170 = None
     if rank == 0 and args.precision == "fp32" and not args.no_alt and not ctx.emulated:
         # the opt-in split-bf16 scoring kernel on the same inputs (reported beside, never as `value`)
@@ -391,6 +406,9 @@ def run_cfg1(args, ctx):
                      "flop_per_pair_algorithmic": flops,
                      "hbm_frac_of_8TBps": B * (2 * D0 * 4 + 4) / (kern_ms * 1e-3) / 1e12 / HBM_PEAK_TBPS},
     }
+    if after_idle is not None:
+        out["first_call_ms"] = after_idle[0]
+        out["roofline"]["launch_ms_after_1s_idle"] = after_idle  # the series: how many launches the ramp lasts
     if sclk_mhz is not None:
         # reporting only: `frac` above stays priced at the nominal 2.4 GHz peak
         out["roofline"]["sclk_mhz_under_kernel"] = sclk_mhz
@@ -742,6 +760,101 @@ def run_cfg5(args, ctx):
     }
 
 
+def run_dropin(args, ctx, B=4096, n_utt=200000, n_valid=1 << 20):
+    """The reference's own loop bodies on this build's modules under compat.install() — what a user who changes nothing
+    but the import path gets (xvector_NeuralPlda_pytorch.py:35-43 and :56-83):
+      literal   optimizer.zero_grad(); data.to(device) x3; load_xvec_trials_from_numbatch(...); output = model(x1, x2);
+                loss = model.loss(output, target); loss.item(); loss.backward(); torch.optim.Adam(...).step()
+      core      model() -> model.loss() -> backward() -> Adam.step() on resident inputs, no .item() (the host running ahead)
+      validate  train.validate() over 1 M trials in chunks of 5 * 2048 (forward + softcdet + cdet + minc)
+    Host-bound figures (Python + launch cost, the device mostly idle): they belong next to alt_cfg2, the same arithmetic as
+    three kernels of one graph replay."""
+    import contextlib
+    import io
+    import neuralplda_amd.compat as compat
+    compat.install()
+    from utils.models import NeuralPlda
+    from utils import sv_trials_loaders as svl
+    from neuralplda_amd import train
+    dev = ctx.dev
+    rng = np.random.default_rng(0)
+    ids = [f"utt{i:07d}" for i in range(n_utt)]
+    mega = svl.XvectorTable.from_matrix(ids, rng.standard_normal((n_utt, 512), dtype=np.float32))
+    num_to_id = dict(enumerate(ids))
+    batches = [(torch.from_numpy(rng.integers(0, n_utt, B)), torch.from_numpy(rng.integers(0, n_utt, B)),
+                torch.from_numpy((rng.random(B) < 0.1).astype(np.float32))) for _ in range(16)]
+    out = {"workload": f"the reference's literal training-loop body (xvector_NeuralPlda_pytorch.py:35-43) at {B} pairs per "
+                       f"batch from a {n_utt}-utterance table, and validate() (:56-83) over {n_valid} trials, both through "
+                       f"neuralplda_amd under compat.install(); torch.optim.Adam(lr 1e-4, weight_decay 1e-5) as the driver "
+                       f"creates it", "unit": "ms"}
+    for D in (150, 170):
+        class NC:
+            xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D, D
+            beta, alpha, device, loss, log_interval, batch_size = [99.0, 199.0], 15.0, str(dev), "SoftCdet", 10 ** 9, 2048
+
+        torch.manual_seed(0)
+        model = NeuralPlda(NC()).to(dev)
+        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)
+        model.train()
+
+        def literal(k):
+            d1, d2, t = batches[k % len(batches)]
+            opt.zero_grad()
+            d1, d2, t = d1.to(dev), d2.to(dev), t.to(dev)
+            x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, d1, d2, dev)
+            output = model(x1, x2)
+            loss = model.loss(output, t)
+            lv = loss.item()
+            loss.backward()
+            opt.step()
+            return lv
+
+        x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, batches[0][0].to(dev), batches[0][1].to(dev), dev)
+        tt = batches[0][2].to(dev)
+
+        def core(k):
+            opt.zero_grad()
+            loss = model.loss(model(x1, x2), tt)
+            loss.backward()
+            opt.step()
+
+        def wall(fn, n, reps=5):
+            for k in range(20):
+                fn(k)
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(reps):
+                t0 = time.perf_counter()
+                for k in range(n):
+                    fn(k)
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t0) / n * 1e3)
+            return float(np.median(ts))
+
+        res = {"literal_step_ms": wall(literal, 60), "core_step_ms": wall(core, 100)}
+        if not np.isfinite(literal(0)):
+            raise SystemExit("non-finite loss in the drop-in loop")
+        # validate(): 1 M trials over the same table
+        ds = svl.TrialIndexDataset(torch.from_numpy(rng.integers(0, n_utt, n_valid)),
+                                   torch.from_numpy(rng.integers(0, n_utt, n_valid)),
+                                   torch.from_numpy((rng.random(n_valid) < 0.1).astype(np.float32)))
+        loader = svl._loader(ds, 5 * 2048)
+        vt = []
+        for _ in range(3):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            with contextlib.redirect_stdout(io.StringIO()):
+                train.validate(NC, model, dev, mega, num_to_id, loader)
+            torch.cuda.synchronize()
+            vt.append((time.perf_counter() - t0) * 1e3)
+        res["validate_1M_trials_ms"] = float(np.median(vt[1:]))
+        res["validate_trials_per_s"] = n_valid / (res["validate_1M_trials_ms"] * 1e-3)
+        res["literal_pairs_per_s"] = B / (res["literal_step_ms"] * 1e-3)
+        out[f"d{D}"] = res
+    compat.uninstall()
+    return out
+
+
 def _compact(r):
     """The fields of a --workload line that travel on the default line as alt_cfg2 / alt_cfg3 / alt_cfg5."""
     keep = {k: r[k] for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "dtype", "roofline")}
@@ -942,6 +1055,11 @@ def main():
             except Exception as e:  # an alt object never takes the headline down with it
                 out[name] = {"error": f"{type(e).__name__}: {e}"}
             torch.cuda.empty_cache()
+        try:
+            out["alt_dropin"] = run_dropin(args, ctx)
+        except Exception as e:
+            out["alt_dropin"] = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
     elif (world > 1 and args.workload == "cfg1" and not args.no_alt and args.precision == "fp32" and args.scaling == "weak"):
         if rank != 0:
             out = {"config": {}}

@@ -242,6 +242,16 @@ int nplda_score_embeddings_f32(const float* z1, int64_t ld1, const float* z2, in
 int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int64_t* idx, int64_t B,
                           int D0, float* out, int64_t ldo, nplda_stream_t stream);
 
+/* load_xvec_trials_from_numbatch (utils/sv_trials_loaders.py:418-426) on the device in ONE launch: the reference looks every
+ * pair's two utterances up as mega_dict[num_to_id_dict[n]]; here `map` (nmap int64, built once per (mega_dict, num_to_id_dict))
+ * takes a trial number to its row of the resident (N, ldt) x-vector table (negative: the utterance is not in the table) and
+ * out1[r, :] = table[map[num1[r]], :], out2[r, :] = table[map[num2[r]], :] (B rows each, row stride ldo).  A number outside
+ * [0, nmap) gives a NaN row and bad[0] |= 1, a number mapped to no row a NaN row and bad[0] |= 2: the caller reads the word
+ * back and raises the reference's KeyError (the word is only ever OR-ed into: the caller clears it). */
+int nplda_gather_pairs_mapped_f32(const float* table, int64_t ldt, int64_t N, const int64_t* map, int64_t nmap,
+                                  const int64_t* num1, const int64_t* num2, int64_t B, int D0, float* out1, float* out2,
+                                  int64_t ldo, int32_t* bad, nplda_stream_t stream);
+
 /* ---- adaptive score normalisation (utils/adaptive_score_normalization.py:27-73) ------------------ */
 
 /* Recommended bytes of workspace: enough for the spilled cohort score matrix (whole matrix up to 4 GiB, else row

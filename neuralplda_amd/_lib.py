@@ -158,6 +158,8 @@ SIGNATURES = {
     "nplda_lda_dgrad_workspace_bytes": (_c_sz, [_c_int, _c_int]),
     "nplda_lda_dgrad_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_f32p, _c_int, _c_int, _c_vp, _c_sz, _c_f32p, _c_f32p,
                                      _c_i64, _c_vp]),
+    "nplda_gather_pairs_mapped_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_int, _c_f32p,
+                                               _c_f32p, _c_i64, _c_vp, _c_vp]),
     "gb_score_pairs_ex_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
                                        _c_f32p, _c_vp]),
 }
@@ -219,5 +221,42 @@ def ptr(t):
 
 
 def current_stream(device=None):
+    """Raw hipStream_t of torch's current stream on `device` (default: the current device).  Through the C entry points
+    torch itself uses: torch.cuda.current_stream() builds a Stream object per call, ~4 us of a ~10 us launch path."""
     import torch
-    return torch.cuda.current_stream(device).cuda_stream
+    if device is None:
+        idx = torch._C._cuda_getDevice()
+    elif isinstance(device, int):
+        idx = device
+    else:
+        idx = device.index
+        if idx is None:
+            idx = torch._C._cuda_getDevice()
+    return torch._C._cuda_getCurrentRawStream(idx)
+
+
+class on_device:
+    """`with on_device(dev):` — torch.cuda.device(dev) without its cost when `dev` is already the current device (the
+    common case: one process per GPU); switches and restores otherwise."""
+    __slots__ = ("idx", "prev")
+
+    def __init__(self, device):
+        import torch
+        idx = device if isinstance(device, int) else device.index
+        self.idx = torch._C._cuda_getDevice() if idx is None else idx
+        self.prev = -1
+
+    def __enter__(self):
+        import torch
+        cur = torch._C._cuda_getDevice()
+        if cur != self.idx:
+            self.prev = cur
+            torch.cuda.set_device(self.idx)
+        return self
+
+    def __exit__(self, *exc):
+        if self.prev >= 0:
+            import torch
+            torch.cuda.set_device(self.prev)
+            self.prev = -1
+        return False

@@ -99,6 +99,35 @@ __global__ __launch_bounds__(kThreads) void gather_rows_kernel(const float* __re
     }
 }
 
+// load_xvec_trials_from_numbatch in one launch: both sides' rows through the trial-number -> table-row map.  Row r of the
+// 2 B outputs (x1 rows, then x2 rows); a number outside the map or mapped to no row gives a NaN row and raises the flag.
+__global__ __launch_bounds__(kThreads) void gather_pairs_mapped_kernel(const float* __restrict__ table, long long ldt,
+                                                                       long long N, const long long* __restrict__ map,
+                                                                       long long nmap, const long long* __restrict__ num1,
+                                                                       const long long* __restrict__ num2, long long B,
+                                                                       int ncol4, float* __restrict__ out1,
+                                                                       float* __restrict__ out2, long long ldo,
+                                                                       int* __restrict__ bad) {
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * (kThreads / 64);
+    for (long long r = (long long)blockIdx.x * (kThreads / 64) + threadIdx.x / 64; r < 2 * B; r += stride) {
+        const bool second = r >= B;
+        const long long p = second ? r - B : r;
+        const long long num = second ? num2[p] : num1[p];
+        const bool in_map = num >= 0 && num < nmap;
+        const long long i = in_map ? map[num] : -1;
+        const bool ok = i >= 0 && i < N;
+        if (!ok && lane == 0) atomicOr(bad, in_map ? 2 : 1);
+        const f32x4* src = reinterpret_cast<const f32x4*>(table + (ok ? i : 0) * ldt);
+        f32x4* dst = reinterpret_cast<f32x4*>((second ? out2 : out1) + p * ldo);
+        for (int c = lane; c < ncol4; c += 64) {
+            f32x4 v = src[c];
+            if (!ok) v = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+            dst[c] = v;  // (plain stores: the rows are read back at once by the forward kernel, out of L2)
+        }
+    }
+}
+
 unsigned grid_for(long long items, int per_block) {
     long long b = (items + per_block - 1) / per_block;
     if (b < 1) b = 1;
@@ -147,6 +176,22 @@ int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int6
     hipLaunchKernelGGL(gather_rows_kernel, dim3(grid_for(B, kThreads / 64)), dim3(kThreads), 0, (hipStream_t)stream,
                        table, (long long)ldt, (long long)N, (const long long*)idx, (long long)B, D0 / 4, out,
                        (long long)ldo);
+    return nplda_launch_status();
+}
+
+int nplda_gather_pairs_mapped_f32(const float* table, int64_t ldt, int64_t N, const int64_t* map, int64_t nmap,
+                                  const int64_t* num1, const int64_t* num2, int64_t B, int D0, float* out1, float* out2,
+                                  int64_t ldo, int32_t* bad, nplda_stream_t stream) {
+    if (B < 0 || N < 0 || nmap < 0 || D0 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
+    if (B == 0) return NPLDA_OK;
+    if (!table || !map || !num1 || !num2 || !out1 || !out2 || !bad || N == 0) return NPLDA_EINVAL;
+    if (ldt < D0 || ldo < D0 || (ldt % 4) != 0 || (ldo % 4) != 0 || !nplda_aligned16(table) || !nplda_aligned16(out1) ||
+        !nplda_aligned16(out2))
+        return NPLDA_EINVAL;
+    hipLaunchKernelGGL(gather_pairs_mapped_kernel, dim3(grid_for(2 * B, kThreads / 64)), dim3(kThreads), 0,
+                       (hipStream_t)stream, table, (long long)ldt, (long long)N, (const long long*)map, (long long)nmap,
+                       (const long long*)num1, (const long long*)num2, (long long)B, D0 / 4, out1, out2, (long long)ldo,
+                       (int*)bad);
     return nplda_launch_status();
 }
 

@@ -76,7 +76,19 @@ def _packed_for(cache, prm, precision):
     key = (precision,) + tuple((t.data_ptr(), t._version, t.device) for t in prm)
     hit = cache.get("key")
     if hit != key:
-        cache["packed"] = ops.pack_params(*prm, precision=precision)
+        where = (precision,) + tuple((k[0], k[2]) for k in key[1:])
+        old = cache.get("packed")
+        if old is not None and cache.get("where") == where and cache.get("contig"):
+            # the same six tensors with new values (an optimiser step between two forwards — every iteration of the
+            # training loop): refresh the image IN PLACE with one raw launch.  The buffer's version is bumped: a graph that
+            # saved it for its backward now fails autograd's saved-tensor check, exactly as it fails on the parameters
+            # themselves, which the optimiser also changed in place.
+            ops.repack_params(old, key[1:])
+            _bump(old.buf)
+        else:
+            cache["packed"] = ops.pack_params(*prm, precision=precision)
+            cache["where"] = where
+            cache["contig"] = all(t.is_contiguous() and t.dtype == torch.float32 and t.is_cuda for t in prm)
         cache["key"] = key
     return cache["packed"]
 
@@ -280,11 +292,15 @@ class _LossFn(torch.autograd.Function):
         dev = _compute_device(output, target)
         s, t = _to_dev(output, dev), _to_dev(target, dev)
         ths = [_to_dev(th, dev) for th in thetas]
-        sums = ops.loss_sums(s, t, ths, alpha, kind)
-        if reduce_sums is not None:
-            sums = reduce_sums(sums)
         need = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[6:]))
-        loss, g, dth = ops.loss_finish(s, t, ths, betas, alpha, kind, sums, want_grad=need)
+        if need and reduce_sums is None and kind != ops.LOSS_HARD_CDET:
+            # one rank, training: both loss passes in ONE call (one launch up to 4096 pairs; same bits as the two below)
+            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, betas, alpha, kind)
+        else:
+            sums = ops.loss_sums(s, t, ths, alpha, kind)
+            if reduce_sums is not None:
+                sums = reduce_sums(sums)
+            loss, g, dth = ops.loss_finish(s, t, ths, betas, alpha, kind, sums, want_grad=need)
         ctx.need = need
         ctx.nth = len(thetas)
         if need:
@@ -298,7 +314,8 @@ class _LossFn(torch.autograd.Function):
         g, dth, output = ctx.saved_tensors[:3]
         thetas = ctx.saved_tensors[3:]
         gl = gl.to(g.device)
-        dths = [_back(dth[k:k + 1] * gl, th) if need else None
+        dthg = dth * gl  # (one product for all thresholds, sliced below)
+        dths = [_back(dthg[k:k + 1], th) if need else None
                 for k, (th, need) in enumerate(zip(thetas, ctx.needs_input_grad[6:]))]
         return (_back(g * gl, output) if ctx.needs_input_grad[0] else None, None, None, None, None, None) + tuple(dths)
 

@@ -69,7 +69,7 @@ def pack_params(W1, b1, W2, b2, P_sqrt, Q, precision="fp32"):
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
     ts = [t.detach().contiguous() for t in (W1, b1, W2, b2, P_sqrt, Q)]
     fn = lib.nplda_pack_params_bf16x3 if b3 else lib.nplda_pack_params_f32
-    with torch.cuda.device(W1.device):
+    with _lib.on_device(W1.device):
         code = fn(*[_lib.ptr(t) for t in ts], D0, D1, D2, _lib.ptr(buf), nbytes, _lib.current_stream())
     _lib.check(code, "nplda_pack_params_bf16x3" if b3 else "nplda_pack_params_f32")
     return PackedParams(buf, D0, D1, D2, lib.nplda_padded_dim(D1, D2), precision)
@@ -86,7 +86,7 @@ def score_pairs(x1, x2, packed):
         ok = all(t.stride(1) == 1 and t.stride(0) % 4 == 0 and t.data_ptr() % 8 == 0 for t in (x1, x2)) and x1.stride(0) == x2.stride(0)
         if ok and B > 0:
             s = torch.empty(B, dtype=torch.float32, device=x1.device)
-            with torch.cuda.device(x1.device):
+            with _lib.on_device(x1.device):
                 code = lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr(), x2.data_ptr(), B, x1.stride(0), _lib.ptr(packed.buf),
                                                           packed.D0, packed.D1, packed.D2, _lib.ptr(s), _lib.current_stream())
             if code == 0:
@@ -111,7 +111,7 @@ def score_pairs(x1, x2, packed):
     if B == 0:
         return s
     fn = lib.nplda_score_pairs_bf16x3 if packed.precision == "bf16x3" else lib.nplda_score_pairs_f32
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         code = fn(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
                   _lib.ptr(s), _lib.current_stream())
     _lib.check(code, "nplda_score_pairs_" + ("bf16x3" if packed.precision == "bf16x3" else "f32"))
@@ -132,7 +132,7 @@ def score_pairs_rows(table, rows1, rows2, packed):
     s = torch.empty(B, dtype=torch.float32, device=table.device)
     if B == 0:
         return s
-    with torch.cuda.device(table.device):
+    with _lib.on_device(table.device):
         code = lib.nplda_score_pairs_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
                                               _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2, _lib.ptr(s),
                                               _lib.current_stream())
@@ -152,7 +152,7 @@ def embed(x, packed, want_q=True):
     if N == 0:
         return z, q
     fn = lib.nplda_embed_bf16x3 if packed.precision == "bf16x3" else lib.nplda_embed_f32
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         code = fn(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2, _lib.ptr(z), packed.ldz,
                   _lib.ptr(q), _lib.current_stream())
     _lib.check(code, "nplda_embed_" + ("bf16x3" if packed.precision == "bf16x3" else "f32"))
@@ -188,7 +188,7 @@ def forward_train(x1, x2, packed):
     z = torch.empty((2 * B, packed.ldz), dtype=torch.float32, device=dev)
     rn = torch.empty(2 * B, dtype=torch.float32, device=dev)
     if B > 0:
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             code = lib.nplda_forward_train_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(packed.buf), packed.D0,
                                                packed.D1, packed.D2, _lib.ptr(s), _lib.ptr(y), _lib.ptr(z),
                                                _lib.ptr(rn), packed.ldz, _lib.current_stream())
@@ -212,7 +212,7 @@ def backward(saved, g, packed, P_sqrt, want_dx=False):
     ps = P_sqrt.detach().contiguous()
     dx1 = torch.empty((B, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
     dx2 = torch.empty((B, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_backward_ex_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld, _lib.ptr(packed.buf), packed.D0, packed.D1,
                                          packed.D2, _lib.ptr(g), _lib.ptr(y), _lib.ptr(z), _lib.ptr(rn), packed.ldz,
                                          _lib.ptr(ps), _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.ptr(dx1), _lib.ptr(dx2),
@@ -232,7 +232,7 @@ def embed_train(x, packed):
     y = torch.empty((N, packed.ldz), dtype=torch.float32, device=dev)
     rn = torch.empty(N, dtype=torch.float32, device=dev)
     if N > 0:
-        with torch.cuda.device(dev):
+        with _lib.on_device(dev):
             code = lib.nplda_embed_train_f32(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
                                              _lib.ptr(z), _lib.ptr(y), _lib.ptr(rn), packed.ldz, _lib.current_stream())
         _lib.check(code, "nplda_embed_train_f32")
@@ -255,7 +255,7 @@ def embed_backward(saved, gz, packed, want_dx=False):
     wsb = lib.nplda_backward_ex_workspace_bytes(N, packed.D0, packed.D1, packed.D2, 1 if want_dx else 0)
     ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
     dx = torch.empty((N, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_embed_backward_f32(_lib.ptr(x), N, ld, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
                                             _lib.ptr(gz), gz.stride(0) if N > 1 else packed.D2, _lib.ptr(y),
                                             _lib.ptr(rn), packed.ldz, _lib.ptr(ws), wsb, _lib.ptr(flat), _lib.ptr(dx),
@@ -286,7 +286,7 @@ def score_embeddings_bwd(z1, z2, P_sqrt, Q, g, want_dz1=True, want_dz2=True):
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
     ld1 = z1.stride(0) if B > 1 else D2
     ld2 = z2.stride(0) if B > 1 else D2
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_score_embeddings_bwd_f32(_lib.ptr(z1), ld1, _lib.ptr(z2), ld2, B, D2,
                                                   _lib.ptr(P_sqrt.contiguous()), _lib.ptr(Q.contiguous()),
                                                   _lib.ptr(g.contiguous()), _lib.ptr(dz1), D2, _lib.ptr(dz2), D2,
@@ -306,7 +306,7 @@ def pack_matrix(src, mode=0):
     if nbytes == 0:
         raise _lib.NpldaHipError(f"a {K} x {N} matrix is outside the resident-matrix GEMM (K <= 512, N % 4 == 0)")
     frag = torch.empty(nbytes // 4, dtype=torch.float32, device=src.device)
-    with torch.cuda.device(src.device):
+    with _lib.on_device(src.device):
         code = lib.nplda_pack_matrix_f32(_lib.ptr(src), src.stride(0), K, N, mode, _lib.ptr(frag), nbytes,
                                          _lib.current_stream())
     _lib.check(code, "nplda_pack_matrix_f32")
@@ -322,7 +322,7 @@ def rows_matmul(rows, packed_matrix, bias=None, rowscale=None):
     out = torch.empty((R, N), dtype=torch.float32, device=rows.device)
     if R == 0:
         return out
-    with torch.cuda.device(rows.device):
+    with _lib.on_device(rows.device):
         code = lib.nplda_rows_matmul_f32(_lib.ptr(rows), ld, R, K, _lib.ptr(frag), N,
                                          _lib.ptr(bias.contiguous()) if bias is not None else None,
                                          _lib.ptr(rowscale.contiguous()) if rowscale is not None else None,
@@ -347,7 +347,7 @@ def lda_backward(x1, x2, paired, rn, dpaired, W1, want_w=True, want_dx=True):
     du = torch.empty((2 * B, Mp), dtype=torch.float32, device=dev)
     dW1 = db1 = dx1 = dx2 = None
     st = _lib.current_stream()
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         _lib.check(lib.nplda_normalize_bwd_paired_f32(_lib.ptr(dpaired), dpaired.stride(0), _lib.ptr(paired),
                                                       paired.stride(0), _lib.ptr(rn), B, D1, _lib.ptr(du), Mp, st),
                    "nplda_normalize_bwd_paired_f32")
@@ -404,7 +404,7 @@ def loss_sums(s, t, thetas, alpha, kind):
     if ns == 0:
         raise _lib.NpldaHipError(f"loss with {K} thresholds is not supported by the compiled kernels (max 4)")
     sums = torch.empty(ns, dtype=torch.float64, device=s.device)
-    with torch.cuda.device(s.device):
+    with _lib.on_device(s.device):
         code = lib.nplda_loss_sums_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), K, float(alpha),
                                        kind, _lib.ptr(sums), _lib.current_stream())
     _lib.check(code, "nplda_loss_sums_f32")
@@ -422,7 +422,7 @@ def loss_finish(s, t, thetas, betas, alpha, kind, sums, want_grad=True):
     g = torch.empty_like(s) if want_grad else None
     dth = torch.empty(K, dtype=torch.float32, device=dev) if want_grad else None
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_loss_finish_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), barr, K,
                                          float(alpha), kind, _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(g),
                                          _lib.ptr(dth), _lib.current_stream())
@@ -450,7 +450,7 @@ def loss_fwd_bwd(s, t, thetas, betas, alpha, kind):
     g = torch.empty_like(s)
     dth = torch.empty(K, dtype=torch.float32, device=dev)
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_loss_fwd_bwd_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), barr, K,
                                           float(alpha), kind, _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(g),
                                           _lib.ptr(dth), _lib.current_stream())
@@ -465,10 +465,24 @@ def pack_params_into(packed, W1, b1, W2, b2, P_sqrt, Q):
     ts = [t.detach().contiguous() for t in (W1, b1, W2, b2, P_sqrt, Q)]
     for n, t in zip(("W1", "b1", "W2", "b2", "P_sqrt", "Q"), ts):
         _require_dev_f32(t, n)
-    with torch.cuda.device(packed.buf.device):
+    with _lib.on_device(packed.buf.device):
         code = lib.nplda_pack_params_f32(*[_lib.ptr(t) for t in ts], packed.D0, packed.D1, packed.D2, _lib.ptr(packed.buf),
                                          packed.buf.numel() * 4, _lib.current_stream())
     _lib.check(code, "nplda_pack_params_f32")
+    return packed
+
+
+def repack_params(packed, keys):
+    """The image of `packed` refreshed from six parameter tensors that were validated when it was first packed (same
+    storage, same device: `keys` = their (data_ptr, version, device) triples) — the raw launch, nothing else."""
+    lib = _lib.load()
+    b3 = packed.precision == "bf16x3"
+    fn = lib.nplda_pack_params_bf16x3 if b3 else lib.nplda_pack_params_f32
+    dev = keys[0][2]
+    with _lib.on_device(dev):
+        code = fn(keys[0][0], keys[1][0], keys[2][0], keys[3][0], keys[4][0], keys[5][0], packed.D0, packed.D1, packed.D2,
+                  packed.buf.data_ptr(), packed.buf.numel() * 4, _lib.current_stream())
+    _lib.check(code, "nplda_pack_params_bf16x3" if b3 else "nplda_pack_params_f32")
     return packed
 
 
@@ -508,7 +522,7 @@ def train_step(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, exp_
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         code = lib.nplda_train_step_f32(_lib.ptr(x1), _lib.ptr(x2), x1.shape[0], ld1, _lib.ptr(target), parr, packed.D0,
                                         packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha), kind,
                                         _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step), float(lr), float(beta1),
@@ -550,7 +564,7 @@ def train_step_grad(x1, x2, target, params, thetas, betas, alpha, kind, step, pa
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         code = lib.nplda_train_step_grad_f32(_lib.ptr(x1), _lib.ptr(x2), x1.shape[0], ld1, _lib.ptr(target),
                                              _lib.ptr(global_counts) if global_counts is not None else None, parr,
                                              packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha),
@@ -587,7 +601,7 @@ def train_step_grad_rows(table, rows1, rows2, target, params, thetas, betas, alp
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_train_step_grad_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
                                                   _lib.ptr(target), _lib.ptr(global_counts) if global_counts is not None else None,
                                                   parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K,
@@ -626,7 +640,7 @@ def train_step_grad_dx(x1, x2, target, params, thetas, betas, alpha, kind, step,
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         code = lib.nplda_train_step_grad_dx_f32(x1.data_ptr(), x2.data_ptr(), B, x1.stride(0), 1 if bf else 0, _lib.ptr(target),
                                                 _lib.ptr(global_counts) if global_counts is not None else None, parr,
                                                 packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha),
@@ -646,7 +660,7 @@ def train_step_apply(flat, params, thetas, betas, alpha, kind, exp_avg, exp_avg_
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(flat.device):
+    with _lib.on_device(flat.device):
         code = lib.nplda_train_step_apply_f32(_lib.ptr(flat), parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas),
                                               barr, K, float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
                                               _lib.ptr(step), float(lr), float(beta1), float(beta2), float(eps),
@@ -685,7 +699,7 @@ def train_step_dx(x1, x2, target, params, thetas, betas, alpha, kind, exp_avg, e
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(x1.device):
+    with _lib.on_device(x1.device):
         code = lib.nplda_train_step_dx_f32(_lib.ptr(x1), _lib.ptr(x2), B, x1.stride(0), 1 if bf else 0, _lib.ptr(target), parr,
                                            packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K, float(alpha), kind,
                                            _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step), float(lr), float(beta1),
@@ -730,7 +744,7 @@ def train_step_rows(table, rows1, rows2, target, params, thetas, betas, alpha, k
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_train_step_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows1), _lib.ptr(rows2), B,
                                              _lib.ptr(target), parr, packed.D0, packed.D1, packed.D2, _theta_array(thetas),
                                              barr, K, float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq),
@@ -763,7 +777,7 @@ def train_step_records(table, cursor, stage, B, params, thetas, betas, alpha, ki
     K = len(thetas)
     parr = (ctypes.c_void_p * 6)(*[q.data_ptr() for q in params])
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
-    with torch.cuda.device(table.device):
+    with _lib.on_device(table.device):
         code = lib.nplda_train_step_records_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(cursor), _lib.ptr(stage), int(B), parr,
                                                 packed.D0, packed.D1, packed.D2, _theta_array(thetas), barr, K,
                                                 float(alpha), kind, _lib.ptr(exp_avg), _lib.ptr(exp_avg_sq), _lib.ptr(step),
@@ -803,7 +817,7 @@ def score_indexed(z, q, i1, i2, packed):
     s = torch.empty(B, dtype=torch.float32, device=dev)
     if B == 0:
         return s
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_score_indexed_f32(_lib.ptr(z), packed.ldz, _lib.ptr(q), z.shape[0], _lib.ptr(i1),
                                            _lib.ptr(i2), B, _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2,
                                            _lib.ptr(s), _lib.current_stream())
@@ -829,7 +843,7 @@ def score_embeddings(z1, z2, P_sqrt, Q):
         return s
     ld1 = z1.stride(0) if B > 1 else D2
     ld2 = z2.stride(0) if B > 1 else D2
-    with torch.cuda.device(z1.device):
+    with _lib.on_device(z1.device):
         code = lib.nplda_score_embeddings_f32(_lib.ptr(z1), ld1, _lib.ptr(z2), ld2, B, D2,
                                               _lib.ptr(P_sqrt.contiguous()), _lib.ptr(Q.contiguous()), _lib.ptr(s),
                                               _lib.current_stream())
@@ -855,11 +869,47 @@ def gather_rows(table, idx, out=None):
             raise ValueError("out must be a contiguous (len(idx), D0) float32 tensor on the table's device")
     if B == 0:
         return out
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_gather_rows_f32(_lib.ptr(table), table.stride(0), table.shape[0], _lib.ptr(idx), B, D0,
                                          _lib.ptr(out), D0, _lib.current_stream())
     _lib.check(code, "nplda_gather_rows_f32")
     return out
+
+
+_BAD_FLAGS = {}
+
+
+def gather_pairs_mapped(table, num_map, num1, num2):
+    """nplda_gather_pairs_mapped_f32: (table[num_map[num1]], table[num_map[num2]]) as two (B, D0) float32 tensors in ONE
+    launch — load_xvec_trials_from_numbatch on the device.  Raises the reference's KeyError (one 4-byte read-back) when a
+    number is outside the map or names an utterance that is not in the table."""
+    lib = _lib.load()
+    _require_dev_f32(table, "table")
+    if table.dim() != 2 or table.stride(1) != 1 or table.stride(0) % 4 != 0 or table.shape[1] % 4 != 0:
+        raise ValueError("table must be (N, D0) float32 with unit inner stride and D0 % 4 == 0")
+    dev = table.device
+    num1, num2 = _idx(num1.reshape(-1), "num1", dev), _idx(num2.reshape(-1), "num2", dev)
+    if num1.shape != num2.shape:
+        raise ValueError("num1 and num2 must have the same length")
+    if num_map.dtype != torch.int64 or num_map.device != dev or not num_map.is_contiguous():
+        raise ValueError("num_map must be a contiguous int64 tensor on the table's device")
+    B, D0 = num1.shape[0], table.shape[1]
+    out = torch.empty((2, B, D0), dtype=torch.float32, device=dev)
+    if B == 0:
+        return out[0], out[1]
+    flag = _BAD_FLAGS.get(dev)
+    if flag is None:
+        flag = _BAD_FLAGS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    code = lib.nplda_gather_pairs_mapped_f32(table.data_ptr(), table.stride(0), table.shape[0], num_map.data_ptr(),
+                                             num_map.numel(), num1.data_ptr(), num2.data_ptr(), B, D0, out[0].data_ptr(),
+                                             out[1].data_ptr(), D0, flag.data_ptr(), _lib.current_stream(dev))
+    _lib.check(code, "nplda_gather_pairs_mapped_f32")
+    bad = int(flag.item())
+    if bad:
+        flag.zero_()
+        raise KeyError("trial index is outside num_to_id_dict" if bad & 1
+                       else "trial index refers to an utterance that is not in mega_dict")
+    return out[0], out[1]
 
 
 # ---- adaptive score normalisation -----------------------------------------------------------------
@@ -898,7 +948,7 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
             if wsb < 256 + ((M + 3) // 4 * 4) * 4:
                 raise ValueError("no workspace size selects the spilling path for this shape")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),
                                           _lib.ptr(q_coh.contiguous()), M, packed.ldz, _lib.ptr(packed.buf), packed.D0,
                                           packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0,
@@ -922,7 +972,7 @@ def row_stats(S, topn=500, select="lowest"):
     stats = torch.empty((R, 4), dtype=torch.float64, device=S.device)
     if R == 0:
         return stats
-    with torch.cuda.device(S.device):
+    with _lib.on_device(S.device):
         code = lib.nplda_row_stats_f32(_lib.ptr(S), S.stride(0) if R > 1 else M, R, M, int(topn),
                                        1 if select == "lowest" else 0, _lib.ptr(stats), _lib.current_stream())
     _lib.check(code, "nplda_row_stats_f32")
@@ -941,7 +991,7 @@ def asnorm_apply(raw, ie, it, stats):
     out = torch.empty((T, 4), dtype=torch.float64, device=dev)
     if T == 0:
         return out
-    with torch.cuda.device(dev):
+    with _lib.on_device(dev):
         code = lib.nplda_asnorm_apply_f64(_lib.ptr(raw), _lib.ptr(ie), _lib.ptr(it), T, _lib.ptr(stats.contiguous()),
                                           stats.shape[0], _lib.ptr(out), _lib.current_stream())
     _lib.check(code, "nplda_asnorm_apply_f64")
@@ -966,7 +1016,7 @@ def gb_pack(W1, b1, mu_t, Lam_t, mu_n, Lam_n):
     if nbytes == 0:
         raise _lib.NpldaHipError(f"GaussianBackend {D0}->{D1} is outside the compiled kernel set")
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
-    with torch.cuda.device(W1.device):
+    with _lib.on_device(W1.device):
         code = lib.gb_pack_params_f32(*[_lib.ptr(t) for t in ts], D0, D1, _lib.ptr(buf), nbytes, _lib.current_stream())
     _lib.check(code, "gb_pack_params_f32")
     return buf, D0, D1
@@ -987,7 +1037,7 @@ def _gb_call(x1, x2, packed, want_s, want_paired, want_rn=False):
     paired = torch.empty((B, 2 * D1), dtype=torch.float32, device=x1.device) if want_paired else None
     rn = torch.empty(2 * B, dtype=torch.float32, device=x1.device) if want_rn else None
     if B > 0:
-        with torch.cuda.device(x1.device):
+        with _lib.on_device(x1.device):
             code = lib.gb_score_pairs_ex_f32(_lib.ptr(x1), _lib.ptr(x2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
                                              _lib.ptr(paired), _lib.ptr(rn), _lib.current_stream())
         _lib.check(code, "gb_score_pairs_ex_f32")
@@ -1023,7 +1073,7 @@ def quadform_pack(W1, b1, M, v, c):
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
     ts = [W1.detach().contiguous(), b1.detach().contiguous(), M.detach().contiguous(),
           None if v is None else v.detach().contiguous()]
-    with torch.cuda.device(W1.device):
+    with _lib.on_device(W1.device):
         code = lib.gb_pack_quadform_f32(_lib.ptr(ts[0]), _lib.ptr(ts[1]), _lib.ptr(ts[2]), _lib.ptr(ts[3]), float(c), D0,
                                         D1, _lib.ptr(buf), nbytes, _lib.current_stream())
     _lib.check(code, "gb_pack_quadform_f32")
@@ -1045,7 +1095,7 @@ def dplda_pack(W1, b1, wlr, blr):
         raise _lib.NpldaHipError(f"model {D0}->{D1} is outside the compiled kernel set")
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
     ts = [t.detach().contiguous() for t in (W1, b1, wlr, blr)]
-    with torch.cuda.device(W1.device):
+    with _lib.on_device(W1.device):
         code = lib.gb_pack_dplda_f32(*[_lib.ptr(t) for t in ts], D0, D1, _lib.ptr(buf), nbytes, _lib.current_stream())
     _lib.check(code, "gb_pack_dplda_f32")
     return buf, D0, D1
@@ -1070,7 +1120,7 @@ def quadform_score_rows(y1, y2, packed):
     B = y1.shape[0]
     s = torch.empty(B, dtype=torch.float32, device=y1.device)
     if B > 0:
-        with torch.cuda.device(y1.device):
+        with _lib.on_device(y1.device):
             code = lib.gb_score_rows_f32(_lib.ptr(y1), _lib.ptr(y2), B, ld1, _lib.ptr(buf), D0, D1, _lib.ptr(s),
                                          _lib.current_stream())
         _lib.check(code, "gb_score_rows_f32")
@@ -1104,7 +1154,7 @@ def dplda_quadform_image(wlr, D1):
         raise _lib.NpldaHipError(f"a {K} x {K} matrix is outside the resident-matrix GEMM (K <= 512, N % 4 == 0)")
     frag = torch.empty(nbytes // 4, dtype=torch.float32, device=w.device)
     v = torch.empty(K, dtype=torch.float32, device=w.device)
-    with torch.cuda.device(w.device):
+    with _lib.on_device(w.device):
         code = lib.nplda_dplda_quadform_f32(_lib.ptr(w), D1, _lib.ptr(frag), nbytes, _lib.ptr(v), _lib.current_stream())
     _lib.check(code, "nplda_dplda_quadform_f32")
     return (frag, K, K), v
@@ -1127,7 +1177,7 @@ def dplda_grad(paired, g, D1):
     ws = torch.empty(nbytes // 4, dtype=torch.float32, device=paired.device)
     out = torch.empty(2 * D1 * D1 + D1 + 1, dtype=torch.float32, device=paired.device)
     gg = g.detach().contiguous()
-    with torch.cuda.device(paired.device):
+    with _lib.on_device(paired.device):
         code = lib.nplda_dplda_grad_f32(_lib.ptr(paired), B, paired.stride(0), D1, _lib.ptr(gg), _lib.ptr(out),
                                         out.data_ptr() + 4 * (out.numel() - 1), _lib.ptr(ws), nbytes, _lib.current_stream())
     _lib.check(code, "nplda_dplda_grad_f32")
@@ -1167,7 +1217,7 @@ def weighted_moments(x, w0, w1=None, out=None):
     if nbytes == 0:
         raise _lib.NpldaHipError(f"row length {n} is outside the compiled kernel set")
     wsb = torch.empty(nbytes // 4, dtype=torch.float32, device=x.device)
-    with torch.cuda.device(x.device):
+    with _lib.on_device(x.device):
         code = lib.nplda_weighted_moments_f32(_lib.ptr(x), B, x.stride(0) if B > 0 else n, n, _lib.ptr(ws[0]),
                                               _lib.ptr(ws[1]) if nc == 2 else None, _lib.ptr(cnt), _lib.ptr(sm),
                                               _lib.ptr(sq), acc, _lib.ptr(wsb), nbytes, _lib.current_stream())
@@ -1208,7 +1258,7 @@ def detcost_sweep(scores, target, betas, exact=False, want_eer=False):
     import ctypes
     barr = (ctypes.c_float * K)(*[float(b) for b in betas])
     base = out.data_ptr()
-    with torch.cuda.device(s.device):
+    with _lib.on_device(s.device):
         code = lib.nplda_detcost_sweep_f32(_lib.ptr(s), _lib.ptr(t), N, barr, K, 1 if exact else 0, base, base + 4 * K,
                                            base + 8 * K, (base + 8 * K + 4) if want_eer else None, _lib.ptr(ws), nbytes,
                                            _lib.current_stream())

@@ -456,16 +456,13 @@ def load_xvec_trials_from_numbatch(mega_dict, num_to_id_dict, data1, data2, devi
         key = (data1.device.type, data1.device.index)
         if key not in devmaps:
             devmaps[key] = torch.from_numpy(m).to(data1.device)
-        mm = devmaps[key]
-        i1, i2 = data1.reshape(-1).long(), data2.reshape(-1).long()
-        # the reference's dict look-up raises KeyError for an unknown number; the gather kernel would write NaN rows
-        if i1.numel() and (int(torch.minimum(i1.min(), i2.min())) < 0
-                           or int(torch.maximum(i1.max(), i2.max())) >= mm.numel()):
-            raise KeyError("trial index is outside num_to_id_dict")
-        r1, r2 = mm[i1], mm[i2]
-        if r1.numel() and int(torch.minimum(r1.min(), r2.min())) < 0:
-            raise KeyError("trial index refers to an utterance that is not in mega_dict")
-        return tab.gather(r1, device), tab.gather(r2, device)
+        # one launch maps both index columns to table rows and gathers both sides; the reference's dict look-up raises
+        # KeyError for an unknown number, here a flag word the kernel raises is read back (ops.gather_pairs_mapped)
+        from . import ops
+        if device == data1.device or device.index is None:
+            return ops.gather_pairs_mapped(tab.on(data1.device), devmaps[key], data1, data2)
+        x1, x2 = ops.gather_pairs_mapped(tab.on(data1.device), devmaps[key], data1, data2)
+        return x1.to(device), x2.to(device)
     d1 = data1.cpu().numpy() if isinstance(data1, torch.Tensor) else np.asarray(data1)
     d2 = data2.cpu().numpy() if isinstance(data2, torch.Tensor) else np.asarray(data2)
     r1, r2 = m[d1.reshape(-1).astype(np.int64)], m[d2.reshape(-1).astype(np.int64)]

@@ -164,7 +164,8 @@ def _free_port():
 def _two_rank_train_worker(rank, world, port, tmp):
     """train.train() in its data-parallel form on `world` gloo ranks sharing cuda:0: 129 trials at batch size 64 leave a
     tail batch of ONE pair, i.e. an EMPTY shard on rank 1 — every rank must still issue the step's single all-reduce and
-    count the step.  Rank 1's generator is deliberately out of step (the epoch's seed is broadcast from rank 0).  The
+    count the step.  (Binary cross-entropy: SoftCdet divides by the batch's target AND non-target counts, one of which is
+    zero in a one-pair batch — NaN in the reference too.)  Rank 1's generator is deliberately out of step (the epoch's seed is broadcast from rank 0).  The
     parameters after the epoch must be the same on both ranks and follow the single-process run on the global batches."""
     import contextlib
     import io
@@ -188,7 +189,7 @@ def _two_rank_train_worker(rank, world, port, tmp):
 
         class Conf:
             xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
-            beta, alpha, device, loss, log_interval = [99.0, 199.0], 15.0, "cuda", "SoftCdet", 1
+            beta, alpha, device, loss, log_interval = [99.0, 199.0], 15.0, "cuda", "crossentropy", 1
 
         def fresh():
             torch.manual_seed(0)

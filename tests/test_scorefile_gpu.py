@@ -104,6 +104,21 @@ def test_device_loaders_equal_reference_gather(hip_lib):
     np.testing.assert_array_equal(X2.cpu().numpy(), g["X2"])
     X1c, _ = L.load_xvec_trials_from_numbatch(mega, num_to_id, d1.cpu(), d2.cpu(), dev)  # CPU indices, device output
     np.testing.assert_array_equal(X1c.cpu().numpy(), g["X1"])
+    # the reference's dict look-ups raise KeyError: a number outside num_to_id_dict, a number whose utterance is not in the
+    # mega dict (one fused map + gather launch raises a flag word; nplda_gather_pairs_mapped_f32) — and the next call is clean
+    import pytest
+    bad = d1.clone()
+    bad[3] = len(utt) + 5
+    with pytest.raises(KeyError):
+        L.load_xvec_trials_from_numbatch(mega, num_to_id, bad, d2, dev)
+    short = dict(num_to_id)
+    short[1] = "not-in-mega"
+    with pytest.raises(KeyError):
+        L.load_xvec_trials_from_numbatch(mega, short, torch.full_like(d1, 1), d2, dev)
+    X1b, X2b = L.load_xvec_trials_from_numbatch(mega, num_to_id, d1.int(), d2.int(), dev)  # any integer dtype
+    assert torch.equal(X1b, X1) and torch.equal(X2b, X2)
+    e1, e2 = L.load_xvec_trials_from_numbatch(mega, num_to_id, d1[:0], d2[:0], dev)
+    assert e1.shape == (0, g["X1"].shape[1]) and e2.shape == e1.shape
     I1, I2 = L.load_xvec_trials_from_idbatch(mega, g["idtrials"], dev)
     np.testing.assert_array_equal(I1.cpu().numpy(), g["I1"])
     np.testing.assert_array_equal(I2.cpu().numpy(), g["I2"])

@@ -5,6 +5,8 @@ usage: rocpd_summary.py [--by-grid] [--drop-first] <results.db> [...]   (prints 
 --by-grid:    kernel-trace rows grouped by (kernel, grid size) — one kernel launched at several problem sizes.
 --drop-first: leave each kernel's FIRST launch of the process out of its statistics (it carries code-object loading and a
               cold clock: 20 ms on a 3 ms kernel, which alone moves a 69-launch average by 8 %).
+--series N:   after the table, the per-launch durations (launch order) of the first N launches of the kernel with the
+              largest total time — the cold start is several launches long, not one (clock ramp from idle).
 Every time row carries calls / total / avg AND min / median / max, so an outlier is visible next to the average it skews.
 """
 import sqlite3
@@ -36,7 +38,13 @@ def kernel_rows(c, by_grid, drop_first):
 def main():
     flags = {"--by-grid", "--drop-first"}
     by_grid, drop_first = "--by-grid" in sys.argv, "--drop-first" in sys.argv
-    for path in [a for a in sys.argv[1:] if a not in flags]:
+    argv = list(sys.argv[1:])
+    series = 0
+    if "--series" in argv:
+        i = argv.index("--series")
+        series = int(argv[i + 1])
+        del argv[i:i + 2]
+    for path in [a for a in argv if a not in flags]:
         c = sqlite3.connect(path)
         print(f"== {path}" + ("   (first launch of each kernel dropped)" if drop_first else ""))
         try:
@@ -56,6 +64,12 @@ def main():
                 line = f"  {short(name, w):{w}s}" + (f" {gx:9d} {wx:5d}" if by_grid else "")
                 print(line + f" {len(d):6d} {sum(d) / 1e3:11.1f} {statistics.fmean(d) / 1e3:9.2f} {min(d) / 1e3:9.2f} "
                              f"{statistics.median(d) / 1e3:9.2f} {max(d) / 1e3:9.2f} {100.0 * sum(d) / total_all:6.2f}")
+        if series and rows:
+            # the dominant kernel's launches one by one, nothing dropped (kernel_rows(..., drop_first=False))
+            allrows = kernel_rows(c, by_grid, False)
+            name, gx, wx, d, _ = max(allrows, key=lambda r: sum(r[3]))
+            print(f"  per-launch series of {short(name, 70)} (grid {gx}), first {min(series, len(d))} of {len(d)} launches, us:")
+            print("    " + " ".join(f"{v / 1e3:.1f}" for v in d[:series]))
         try:
             q = ("select kernel_name, counter_name, count(*), avg(value), min(value), max(value), avg(duration), "
                  "max(vgpr_count), max(accum_vgpr_count), max(sgpr_count), max(lds_block_size), max(grid_size), "
