@@ -227,8 +227,13 @@ struct FusedArgs {
 // instruction drops a finished 1 KiB A-fragment into LDS), double buffered, ONE barrier per tile instead of eleven,
 // a quarter of the L2 -> LDS traffic per MFMA (a tile serves 256 rows, and no row operand is staged at all), and the
 // epilogue works on 32 accumulator registers at a time.
-template <bool LOWEST, int NB>
+// RGW: 16-row groups per wave — 2 (a block owns 256 rows: two MFMAs per A fragment read from LDS) or 1 (128 rows: twice as
+// many work items of half the size, for calls with so few rows that 256-row items leave CUs idle — an 8-way row shard of
+// cfg3 is 11 such tiles for 256 CUs).  A row's lists and sums are formed by the same lanes in the same column order either
+// way: the results do not depend on it, bit for bit.
+template <bool LOWEST, int NB, int RGW = 2>
 __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a) {
+    constexpr int RPB = 8 * 16 * RGW;  // rows of a block's row tile
     constexpr int NF = 4 * NB;  // 1 KiB fragments of a 64-column tile: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..
     __shared__ f32x4 smem[2 * NF * 64 + 2 * 16 + NB * 4 + 2];
     f32x4* tbuf = smem;
@@ -253,12 +258,12 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         if (band >= a.nbands) return false;
         const int r = slot - kb * per_kb;
         if (r < a.nfull) {
-            rb = (long long)r * 256;
+            rb = (long long)r * RPB;
             lb0 = band * a.q;
             lbn = lb0 + a.q;
         } else {
             const int r2 = r - a.nfull;
-            rb = (long long)(a.nfull + r2 / a.q) * 256;
+            rb = (long long)(a.nfull + r2 / a.q) * RPB;
             lb0 = band * a.q + r2 % a.q;
             lbn = lb0 + 1;
         }
@@ -293,13 +298,13 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     int npar = 1;                                          // which word holds the next item's slot
 
     // per-lane state of a work item: the lane's two rows (wave's row group A / B, row i16), their operand fragments
-    f32x4 brow[2][NB];
-    float cen[2], thr[2], qrv[2], s2[2];
-    unsigned cur[2];
+    f32x4 brow[RGW][NB];
+    float cen[RGW], thr[RGW], qrv[RGW], s2[RGW];
+    unsigned cur[RGW];
     auto item_rows = [&](long long rb_) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            long long row = rb_ + wave * 32 + 16 * g + i16;
+        for (int g = 0; g < RGW; ++g) {
+            long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
             if (row >= a.R) row = a.R - 1;
             const f32x4* zp = reinterpret_cast<const f32x4*>(a.zr + row * a.ldz + 4 * g4);
 #pragma unroll
@@ -308,8 +313,8 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     };
     auto item_state = [&](long long rb_, int band_) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const long long row = rb_ + wave * 32 + 16 * g + i16;
+        for (int g = 0; g < RGW; ++g) {
+            const long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
             const bool ok = row < a.R;
             const long long rc = ok ? row : a.R - 1;
             cen[g] = a.crow[rc];
@@ -321,8 +326,8 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     };
     auto item_end = [&](long long rb_, int band_) {
 #pragma unroll
-        for (int g = 0; g < 2; ++g) {
-            const long long row = rb_ + wave * 32 + 16 * g + i16;
+        for (int g = 0; g < RGW; ++g) {
+            const long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
             // the four lane groups of a row: fixed association ((g0 + g1) + (g2 + g3)) by two exchanges
             double u2 = (double)s2[g];
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 16, 64), __shfl_xor(__double2loint(u2), 16, 64));
@@ -356,9 +361,9 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             have_next = decode(__builtin_amdgcn_readfirstlane((int)nxt_s[npar]), nrb, nlb0, nlbn);
             if (have_next) tile_in(lb_tile(nlb0), buf ^ 1);
         }
-        f32x4 acc[2][4];
+        f32x4 acc[RGW][4];
 #pragma unroll
-        for (int g = 0; g < 2; ++g)
+        for (int g = 0; g < RGW; ++g)
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4* tb = tbuf + buf * NF * 64 + lane;
@@ -375,8 +380,9 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[0][ks][kk], acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[1][ks][kk], acc[1][c], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < RGW; ++g)
+                        acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[g][ks][kk], acc[g][c], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
             if (ks + 1 < NB) {
@@ -388,8 +394,9 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             for (int kk = 2; kk < 4; ++kk)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    acc[0][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[0][ks][kk], acc[0][c], 0, 0, 0);
-                    acc[1][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[1][ks][kk], acc[1][c], 0, 0, 0);
+#pragma unroll
+                    for (int g = 0; g < RGW; ++g)
+                        acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[g][ks][kk], acc[g][c], 0, 0, 0);
                 }
         }
         // (No barrier here.  Cycle stamps show the two waves of a SIMD falling into alternation — one in its MFMA loop while
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             constexpr bool MASKED = decltype(masked)::value;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
-            for (int g = 0; g < 2; ++g) {
+            for (int g = 0; g < RGW; ++g) {
                 const float c0 = cen[g], th = thr[g], qr_ = qrv[g];
                 f32x2 pq2 = {s2[g], 0.f};
                 unsigned o = cur[g];
@@ -454,7 +461,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                 }
                 s2[g] = pq2[0] + pq2[1];
                 // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
-                long long rc = rb + wave * 32 + 16 * g + i16;
+                long long rc = rb + wave * (16 * RGW) + 16 * g + i16;
                 if (rc >= a.R) rc = a.R - 1;
                 const unsigned lim = 4u * (unsigned)(((rc * nlb + band) * a.ksub + (a.ksub - kSubSlack)) * 4 + g4);
                 cur[g] = o < lim ? o : lim;
@@ -853,7 +860,13 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
 
     FusedArgs fa = {};
     fa.zr = z_rows; fa.qr = q_rows; fa.zc = z_coh; fa.qc = q_coh; fa.P = P;
-    fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + 255) / 256); fa.nx = p.nx;
+    // Row tiles of 256 rows — or of 128 when the call has so few rows that 256-row items would leave most CUs idle in the
+    // last round (fewer than three items per resident block: an 8-way row shard of cfg3 is 11 tiles x 32 list bands for
+    // 256 CUs, 1.4 items each; as 22 x 32 half-size items the slowest CU carries 7.5 tile-units instead of 10).  Same
+    // results, bit for bit (cohort_fused2_kernel).
+    const bool half_tiles = p.q > 1 && ((R + 255) / 256) * p.nbands * p.q < 3 * resident;
+    const int rpb = half_tiles ? 128 : 256;
+    fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + rpb - 1) / rpb); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
     fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub;
     long long grid = (long long)fa.ny * p.nbands * p.q;  // at most one block per work item
@@ -862,9 +875,12 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
         const long long per_xcd = grid / 8 > 0 ? grid / 8 : 1;
         fa.nfull = p.q > 1 ? (int)(fa.ny / per_xcd * per_xcd) : fa.ny;
     }
-#define NPLDA_LAUNCH(NBV)                                                                                          \
-    if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa);  \
-    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+#define NPLDA_LAUNCH(NBV)                                                                                                   \
+    if (half_tiles) {                                                                                                       \
+        if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);    \
+        else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);          \
+    } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
+    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa)
     switch (ksteps) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
@@ -886,7 +902,7 @@ long long cohort_fused_resident_blocks() {
     int dev = 0, cus = 0, per_cu = 0;
     if (hipGetDevice(&dev) != hipSuccess ||
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
-        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused2_kernel<true, 12>, 512, 0) != hipSuccess)
+        hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, cohort_fused2_kernel<true, 12, 2>, 512, 0) != hipSuccess)
         return 0;
     long long r = (long long)cus * per_cu / 8 * 8;
     return r < 8 ? 8 : r;

@@ -118,3 +118,20 @@ def test_rows_with_more_candidates_than_the_key_run_take_the_exact_path(hip_lib)
     r = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "overflow rows" in r.stdout
+
+
+def test_row_tile_size_does_not_change_a_row(hip_lib):
+    """A call with few rows walks 128-row tiles (twice as many, half-size work items: an 8-way row shard of cfg3 is 11 tiles
+    of 256 rows for 256 CUs), a large call 256-row tiles.  The same row must get the same four statistics either way, bit
+    for bit: what a rank computes for its row shard IS the single-GPU result."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(77)
+    D, M, Rbig = 150, 10000, 6400
+    p = rand_params(rng, 512, D, D)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    zr, qr = ops.embed(torch.from_numpy(rng.standard_normal((Rbig, 512)).astype(np.float32)).cuda(), packed)
+    zc, qc = ops.embed(torch.from_numpy(rng.standard_normal((M, 512)).astype(np.float32)).cuda(), packed)
+    big = ops.cohort_stats(zr, qr, zc, qc, packed, topn=500)                      # 25 tiles x 32 list bands: 256-row tiles
+    for lo, hi in ((0, 300), (1000, 3750), (6399, 6400), (5000, 5129)):
+        part = ops.cohort_stats(zr[lo:hi].contiguous(), qr[lo:hi].contiguous(), zc, qc, packed, topn=500)  # 128-row tiles
+        assert torch.equal(part, big[lo:hi]), (lo, hi)

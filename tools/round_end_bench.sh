@@ -1,7 +1,36 @@
-mkdir -p gpurun_out/r03m
-python bench.py > gpurun_out/r03m/bench.json 2> gpurun_out/r03m/bench.err
-for w in cfg2 cfg3 cfg5; do python bench.py --workload $w > gpurun_out/r03m/bench_$w.json 2> gpurun_out/r03m/bench_$w.err; done
-R=$PWD; cd /tmp; export TMPDIR=/tmp
-rocprofv3 --kernel-trace -d /tmp/c3 -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 > /tmp/c3.log 2>&1
-python $R/tools/rocpd_summary.py --drop-first --by-grid /tmp/c3/*/*.db > $R/gpurun_out/r03m/cfg3_trace.txt
-tail -c 600 $R/gpurun_out/r03m/bench.json
+#!/bin/bash
+# Round-end evidence in ONE gpurun call: the driver's bench line, the --workload lines, kernel traces (with the per-launch
+# series of the dominant kernel: the cold start is several launches long), PMC passes of every headline kernel, and
+# profiles/traffic.json REGENERATED from those passes (tools/traffic_from_pmc.py).   usage: round_end_bench.sh <tag, e.g. r04z>
+TAG=${1:-r04z}
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+O=$R/gpurun_out/$TAG
+mkdir -p $O
+cd $R
+python bench.py > $O/bench.json 2> $O/bench.err
+for w in cfg2 cfg3 cfg5; do python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; done
+python tools/size_sweep.py 150 > $O/size_sweep.txt 2>&1
+python tools/size_sweep.py 170 >> $O/size_sweep.txt 2>&1
+cd /tmp; export TMPDIR=/tmp
+rocprofv3 --kernel-trace -d /tmp/tr1 -- python $R/bench.py --no-cpu-baseline --no-alt --no-clock-probe --steps 60 > /tmp/tr1.log 2>&1
+python $R/tools/rocpd_summary.py --series 12 /tmp/tr1/*/*.db > $O/bench_trace.txt
+rocprofv3 --kernel-trace -d /tmp/tr2 -- python $R/bench.py --workload cfg3 --no-cpu-baseline --steps 20 > /tmp/tr2.log 2>&1
+python $R/tools/rocpd_summary.py --drop-first --by-grid /tmp/tr2/*/*.db > $O/cfg3_trace.txt
+rocprofv3 --kernel-trace -d /tmp/tr3 -- python $R/bench.py --workload cfg2 --no-cpu-baseline --steps 200 > /tmp/tr3.log 2>&1
+python $R/tools/rocpd_summary.py --drop-first /tmp/tr3/*/*.db > $O/cfg2_trace.txt
+cd $R
+# PMC passes (each counter group in its own rocprofv3 run, --kernel-trace only)
+bash tools/pmc_cmd.sh $TAG/pmc_fwd150 python $R/bench.py --no-cpu-baseline --no-alt --no-clock-probe --steps 20
+bash tools/pmc_cmd.sh $TAG/pmc_fwd170 python $R/bench.py --no-cpu-baseline --no-alt --no-clock-probe --steps 20 --dim 170
+bash tools/pmc_cmd.sh $TAG/pmc_cfg2 python $R/bench.py --workload cfg2 --steps 50 --warmup 10
+bash tools/pmc_cmd.sh $TAG/pmc_cfg3 python $R/bench.py --workload cfg3 --steps 10 --warmup 3
+bash tools/pmc_cmd.sh $TAG/pmc_cfg5 python $R/bench.py --workload cfg5 --steps 50 --warmup 10
+cp $R/profiles/traffic.json $O/traffic.json
+python tools/traffic_from_pmc.py $O/traffic.json \
+  score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v3_kernel \
+  score_pairs_D170_B1048576=$O/pmc_fwd170:nplda_fwd_v5_kernel \
+  train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
+  head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+dx_small_kernel+train_update_kernel \
+  > $O/traffic.log 2>&1
+tail -3 $O/traffic.log
+tail -c 400 $O/bench.json
