@@ -1384,6 +1384,9 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                                  st, &ls, &ua.r, true, &ua.tail, &tail_done))
         return rc;
     if (dxa) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
+        // (Measured and NOT kept, round 4: this launch on a side stream, forked behind the first kernel and joined in front of
+        // the update — two branches of the captured graph.  The weight-gradient blocks (512 threads, 90 KB of LDS) and these
+        // do not share a CU to any effect: cfg5 0.0820 -> 0.0810 ms, not worth a library that creates streams.)
         if (int rc = input_grad_from_du(bws + W.du, 2 * B, S.ldz, (const float*)packed, L, nullptr, dxa, dxb, B, lddx, st, io_bf16))
             return rc;
     }

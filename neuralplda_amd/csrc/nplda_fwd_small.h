@@ -15,6 +15,7 @@
 // Same arithmetic per element as the streaming kernels except the order of the cross-feature sums.
 #pragma once
 #include "nplda_fwd_kernel.h"
+#include "nplda_l1_ksplit.h"
 
 namespace nplda {
 
@@ -44,7 +45,11 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     constexpr bool HALF = NB == 10 && (MODE == MODE_PAIR || MODE == MODE_TRAIN);
     constexpr int NBF = HALF ? NB / NW : NBW;  // slots holding a whole block (both sides)
     constexpr int HS = NBF;                    // the half slot (HALF only)
-    __shared__ f32x4 ylds[2][NB][64];        // normalised layer-1 output, accumulator layout
+    // 512-d pairs at the recipe sizes: layer 1 split over the waves by K (nplda_l1_ksplit.h), its LDS exchange region reused
+    // for the y tiles
+    constexpr bool KSPLIT = KS1C == 32 && (NB == 10 || NB == 11) && (MODE == MODE_PAIR || MODE == MODE_TRAIN);
+    __shared__ f32x4 lbuf[KSPLIT ? l1k_lds_f4(NB) : 2 * NB * 64];
+    f32x4 (*ylds)[NB][64] = reinterpret_cast<f32x4 (*)[NB][64]>(lbuf);  // normalised layer-1 output, accumulator layout
     __shared__ float red[NW][2][16];         // cross-wave partials (norms, then scores)
     __shared__ f32x4 zx[HALF ? NW : 1][64];  // z of the half slots, for the wave holding the block's other side
 
@@ -121,11 +126,13 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
         xa[slot] = load_x4c<false>(sa, 16 * ks + 4 * g, D0);
         xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
     };
+    if constexpr (!KSPLIT) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
+        for (int s = 0; s < PF; ++s) {
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
-        fetchx(s, s);
+            for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
+            fetchx(s, s);
+        }
     }
     auto step = [&](int ks, int slot, int rs) {
         f32x4 xh;  // the half slot's side: a select (4 VALU) — a third x load per step cost more (every load instruction of
@@ -147,7 +154,23 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     };
     static_assert(NBW <= 3, "one weight load per MFMA quarter, the x loads after the last");
     NPLDA_STAMP(1);
-    if constexpr (KS1C > 0) {
+    if constexpr (KSPLIT) {
+        f32x4 uF[2][2], uL[1][2];
+        const int swz = l1_ksplit_tile<NB, false, false>(a.packed, a.total, sa, sb, nullptr, nullptr, false, b1p, wave, lane, lbuf,
+                                                         uF, uL);
+        // back to the feature split the rest of the kernel is written for: blocks w, w + 4 (both sides), the left-over slot
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accA[i] = swz ? uF[i][1] : uF[i][0];
+            accB[i] = swz ? uF[i][0] : uF[i][1];
+        }
+        if constexpr (HALF) {
+            accA[HS] = uL[0][0];  // (block 8 + w / 2, side w & 1 = rho 0)
+        } else {
+            accA[2] = uL[0][0];
+            accB[2] = uL[0][1];
+        }
+    } else if constexpr (KS1C > 0) {
 #pragma unroll
         for (int ks = 0; ks < KS1C; ++ks) {
             if (ks == 8) NPLDA_STAMP(2);

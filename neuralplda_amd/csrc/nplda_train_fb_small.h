@@ -11,6 +11,7 @@
 #pragma once
 #include "nplda_bwd_loss.h"
 #include "nplda_fwd_kernel.h"
+#include "nplda_l1_ksplit.h"
 
 namespace nplda {
 
@@ -68,7 +69,11 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
     constexpr int HS = NBF;                    // the half slot (HALF only)
     constexpr int PF = 4, PF1 = PF + 1;
     static_assert(NBW <= 3, "one weight load per MFMA quarter, the x loads after the last");
-    __shared__ f32x4 ylds[2][NB][64];        // y for layer 2 (accumulator layout), then dz for the dy chain
+    // 512-d pairs at the recipe sizes: layer 1 split over the waves by K (nplda_l1_ksplit.h: the same function, hence the same
+    // bits, as nplda_fwd_small_kernel<MODE_TRAIN>), its LDS exchange region reused for the y / dz tiles
+    constexpr bool KSPLIT = KS1C == 32 && (NB == 10 || NB == 11);
+    __shared__ f32x4 lbuf[KSPLIT ? l1k_lds_f4(NB) : 2 * NB * 64];
+    f32x4 (*ylds)[NB][64] = reinterpret_cast<f32x4 (*)[NB][64]>(lbuf);  // y for layer 2 (accumulator layout), then dz for the dy chain
     __shared__ float red[NW][2][16];
     __shared__ float cnt_s[NW];
     __shared__ double lacc[16][kLossNS];
@@ -165,19 +170,26 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             xb[slot] = load_x4c<false>(sb, 16 * ks + 4 * g, D0);
         }
     };
+    if constexpr (!KSPLIT) {
 #pragma unroll
-    for (int s = 0; s < PF; ++s) {
+        for (int s = 0; s < PF; ++s) {
 #pragma unroll
-        for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
-        fetchx(s, s);
+            for (int i = 0; i < NBW; ++i) fetchw(s, s, i);
+            fetchx(s, s);
+        }
     }
     NPLDA_FB_STAMP(1);
     // the batch's targets: loaded now, behind the first fragments, counted after layer 1 (no wait, no barrier of their own)
+    // (K-split layer 1: issued behind its last MFMAs instead, in front of the exchange barrier — the loop needs the registers)
     TargetEarly te;
-    if (ls.B >= 4) target_count_issue(ls, te);
-    const float ti = ls.t[rA];
+    float ti;
     PairLossConsts lc;
-    loss_consts_theta(ls, lc);
+    auto early_loads = [&]() {
+        if (ls.B >= 4) target_count_issue(ls, te);
+        ti = ls.t[rA];
+        loss_consts_theta(ls, lc);
+    };
+    if constexpr (!KSPLIT) early_loads();
     __builtin_amdgcn_sched_barrier(0);
     NPLDA_FB_STAMP(2);
 
@@ -203,7 +215,24 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
             __builtin_amdgcn_sched_barrier(0);
         }
     };
-    if constexpr (KS1C > 0) {
+    if constexpr (KSPLIT) {
+        f32x4 uF[2][2], uL[1][2];
+        const int swz = l1_ksplit_tile<NB, XBF, ROWS>(
+            a.packed, a.oP + 16 * NB, XBF ? reinterpret_cast<const float*>(sah4 - 4 * (lane >> 4)) : sa,
+            XBF ? reinterpret_cast<const float*>(sbh4 - 4 * (lane >> 4)) : sb, ROWS ? a.xsa + rA * a.ldxs : nullptr,
+            ROWS ? a.xsb + rA * a.ldxs : nullptr, ok, b1p, wave, lane, lbuf, uF, uL, early_loads);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            accA[i] = swz ? uF[i][1] : uF[i][0];
+            accB[i] = swz ? uF[i][0] : uF[i][1];
+        }
+        if constexpr (HALF) {
+            accA[HS] = uL[0][0];  // (block 8 + w / 2, side w & 1 = rho 0)
+        } else {
+            accA[2] = uL[0][0];
+            accB[2] = uL[0][1];
+        }
+    } else if constexpr (KS1C > 0) {
 #pragma unroll
         for (int ks = 0; ks < KS1C; ++ks) step(ks, ks % PF1, (ks + PF) % PF1);
     } else {

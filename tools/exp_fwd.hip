@@ -166,6 +166,9 @@ int main(int argc, char** argv) {
                    (st[5] - st[0]) / 100.0, (st[6] - st[0]) / 100.0, (st[7] - st[0]) / 100.0);
             printf("   shader clock over steps 8..KS1: %.0f MHz (%llu cycles / %.2f us)\n", (double)(st[11] - st[10]) / ((st[3] - st[2]) / 100.0),
                    st[11] - st[10], (st[3] - st[2]) / 100.0);
+            printf("   layer 1 (stamp 1 -> 3): %.2f us, %llu shader cycles = %.0f MHz; layer 2 (5 -> 6): %.2f us, %llu cycles\n",
+                   (st[3] - st[1]) / 100.0, st[11] - st[9], (double)(st[11] - st[9]) / ((st[3] - st[1]) / 100.0),
+                   (st[6] - st[5]) / 100.0, st[14] - st[13]);
         }
         return 0;
     }
