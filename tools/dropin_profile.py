@@ -131,6 +131,13 @@ def main():
     torch.cuda.synchronize()
     res["ms_torch_adam_step_alone"] = 1e3 * (time.perf_counter() - t0) / 200
     print(json.dumps(res, indent=1))
+    if "--torchprof" in sys.argv:
+        from torch.profiler import profile, ProfilerActivity
+        with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA]) as prof:
+            for k in range(100):
+                body3()
+            torch.cuda.synchronize()
+        print(prof.key_averages().table(sort_by="self_cpu_time_total", row_limit=45, max_name_column_width=60))
     if "--cprofile" in sys.argv:
         import cProfile
         import pstats
