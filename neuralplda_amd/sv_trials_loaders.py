@@ -189,6 +189,13 @@ class TrialLoader(DataLoader):
         tail = (e1[lo:], e2[lo:], el[lo:]) if lo < n else None
         return self._pack_records(n, e1, e2, el, device), tail
 
+    def device_columns(self, device, num_to_row=None):
+        """The whole trial list in FILE order as three device arrays (n, rows1, rows2, labels) — for a consumer to whom
+        neither order nor batching means anything (validate(): its metrics are functions of the set of (score, label)
+        pairs, so it scores in chunks sized for the kernels, not for the loader).  The global RNG moves on exactly as one
+        iteration of the loader would move it."""
+        return self._device_epoch_arrays(device, num_to_row, permute=False)
+
     def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None, group=None):
         """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the
         batches yielded as device views: three host-to-device copies per epoch instead of three per batch.
