@@ -459,8 +459,7 @@ def run_cfg3(args, ctx):
         del zc0, qc0, zr0, qr0
 
     def step():
-        zc, qc = ops.embed(x_coh, packed)
-        zr, qr = ops.embed(x_rows[rlo:rhi], packed)
+        (zr, qr), (zc, qc) = ops.embed_pair(x_rows[rlo:rhi], x_coh, packed)  # rows and cohort: one launch
         ev["stats"][0].record()
         local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn)
         ev["stats"][1].record()

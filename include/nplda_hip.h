@@ -101,6 +101,14 @@ const char* nplda_score_pairs_kernel_name(int64_t B, int D0, int D1, int D2);
 int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, int D0, int D1,
                     int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream);
 
+/* extract_plda_embeddings of TWO tables in one launch: rows [0, Na) of z / q are xa's rows, rows [Na, Na + Nb) xb's (same
+ * row stride ldx) — the enroll / test rows and the cohort of one adaptive-score-normalisation call
+ * (utils/adaptive_score_normalization.py:27-36 needs both embedded; utils/models.py:366-370 per row).  Same values as two
+ * nplda_embed_f32 calls; one launch where the balanced-tile kernel applies (D0 == 512, D1 and D2 in 145..176, a few tiles per
+ * CU), two launches otherwise. */
+int nplda_embed_pair_f32(const float* xa, int64_t Na, const float* xb, int64_t Nb, int64_t ldx, const void* packed, int D0,
+                         int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream);
+
 /* Row width (floats) the kernels use for layer outputs of a D1/D2 model: both layers are padded
  * to the same multiple of 16 (the compiled square kernel size). 0 if unsupported. */
 int nplda_padded_dim(int D1, int D2);

@@ -160,6 +160,8 @@ SIGNATURES = {
                                      _c_i64, _c_vp]),
     "nplda_gather_pairs_mapped_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp, _c_i64, _c_int, _c_f32p,
                                                _c_f32p, _c_i64, _c_vp, _c_vp]),
+    "nplda_embed_pair_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
+                                      _c_f32p, _c_vp]),
     "gb_score_pairs_ex_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_f32p, _c_f32p,
                                        _c_f32p, _c_vp]),
 }

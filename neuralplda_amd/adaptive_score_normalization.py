@@ -101,11 +101,11 @@ def asnorm_scores(model, x_rows, x_cohort, raw, ie, it, topN=ASnorm_topN, select
                                                 model.centering_and_wccn_plda.bias, model.P_sqrt, model.Q)]
     with torch.no_grad():
         packed = ops.pack_params(*prm)
-        zc, qc = ops.embed(x_cohort, packed)
         rank, ws = ndist.world(group)
         R = x_rows.shape[0]
         lo, hi = ndist.shard_bounds(R, ws, rank)
-        zr, qr = ops.embed(x_rows[lo:hi], packed)
+        # this rank's rows and the (replicated) cohort in ONE embedding launch (nplda_embed_pair_f32)
+        (zr, qr), (zc, qc) = ops.embed_pair(x_rows[lo:hi], x_cohort, packed)
         local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topN, select=select)
         stats = ndist.all_gather_rows(local, R, group)  # the ONE exchange step: R x 4 doubles
         raw = torch.as_tensor(raw)

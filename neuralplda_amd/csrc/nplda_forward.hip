@@ -107,4 +107,29 @@ int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, 
     return launch_fwd<MODE_EMBED>(a, L, (hipStream_t)stream);
 }
 
+int nplda_embed_pair_f32(const float* xa, int64_t Na, const float* xb, int64_t Nb, int64_t ldx, const void* packed, int D0,
+                         int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream) {
+    if (Na < 0 || Nb < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (Na == 0) return nplda_embed_f32(xb, Nb, ldx, packed, D0, D1, D2, z, ldz, q, stream);
+    if (Nb == 0) return nplda_embed_f32(xa, Na, ldx, packed, D0, D1, D2, z, ldz, q, stream);
+    if (!packed || !nplda_aligned16(packed) || !rows_ok(xa, ldx, D0) || !rows_ok(xb, ldx, D0)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
+    const long long N = Na + Nb;
+    // one launch where the balanced-tile kernel embeds (its row addressing takes the second table); two otherwise
+    const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32 &&
+                        pair_kernel_choice((N + 1) / 2, L, mid_cus()) == FWD_MID;
+    if (!mid_ok) {
+        if (int rc = nplda_embed_f32(xa, Na, ldx, packed, D0, D1, D2, z, ldz, q, stream)) return rc;
+        return nplda_embed_f32(xb, Nb, ldx, packed, D0, D1, D2, z + Na * ldz, ldz, q ? q + Na : nullptr, stream);
+    }
+    FwdArgs a = {};
+    a.xa = xa; a.xb = xb; a.n = N; a.nsplit = Na; a.ldx = ldx; a.packed = (const float*)packed;
+    a.out_z = z; a.ldz = ldz; a.out_q = q;
+    a.D0 = L.D0; a.KS1 = L.KS1;
+    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+    return launch_fwd_mid<true>(a, L, (hipStream_t)stream);
+}
+
 }  // extern "C"

@@ -123,6 +123,10 @@ struct FwdArgs {
     const long long* ia;
     const long long* ib;
     long long ntab;
+    // Two-table embedding (nplda_fwd_mid.h, embed mode only: nplda_embed_pair_f32): rows [0, nsplit) are rows of xa, rows
+    // [nsplit, n) rows of xb (same ldx) — e.g. the enroll / test rows and the cohort of one AS-norm call in ONE launch.
+    // 0 = off (one table, xa).
+    long long nsplit;
 };
 
 // WAVES waves per block, each owning 16 pairs (or 32 rows); KPB k16-steps of weights per barrier.

@@ -88,7 +88,8 @@ __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int 
         long long row = EMBED ? (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + (lane & 15) : (tile0 + (rg >> 1)) * 16 + (lane & 15);
         if (row >= a.n) row = a.n - 1;
         if (EMBED) {
-            A.xr[rho] = a.xa + row * a.ldx + 4 * (lane >> 4) + 32 * wave;
+            const bool second = a.nsplit > 0 && row >= a.nsplit;  // two-table form: the row's own table
+            A.xr[rho] = (second ? a.xb : a.xa) + (second ? row - a.nsplit : row) * a.ldx + 4 * (lane >> 4) + 32 * wave;
             continue;
         }
         if (a.ia != nullptr) {  // indexed pairs: the pair's row of the x-vector table (one dependent load per group, a group ahead)

@@ -159,6 +159,27 @@ def embed(x, packed, want_q=True):
     return z, q
 
 
+def embed_pair(xa, xb, packed):
+    """nplda_embed_pair_f32: the z tables and q vectors of two row sets, ((za, qa), (zb, qb)) — views of ONE (Na + Nb, ldz)
+    table filled by one launch where the balanced-tile kernel applies (same values as two embed() calls)."""
+    lib = _lib.load()
+    if packed.precision != "fp32":
+        return embed(xa, packed), embed(xb, packed)
+    xa, lda = _rows(xa, "xa", packed.D0)
+    xb, ldb = _rows(xb, "xb", packed.D0)
+    if lda != ldb or xa.device != xb.device:
+        return embed(xa, packed), embed(xb, packed)
+    Na, Nb = xa.shape[0], xb.shape[0]
+    z = torch.empty((Na + Nb, packed.ldz), dtype=torch.float32, device=xa.device)
+    q = torch.empty(Na + Nb, dtype=torch.float32, device=xa.device)
+    if Na + Nb > 0:
+        with _lib.on_device(xa.device):
+            code = lib.nplda_embed_pair_f32(_lib.ptr(xa), Na, _lib.ptr(xb), Nb, lda, _lib.ptr(packed.buf), packed.D0, packed.D1,
+                                            packed.D2, _lib.ptr(z), packed.ldz, _lib.ptr(q), _lib.current_stream())
+        _lib.check(code, "nplda_embed_pair_f32")
+    return (z[:Na], q[:Na]), (z[Na:], q[Na:])
+
+
 # ---- training ---------------------------------------------------------------------------------
 
 LOSS_SOFTCDET, LOSS_BCE, LOSS_HARD_CDET = 0, 1, 2

@@ -386,3 +386,30 @@ def test_bf16_rows_are_scored_without_an_fp32_copy(hip_lib, D1):
     # misaligned rows are refused by the entry point (the wrapper widens instead)
     assert lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr() + 2, x2.data_ptr(), 1, 512, _lib.ptr(packed.buf), 512, D1, D1,
                                               _lib.ptr(out), _lib.current_stream()) != 0
+
+
+@pytest.mark.parametrize("D,Na,Nb", [(150, 2750, 10000), (170, 22000, 10000), (150, 1, 9000), (150, 33, 31), (150, 0, 5000),
+                                     (150, 5000, 0), (64, 3000, 7000)])
+def test_embed_pair_equals_two_embed_calls(hip_lib, D, Na, Nb):
+    """nplda_embed_pair_f32: the enroll / test rows and the cohort of one AS-norm call embedded by ONE launch where the
+    balanced-tile kernel applies — rows of the two tables may share a 32-row tile; every row must come out as
+    nplda_embed_f32 gives it for the concatenated table, bit for bit (z and q), including the shapes that fall back to two
+    launches, and within the forward tolerance of the fp64 oracle."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D + Na + Nb)
+    p = rand_params(rng, 512, D, D)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    xa = torch.from_numpy(rng.standard_normal((Na, 512)).astype(np.float32)).cuda()
+    xb = torch.from_numpy(rng.standard_normal((Nb, 512)).astype(np.float32)).cuda()
+    (za, qa), (zb, qb) = ops.embed_pair(xa, xb, packed)
+    za0, qa0 = ops.embed(xa, packed)
+    zb0, qb0 = ops.embed(xb, packed)
+    assert za.shape == za0.shape and zb.shape == zb0.shape
+    # (one table of Na + Nb rows may take another kernel than either table alone: compare against the SAME dispatch too)
+    if Na and Nb:
+        zc0, qc0 = ops.embed(torch.cat([xa, xb]), packed)
+        assert torch.equal(torch.cat([za, zb]), zc0) and torch.equal(torch.cat([qa, qb]), qc0)
+    ref = orc.extract_plda_embeddings(np.concatenate([xa.cpu().numpy(), xb.cpu().numpy()]), p, np.float64)
+    got = torch.cat([za, zb])[:, :D].cpu().numpy()
+    assert np.all(np.abs(got - ref) <= 2e-5 + 1e-5 * np.abs(ref))
+    assert za.stride(0) == packed.ldz and zb.stride(0) == packed.ldz
