@@ -1061,3 +1061,36 @@ def test_step_records_several_steps_per_graph_launch(hip_lib):
     sa.step_records(2)
     sb.step_record(); sb.step_record()
     assert torch.equal(next(iter(m_a.state_dict().values())), next(iter(m_b.state_dict().values())))
+
+
+def test_validate_scores_in_kernel_sized_chunks(hip_lib):
+    """validate()'s device-resident pass scores the trial list in chunks sized for the kernels (c x 4096 pairs, gather folded
+    into the balanced-tile kernel), not in the loader's batches.  Over a list longer than one chunk the metrics must agree
+    with the loader-batched scoring of the same pairs (another kernel regime: same scores to the forward tolerance)."""
+    import contextlib
+    import io
+    from neuralplda_amd import metrics, sv_trials_loaders as svl, train
+    rng = np.random.default_rng(12)
+    n_utt, n = 5000, 250000
+    ids = [f"u{i:05d}" for i in range(n_utt)]
+    spk = rng.integers(0, 200, n_utt)
+    cent = rng.standard_normal((200, 512)).astype(np.float32)
+    mat = (cent[spk] + 0.7 * rng.standard_normal((n_utt, 512))).astype(np.float32)
+    mega = svl.XvectorTable.from_matrix(ids, mat)
+    num_to_id = dict(enumerate(ids))
+    a, b = rng.integers(0, n_utt, n), rng.integers(0, n_utt, n)
+    lab = (spk[a] == spk[b]).astype(np.float32)
+    ds = svl.TrialIndexDataset(torch.from_numpy(a), torch.from_numpy(b), torch.from_numpy(lab))
+    loader = svl._loader(ds, 5 * 2048)
+    nc = NC(D1=150, D2=150, loss="SoftCdet")
+    nc.batch_size = 2048
+    m = model_from(rand_params(rng, 512, 150, 150), nc, thetas=[-0.5, -0.3])
+    assert train._validate_chunk(m) > 5 * 2048 and train._validate_chunk(m) < n  # more than one chunk, none loader-sized
+    with contextlib.redirect_stdout(io.StringIO()):
+        mc, th = train.validate(nc, m, torch.device("cuda"), mega, num_to_id, loader)
+    X = torch.from_numpy(mat).cuda()
+    ia, ib = torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda()
+    with torch.no_grad():
+        s = torch.cat([m(X[ia[lo:lo + 10240]], X[ib[lo:lo + 10240]]) for lo in range(0, n, 10240)])
+    mc_ref, th_ref = metrics.minc(s, torch.from_numpy(lab).cuda(), nc.beta)
+    assert abs(float(mc) - float(mc_ref)) <= 1e-4  # (the arg-min thresholds may sit on different scores where the cost is flat)
