@@ -741,8 +741,8 @@ def run_cfg5(args, ctx):
                                f"SoftCdet, backward incl. dL/dx, Adam(1e-4, wd 1e-5); extractor out of scope (SURVEY 2 #4)",
                    "global_batch": B * world, "pairs_per_gpu_per_step": B, "params": psrc,
                    "step": (step_fn.describe() if world == 1 else
-                            "nplda_train_step_grad_dx_f32 (forward + loss + data gradients with the global label counts | weight-"
-                            "gradient slabs | dx = du . W1 | flat gradient) -> ONE all-reduce -> nplda_train_step_apply_f32"),
+                            "nplda_train_step_grad_dx_f32 (forward + loss + data gradients with the global label counts + dx = du . W1 "
+                            "in one kernel | weight-gradient slabs | flat gradient) -> ONE all-reduce -> nplda_train_step_apply_f32"),
                    "parallelism": f"data parallel x{world}", "final_loss": float(loss), "ranks_in_group": world,
                    "graph_replay": bool(graph),
                    "collective": (None if world == 1 or ctx.emulated else

@@ -1333,6 +1333,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     }
     const WsLayout W = ws_layout(2 * B, L, false);
     float* bws = wsf + S.bwd;
+    bool dx_fused = false;
     {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h)
         TrainFbArgs fb = {};
         fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
@@ -1347,8 +1348,14 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
         const bool k32 = L.KS1 == 32 && L.D0 == 512;
         if (io_bf16 && !(k32 && L.NB >= 10)) return NPLDA_EUNSUPPORTED;
+        // dL/dx inside the first kernel (its DX form) at the recipe shapes: no dx launch, du is not read back
+        dx_fused = dxa != nullptr && k32 && L.NB >= 10;
+        if (dx_fused) { fb.oW1T = L.oW1T; fb.dx0 = dxa; fb.dx1 = dxb; fb.lddx = lddx; }
 #define NPLDA_LAUNCH(NBV)                                                                                   \
-    if (io_bf16) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, true, true>), grid, block, 0, st, fb); \
+    if (dx_fused && io_bf16) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, true, true, 2>), grid, block, 0, st, fb); \
+    else if (dx_fused && rows) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, true, false, 1>), grid, block, 0, st, fb); \
+    else if (dx_fused) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, false, false, 1>), grid, block, 0, st, fb); \
+    else if (io_bf16) hipLaunchKernelGGL((train_fb_small_kernel<(NBV >= 10 ? NBV : 10), 32, true, true>), grid, block, 0, st, fb); \
     else if (k32 && rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, true>), grid, block, 0, st, fb);      \
     else if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, false>), grid, block, 0, st, fb);        \
     else if (rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, true>), grid, block, 0, st, fb);         \
@@ -1383,7 +1390,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
                                  st, &ls, &ua.r, true, &ua.tail, &tail_done))
         return rc;
-    if (dxa) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
+    if (dxa && !dx_fused) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
         // (Measured and NOT kept, round 4: this launch on a side stream, forked behind the first kernel and joined in front of
         // the update — two branches of the captured graph.  The weight-gradient blocks (512 threads, 90 KB of LDS) and these
         // do not share a CU to any effect: cfg5 0.0820 -> 0.0810 ms, not worth a library that creates streams.)

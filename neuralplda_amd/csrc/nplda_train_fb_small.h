@@ -45,6 +45,13 @@ struct TrainFbArgs {
     float* xsa;
     float* xsb;
     long long ldxs;
+    // DX form (the head's step of an end-to-end fine-tune, nplda_train_step_dx_f32): the block goes on to dL/dx = du . W1 of
+    // its own 32 rows — the chain of dx_small_kernel (csrc/nplda_matmul.hip) on the du it has just formed, instead of a launch
+    // of its own that reads du back
+    size_t oW1T;          // W1^T fragment image inside `packed`
+    void* dx0;            // (n, lddx) dL/dx1: fp32, or bfloat16 when DXBF
+    void* dx1;            // (n, lddx) dL/dx2
+    long long lddx;
     float* step_bump;     // optional: Adam's step counter, incremented here (one thread) for the update kernel of this step
     long long* rec_bump;  // optional (nplda_train_step_records_f32): rec_bump[0] += 1 — the epoch's record counter, read by
                           // the update kernel of this step, which stages the next record (a launch later: no race)
@@ -53,9 +60,11 @@ struct TrainFbArgs {
 // ROWS: the indexed form (pairs named by table rows — or, ia == nullptr, the batch's own rows — with the x rows staged in
 // fp32 for K-B); XBF: the x rows are bfloat16 (ldx in elements): what a jointly trained extractor hands over (cfg 5) —
 // widened in registers (one shift / mask per value), staged in fp32 like gathered rows
-template <int NB, int KS1C, bool ROWS, bool XBF = false>
+// DX: 0 = no input gradients, 1 = dL/dx in fp32, 2 = in bfloat16 (round to nearest even) — 512-d x-vectors, NB >= 8
+template <int NB, int KS1C, bool ROWS, bool XBF = false, int DX = 0>
 __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArgs a) {
     static_assert(!XBF || (ROWS && KS1C > 0), "bf16 rows: the staged 512-d form only");
+    static_assert(DX == 0 || (KS1C == 32 && NB >= 8), "dL/dx in this kernel: 512-d x-vectors");
     constexpr int NW = 4;
     constexpr int NBW = (NB + NW - 1) / NW;  // feature-block slots per wave
     // NB = 10: blocks 0 .. 7 go two to a wave, and the two left-over blocks are split by SIDE — wave w takes block
@@ -532,17 +541,86 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 #pragma unroll
     for (int i = 0; i < NBF; ++i) {
         const int nb = wave + NW * i;
-        if (nb < NB && ok) {
-            *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g) = du_of(dyA[i], accA[i], dotA, invA);
-            *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g) = du_of(dyB[i], accB[i], dotB, invB);
+        if (nb < NB) {
+            const f32x4 uA = du_of(dyA[i], accA[i], dotA, invA), uB = du_of(dyB[i], accB[i], dotB, invB);
+            if (ok) {
+                *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g) = uA;
+                *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g) = uB;
+            }
+            if constexpr (DX != 0) {  // (every wave is past the dy chain: its dz tiles are free)
+                ylds[0][nb][lane] = uA;
+                ylds[1][nb][lane] = uB;
+            }
         }
     }
     if constexpr (HALF) {
-        if (ok)
-            *reinterpret_cast<f32x4*>(a.du + rH * a.ldz + 16 * hb + 4 * g) =
-                du_of(dyA[HS], accA[HS], hside ? dotB : dotA, hside ? invB : invA);
+        const f32x4 uH = du_of(dyA[HS], accA[HS], hside ? dotB : dotA, hside ? invB : invA);
+        if (ok) *reinterpret_cast<f32x4*>(a.du + rH * a.ldz + 16 * hb + 4 * g) = uH;
+        if constexpr (DX != 0) ylds[hside ? 1 : 0][hb][lane] = uH;
     }
     NPLDA_FB_STAMP(9);
+    if constexpr (DX != 0) {
+        // ---- dL/dx = du . W1 of the tile's 32 rows: the chain of dx_small_kernel, instruction for instruction (same bits) —
+        // wave w forms output column blocks 8 w .. 8 w + 7 of both sides from all of du (LDS) and the W1^T fragments (L2) ----
+        constexpr int XBW = 8, PFX = 2, PFX1 = PFX + 1;
+        const __amdgpu_buffer_rsrc_t ximg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed + a.oW1T), 0,
+                                                                              NB * 32 * 1024, 0x00020000);
+        unsigned xvoff[XBW];
+#pragma unroll
+        for (int u = 0; u < XBW; ++u) xvoff[u] = (unsigned)(((XBW * wave + u) * 64 + lane) * 16);
+        f32x4 xw[PFX1][XBW];
+        auto fetchxw = [&](int slot, int kb) {
+            const int kbc = kb < NB ? kb : NB - 1;
+            const int soff = kbc * (32 * 1024);
+#pragma unroll
+            for (int u = 0; u < XBW; ++u)
+                xw[slot][u] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ximg, (int)xvoff[u], soff, 0));
+        };
+#pragma unroll
+        for (int p = 0; p < PFX; ++p) fetchxw(p, p);
+        __syncthreads();  // du of the tile in LDS
+        f32x4 xacc[2][XBW];
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int sl = kb % PFX1;
+            const f32x4 d0 = ylds[0][kb][lane], d1 = ylds[1][kb][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int u = 0; u < XBW; ++u) {
+                    xacc[0][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[sl][u][r], d0[r], (kb == 0 && r == 0) ? zero4 : xacc[0][u], 0, 0, 0);
+                    xacc[1][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[sl][u][r], d1[r], (kb == 0 && r == 0) ? zero4 : xacc[1][u], 0, 0, 0);
+                }
+                if (r == 0 && kb + PFX < NB) fetchxw((kb + PFX) % PFX1, kb + PFX);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ok) {
+#pragma unroll
+            for (int rg = 0; rg < 2; ++rg) {
+#pragma unroll
+                for (int u = 0; u < XBW; ++u) {
+                    const int col = 16 * (XBW * wave + u) + 4 * g;
+                    const f32x4 v = xacc[rg][u];
+                    if constexpr (DX == 2) {  // round to nearest even, as torch's .to(bfloat16)
+                        unsigned short* dst = reinterpret_cast<unsigned short*>(rg ? a.dx1 : a.dx0) + (t0 + j) * a.lddx + col;
+                        unsigned w[4];
+#pragma unroll
+                        for (int c = 0; c < 4; ++c) {
+                            const unsigned b = __float_as_uint(v[c]);
+                            w[c] = (b & 0x7fffffffu) > 0x7f800000u ? ((b >> 16) | 0x40u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+                        }
+                        typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                        *reinterpret_cast<u32x2*>(dst) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+                    } else {
+                        float* dst = reinterpret_cast<float*>(rg ? a.dx1 : a.dx0) + (t0 + j) * a.lddx + col;
+                        *reinterpret_cast<f32x4*>(dst) = v;
+                    }
+                }
+            }
+        }
+    }
 }
 
 }  // namespace nplda

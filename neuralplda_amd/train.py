@@ -779,8 +779,9 @@ class HeadStepWithInputGrads(FusedTrainStep):
 
     def describe(self):
         if self._fused_ok(self.x1 if self.use_graph else torch.empty(1, self.dims[0], dtype=self.io_dtype)):
-            return ("nplda_train_step_dx_f32: forward + loss + data gradients (bf16 rows widened in registers) | weight-gradient "
-                    "slabs | dx = du . W1 (bf16 out) | slab sums + Adam + image" + (", one HIP-graph replay" if self.use_graph else ""))
+            return ("nplda_train_step_dx_f32: forward + loss + data gradients + dx = du . W1 in ONE kernel (bf16 rows widened in "
+                    "registers, bf16 out) | weight-gradient slabs | slab sums + Adam + image" +
+                    (", one HIP-graph replay" if self.use_graph else ""))
         return ("x.float() x2, pack, nplda_forward_train_f32, nplda_loss_fwd_bwd_f32, nplda_backward_ex_f32 (flat gradient + "
                 "dx1, dx2), nplda_adam_step_f32, dx.to(dtype) x2" + (", one HIP-graph replay" if self.use_graph else ""))
 
