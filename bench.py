@@ -1062,7 +1062,18 @@ def main():
     elif (world > 1 and args.workload == "cfg1" and not args.no_alt and args.precision == "fp32" and args.scaling == "weak"):
         if rank != 0:
             out = {"config": {}}
-        multi_rank_alts(args, ctx, out)
+        try:
+            multi_rank_alts(args, ctx, out)
+        except BaseException as e:  # an alt workload never takes the headline down with it
+            # (the other ranks may be waiting in a collective this rank will not join: their watchdogs print / end them)
+            if rank == 0:
+                out["alts_error"] = f"{type(e).__name__}: {e}"
+                out["config"]["ranks_in_group"] = world
+                out["lib"] = _lib.build_info()
+                print(json.dumps(out), flush=True)
+            sys.stderr.write(f"bench.py rank {rank}: multi-rank alt workloads failed: {type(e).__name__}: {e}\n")
+            sys.stderr.flush()
+            os._exit(0)
     if rank == 0 or emu is not None:
         out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
         out["lib"] = _lib.build_info()
