@@ -224,3 +224,19 @@ def test_driver_scale_command_carries_the_collective_workloads(hip_lib):
     a5 = d["alt_cfg5"]
     assert a5["ranks_in_group"] == 2 and a5["global_batch"] == 8192 and "eager collectives" in a5["mode"]
     assert list(a5["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]
+
+
+def test_scale_command_watchdog_keeps_the_headline(hip_lib):
+    """A collective of the alt workloads that never returns must not cost the driver its line: with a 0.2-second budget the
+    watchdog fires inside the alts, rank 0 prints the line assembled so far (the weak cfg1 headline + `alts_aborted`) and
+    every rank leaves with status 0."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", NPLDA_BENCH_BACKEND="gloo", NPLDA_BENCH_ALT_SECONDS="0.2")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29543", os.path.join(ROOT, "bench.py"),
+                          "--gpus", "2", "--steps", "3", "--warmup", "1"],
+                         capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-3000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "watchdog" in d["alts_aborted"] and d["config"]["ranks_in_group"] == 2
