@@ -30,7 +30,7 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v3_kernel \
   score_pairs_D170_B1048576=$O/pmc_fwd170:nplda_fwd_v5_kernel \
   train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
-  head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+dx_small_kernel+train_update_kernel \
+  head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   cohort_stats_D150_R22000_M10000=$O/pmc_cfg3:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
   > $O/traffic.log 2>&1
 tail -3 $O/traffic.log
