@@ -75,16 +75,22 @@ def _packed_for(cache, prm, precision):
         return ops.pack_params(*prm, precision=precision)
     key = (precision,) + tuple((t.data_ptr(), t._version, t.device) for t in prm)
     hit = cache.get("key")
+    old = cache.get("packed")
+    if old is not None and old.buf.is_inference() and not torch.is_inference_mode_enabled():
+        # an image built under torch.inference_mode() cannot be saved for a backward (and has no version counter): outside
+        # inference mode it is built anew
+        hit = old = None
+        cache.pop("where", None)
     if hit != key:
         where = (precision,) + tuple((k[0], k[2]) for k in key[1:])
-        old = cache.get("packed")
         if old is not None and cache.get("where") == where and cache.get("contig"):
             # the same six tensors with new values (an optimiser step between two forwards — every iteration of the
             # training loop): refresh the image IN PLACE with one raw launch.  The buffer's version is bumped: a graph that
             # saved it for its backward now fails autograd's saved-tensor check, exactly as it fails on the parameters
             # themselves, which the optimiser also changed in place.
             ops.repack_params(old, key[1:])
-            _bump(old.buf)
+            if not old.buf.is_inference():  # (an image first built under torch.inference_mode() has no version counter)
+                _bump(old.buf)
         else:
             cache["packed"] = ops.pack_params(*prm, precision=precision)
             cache["where"] = where

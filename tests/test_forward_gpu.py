@@ -413,3 +413,29 @@ def test_embed_pair_equals_two_embed_calls(hip_lib, D, Na, Nb):
     got = torch.cat([za, zb])[:, :D].cpu().numpy()
     assert np.all(np.abs(got - ref) <= 2e-5 + 1e-5 * np.abs(ref))
     assert za.stride(0) == packed.ldz and zb.stride(0) == packed.ldz
+
+
+def test_forward_under_inference_mode_then_training(hip_lib):
+    """The packed-image cache is refreshed in place when only the parameters' values changed; an image first built under
+    torch.inference_mode() has no version counter to bump — the refresh must still work and score with the new values."""
+    from neuralplda_amd import models
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, 150, 150
+        beta, alpha, device, loss = [99.0, 199.0], 15.0, "cuda", "SoftCdet"
+
+    torch.manual_seed(0)
+    m = models.NeuralPlda(NC()).cuda()
+    x1, x2 = torch.randn(64, 512, device="cuda"), torch.randn(64, 512, device="cuda")
+    with torch.inference_mode():
+        s0 = m(x1, x2).clone()
+    with torch.no_grad():
+        m.Q.mul_(1.5)
+    with torch.inference_mode():
+        s1 = m(x1, x2).clone()
+    with torch.no_grad():
+        s2 = m(x1, x2)
+    assert not torch.equal(s0, s1) and torch.equal(s1, s2)
+    t = (torch.rand(64, device="cuda") < 0.3).float()
+    m.loss(m(x1, x2), t).backward()
+    assert m.Q.grad is not None and torch.isfinite(m.Q.grad).all()
