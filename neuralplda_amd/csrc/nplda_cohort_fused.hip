@@ -214,6 +214,9 @@ struct FusedArgs {
     unsigned* counts;       // [R][nsub]
     double* part;           // [R][nsub / 4]: sum over the list band's columns of (s - c_r)^2, c_r = the row's mean in fp32
     int nsub;               // nlb * 4 (lane groups)
+    int prio;               // static priority 1 for the block's second-dispatched waves (4 .. 7): they lose every VALU
+                            // arbitration to the older half otherwise; -0.8 % on the statistics call in interleaved runs
+                            // (NPLDA_COHORT_PRIO=0 switches it off for A/B)
     int q, ksub, nfull;     // list bands per band, slots per sub-list; row tiles [0, nfull) are handed out as whole bands,
                             // the rest one list band at a time (the tail of the work queue in quarters)
 };
@@ -286,6 +289,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         }
     };
 
+    if (a.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
     long long rb = 0, nrb = 0;
     int band = 0, lbn = 0, t = 0, t1 = 0, nlb0 = 0, nlbn = 0;  // `band`: the list band being filled; the item ends at lbn
     if (tid == 0) nxt_s[0] = atomicAdd(a.ctr + xcd, 1u);
@@ -869,6 +873,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + rpb - 1) / rpb); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
     fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub;
+    { static const int pr = getenv("NPLDA_COHORT_PRIO") ? atoi(getenv("NPLDA_COHORT_PRIO")) : 1; fa.prio = pr; }
     long long grid = (long long)fa.ny * p.nbands * p.q;  // at most one block per work item
     if (grid > resident) grid = resident;
     {   // whole-band items for as many row tiles as fill complete rounds of an XCD's blocks, the rest in list bands
