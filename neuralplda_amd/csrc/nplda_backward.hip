@@ -766,7 +766,6 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
         if (tail_done) *tail_done = true;
     }
     fa.xcd_groups = (wide && !tail) ? 1 : 0;
-    { static const int pr = getenv("NPLDA_WGRAD_PRIO") ? atoi(getenv("NPLDA_WGRAD_PRIO")) : 1; fa.prio = pr; }  // (interleaved A/B: -0.3 % cfg2 step, -0.5 .. -1 % streaming backward)
     const dim3 grid((unsigned)(tiles * wa.ksplit + (tail ? 1 : 0))), block(kFmWaves * 64);
 #define NPLDA_FM(NBV)                                                                        \
     if (wide) hipLaunchKernelGGL((wgrad_fm_kernel<NBV, (NBV <= 10 ? kFmPF : 3), 4>), grid, block, 0, st, fa);  \

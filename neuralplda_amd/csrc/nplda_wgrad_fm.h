@@ -74,7 +74,6 @@ struct WgradFmArgs {
     int ps_cols;      // pair-sum columns per block (of 2 Mp), 0 = none
     int xcd_groups;   // 1: k-groups are laid out XCD by XCD (streaming sizes; no tail block)
     int has_tail;     // one more block after the GEMM blocks: the loss / threshold tail of the training step
-    int prio;         // static priority 1 for the block's second-dispatched waves (4 .. 7); NPLDA_WGRAD_PRIO=0 switches it off
     LossTail tail;
 };
 
@@ -344,7 +343,6 @@ __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradF
         loss_tail_block(fa.tail, red);
         return;
     }
-    if (fa.prio && threadIdx.x >= 256) __builtin_amdgcn_s_setprio(1);
     int ks, tile;
     if (fa.xcd_groups) {
         // Streaming sizes: the strips of one k-group read the same A rows (640 B each) and must share them through ONE L2.
