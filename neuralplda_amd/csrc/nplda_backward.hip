@@ -735,6 +735,14 @@ static inline bool wgrad_fm_rows(long long K, int NB) { return NB >= 10 && NB <=
 // streaming sizes: 64-column strips (NB = 12 keeps the 32-column form: 192 accumulator registers + the ring do not fit 256)
 static inline bool fm_wide(long long K, int NB) { return K > 32 * 1024 && NB <= 11; }
 
+// Can the training step's weight-gradient launch read the batch's own bfloat16 x rows (full-M form, 32-column strips)?
+// Mirrors the conditions of wgrad_launch for the step's two problems (K = 2 B rows, split at B).
+static inline bool wgrad_fm_bf16_ok(long long B, long long ldx, const NpldaLayout& L) {
+    const long long K = 2 * B;
+    return wgrad_fm_rows(K, L.NB) && !fm_wide(K, L.NB) && (B % 4) == 0 && (ldx % 2) == 0 && ldx * 4 < (1 << 20) &&
+           (L.D0 % 2) == 0;
+}
+
 // The weight-gradient launch: full-M form where it applies, the 64 x 64 form otherwise.  nprob: problems in use (1 or 2).
 // tail: the training step's loss tail, to ride along if the full-M form runs (*tail_done reports it).
 static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const LossTail* tail = nullptr,
@@ -747,6 +755,7 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
              (P.N % 2) == 0 && (P.Np % 2) == 0 && P.lda * 4 < (1 << 20) && P.ldb * 4 < (1 << 20);
     }
     if (!fm) {
+        if (wa.p[0].b_bf16) return NPLDA_EUNSUPPORTED;
         hipLaunchKernelGGL(wgrad_kernel, dim3((unsigned)wa.nw), dim3(256), 0, st, wa);
         return nplda_launch_status();
     }
@@ -767,8 +776,11 @@ static int wgrad_launch(WgradArgs& wa, int NB, int nprob, hipStream_t st, const 
     }
     fa.xcd_groups = (wide && !tail) ? 1 : 0;
     const dim3 grid((unsigned)(tiles * wa.ksplit + (tail ? 1 : 0))), block(kFmWaves * 64);
+    const bool bbf = wa.p[0].b_bf16 != 0;
+    if (bbf && (wide || nprob < 2)) return NPLDA_EUNSUPPORTED;  // (callers ask wgrad_fm_bf16_ok first)
 #define NPLDA_FM(NBV)                                                                        \
     if (wide) hipLaunchKernelGGL((wgrad_fm_kernel<NBV, (NBV <= 10 ? kFmPF : 3), 4>), grid, block, 0, st, fa);  \
+    else if (bbf) hipLaunchKernelGGL((wgrad_fm_kernel<NBV, kFmPF, 2, true>), grid, block, 0, st, fa);           \
     else hipLaunchKernelGGL((wgrad_fm_kernel<NBV, kFmPF, 2>), grid, block, 0, st, fa)
     switch (NB) {
         case 10: NPLDA_FM(10); break;
@@ -1029,7 +1041,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
                     float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
                     ReduceArgs* defer_reduce = nullptr, bool data_done = false, const LossTail* tail = nullptr,
-                    bool* tail_done = nullptr) {
+                    bool* tail_done = nullptr, bool x_bf16 = false) {
     BwdArgs b = {};
     if (ls) {
         if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
@@ -1084,6 +1096,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     WgradProblem& p1 = wa.p[0];  // dW1 = du^T [x1; x2]
     p1.A = wsf + W.du; p1.lda = ldz; p1.B0 = xa; p1.B1 = xb; p1.ldb = ldx; p1.M = W.Mp; p1.N = L.D0;
     p1.MT = (W.Mp + 63) / 64; p1.NT = (L.D0 + 63) / 64; p1.slab = wsf + W.slab1; p1.Mp = W.Mp; p1.Np = W.Np1; p1.extras = 1;
+    p1.b_bf16 = x_bf16 ? 1 : 0;  // (xa / xb then point at bfloat16 rows, ldx counts elements)
     WgradProblem& p2 = wa.p[1];  // dW2 = dz^T [y1; y2]
     p2.A = wsf + W.dz; p2.lda = ldz; p2.B0 = y; p2.B1 = y + (size_t)nsplit * ldz; p2.ldb = ldz; p2.M = W.Mp; p2.N = W.Mp;
     p2.MT = (W.Mp + 63) / 64; p2.NT = (W.Mp + 63) / 64; p2.slab = wsf + W.slab2; p2.Mp = W.Mp; p2.Np = W.Mp;
@@ -1333,7 +1346,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     }
     const WsLayout W = ws_layout(2 * B, L, false);
     float* bws = wsf + S.bwd;
-    bool dx_fused = false;
+    bool dx_fused = false, x_direct = false;
     {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h)
         TrainFbArgs fb = {};
         fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
@@ -1343,7 +1356,10 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         if (rows) {
             fb.ia = (const long long*)rows1; fb.ib = (const long long*)rows2; fb.ntab = rows1 ? ntab : B;
             fb.rec_bump = cursor ? cursor + 1 : nullptr;
-            fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs;
+            // bf16 rows of the batch itself: the weight-gradient kernel reads them as they are (widened in registers) — no
+            // fp32 copy staged here, 16.8 MB less left dirty behind this kernel at B = 4096
+            x_direct = io_bf16 && !rows1 && wgrad_fm_bf16_ok(B, ldx, L);
+            if (!x_direct) { fb.xsa = wsf + S.xs; fb.xsb = wsf + S.xs + (size_t)B * S.ldxs; fb.ldxs = S.ldxs; }
         }
         const dim3 grid((unsigned)((B + 15) / 16)), block(256);
         const bool k32 = L.KS1 == 32 && L.D0 == 512;
@@ -1384,11 +1400,12 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     ua.grad_only = dp_flat ? 1 : 0;
     bool tail_done = false;
     // the weight gradients read the x rows: the caller's, or the ones the first kernel gathered
-    const float* wx1 = rows ? wsf + S.xs : x1;
-    const float* wx2 = rows ? wsf + S.xs + (size_t)B * S.ldxs : x2;
-    if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, rows ? S.ldxs : ldx, (const float*)packed, L, nullptr,
+    const bool staged = rows && !x_direct;
+    const float* wx1 = staged ? wsf + S.xs : x1;
+    const float* wx2 = staged ? wsf + S.xs + (size_t)B * S.ldxs : x2;
+    if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, staged ? S.ldxs : ldx, (const float*)packed, L, nullptr,
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
-                                 st, &ls, &ua.r, true, &ua.tail, &tail_done))
+                                 st, &ls, &ua.r, true, &ua.tail, &tail_done, x_direct))
         return rc;
     if (dxa && !dx_fused) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
         // (Measured and NOT kept, round 4: this launch on a side stream, forked behind the first kernel and joined in front of

@@ -127,7 +127,7 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
     };
     auto stage_step = [&](int i) {
         if constexpr (STAGE) {
-            if (ok) {
+            if (ok && stage0 != nullptr) {  // (null: the caller keeps no fp32 copy of the rows)
 #pragma unroll
                 for (int rho = 0; rho < RG; ++rho) *reinterpret_cast<f32x4*>(xs[rho] + kofs(i)) = xf[i % XD][rho];
             }

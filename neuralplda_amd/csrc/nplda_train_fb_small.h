@@ -42,7 +42,7 @@ struct TrainFbArgs {
     const long long* ia;
     const long long* ib;
     long long ntab;
-    float* xsa;
+    float* xsa;           // (null: nothing is staged — the weight-gradient kernel reads the batch's bf16 rows itself)
     float* xsb;
     long long ldxs;
     // DX form (the head's step of an end-to-end fine-tune, nplda_train_step_dx_f32): the block goes on to dL/dx = du . W1 of
@@ -204,7 +204,7 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
 
     auto step = [&](int ks, int slot, int rs) {
         if constexpr (ROWS) {  // every wave leaves a quarter of the k16-steps of the fetched rows (D0 % 16 == 0 here)
-            if ((ks & (NW - 1)) == wave && ok) {
+            if ((ks & (NW - 1)) == wave && ok && a.xsa != nullptr) {
                 *reinterpret_cast<f32x4*>(a.xsa + rA * a.ldxs + 16 * ks + 4 * g) = xa[slot];
                 *reinterpret_cast<f32x4*>(a.xsb + rA * a.ldxs + 16 * ks + 4 * g) = xb[slot];
             }
@@ -228,8 +228,9 @@ __global__ __launch_bounds__(256, 2) void train_fb_small_kernel(const TrainFbArg
         f32x4 uF[2][2], uL[1][2];
         const int swz = l1_ksplit_tile<NB, XBF, ROWS>(
             a.packed, a.oP + 16 * NB, XBF ? reinterpret_cast<const float*>(sah4 - 4 * (lane >> 4)) : sa,
-            XBF ? reinterpret_cast<const float*>(sbh4 - 4 * (lane >> 4)) : sb, ROWS ? a.xsa + rA * a.ldxs : nullptr,
-            ROWS ? a.xsb + rA * a.ldxs : nullptr, ok, b1p, wave, lane, lbuf, uF, uL, early_loads);
+            XBF ? reinterpret_cast<const float*>(sbh4 - 4 * (lane >> 4)) : sb,
+            ROWS && a.xsa != nullptr ? a.xsa + rA * a.ldxs : nullptr, ROWS && a.xsa != nullptr ? a.xsb + rA * a.ldxs : nullptr,
+            ok, b1p, wave, lane, lbuf, uF, uL, early_loads);
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
             accA[i] = swz ? uF[i][1] : uF[i][0];

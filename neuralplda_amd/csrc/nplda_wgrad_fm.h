@@ -20,6 +20,9 @@ struct WgradProblem {
     int Mp, Np;
     int extras;           // 0 none, 1 = {db1 from A}, 2 = {db2 from A, dQ, dP from z and g}, 3 = {db2 from A; dQ = dP = 0},
                           // 4 = {db2 from A; the dQ / dP rows are summed by the pair-sum blocks from K-A's per-block sums}
+    int b_bf16;           // full-M form, 32-column strips only: the B rows are bfloat16 (B0 / B1 point at 2-byte elements, ldb
+                          // counts elements) — the head step's own bf16 x rows, read as they are and widened in registers
+                          // instead of an fp32 copy staged by the first kernel
 };
 
 struct WgradArgs {
@@ -87,7 +90,7 @@ template <> struct FmVec<4> { typedef float type __attribute__((ext_vector_type(
 // (64 columns, streaming sizes: 40 MFMAs per four loads instead of 20, and the A rows cross L2 -> CU 11 times instead of 21).
 template <int NSB> struct FmRounds { static constexpr int RB(int NB) { return NSB == 2 ? (NB + 1) / 2 : (NB + 3) / 4; } };
 
-template <int NB, bool EXT, int PF = kFmPF, int NSB = 2>
+template <int NB, bool EXT, int PF = kFmPF, int NSB = 2, bool BBF = false>
 __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const WgradProblem P, int tile_all, int nt, int ks,
                                               f32x4 (*red)[FmRounds<NSB>::RB(NB) * NSB][64], f32x4 (*rede)[3][16],
                                               float* psum) {
@@ -139,21 +142,23 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
     // instructions per step, four of them 4 bytes per lane, cost more in the vector memory pipe than they save.)
     typedef typename FmVec<CL>::type fvCL;
     typedef typename FmVec<NSB>::type fvB;
-    struct Ops { f32x4 a0, a1; fvCL a2; fvB b; };
+    static_assert(!BBF || NSB == 2, "bf16 B rows: 32-column strips");
+    struct Ops { f32x4 a0, a1; fvCL a2; fvB b; };  // (BBF: b[0] holds the lane's two bf16 values as loaded, b[1] is unused)
     constexpr int NLD = 4;                                                 // loads per unit
     static_assert((PF - 2) * NLD < 64, "vmcnt immediate (6 bits on gfx9+)");
     unsigned offA = (unsigned)((g4 * lda + 4 * i16) * 4);
     unsigned offA2 = (unsigned)((g4 * lda + 128 + CL * i16) * 4);
-    unsigned offB = (unsigned)((g4 * ldb + (nval ? n0 + NSB * i16 : 0)) * 4);
+    constexpr int BE = BBF ? 2 : 4;  // bytes per B element
+    unsigned offB = (unsigned)((g4 * ldb + (nval ? n0 + NSB * i16 : 0)) * BE);
     const char* PA = reinterpret_cast<const char*>(P.A);
     const char* PB0 = reinterpret_cast<const char*>(P.B0);
-    const char* PB1 = reinterpret_cast<const char*>(P.B1) - nsplit * ldb * 4;  // row r >= nsplit: PB1 + r ldb
+    const char* PB1 = reinterpret_cast<const char*>(P.B1) - nsplit * ldb * BE;  // row r >= nsplit: PB1 + r ldb
     // the four loads of unit u (4 rows) into a register set, one at a time: piece 0, 1 = A columns 0..63, 64..127,
     // 2 = the last A group, 3 = B
     auto load1 = [&](Ops& o, long long u, int piece) {
         const long long row = u << 2;
         const char* ab = PA + row * lda * 4;
-        const char* bb = (row < nsplit ? PB0 : PB1) + row * ldb * 4;
+        const char* bb = (row < nsplit ? PB0 : PB1) + row * ldb * BE;
         if (piece == 0) asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a0) : "v"(offA), "s"(ab) : "memory");
         if (piece == 1) asm volatile("global_load_dwordx4 %0, %1, %2 offset:256" : "=v"(o.a1) : "v"(offA), "s"(ab) : "memory");
         if (piece == 2) {
@@ -162,7 +167,8 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
             else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.a2) : "v"(offA2), "s"(ab) : "memory");
         }
         if (piece == 3) {
-            if constexpr (NSB == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
+            if constexpr (BBF) asm volatile("global_load_dword %0, %1, %2" : "=v"(o.b[0]) : "v"(offB), "s"(bb) : "memory");
+            else if constexpr (NSB == 2) asm volatile("global_load_dwordx2 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
             else asm volatile("global_load_dwordx4 %0, %1, %2" : "=v"(o.b) : "v"(offB), "s"(bb) : "memory");
         }
     };
@@ -211,6 +217,11 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
                     fvB bv;
 #pragma unroll
                     for (int cb = 0; cb < NSB; ++cb) bv[cb] = nval ? o.b[cb] : 0.f;
+                    if constexpr (BBF) {  // two bf16 columns in one dword: widen (low half = the first column)
+                        const unsigned raw = __float_as_uint(o.b[0]);
+                        bv[0] = nval ? __uint_as_float(raw << 16) : 0.f;
+                        bv[1] = nval ? __uint_as_float(raw & 0xffff0000u) : 0.f;
+                    }
                     // the set of the previous step is refilled one load at a time between groups of MFMAs (all four in one
                     // place: 2-3 % slower)
                     Ops& n = ring[(s + PF - 1) % PF];
@@ -332,7 +343,7 @@ __device__ __forceinline__ void wgrad_fm_body(const WgradFmArgs& fa, const Wgrad
 
 // PF: operand register sets per wave.  4 at minibatch sizes (everything comes out of L2); streaming sizes (K > 32 768 rows: the
 // B rows come from HBM) take a deeper ring.
-template <int NB, int PF = kFmPF, int NSB = 2>
+template <int NB, int PF = kFmPF, int NSB = 2, bool BBF = false>
 __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradFmArgs fa) {
     __shared__ f32x4 red[kFmWaves][FmRounds<NSB>::RB(NB) * NSB][64];
     __shared__ f32x4 rede[kFmWaves][3][16];
@@ -378,6 +389,13 @@ __global__ __launch_bounds__(kFmWaves * 64, 1) void wgrad_fm_kernel(const WgradF
     const int pi = tile >= fa.nt0 ? 1 : 0;
     const WgradProblem P = pi ? fa.w.p[1] : fa.w.p[0];
     const int nt = pi ? tile - fa.nt0 : tile;
+    if constexpr (BBF) {  // (problem 0's B rows are bf16: its strips take the widening body)
+        if (pi == 0) {
+            if (nt == 0 && P.extras) wgrad_fm_body<NB, true, PF, NSB, true>(fa, P, tile, nt, ks, red, rede, psum);
+            else wgrad_fm_body<NB, false, PF, NSB, true>(fa, P, tile, nt, ks, red, rede, psum);
+            return;
+        }
+    }
     if (nt == 0 && P.extras) wgrad_fm_body<NB, true, PF, NSB>(fa, P, tile, nt, ks, red, rede, psum);
     else wgrad_fm_body<NB, false, PF, NSB>(fa, P, tile, nt, ks, red, rede, psum);
 }
