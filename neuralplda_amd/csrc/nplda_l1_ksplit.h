@@ -71,8 +71,11 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
         else xr[rho] = p + 4 * g + 32 * wave;
         if constexpr (STAGE) xs[rho] = (second ? stage1 : stage0) + 4 * g + 32 * wave;
     }
+    // (the permuted block's offset is wave-uniform: it goes into the load's SCALAR offset, NB SGPRs instead of NB VGPRs —
+    // the staged NB = 11 form of the training kernel spilled with a vector offset per slot)
+    const unsigned lane16 = (unsigned)lane * 16u;
 #pragma unroll
-    for (int s = 0; s < NB; ++s) voff[s] = (unsigned)(blk(s) * 64 + lane) * 16u;
+    for (int s = 0; s < NB; ++s) voff[s] = (unsigned)__builtin_amdgcn_readfirstlane(blk(s) * 1024);
     auto kofs = [](int i) { return 16 * (8 * (i >> 1) + (i & 1)); };  // column offset of step i inside the wave's share
     auto ldx = [&](int i, int rho) -> f32x4 {
         if constexpr (XBF) {
@@ -90,7 +93,7 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
 #pragma unroll
         for (int rho = 0; rho < RG; ++rho) xf[i][rho] = ldx(i, rho);
 #pragma unroll
-    for (int s = 0; s < NB; ++s) wf[0][s] = mid_ldw(img, voff[s], mid_w1_step<NB>(0, wave));
+    for (int s = 0; s < NB; ++s) wf[0][s] = mid_ldw(img, lane16, mid_w1_step<NB>(0, wave) + (int)voff[s]);
 
     // where unit (slot s, row group rho) of this wave's partial sums goes: wave v, index u, red[v][(src - v - 1) & 3][u]
     auto export_unit = [&](int s, int rho, const f32x4& val) {
@@ -122,7 +125,7 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
         if (q < RG) {
             if (i + XD - 1 < KSW) xf[(i + XD - 1) % XD][q] = ldx(i + XD - 1, q);
         } else if (q >= NB && q < 2 * NB) {
-            if (i + 1 < KSW) wf[(i + 1) & 1][q - NB] = mid_ldw(img, voff[q - NB], wnext);
+            if (i + 1 < KSW) wf[(i + 1) & 1][q - NB] = mid_ldw(img, lane16, wnext + (int)voff[q - NB]);
         }
     };
     auto stage_step = [&](int i) {
