@@ -37,7 +37,7 @@ __device__ __forceinline__ void loss_consts_theta(const BwdLoss& L, PairLossCons
     const int nth = L.kind == 1 ? 1 : L.K;
 #pragma unroll
     for (int k = 0; k < nplda_loss::kMaxK; ++k) {
-        c.theta[k] = L.th.p[k < nth ? k : 0][0];
+        c.theta[k] = (k < nth ? L.th.p[k] : L.th.p[0])[0];  // (static indices: a dynamic one copies the pointer array to scratch)
         c.cn[k] = 0.f;
     }
     c.ct = 0.f;
