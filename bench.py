@@ -1051,8 +1051,16 @@ def main():
             a2.scaling = "weak"
             try:
                 out[name] = _compact(fn(a2, ctx))
+                # the same workload at the reference's shipped shape (512 -> 170 -> 170: every conf/*.cfg)
+                a3 = argparse.Namespace(**vars(a2))
+                a3.dim = 170
+                r170 = fn(a3, ctx)
+                out[name]["d170"] = {"ms_per_step": r170["ms_per_step"], "value": r170["value"],
+                                     "frac": r170["roofline"]["frac"]}
+                if "stats_ms" in r170["config"]:
+                    out[name]["d170"]["stats_ms"] = r170["config"]["stats_ms"]
             except Exception as e:  # an alt object never takes the headline down with it
-                out[name] = {"error": f"{type(e).__name__}: {e}"}
+                out.setdefault(name, {})["error"] = f"{type(e).__name__}: {e}"
             torch.cuda.empty_cache()
         try:
             out["alt_dropin"] = run_dropin(args, ctx)

@@ -62,6 +62,7 @@ def test_bench_single_process_contract(hip_lib):
         assert "error" not in o, o
         assert o["unit"] == unit and o["value"] > 0 and o["ms_per_step"] > 0 and o["workload"].startswith(k[4:])
         assert o["roofline"]["bound"] == "mfma" and 0 < o["roofline"]["frac"] < 1
+        assert o["d170"]["ms_per_step"] > 0 and 0 < o["d170"]["frac"] < 1  # the reference's shipped shape beside it
     assert d["alt_cfg2"]["ms_per_step"] < 0.2 and d["alt_cfg3"]["stats_ms"] <= 1.0 and d["alt_cfg5"]["ms_per_step"] < 0.3
 
 
