@@ -1,4 +1,5 @@
-"""Random shapes (D = 145 .. 176, B = 1 .. 4096) through the small-batch scoring / training-forward / backward kernels against\nthe fp64 oracle: scores within the forward tolerance, flat gradient to 2e-4 of its max.  usage: fuzz_small_batch.py"""
+"""Random shapes (D = 145 .. 176, B = 1 .. 4096) through the small-batch scoring / training-forward / backward kernels against
+the fp64 oracle: scores within the forward tolerance, flat gradient to 2e-4 of its max.  usage: fuzz_small_batch.py"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
