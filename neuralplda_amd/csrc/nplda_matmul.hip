@@ -109,11 +109,10 @@ __global__ __launch_bounds__(WAVES * 64) void rows_matmul_kernel(const MatmulArg
     }
     __syncthreads();
     const int kmax = a.K - 4;
-    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+    // the first k-block of a tile's rows is fetched while the PREVIOUS tile's results are being stored (a tile is only KB
+    // steps long: its first load, out of HBM at streaming sizes, was exposed once per tile)
+    auto rows_of = [&](int tile, long long (&row)[2], bool (&ok)[2], const float* (&src)[2]) {
         const long long r0 = ((long long)tile * WAVES + wave) * 32;
-        long long row[2];
-        bool ok[2];
-        const float* src[2];
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
             row[rg] = r0 + 16 * rg + j;
@@ -121,6 +120,25 @@ __global__ __launch_bounds__(WAVES * 64) void rows_matmul_kernel(const MatmulArg
             if (!ok[rg]) row[rg] = a.R - 1;
             src[rg] = a.in + row[rg] * a.ldin;
         }
+    };
+    auto ld4p = [&](const float* p, int kb) -> f32x4 {
+        int c = 16 * kb + 4 * g;
+        c = c < kmax ? c : kmax;
+        return *reinterpret_cast<const f32x4*>(p + c);
+    };
+    long long nrow[2];
+    bool nok[2];
+    const float* nsrc[2];
+    f32x4 ncur[2];
+    if ((int)blockIdx.x < a.ntiles) {
+        rows_of(blockIdx.x, nrow, nok, nsrc);
+        ncur[0] = ld4p(nsrc[0], 0);
+        ncur[1] = ld4p(nsrc[1], 0);
+    }
+    for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
+        long long row[2] = {nrow[0], nrow[1]};
+        bool ok[2] = {nok[0], nok[1]};
+        const float* src[2] = {nsrc[0], nsrc[1]};
         f32x4 acc[2][NS];
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg)
@@ -133,7 +151,7 @@ __global__ __launch_bounds__(WAVES * 64) void rows_matmul_kernel(const MatmulArg
             c = c < kmax ? c : kmax;
             return *reinterpret_cast<const f32x4*>(src[rg] + c);
         };
-        f32x4 cur[2] = {ld4(0, 0), ld4(1, 0)};
+        f32x4 cur[2] = {ncur[0], ncur[1]};
         for (int kb = 0; kb < KB; ++kb) {
             const int kn = kb + 1 < KB ? kb + 1 : KB - 1;
             const f32x4 nxt0 = ld4(0, kn), nxt1 = ld4(1, kn);
@@ -150,6 +168,11 @@ __global__ __launch_bounds__(WAVES * 64) void rows_matmul_kernel(const MatmulArg
             }
             cur[0] = nxt0;
             cur[1] = nxt1;
+        }
+        if (tile + (int)gridDim.x < a.ntiles) {  // the next tile's first loads, under this tile's stores
+            rows_of(tile + gridDim.x, nrow, nok, nsrc);
+            ncur[0] = ld4p(nsrc[0], 0);
+            ncur[1] = ld4p(nsrc[1], 0);
         }
 #pragma unroll
         for (int rg = 0; rg < 2; ++rg) {
