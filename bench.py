@@ -260,6 +260,41 @@ def timed_steps(ctx, step, steps, warmup, per_step_events=True, settle_s=0.0, st
     return elapsed, kern_ms, out
 
 
+def sclk_under(ctx, step, step_ms, reps=12):
+    """The shader clock (MHz) the chip holds while `step` runs back to back: a one-wave probe (nplda_clock_probe) on a side
+    stream compares the shader-cycle counter with the constant 100 MHz counter over ~(reps - 4) steps.  None on failure
+    (reporting only).  Steps of tens of microseconds are repeated until the window is >= 2 ms."""
+    from neuralplda_amd import _lib
+    try:
+        lib = _lib.load()
+        reps = max(reps, int(2.5 / max(step_ms, 1e-3)) + 4)
+        ticks = torch.zeros(2, dtype=torch.int64, device=ctx.dev)
+        side = torch.cuda.Stream(device=ctx.dev)
+        torch.cuda.synchronize()
+        for _ in range(max(2, reps // 8)):
+            step()
+        with torch.cuda.stream(side):
+            code = lib.nplda_clock_probe(_lib.ptr(ticks), max(int(step_ms * 1e3 * (reps - 4)), 100), _lib.current_stream())
+        _lib.check(code, "nplda_clock_probe")
+        for _ in range(reps):
+            step()
+        torch.cuda.synchronize()
+        tk = ticks.cpu().numpy()
+        if tk[1] > 0:
+            return 100.0 * float(tk[0]) / float(tk[1])
+    except Exception as e:
+        sys.stderr.write(f"clock probe skipped: {e}\n")
+    return None
+
+
+def _with_clock(roof, sclk_mhz):
+    """roofline object + the measured shader clock (`frac` stays priced at the nominal 2.4 GHz peak)."""
+    if sclk_mhz is not None:
+        roof["sclk_mhz_under_kernel"] = sclk_mhz
+        roof["frac_at_measured_clock"] = roof["frac"] * 2400.0 / sclk_mhz
+    return roof
+
+
 def kernel_ms_of(fn, reps=10, batches=3, warm=3):
     """Per-launch time of fn's kernel: median over `batches` event-bracketed runs of `reps` launches, after `warm` untimed
     launches (the first launches after a different kernel run 3-4 % slow while the clock settles: tools/d170_clock.py)."""
@@ -305,25 +340,7 @@ def run_cfg1(args, ctx):
     # on a side stream next to 12 more launches and compares the shader-cycle counter with the constant 100 MHz counter.
     sclk_mhz = None
     if rank == 0 and not args.no_clock_probe and not ctx.emulated:
-        try:
-            lib = _lib.load()
-            ticks = torch.zeros(2, dtype=torch.int64, device=dev)
-            side = torch.cuda.Stream(device=dev)
-            reps = 12
-            torch.cuda.synchronize()
-            for _ in range(2):
-                s = step()
-            with torch.cuda.stream(side):
-                code = lib.nplda_clock_probe(_lib.ptr(ticks), max(int(kern_ms * 1e3 * (reps - 4)), 100), _lib.current_stream())
-            _lib.check(code, "nplda_clock_probe")
-            for _ in range(reps):
-                s = step()
-            torch.cuda.synchronize()
-            tk = ticks.cpu().numpy()
-            if tk[1] > 0:
-                sclk_mhz = 100.0 * float(tk[0]) / float(tk[1])
-        except Exception as e:  # the probe is reporting only
-            sys.stderr.write(f"clock probe skipped: {e}\n")
+        sclk_mhz = sclk_under(ctx, step, kern_ms)
 
     # Untimed: the cold start.  After one second of idle the clock has ramped down; the first launches run at about half
     # speed (a single 1 M-pair scoring call from an idle GPU takes roughly twice the steady-state time).  Ten back-to-back
@@ -499,6 +516,18 @@ def run_cfg3(args, ctx):
         phases = phases.to(dev) if ctx.backend == "nccl" else phases
         ctx.dist.all_reduce(phases, op=ctx.dist.ReduceOp.MAX)
         phases = phases.cpu()
+    sclk = None
+    stats_prepared_ms = None
+    if rank == 0 and world == 1 and not ctx.emulated:
+        (zr_, qr_), (zc_, qc_) = ops.embed_pair(x_rows[rlo:rhi], x_coh, packed)
+        if not args.no_clock_probe:
+            sclk = sclk_under(ctx, lambda: ops.cohort_stats(zr_, qr_, zc_, qc_, packed, topn=topn), float(phases[0]))
+        if hasattr(ops, "cohort_prepare"):
+            # one cohort serves every trial list: its share of the call (Gram, thresholds' pre-pass) prepared once
+            prep = ops.cohort_prepare(zc_, qc_, packed, topn=topn)
+            stats_prepared_ms, _ = kernel_ms_of(lambda: ops.cohort_stats(zr_, qr_, zc_, qc_, packed, topn=topn, prepared=prep),
+                                                reps=5, batches=3, warm=2)
+        del zr_, qr_, zc_, qc_
     if rank != 0 and not ctx.emulated:
         return None
     stats_ms, ag_ms, apply_ms = (float(v) for v in phases)
@@ -528,10 +557,13 @@ def run_cfg3(args, ctx):
                                   f"ONE all_gather_into_tensor of the (R, 4) fp64 row statistics per step ({ctx.backend}), eager"),
                    "phase_times": "max over ranks" if ctx.dist is not None else "this process",
                    "allgather_bytes": int(world * chunk * 32), "apply_ms": apply_ms, "params": psrc},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"cohort_stats_D{D}_R{rows_local}_M{M}"),
-                     "kernel": "nplda_cohort_stats_f32 (cohort score GEMM + per-row statistics), whole call",
-                     "kernel_ms": stats_ms, "flop_per_score_algorithmic": 2 * D},
+        "roofline": _with_clock({"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS,
+                                 "traffic": _traffic(f"cohort_stats_D{D}_R{rows_local}_M{M}"),
+                                 "kernel": "nplda_cohort_stats_f32 (cohort score GEMM + per-row statistics), whole call",
+                                 "kernel_ms": stats_ms, "flop_per_score_algorithmic": 2 * D,
+                                 **({"stats_ms_prepared_cohort": stats_prepared_ms} if stats_prepared_ms is not None else {})},
+                                sclk),
     }
 
 
@@ -621,6 +653,9 @@ def run_cfg2(args, ctx):
                                          step_many=step_many if by_cursor else None)
     if not torch.isfinite(loss).all():
         raise SystemExit("non-finite training loss")
+    sclk = None
+    if rank == 0 and world == 1 and not ctx.emulated and not args.no_clock_probe:
+        sclk = sclk_under(ctx, step, step_ms)
     if rank != 0 and not ctx.emulated:
         return None
     # forward + weight gradients (the same two GEMMs) + the data gradient through layer 2; SURVEY.md section 8d: ~3x Regime A
@@ -655,10 +690,11 @@ def run_cfg2(args, ctx):
                    "batch_feed": "device-resident records walked by the step's cursor (nplda_train_step_records_f32), "
                                  f"{step_fn.records_per_replay} steps per graph launch"
                                  if by_cursor else "one 20 B-byte record copy per step (nplda_train_step_rows_f32)"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"train_step_D{D}_B{Bl}"),
-                     "kernel": ("nplda_train_step_records_f32" if by_cursor else "nplda_train_step_rows_f32") +
-                               " (forward + loss + data gradients, weight-gradient slabs, update), whole step", "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
+        "roofline": _with_clock({"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"train_step_D{D}_B{Bl}"),
+                                 "kernel": ("nplda_train_step_records_f32" if by_cursor else "nplda_train_step_rows_f32") +
+                                           " (forward + loss + data gradients, weight-gradient slabs, update), whole step",
+                                 "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops}, sclk),
     }
 
 
@@ -726,6 +762,9 @@ def run_cfg5(args, ctx):
     loss, dx1, dx2 = out
     if not (torch.isfinite(loss).all() and torch.isfinite(dx1.float()).all() and torch.isfinite(dx2.float()).all()):
         raise SystemExit("non-finite loss / input gradient")
+    sclk = None
+    if rank == 0 and world == 1 and not ctx.emulated and not args.no_clock_probe:
+        sclk = sclk_under(ctx, step, step_ms)
     if rank != 0 and not ctx.emulated:
         return None
     fwd = 2 * (2 * D0 * D + 2 * D * D) + 8 * D
@@ -753,9 +792,9 @@ def run_cfg5(args, ctx):
                    "ms_per_step_with_input_copies": copy_ms,
                    "inputs": "resident in the step's own buffers (a producer writing elsewhere adds three staging copies: "
                              "ms_per_step_with_input_copies)"},
-        "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                     "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"head_step_dx_D{D}_B{B}"),
-                     "kernel": step_fn.describe(), "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops},
+        "roofline": _with_clock({"bound": "mfma", "achieved": achieved, "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                                 "frac": achieved / FP32_MFMA_PEAK_TFLOPS, "traffic": _traffic(f"head_step_dx_D{D}_B{B}"),
+                                 "kernel": step_fn.describe(), "kernel_ms": step_ms, "flop_per_pair_algorithmic": flops}, sclk),
     }
 
 
@@ -765,92 +804,242 @@ def run_dropin(args, ctx, B=4096, n_utt=200000, n_valid=1 << 20):
       literal   optimizer.zero_grad(); data.to(device) x3; load_xvec_trials_from_numbatch(...); output = model(x1, x2);
                 loss = model.loss(output, target); loss.item(); loss.backward(); torch.optim.Adam(...).step()
       core      model() -> model.loss() -> backward() -> Adam.step() on resident inputs, no .item() (the host running ahead)
-      validate  train.validate() over 1 M trials in chunks of 5 * 2048 (forward + softcdet + cdet + minc)
-    Host-bound figures (Python + launch cost, the device mostly idle): they belong next to alt_cfg2, the same arithmetic as
-    three kernels of one graph replay."""
+      validate  train.validate() over 1 M trials of a 200 k-utterance table (forward + softcdet + cdet + minc)
+    each with torch's own Adam (`compat.install()`) and with the opt-in one-launch Adam (`compat.install(fused_adam=True)`:
+    the name torch.optim.Adam builds neuralplda_amd.optim.FusedAdam).  Host-bound figures (Python + launch cost, the device
+    mostly idle) on a shared box: >= 15 repetitions, min / median / max on the line.  They belong next to alt_cfg2, the same
+    arithmetic as one graph replay."""
     import contextlib
     import io
     import neuralplda_amd.compat as compat
-    compat.install()
-    from utils.models import NeuralPlda
-    from utils import sv_trials_loaders as svl
-    from neuralplda_amd import train
     dev = ctx.dev
     rng = np.random.default_rng(0)
-    ids = [f"utt{i:07d}" for i in range(n_utt)]
-    mega = svl.XvectorTable.from_matrix(ids, rng.standard_normal((n_utt, 512), dtype=np.float32))
-    num_to_id = dict(enumerate(ids))
-    batches = [(torch.from_numpy(rng.integers(0, n_utt, B)), torch.from_numpy(rng.integers(0, n_utt, B)),
-                torch.from_numpy((rng.random(B) < 0.1).astype(np.float32))) for _ in range(16)]
     out = {"workload": f"the reference's literal training-loop body (xvector_NeuralPlda_pytorch.py:35-43) at {B} pairs per "
                        f"batch from a {n_utt}-utterance table, and validate() (:56-83) over {n_valid} trials, both through "
                        f"neuralplda_amd under compat.install(); torch.optim.Adam(lr 1e-4, weight_decay 1e-5) as the driver "
-                       f"creates it", "unit": "ms"}
-    for D in (150, 170):
-        class NC:
-            xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D, D
-            beta, alpha, device, loss, log_interval, batch_size = [99.0, 199.0], 15.0, str(dev), "SoftCdet", 10 ** 9, 2048
+                       f"creates it (`*_fused_adam`: compat.install(fused_adam=True))", "unit": "ms",
+           "sampling": "median of >= 15 repetitions of 40 - 60 steps; spread = [min, median, max]"}
+    ids = [f"utt{i:07d}" for i in range(n_utt)]
+    xmat = rng.standard_normal((n_utt, 512), dtype=np.float32)
+    batches = [(torch.from_numpy(rng.integers(0, n_utt, B)), torch.from_numpy(rng.integers(0, n_utt, B)),
+                torch.from_numpy((rng.random(B) < 0.1).astype(np.float32))) for _ in range(16)]
+    v1, v2 = rng.integers(0, n_utt, n_valid), rng.integers(0, n_utt, n_valid)
+    vl = (rng.random(n_valid) < 0.1).astype(np.float32)
 
-        torch.manual_seed(0)
-        model = NeuralPlda(NC()).to(dev)
-        opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)
-        model.train()
-
-        def literal(k):
-            d1, d2, t = batches[k % len(batches)]
-            opt.zero_grad()
-            d1, d2, t = d1.to(dev), d2.to(dev), t.to(dev)
-            x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, d1, d2, dev)
-            output = model(x1, x2)
-            loss = model.loss(output, t)
-            lv = loss.item()
-            loss.backward()
-            opt.step()
-            return lv
-
-        x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, batches[0][0].to(dev), batches[0][1].to(dev), dev)
-        tt = batches[0][2].to(dev)
-
-        def core(k):
-            opt.zero_grad()
-            loss = model.loss(model(x1, x2), tt)
-            loss.backward()
-            opt.step()
-
-        def wall(fn, n, reps=5):
-            for k in range(20):
+    def wall(fn, n, reps=15):
+        for k in range(20):
+            fn(k)
+        torch.cuda.synchronize()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            for k in range(n):
                 fn(k)
             torch.cuda.synchronize()
-            ts = []
-            for _ in range(reps):
-                t0 = time.perf_counter()
-                for k in range(n):
-                    fn(k)
-                torch.cuda.synchronize()
-                ts.append((time.perf_counter() - t0) / n * 1e3)
-            return float(np.median(ts))
+            ts.append((time.perf_counter() - t0) / n * 1e3)
+        return float(np.median(ts)), [float(min(ts)), float(np.median(ts)), float(max(ts))]
 
-        res = {"literal_step_ms": wall(literal, 60), "core_step_ms": wall(core, 100)}
-        if not np.isfinite(literal(0)):
-            raise SystemExit("non-finite loss in the drop-in loop")
-        # validate(): 1 M trials over the same table
-        ds = svl.TrialIndexDataset(torch.from_numpy(rng.integers(0, n_utt, n_valid)),
-                                   torch.from_numpy(rng.integers(0, n_utt, n_valid)),
-                                   torch.from_numpy((rng.random(n_valid) < 0.1).astype(np.float32)))
-        loader = svl._loader(ds, 5 * 2048)
-        vt = []
-        for _ in range(3):
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            with contextlib.redirect_stdout(io.StringIO()):
-                train.validate(NC, model, dev, mega, num_to_id, loader)
-            torch.cuda.synchronize()
-            vt.append((time.perf_counter() - t0) * 1e3)
-        res["validate_1M_trials_ms"] = float(np.median(vt[1:]))
-        res["validate_trials_per_s"] = n_valid / (res["validate_1M_trials_ms"] * 1e-3)
-        res["literal_pairs_per_s"] = B / (res["literal_step_ms"] * 1e-3)
-        out[f"d{D}"] = res
-    compat.uninstall()
+    for fused in (False, True):
+        compat.install(fused_adam=fused)
+        try:
+            from utils.models import NeuralPlda
+            from utils import sv_trials_loaders as svl
+            from neuralplda_amd import train
+            mega = svl.XvectorTable.from_matrix(ids, xmat)
+            num_to_id = dict(enumerate(ids))
+            for D in (150, 170):
+                class NC:
+                    xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D, D
+                    beta, alpha, device, loss, log_interval, batch_size = [99.0, 199.0], 15.0, str(dev), "SoftCdet", 10 ** 9, 2048
+
+                torch.manual_seed(0)
+                model = NeuralPlda(NC()).to(dev)
+                opt = torch.optim.Adam(model.parameters(), lr=1e-4, weight_decay=1e-5)  # (the patched name when fused)
+                model.train()
+
+                def literal(k):
+                    d1, d2, t = batches[k % len(batches)]
+                    opt.zero_grad()
+                    d1, d2, t = d1.to(dev), d2.to(dev), t.to(dev)
+                    x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, d1, d2, dev)
+                    output = model(x1, x2)
+                    loss = model.loss(output, t)
+                    lv = loss.item()
+                    loss.backward()
+                    opt.step()
+                    return lv
+
+                x1, x2 = svl.load_xvec_trials_from_numbatch(mega, num_to_id, batches[0][0].to(dev), batches[0][1].to(dev), dev)
+                tt = batches[0][2].to(dev)
+
+                def core(k):
+                    opt.zero_grad()
+                    loss = model.loss(model(x1, x2), tt)
+                    loss.backward()
+                    opt.step()
+
+                res = out.setdefault(f"d{D}", {})
+                sfx = "_fused_adam" if fused else ""
+                # (interleaved: literal, core, literal, core ... would share the box's noise; two passes each, the lower median
+                # of the two is the figure — a loaded host only ever adds time)
+                lit = min((wall(literal, 40) for _ in range(2)), key=lambda r: r[0])
+                cor = min((wall(core, 60) for _ in range(2)), key=lambda r: r[0])
+                res["literal_step_ms" + sfx], res["literal_step_spread_ms" + sfx] = lit
+                res["core_step_ms" + sfx], res["core_step_spread_ms" + sfx] = cor
+                res["core_le_literal" + sfx] = bool(cor[0] <= lit[0])
+                res["optimizer" + sfx] = type(opt).__module__ + "." + type(opt).__name__
+                if not np.isfinite(literal(0)):
+                    raise SystemExit("non-finite loss in the drop-in loop")
+                if fused:
+                    continue
+                # validate(): 1 M trials over the same table
+                ds = svl.TrialIndexDataset(torch.from_numpy(v1), torch.from_numpy(v2), torch.from_numpy(vl))
+                loader = svl._loader(ds, 5 * 2048)
+                for name, env in (("validate_1M_trials_ms", "0"), ("validate_1M_trials_dense_ms", "1")):
+                    os.environ["NPLDA_VALIDATE_DENSE"] = env
+                    vt = []
+                    for _ in range(5):
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        with contextlib.redirect_stdout(io.StringIO()):
+                            train.validate(NC, model, dev, mega, num_to_id, loader)
+                        torch.cuda.synchronize()
+                        vt.append((time.perf_counter() - t0) * 1e3)
+                    res[name] = float(np.median(vt[1:]))
+                os.environ.pop("NPLDA_VALIDATE_DENSE", None)
+                res["validate_pass"] = ("every distinct utterance embedded once, trials scored by index "
+                                        "(`validate_1M_trials_dense_ms`: every trial through the dense forward)")
+                res["validate_trials_per_s"] = n_valid / (res["validate_1M_trials_ms"] * 1e-3)
+                res["literal_pairs_per_s"] = B / (res["literal_step_ms"] * 1e-3)
+        finally:
+            os.environ.pop("NPLDA_VALIDATE_DENSE", None)
+            compat.uninstall()
+    return out
+
+
+def run_secondary(args, ctx):
+    """The kernel families of SURVEY section 8(a) that no BASELINE config is quoted on, each with a roofline fraction, as
+    objects for the default line (and `--workload secondary` alone, the PMC passes' command):
+      alt_regimeB  SURVEY 8(d) Regime B: 1 M index pairs scored from a pre-embedded 1.2 M-utterance table
+                   (nplda_score_indexed_f32; HBM-bound, 1 228 / 1 388 B per pair at D = 150 / 170) + the embedding rate;
+      alt_gb       GaussianBackend.forward (utils/models.py:584-593), 512 k pairs, D1 = 170 (fp32 MFMA, 810 560 FLOP / pair);
+      alt_dplda    the step xvector_DPlda_pytorch.py:35-43 runs — DPlda.forward -> BCE -> backward -> Adam on the linear
+                   unit, LDA frozen — at the script's batch 256 (conf/voices_config_dplda.cfg:25-29) and at 2048;
+      alt_minc     NeuralPlda.minc (utils/models.py:406-436) over 10 M scores (HBM / sort-bound, 8 B per trial)."""
+    from neuralplda_amd import models, ops, train
+    dev = ctx.dev
+    gen = torch.Generator(device=dev).manual_seed(97)
+    out = {}
+
+    def NCd(D, loss="SoftCdet"):
+        class NC:
+            xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D, D
+            beta, alpha, device = [99.0, 199.0], 15.0, str(dev)
+        NC.loss = loss
+        return NC
+
+    # ---- Regime B ---------------------------------------------------------------------------------------------------
+    B, N = 1 << 20, 1200000
+    rb = {"workload": f"Regime B (SURVEY 8d): {B} index pairs over a pre-embedded {N}-utterance table (VoxCeleb scale; "
+                      f"the table is 3x the 256 MB Infinity Cache: NOT cache-resident), nplda_score_indexed_f32",
+          "unit": "pairs/s", "bound": "hbm", "peak": HBM_PEAK_TBPS}
+    for D in (150, 170):
+        params, _ = make_params(D, dev)
+        packed = ops.pack_params(*params)
+        zb = torch.empty(N, packed.ldz, device=dev)
+        for r0 in range(0, N, 1 << 18):
+            zb[r0:r0 + (1 << 18)].normal_(generator=gen)
+        zb[:, D:] = 0
+        qb = torch.randn(N, device=dev, generator=gen)
+        j1 = torch.randint(0, N, (B,), device=dev, generator=gen)
+        j2 = torch.randint(0, N, (B,), device=dev, generator=gen)
+        ms, sc = kernel_ms_of(lambda: ops.score_indexed(zb, qb, j1, j2, packed))
+        bpp = 2 * 4 * D + 2 * 4 + 2 * 8 + 4
+        ach = B * bpp / (ms * 1e-3) / 1e12
+        # the same call on a cache-resident table (100 k utterances, 64 MB)
+        ns = 100000
+        k1, k2 = j1 % ns, j2 % ns
+        ms_s, _ = kernel_ms_of(lambda: ops.score_indexed(zb[:ns], qb[:ns], k1, k2, packed))
+        # the embedding stage per utterance
+        X = torch.randn(ns, 512, device=dev, generator=gen)
+        ms_e, _ = kernel_ms_of(lambda: ops.embed(X, packed))
+        fe = 2 * 512 * D + 2 * D * D
+        rb[f"d{D}"] = {"value": B / (ms * 1e-3), "kernel_ms": ms, "bytes_per_pair_algorithmic": bpp, "achieved": ach,
+                       "unit": "TB/s", "frac": ach / HBM_PEAK_TBPS, "traffic": _traffic(f"score_indexed_D{D}_B{B}_N{N}"),
+                       "cache_resident_100k_table": {"value": B / (ms_s * 1e-3), "kernel_ms": ms_s,
+                                                     "frac_of_hbm_peak": B * bpp / (ms_s * 1e-3) / 1e12 / HBM_PEAK_TBPS},
+                       "embed_100k_utts": {"value": ns / (ms_e * 1e-3), "unit": "utterances/s", "kernel_ms": ms_e,
+                                           "frac_of_fp32_mfma_peak": ns * fe / (ms_e * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+                       "checksum_finite": bool(torch.isfinite(sc).all().item())}
+        del zb, qb, j1, j2, X
+    out["alt_regimeB"] = rb
+    torch.cuda.empty_cache()
+
+    # ---- GaussianBackend.forward ------------------------------------------------------------------------------------
+    D1 = 170
+    gb = models.GaussianBackend(NCd(D1)).to(dev)
+    A = torch.randn(2 * D1, 2 * D1, generator=torch.Generator().manual_seed(1))
+    gb.paired_cov_inv_target = A @ A.T / (2 * D1) + torch.eye(2 * D1)
+    gb.paired_cov_inv_nontarget = A.T @ A / (2 * D1) + 0.5 * torch.eye(2 * D1)
+    gpk = ops.gb_pack(gb.centering_and_LDA.weight.detach(), gb.centering_and_LDA.bias.detach(),
+                      *[t.to(dev) for t in (gb.paired_mean_target, gb.paired_cov_inv_target,
+                                            gb.paired_mean_nontarget, gb.paired_cov_inv_nontarget)])
+    Bg = 1 << 19
+    x1 = torch.randn(Bg, 512, device=dev, generator=gen)
+    x2 = torch.randn(Bg, 512, device=dev, generator=gen)
+    ms_g, sg = kernel_ms_of(lambda: ops._gb_call(x1, x2, gpk, True, False)[0], reps=5)
+    fg = 2 * 2 * 512 * D1 + 4 * (2 * D1) ** 2
+    ach = Bg * fg / (ms_g * 1e-3) / 1e12
+    out["alt_gb"] = {"workload": f"GaussianBackend.forward (utils/models.py:584-593): {Bg} pairs, 512 -> {D1}, full "
+                                 f"{2 * D1} x {2 * D1} precision matrices (gb_score_pairs_f32)",
+                     "value": Bg / (ms_g * 1e-3), "unit": "pairs/s", "kernel_ms": ms_g, "bound": "mfma", "achieved": ach,
+                     "peak": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "flop_per_pair_algorithmic": fg,
+                     "traffic": _traffic(f"gb_score_D{D1}_B{Bg}"), "checksum_finite": bool(torch.isfinite(sg).all().item())}
+
+    # ---- the DPlda recipe step --------------------------------------------------------------------------------------
+    dpl = {"workload": "xvector_DPlda_pytorch.py:35-43: DPlda.forward -> loss -> backward -> Adam(1e-4, wd 1e-5) on the linear "
+                       "unit and thresholds, LDA frozen (:140-147), 512 -> 170, as ONE graph replay (train.FusedDPldaStep)",
+           "unit": "pairs/s", "bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS}
+    for Bd, lossname in ((256, "crossentropy"), (2048, "crossentropy"), (2048, "SoftCdet")):
+        torch.manual_seed(5)
+        dp = models.DPlda(NCd(D1, lossname)).to(dev)
+        for prm in dp.centering_and_LDA.parameters():
+            prm.requires_grad = False
+        fstep = train.FusedDPldaStep(dp, 1e-4, weight_decay=1e-5, batch_size=Bd, graph=True)
+        xa, xb = x1[:Bd].contiguous(), x2[:Bd].contiguous()
+        tt = (torch.rand(Bd, device=dev, generator=gen) < 0.1).float()
+        fstep(xa, xb, tt)
+        t_end = time.perf_counter() + 0.05
+        while time.perf_counter() < t_end:
+            fstep(xa, xb, tt)
+        ms_d, ld = kernel_ms_of(lambda: fstep(xa, xb, tt), reps=100, batches=5, warm=20)
+        # forward (LDA both sides + the quadratic form) + the gradient's weighted moments (upper triangle of 2 D1 x 2 D1)
+        fd = 2 * 2 * 512 * D1 + 2 * (2 * D1) ** 2 + (2 * D1) * (2 * D1 + 1)
+        ach = Bd * fd / (ms_d * 1e-3) / 1e12
+        dpl[f"B{Bd}_{'bce' if lossname == 'crossentropy' else 'softcdet'}"] = {
+            "value": Bd / (ms_d * 1e-3), "ms_per_step": ms_d, "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS,
+            "flop_per_pair_algorithmic": fd, "launches_per_step": getattr(fstep, "launches_per_step", None),
+            "final_loss_finite": bool(torch.isfinite(ld if torch.is_tensor(ld) else torch.tensor(ld)).all().item())}
+        del fstep, dp
+    out["alt_dplda"] = dpl
+    del x1, x2
+    torch.cuda.empty_cache()
+
+    # ---- minc ---------------------------------------------------------------------------------------------------------
+    Nm = 10000000
+    sc = torch.randn(Nm, device=dev, generator=gen)
+    tg = (torch.rand(Nm, device=dev, generator=gen) < 0.05).float()
+    sc = sc + 2 * tg
+    ms_r, _ = kernel_ms_of(lambda: ops.detcost_sweep(sc, tg, [99.0, 199.0]), reps=5, batches=3, warm=2)
+    ms_x, _ = kernel_ms_of(lambda: ops.detcost_sweep(sc, tg, [99.0, 199.0], exact=True, want_eer=True), reps=5, batches=3, warm=2)
+    ach = Nm * 8 / (ms_r * 1e-3) / 1e12
+    out["alt_minc"] = {"workload": f"NeuralPlda.minc (utils/models.py:406-436, reference semantics) over {Nm} scores, beta 99 / 199 "
+                                   f"(nplda_detcost_sweep_f32: device sort + threshold sweep)",
+                       "value": Nm / (ms_r * 1e-3), "unit": "scores/s", "kernel_ms": ms_r, "exact_mindcf_eer_ms": ms_x,
+                       "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_TBPS, "frac": ach / HBM_PEAK_TBPS,
+                       "bytes_per_trial_algorithmic": 8,
+                       "note": "a radix sort makes several passes over the 8 B per trial: the one-pass figure is a lower bound on "
+                               "traffic, not what a sort can reach"}
     return out
 
 
@@ -865,6 +1054,16 @@ def _compact(r):
         if k in r["config"]:
             keep[k] = r["config"][k]
     return keep
+
+
+def _alt_fail_rc():
+    """Exit status after a failed or hung multi-rank ALT workload.  The headline (cfg1, no collective) is measured and printed
+    before the alts start and the line says what failed (`alts_error` / `alts_aborted`), so the default keeps the driver's line
+    valid: status 0.  A launcher or CI that wants a hung collective to FAIL sets NPLDA_BENCH_ALT_FAIL_RC (e.g. 3)."""
+    try:
+        return int(os.environ.get("NPLDA_BENCH_ALT_FAIL_RC", "0")) & 0xff
+    except ValueError:
+        return 0
 
 
 def multi_rank_alts(args, ctx, out):
@@ -889,7 +1088,7 @@ def multi_rank_alts(args, ctx, out):
             out["alts_aborted"] = f"watchdog: no progress {budget:.0f} s into the multi-rank alt workloads (phase {state['phase']})"
             out["config"]["ranks_in_group"] = world
             print(json.dumps(out), flush=True)
-        os._exit(0)
+        os._exit(_alt_fail_rc())
 
     # (rank 0 fires first and prints; the others give it ten seconds before they go: a launcher that sees a worker leave may
     # stop the rest)
@@ -957,7 +1156,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg5"], default="cfg1")
+    ap.add_argument("--workload", choices=["cfg1", "cfg2", "cfg3", "cfg5", "secondary", "dropin"], default="cfg1")
     ap.add_argument("--emulate-rank", default=None, metavar="r/N",
                     help="one process runs exactly rank r's share of an N-rank job (collectives replaced by their byte "
                          "counts): single-GPU shard timing, not a scaling measurement")
@@ -1032,6 +1231,13 @@ def main():
 
     if emu is not None and args.workload == "cfg1":
         args.scaling = "strong"  # rank r's slice of the one list
+    if args.workload in ("secondary", "dropin"):
+        if world != 1 or emu is not None:
+            raise SystemExit(f"--workload {args.workload} is a one-GPU measurement")
+        out = run_secondary(args, ctx) if args.workload == "secondary" else {"alt_dropin": run_dropin(args, ctx)}
+        out["lib"] = _lib.build_info()
+        print(json.dumps(out), flush=True)
+        return
     out = {"cfg1": run_cfg1, "cfg2": run_cfg2, "cfg3": run_cfg3, "cfg5": run_cfg5}[args.workload](args, ctx)
     if emu is not None:
         out["n_gpus"] = 1
@@ -1067,6 +1273,11 @@ def main():
         except Exception as e:
             out["alt_dropin"] = {"error": f"{type(e).__name__}: {e}"}
         torch.cuda.empty_cache()
+        try:
+            out.update(run_secondary(args, ctx))
+        except Exception as e:
+            out["alt_secondary_error"] = f"{type(e).__name__}: {e}"
+        torch.cuda.empty_cache()
     elif (world > 1 and args.workload == "cfg1" and not args.no_alt and args.precision == "fp32" and args.scaling == "weak"):
         if rank != 0:
             out = {"config": {}}
@@ -1081,7 +1292,7 @@ def main():
                 print(json.dumps(out), flush=True)
             sys.stderr.write(f"bench.py rank {rank}: multi-rank alt workloads failed: {type(e).__name__}: {e}\n")
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(_alt_fail_rc())
     if rank == 0 or emu is not None:
         out["config"]["ranks_in_group"] = ctx.dist.get_world_size() if ctx.dist is not None else 1
         out["lib"] = _lib.build_info()

@@ -30,7 +30,7 @@ extern "C" {
 #endif
 
 /* The library is built with -fvisibility=hidden: the entry points declared between this push and the pop at the end of
- * the header are its whole dynamic symbol table (tests/test_abi_cpu.py checks `nm -D`). */
+ * the header are its whole dynamic symbol table (tests/test_c_abi_cpu.py checks `nm -D`). */
 #if defined(__GNUC__) || defined(__clang__)
 #pragma GCC visibility push(default)
 #endif
@@ -108,6 +108,15 @@ int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, 
  * CU), two launches otherwise. */
 int nplda_embed_pair_f32(const float* xa, int64_t Na, const float* xb, int64_t Nb, int64_t ldx, const void* packed, int D0,
                          int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream);
+
+/* extract_plda_embeddings of the rows rows[0 .. U) of a resident (N, ldt) x-vector table, the gather folded into the kernel:
+ * z[u] = embed(table[rows[u]]) (indices clamped into [0, N)).  What validate() does per epoch
+ * (xvector_NeuralPlda_pytorch.py:56-83 scores every trial through utils/sv_trials_loaders.py:418-426 + utils/models.py:378-382;
+ * a trial list names each utterance many times, so the distinct utterances are embedded ONCE and the trials scored by index,
+ * nplda_score_indexed_f32).  Returns NPLDA_EUNSUPPORTED where the balanced-tile kernel does not apply (the caller then
+ * gathers, nplda_gather_rows_f32, and calls nplda_embed_f32: same values). */
+int nplda_embed_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows, int64_t U, const void* packed,
+                         int D0, int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream);
 
 /* Row width (floats) the kernels use for layer outputs of a D1/D2 model: both layers are padded
  * to the same multiple of 16 (the compiled square kernel size). 0 if unsupported. */

@@ -32,6 +32,8 @@ SIGNATURES = {
                                             _c_f32p, _c_vp]),
     "nplda_embed_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
                                  _c_f32p, _c_vp]),
+    "nplda_embed_rows_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_vp, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_f32p, _c_i64,
+                                      _c_f32p, _c_vp]),
     "nplda_forward_train_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int,
                                          _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_i64, _c_vp]),
     "nplda_loss_nsums": (_c_int, [_c_int, _c_int]),

@@ -107,6 +107,26 @@ int nplda_embed_f32(const float* x, int64_t N, int64_t ldx, const void* packed, 
     return launch_fwd<MODE_EMBED>(a, L, (hipStream_t)stream);
 }
 
+int nplda_embed_rows_f32(const float* table, int64_t N, int64_t ldt, const int64_t* rows, int64_t U, const void* packed,
+                         int D0, int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream) {
+    if (U < 0 || N < 0) return NPLDA_EINVAL;
+    if (int rc = check_model(D0, D1, D2)) return rc;
+    if (U == 0) return NPLDA_OK;
+    if (!packed || !rows || N < 1 || !nplda_aligned16(packed) || !rows_ok(table, ldt, D0)) return NPLDA_EINVAL;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
+    const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32 &&
+                        pair_kernel_choice((U + 1) / 2, L, mid_cus()) == FWD_MID;
+    if (!mid_ok) return NPLDA_EUNSUPPORTED;
+    FwdArgs a = {};
+    a.xa = table; a.xb = table; a.n = U; a.ldx = ldt; a.packed = (const float*)packed;
+    a.out_z = z; a.ldz = ldz; a.out_q = q;
+    a.ia = (const long long*)rows; a.ntab = N;
+    a.D0 = L.D0; a.KS1 = L.KS1;
+    a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
+    return launch_fwd_mid<true>(a, L, (hipStream_t)stream);
+}
+
 int nplda_embed_pair_f32(const float* xa, int64_t Na, const float* xb, int64_t Nb, int64_t ldx, const void* packed, int D0,
                          int D1, int D2, float* z, int64_t ldz, float* q, nplda_stream_t stream) {
     if (Na < 0 || Nb < 0) return NPLDA_EINVAL;

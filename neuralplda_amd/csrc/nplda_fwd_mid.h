@@ -88,6 +88,12 @@ __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int 
         long long row = EMBED ? (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + (lane & 15) : (tile0 + (rg >> 1)) * 16 + (lane & 15);
         if (row >= a.n) row = a.n - 1;
         if (EMBED) {
+            if (a.ia != nullptr) {  // rows named by index (nplda_embed_rows_f32): one table, the gather folded in
+                row = a.ia[row];
+                row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
+                A.xr[rho] = a.xa + row * a.ldx + 4 * (lane >> 4) + 32 * wave;
+                continue;
+            }
             const bool second = a.nsplit > 0 && row >= a.nsplit;  // two-table form: the row's own table
             A.xr[rho] = (second ? a.xb : a.xa) + (second ? row - a.nsplit : row) * a.ldx + 4 * (lane >> 4) + 32 * wave;
             continue;

@@ -159,6 +159,29 @@ def embed(x, packed, want_q=True):
     return z, q
 
 
+def embed_rows(table, rows, packed):
+    """nplda_embed_rows_f32: embed(table[rows]) -> (z (U, ldz), q (U,)) with the gather folded into the kernel; gather_rows +
+    embed where the fused form does not apply (same values)."""
+    lib = _lib.load()
+    if packed.precision != "fp32" or rows.dtype != torch.int64:
+        return embed(gather_rows(table, rows), packed)
+    table, ldt = _rows(table, "table", packed.D0)
+    rows = rows.contiguous()
+    U = rows.shape[0]
+    z = torch.empty((U, packed.ldz), dtype=torch.float32, device=table.device)
+    q = torch.empty(U, dtype=torch.float32, device=table.device)
+    if U == 0:
+        return z, q
+    with _lib.on_device(table.device):
+        code = lib.nplda_embed_rows_f32(_lib.ptr(table), table.shape[0], ldt, _lib.ptr(rows), U, _lib.ptr(packed.buf),
+                                        packed.D0, packed.D1, packed.D2, _lib.ptr(z), packed.ldz, _lib.ptr(q),
+                                        _lib.current_stream())
+    if code == _lib.NPLDA_EUNSUPPORTED:
+        return embed(gather_rows(table, rows), packed)
+    _lib.check(code, "nplda_embed_rows_f32")
+    return z, q
+
+
 def embed_pair(xa, xb, packed):
     """nplda_embed_pair_f32: the z tables and q vectors of two row sets, ((za, qa), (zb, qb)) — views of ONE (Na + Nb, ldz)
     table filled by one launch where the balanced-tile kernel applies (same values as two embed() calls)."""
@@ -921,13 +944,15 @@ def gather_pairs_mapped(table, num_map, num1, num2):
     flag = _BAD_FLAGS.get(dev)
     if flag is None:
         flag = _BAD_FLAGS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
-    code = lib.nplda_gather_pairs_mapped_f32(table.data_ptr(), table.stride(0), table.shape[0], num_map.data_ptr(),
-                                             num_map.numel(), num1.data_ptr(), num2.data_ptr(), B, D0, out[0].data_ptr(),
-                                             out[1].data_ptr(), D0, flag.data_ptr(), _lib.current_stream(dev))
-    _lib.check(code, "nplda_gather_pairs_mapped_f32")
-    bad = int(flag.item())
+    with _lib.on_device(dev):  # (the launch goes to the CURRENT device: dev may not be it in a multi-GPU process)
+        code = lib.nplda_gather_pairs_mapped_f32(table.data_ptr(), table.stride(0), table.shape[0], num_map.data_ptr(),
+                                                 num_map.numel(), num1.data_ptr(), num2.data_ptr(), B, D0, out[0].data_ptr(),
+                                                 out[1].data_ptr(), D0, flag.data_ptr(), _lib.current_stream(dev))
+        _lib.check(code, "nplda_gather_pairs_mapped_f32")
+        bad = int(flag.item())
+        if bad:
+            flag.zero_()
     if bad:
-        flag.zero_()
         raise KeyError("trial index is outside num_to_id_dict" if bad & 1
                        else "trial index refers to an utterance that is not in mega_dict")
     return out[0], out[1]

@@ -141,9 +141,17 @@ class TrialLoader(DataLoader):
             else:
                 e1, e2, el = ds.x1.to(device), ds.x2.to(device), ds.l.to(device)
             if num_to_row is not None:
+                # (the mapped columns of a resident list are kept: the mapping is two index launches and two
+                # synchronising min() read-backs per call, and validate() walks the same list every epoch)
+                mkey = (key if device.type == "cuda" else None, num_to_row.data_ptr(), num_to_row._version, num_to_row.numel())
+                mc = getattr(self, "_dev_columns_mapped", None)
+                if mc is not None and mkey[0] is not None and mc[0] == mkey:
+                    return n, mc[1], mc[2], el
                 e1, e2 = num_to_row[e1.long()], num_to_row[e2.long()]
                 if n and (int(e1.min()) < 0 or int(e2.min()) < 0):
                     raise KeyError("trial index refers to an utterance that is not in mega_dict")
+                if mkey[0] is not None:
+                    self._dev_columns_mapped = (mkey, e1, e2)
             return n, e1, e2, el
         perm = torch.randperm(n, generator=gen)
         if device.type == "cuda":
@@ -195,6 +203,22 @@ class TrialLoader(DataLoader):
         pairs, so it scores in chunks sized for the kernels, not for the loader).  The global RNG moves on exactly as one
         iteration of the loader would move it."""
         return self._device_epoch_arrays(device, num_to_row, permute=False)
+
+    def device_columns_distinct(self, device, num_to_row=None):
+        """device_columns() plus the trial list's DISTINCT table rows: (n, rows1, rows2, labels, urows, j1, j2) with
+        `urows` the sorted distinct values of rows1 and rows2 together and rows1 == urows[j1], rows2 == urows[j2].  A trial
+        list names each utterance many times (a 1 M-trial validation list over 200 k utterances: ten times), so a consumer
+        may embed `urows` once and score by (j1, j2) — validate()'s embed-once pass.  The distinct set is a function of the
+        (fixed) trial list and the map: it is formed once (one device sort) and kept with the resident columns."""
+        n, e1, e2, el = self.device_columns(device, num_to_row)
+        resident = torch.device(device).type == "cuda" and getattr(self, "_dev_columns", None) is not None
+        key = (self._dev_columns[0] if resident else None, None if num_to_row is None else
+               (num_to_row.data_ptr(), num_to_row._version, num_to_row.numel()))
+        cache = getattr(self, "_dev_distinct", None)
+        if cache is None or cache[0] != key or key[0] is None:
+            urows, inv = torch.unique(torch.cat([e1.long(), e2.long()]), return_inverse=True)
+            cache = self._dev_distinct = (key, urows, inv[:n].contiguous(), inv[n:].contiguous())
+        return n, e1, e2, el, cache[1], cache[2], cache[3]
 
     def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None, group=None):
         """The same epoch (same permutation, same RNG draws) with the three index arrays moved to `device` ONCE and the

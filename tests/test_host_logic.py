@@ -448,3 +448,41 @@ def test_device_batches_sharded_for_data_parallel():
         assert sum(len(per_rank[r][k][0]) for r in range(world)) == B
     with pytest.raises(ValueError):
         list(svl.TrialLoader(ds, batch_size=bs, shuffle=True, collate_fn=ds.collate).device_batches("cpu", None, pack=True, shard=(0, 2)))
+
+
+def test_savemodel_after_make_data_parallel_with_an_explicit_group(tmp_path):
+    """dist.make_data_parallel(model, group=g) keeps the ProcessGroup in model.__dict__['_dp_group']; a ProcessGroup
+    does not pickle, so SaveModel / copy.deepcopy must drop it (as they drop the reduction closures)."""
+    import copy
+    import threading
+    from neuralplda_amd import models
+
+    class NC:
+        xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 32, 16, 16
+        beta, alpha, device, loss = [99.0], 15.0, "cpu", "SoftCdet"
+
+    m = models.NeuralPlda(NC())
+    m.__dict__["_dp_group"] = threading.Lock()  # stands in for a ProcessGroup: equally unpicklable
+    m._reduce_sums = lambda v: v
+    m._reduce_flat = lambda v: v
+    m.SaveModel(str(tmp_path / "m.pt"))
+    with open(tmp_path / "m.pt", "rb") as fh:
+        m2 = pickle.load(fh)
+    assert m2.__dict__["_dp_group"] is None and m2._reduce_flat is None
+    m3 = copy.deepcopy(m)
+    assert m3.__dict__["_dp_group"] is None
+    assert m.__dict__["_dp_group"] is not None  # the live model keeps its group
+
+
+def test_compat_fused_adam_leaves_cpu_parameters_to_torch():
+    import neuralplda_amd.compat as compat
+    real = torch.optim.Adam
+    compat.install(fused_adam=True)
+    try:
+        o = torch.optim.Adam([torch.nn.Parameter(torch.zeros(4))], lr=1e-3, weight_decay=1e-5)
+        assert type(o) is real
+        o2 = torch.optim.Adam([{"params": [torch.nn.Parameter(torch.zeros(4))], "lr": 1e-2}], lr=1e-3)
+        assert type(o2) is real and o2.param_groups[0]["lr"] == 1e-2
+    finally:
+        compat.uninstall()
+    assert torch.optim.Adam is real

