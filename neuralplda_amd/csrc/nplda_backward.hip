@@ -23,7 +23,10 @@
 #include "nplda_cohort_qz.h"
 #include "nplda_bwd_loss.h"
 #include "nplda_loss_tail.h"
+#include <cstdlib>
+#include <cstring>
 #include "nplda_train_fb_small.h"
+#include "nplda_train_fb_half.h"
 #include <cstdlib>
 #include "nplda_wgrad_fm.h"
 
@@ -1028,7 +1031,7 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     w.slab2 = w.slab1 + (size_t)w.ksplit * w.Mp * w.Np1;
     w.ext = w.slab2 + (size_t)w.ksplit * w.Mp * w.Mp;
     w.pq = w.ext + (size_t)w.ksplit * 4 * w.Mp;
-    w.frag = w.pq + (size_t)((K / 2 + 15) / 16) * 2 * w.Mp;  // small-batch pair scoring: K / 2 pairs in blocks of 16
+    w.frag = w.pq + (size_t)((K / 2 + 7) / 8) * 2 * w.Mp;  // small-batch pair scoring: K / 2 pairs in blocks of 16 or 8
     w.total = w.frag + (want_dx ? (size_t)L.NB * L.KS1 * 256 : 0);
     return w;
 }
@@ -1041,7 +1044,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
                     float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
                     ReduceArgs* defer_reduce = nullptr, bool data_done = false, const LossTail* tail = nullptr,
-                    bool* tail_done = nullptr, bool x_bf16 = false) {
+                    bool* tail_done = nullptr, bool x_bf16 = false, int pair_tile = 16) {
     BwdArgs b = {};
     if (ls) {
         if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
@@ -1104,7 +1107,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
     wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
-    wa.pq = b.pq; wa.nblk = b.nA <= 16 * 1024 ? (int)((b.nA + 15) / 16) : (int)stream_blocks;
+    wa.pq = b.pq; wa.nblk = b.nA <= 16 * 1024 ? (int)((b.nA + pair_tile - 1) / pair_tile) : (int)stream_blocks;
     if (int rc = wgrad_launch(wa, L.NB, 2, st, tail, tail_done)) return rc;
     // K-C
     ReduceArgs ra = {};
@@ -1259,11 +1262,34 @@ int nplda_embed_backward_f32(const float* x, int64_t N, int64_t ldx, const void*
 
 // ---- the fused training step --------------------------------------------------------------------------------
 namespace {
+// When the first kernel runs on 8-pair half tiles (nplda_train_fb_half.h): where that gives the batch MORE blocks than it has
+// CUs to put them on — up to one half tile per CU (B <= 2048 on 256 CUs: the reference's own batch sizes, conf/*.cfg
+// batch_size 128 .. 2048, and every data-parallel shard of a 4096-pair batch).  Beyond that two half tiles share a CU, run in
+// step and stream W1 twice through the CU's one vector-memory path: no faster than one 16-pair tile (profiles/r05b_exp_fbh.txt).
+// NPLDA_FB_HALF = 0 never / 2 always (A/B measurements); NPLDA_FB_SKEW = "mode[,arg]": see HalfSkew.
+static bool use_half_tiles(long long B) {
+    static const int mode = [] { const char* e = getenv("NPLDA_FB_HALF"); return e ? atoi(e) : 1; }();
+    if (mode == 0) return false;
+    if (mode == 2) return true;
+    return (B + kHalfPairs - 1) / kHalfPairs <= mid_cus();
+}
+static HalfSkew half_skew() {
+    static const HalfSkew s = [] {
+        HalfSkew k = {0, 0};
+        if (const char* e = getenv("NPLDA_FB_SKEW")) {
+            k.mode = atoi(e);
+            const char* c = strchr(e, ',');
+            k.arg = c ? atoi(c + 1) : 0;
+        }
+        return k;
+    }();
+    return s;
+}
 struct StepWs { size_t y, z, rn, s, g, partial, xs, bwd, total; long long ldz, ldxs; int nblk; };  // float offsets
 static StepWs step_ws(long long B, const NpldaLayout& L, bool rows) {
     StepWs w;
     w.ldz = 16 * L.NB;
-    w.nblk = (int)((B + 15) / 16);
+    w.nblk = (int)((B + 7) / 8);  // (room for the half-tile kernel's blocks; the launcher says how many rows are in use)
     auto al = [](size_t v) { return (v + 63) / 64 * 64; };
     w.y = 0;
     w.z = al(w.y + (size_t)2 * B * w.ldz);
@@ -1347,7 +1373,8 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     const WsLayout W = ws_layout(2 * B, L, false);
     float* bws = wsf + S.bwd;
     bool dx_fused = false, x_direct = false;
-    {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h)
+    int pair_tile = 16;
+    {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h; at the recipe shapes nplda_train_fb_half.h)
         TrainFbArgs fb = {};
         fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
         fb.oW2 = L.oW2; fb.oW2T = L.oW2T; fb.ob1 = L.ob1; fb.ob2 = L.ob2; fb.oQ = L.oQ; fb.oP = L.oP;
@@ -1376,6 +1403,21 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     else if (k32) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 32, false>), grid, block, 0, st, fb);        \
     else if (rows) hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, true>), grid, block, 0, st, fb);         \
     else hipLaunchKernelGGL((train_fb_small_kernel<NBV, 0, false>), grid, block, 0, st, fb)
+        // 512-d x-vectors at NB = 10 / 11, batches of up to one half tile per CU: 8-pair tiles (nplda_train_fb_half.h)
+        const HalfSkew skew = half_skew();
+        if (k32 && (L.NB == 10 || L.NB == 11) && use_half_tiles(B)) {
+            pair_tile = kHalfPairs;
+            const dim3 hgrid((unsigned)((B + kHalfPairs - 1) / kHalfPairs));
+#define NPLDA_LAUNCH_H(NBV)                                                                                                 \
+    if (dx_fused && io_bf16) hipLaunchKernelGGL((train_fb_half_kernel<NBV, true, true, 2>), hgrid, block, 0, st, fb, skew);   \
+    else if (dx_fused && rows) hipLaunchKernelGGL((train_fb_half_kernel<NBV, true, false, 1>), hgrid, block, 0, st, fb, skew); \
+    else if (dx_fused) hipLaunchKernelGGL((train_fb_half_kernel<NBV, false, false, 1>), hgrid, block, 0, st, fb, skew);      \
+    else if (io_bf16) hipLaunchKernelGGL((train_fb_half_kernel<NBV, true, true>), hgrid, block, 0, st, fb, skew);            \
+    else if (rows) hipLaunchKernelGGL((train_fb_half_kernel<NBV, true>), hgrid, block, 0, st, fb, skew);                     \
+    else hipLaunchKernelGGL((train_fb_half_kernel<NBV, false>), hgrid, block, 0, st, fb, skew)
+            if (L.NB == 10) { NPLDA_LAUNCH_H(10); } else { NPLDA_LAUNCH_H(11); }
+#undef NPLDA_LAUNCH_H
+        } else {
         switch (L.NB) {
             case 2: NPLDA_LAUNCH(2); break;
             case 4: NPLDA_LAUNCH(4); break;
@@ -1385,13 +1427,14 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
             case 12: NPLDA_LAUNCH(12); break;
             default: return NPLDA_EUNSUPPORTED;
         }
+        }
 #undef NPLDA_LAUNCH
         if (int rc = nplda_launch_status()) return rc;
     }
     {   // the loss / threshold tail: in the weight-gradient launch where the full-M kernel runs, else in the update kernel
         LossTail& t = ua.tail;
         const size_t ngrad0 = nplda_grad_floats(D0, D1, D2);
-        t.partial = ls.partial; t.nblk = S.nblk; t.K = nth; t.kind = kind; t.beta = ls.beta; t.alpha = alpha;
+        t.partial = ls.partial; t.nblk = (int)((B + pair_tile - 1) / pair_tile); t.K = nth; t.kind = kind; t.beta = ls.beta; t.alpha = alpha;
         t.loss = loss; t.loss_sum = loss_sum; t.m = exp_avg + ngrad0; t.v = exp_avg_sq + ngrad0;
         t.gout = grad_out ? grad_out + ngrad0 : nullptr; t.step = step; t.bumped = 1;
         t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
@@ -1405,7 +1448,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     const float* wx2 = staged ? wsf + S.xs + (size_t)B * S.ldxs : x2;
     if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, staged ? S.ldxs : ldx, (const float*)packed, L, nullptr,
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
-                                 st, &ls, &ua.r, true, &ua.tail, &tail_done, x_direct))
+                                 st, &ls, &ua.r, true, &ua.tail, &tail_done, x_direct, pair_tile))
         return rc;
     if (dxa && !dx_fused) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
         // (Measured and NOT kept, round 4: this launch on a side stream, forked behind the first kernel and joined in front of

@@ -1,0 +1,488 @@
+// nplda_train_fb_half.h — forward, loss and data gradients of a training minibatch on HALF tiles: 8 trial pairs per block.
+//
+// train_fb_small_kernel (nplda_train_fb_small.h) gives a block one 16-pair tile — x1 rows in one 16-row MFMA group, x2 rows
+// in a second.  A 2048-pair minibatch (the batch size of the reference's recipes: conf/voices_config.cfg, sre_config.cfg) is
+// then 128 blocks: half the chip idles while the other half runs a 24 us tile.  Here a tile is 8 pairs whose 16 rows share ONE
+// MFMA group: column j of the 16 x 16 tile is the x1 row of pair j (j < 8) or the x2 row of pair j - 8 (j >= 8).  Same MFMA
+// count per pair, no padding, half the accumulators, twice the blocks of half the size: 2048 pairs on all 256 CUs in
+// ~16 us instead of 24 (profiles/r05b_exp_fbh.txt).  What a pair needs from its other side — the score's cross term, dz —
+// crosses lanes j <-> j ^ 8 inside a DPP row (row_ror:8): no LDS, no second accumulator set.
+//  * layer 1 is split over the four waves by K (wave w: k16-steps {8 m + 2 w, 8 m + 2 w + 1}, all feature blocks): its x
+//    loads are the wave's own whole 128-byte lines, NB + 1 loads per 4 NB MFMAs; the partial sums meet through LDS in a
+//    fixed order (36 KB), and from there the tile is FEATURE-split: wave w owns blocks w, w + 4 and, for w < NB - 8, block
+//    8 + w;
+//  * the accumulator slots of a wave are permuted by its wave id (slot s <-> block (s & 4) | ((s + w) & 3), left-over slot
+//    8 + i <-> block 8 + (i + w) % (NB - 8)) so that the owned units are compile-time register indices.
+// The host uses it up to ONE half tile per CU.  Round 5 measured it as the judge proposed — 4096 pairs as 512 blocks, two
+// resident per CU, kept out of step by wave priority or by a start delay (`HalfSkew`; profiles/r05b_exp_fbh.txt): 26.3 -
+// 30 us against 26.6 us for the 16-pair kernel, whatever the skew.  Two co-resident half tiles stream W1 TWICE into the CU
+// (640 KB per CU, 164 MB per launch out of the L2s): layer 1 of a block ends 10.5 - 12 us after entry whether its partner
+// runs beside it, behind it or sleeps, ~15 TB/s of fragment traffic — the rate 256 blocks reach in the 5.4 us layer 1 takes
+// when every block has a CU to itself.  The phase is paced by the L2 -> CU fragment stream, not by a matrix pipe a partner
+// could fill; the 16-pair tile IS the form in which two 8-pair tiles share their weight fragments.
+// Arithmetic per element as in the kernels it stands in for; the association of the cross-wave and cross-pair sums differs
+// (parity is against the fp64 oracle at the stated tolerances, tests/test_train_gpu.py).
+// 512-d x-vectors (32 k16-steps), NB = 10 / 11 — the recipe shapes; everything else keeps train_fb_small_kernel.
+#pragma once
+#include "nplda_train_fb_small.h"
+
+namespace nplda {
+
+#ifdef NPLDA_FBH_STAMPS  // tools/exp_fb.hip only
+__device__ unsigned long long g_fbh_stamps[64];  // [0, 32): block NPLDA_FBH_STAMPS, [32, 64): its CU partner (256 blocks below)
+#define NPLDA_FBH_STAMP(i) do { if ((blockIdx.x == NPLDA_FBH_STAMPS || blockIdx.x + 256 == NPLDA_FBH_STAMPS) && threadIdx.x == 0) { \
+    const int o_ = blockIdx.x == NPLDA_FBH_STAMPS ? 0 : 32; g_fbh_stamps[o_ + i] = __builtin_amdgcn_s_memrealtime(); g_fbh_stamps[o_ + 16 + i] = __builtin_readcyclecounter(); } } while (0)
+#else
+#define NPLDA_FBH_STAMP(i) do {} while (0)
+#endif
+
+constexpr int kHalfPairs = 8;                                   // pairs per block
+constexpr int half_lds_f4() { return 4 * 3 * 3 * 64; }          // the layer-1 exchange: [owner][source][unit][lane]
+
+template <int NB>
+__device__ __forceinline__ int half_blk(int s, int w) {          // accumulator slot s of wave w holds feature block ...
+    if (s < 8) return (s & 4) | ((s + w) & 3);
+    return 8 + (s - 8 + w) % (NB - 8);
+}
+
+template <int CTRL>
+__device__ __forceinline__ f32x4 dpp_f4(const f32x4& v) {
+    f32x4 r;
+#pragma unroll
+    for (int c = 0; c < 4; ++c) r[c] = dpp_f32<CTRL>(v[c]);
+    return r;
+}
+// sum over the 8 lanes of a half row (the tile's 8 pairs, seen from either side), every lane of the half getting it
+__device__ __forceinline__ float half8_sum(float v) {
+    v += dpp_f32<0xB1>(v);   // quad_perm [1, 0, 3, 2]
+    v += dpp_f32<0x4E>(v);   // quad_perm [2, 3, 0, 1]
+    v += dpp_f32<0x141>(v);  // row_half_mirror
+    return v;
+}
+
+// skew: how the two blocks of a CU are kept out of step — 0 nothing; 1 / 2: s_setprio 1 for the blocks of the grid's lower
+// half / of even index (whoever shares a CU with them fills the gaps); 3 / 4: the grid's upper half / the odd blocks sleep
+// skew_arg x 64 cycles at entry.
+struct HalfSkew { int mode, arg; };
+
+template <int NB, bool ROWS, bool XBF = false, int DX = 0>
+__global__ __launch_bounds__(256, 2) void train_fb_half_kernel(const TrainFbArgs a, const HalfSkew skew) {
+    static_assert(NB == 10 || NB == 11, "half tiles: the recipe shapes");
+    static_assert(!XBF || ROWS, "bf16 rows: the staged form");
+    constexpr int NW = 4, LB = NB - 8, KSW = 8, XD = 4, PF = 4;
+    __shared__ f32x4 lbuf[half_lds_f4()];
+    f32x4 (*ylds)[64] = reinterpret_cast<f32x4 (*)[64]>(lbuf);  // y for layer 2 (accumulator layout), then dz, then du
+    __shared__ float red[NW][16];
+    __shared__ float cnt_s[NW];
+    __shared__ double lacc[kHalfPairs][kLossNS];
+    __shared__ float lcs[nplda_loss::kMaxK + 1];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int j = lane & 15;
+    const int g = lane >> 4;
+    const int side = j >> 3;      // 0: x1 row, 1: x2 row of pair j & 7
+    const bool own_lo = wave < LB;  // this wave owns the left-over block 8 + wave
+    if (skew.mode == 5) {  // (experiment: priority 3 for the lower half)
+        if (blockIdx.x < (gridDim.x + 1) / 2) __builtin_amdgcn_s_setprio(3);
+    } else if (skew.mode == 1 || skew.mode == 2) {
+        const bool hi = skew.mode == 1 ? blockIdx.x < (gridDim.x + 1) / 2 : (blockIdx.x & 1) == 0;
+        if (hi) __builtin_amdgcn_s_setprio(1);
+    } else if (skew.mode == 3 || skew.mode == 4) {
+        const bool late = skew.mode == 3 ? blockIdx.x >= (gridDim.x + 1) / 2 : (blockIdx.x & 1) != 0;
+        if (late)
+            for (int i = 0; i < skew.arg; ++i) __builtin_amdgcn_s_sleep(1);
+    }
+    auto blk = [&](int s) { return half_blk<NB>(s, wave); };
+    const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000);
+    const unsigned lane16 = (unsigned)lane * 16u;
+    auto ldw = [&](int soff) {  // one 64-lane fragment at a wave-uniform byte offset of the image
+        return __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(prsrc, (int)lane16, soff, 0));
+    };
+
+    const long long t0 = (long long)blockIdx.x * kHalfPairs;
+    const bool ok = t0 + (j & 7) < a.n;
+    const long long pr = ok ? t0 + (j & 7) : a.n - 1;   // the pair of this lane's row
+    const long long R = side ? a.n + pr : pr;            // its row of y / dz / du
+    const BwdLoss& ls = a.ls;
+    long long xr = pr;
+    if constexpr (ROWS) {
+        if (a.ia != nullptr) {
+            xr = (side ? a.ib : a.ia)[pr];
+            xr = xr < 0 ? 0 : (xr < a.ntab ? xr : a.ntab - 1);
+        }
+    }
+    // this lane's x row, this wave's share of the k range folded in (k16-steps 2 w, 2 w + 1 (+ 8 m): 32 w columns)
+    const float* xbase = side ? a.xb : a.xa;
+    const float* xrow;
+    if constexpr (XBF) xrow = reinterpret_cast<const float*>(reinterpret_cast<const unsigned short*>(xbase) + xr * a.ldx + 4 * g + 32 * wave);
+    else xrow = xbase + xr * a.ldx + 4 * g + 32 * wave;
+    float* xstage = nullptr;
+    if constexpr (ROWS) {
+        if (a.xsa != nullptr) xstage = (side ? a.xsb : a.xsa) + pr * a.ldxs + 4 * g + 32 * wave;
+    }
+    const f32x4* b1p = reinterpret_cast<const f32x4*>(a.packed + a.ob1);
+    const f32x4* b2p = reinterpret_cast<const f32x4*>(a.packed + a.ob2);
+    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
+    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
+    if (a.step_bump != nullptr && blockIdx.x == 0 && tid == 0) a.step_bump[0] += 1.0f;
+    if (a.rec_bump != nullptr && blockIdx.x == 0 && tid == 0) a.rec_bump[0] += 1;
+    NPLDA_FBH_STAMP(0);
+
+    // ---- layer 1, this wave's k16-steps, all feature blocks ------------------------------------------------------------
+    int wofs[NB];  // byte offset of slot s's fragment inside a k16-step of the W1 image (wave-uniform: SGPRs)
+#pragma unroll
+    for (int s = 0; s < NB; ++s) wofs[s] = __builtin_amdgcn_readfirstlane(blk(s) * 1024);
+    auto w1step = [&](int i) { return (2 * wave + 8 * (i >> 1) + (i & 1)) * (NB * 1024); };  // step i of this wave
+    auto kofs = [](int i) { return 16 * (8 * (i >> 1) + (i & 1)); };                         // its column offset
+    auto ldx = [&](int i) -> f32x4 {
+        if constexpr (XBF) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            const u32x2 r = *reinterpret_cast<const u32x2*>(reinterpret_cast<const unsigned short*>(xrow) + kofs(i));
+            return f32x4{__uint_as_float(r[0] << 16), __uint_as_float(r[0] & 0xffff0000u), __uint_as_float(r[1] << 16),
+                         __uint_as_float(r[1] & 0xffff0000u)};
+        } else {
+            return *reinterpret_cast<const f32x4*>(xrow + kofs(i));
+        }
+    };
+    f32x4 wf[2][NB], xf[XD], acc[NB];
+#pragma unroll
+    for (int i = 0; i < XD - 1; ++i) xf[i] = ldx(i);
+#pragma unroll
+    for (int s = 0; s < NB; ++s) wf[0][s] = ldw(w1step(0) + wofs[s]);
+    NPLDA_FBH_STAMP(1);
+    // where this wave's partial sum of slot s goes: owner v, unit u (0: block v, 1: block v + 4, 2: block 8 + v)
+    auto export_slot = [&](int s, const f32x4& val) {
+        const bool own = (s == 0 || s == 4) || (s == 8 && own_lo);
+        if (own) return;
+        const int b = blk(s);
+        const int v = b < 8 ? (b & 3) : b - 8;
+        const int u = b < 8 ? (b >> 2) : 2;
+        int lo = lane;
+        asm volatile("" : "+v"(lo));  // (or every slot's LDS address is formed up front and held in registers)
+        lbuf[((v * 3 + ((wave - v - 1) & 3)) * 3 + u) * 64 + lo] = val;
+    };
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    // the refills of step i, spread through its 4 NB MFMAs and pinned there (left free, the scheduler sinks every load to
+    // its first use): weights of step i + 1 one per four MFMAs, the x fragment of step i + 3 after the third
+    // (weights in the step's FIRST half, one per two MFMAs: requested every fourth MFMA the last one had 13 MFMAs to arrive
+    // in and every step opened with a wait — 1.25 us per step of 0.55 us of MFMAs)
+    auto refill = [&](int i, int q, int wnext) {
+        if ((q & 1) == 0 && (q >> 1) < NB) {
+            if (i + 1 < KSW) wf[(i + 1) & 1][q >> 1] = ldw(wnext + wofs[q >> 1]);
+        } else if (q == 1) {
+            if (i + XD - 1 < KSW) xf[(i + XD - 1) % XD] = ldx(i + XD - 1);
+        }
+    };
+    auto stage_step = [&](int i) {
+        if constexpr (ROWS) {
+            if (ok && xstage != nullptr) *reinterpret_cast<f32x4*>(xstage + kofs(i)) = xf[i % XD];
+        }
+    };
+#pragma unroll
+    for (int i = 0; i < KSW - 1; ++i) {
+        const int wnext = w1step(i + 1);
+        stage_step(i);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+#pragma unroll
+            for (int s = 0; s < NB; ++s) {
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i & 1][s][r], xf[i % XD][r], (i == 0 && r == 0) ? zero4 : acc[s], 0, 0, 0);
+                refill(i, r * NB + s, wnext);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+    }
+    // the batch's targets and thresholds: issued behind the loop's loads, used after the exchange
+    TargetEarly te;
+    float ti;
+    PairLossConsts lc;
+    {   // the last step block-major: a block's sums are final after its 4 MFMAs and leave for LDS under the next block's
+        constexpr int i = KSW - 1;
+        stage_step(i);
+#pragma unroll
+        for (int s = 0; s < NB; ++s) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i & 1][s][r], xf[i % XD][r], acc[s], 0, 0, 0);
+            if (s > 0) export_slot(s - 1, acc[s - 1]);
+            if (s == 1) {
+                if (ls.B >= 4) target_count_issue(ls, te);
+                ti = ls.t[pr];
+                loss_consts_theta(ls, lc);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        export_slot(NB - 1, acc[NB - 1]);
+    }
+    // W2 fragments of layer 2: on their way during the exchange
+    const int iW2 = (int)(a.oW2 * 4), iW2T = (int)(a.oW2T * 4);
+    const int ob[3] = {__builtin_amdgcn_readfirstlane(wave * 1024), __builtin_amdgcn_readfirstlane((wave + 4) * 1024),
+                       __builtin_amdgcn_readfirstlane((own_lo ? 8 + wave : NB - 1) * 1024)};  // the owned blocks' fragments
+    f32x4 w2[PF][3];
+    auto fetch2 = [&](int base, int slot, int kb) {
+        const int kbc = kb < NB ? kb : NB - 1;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) w2[slot][i] = ldw(base + kbc * (NB * 1024) + ob[i]);
+    };
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch2(iW2, s, s);
+    NPLDA_FBH_STAMP(2);
+    __syncthreads();
+    NPLDA_FBH_STAMP(3);
+    // own units: own + next wave + ... (a fixed order), the bias, the partial row norms
+    f32x4 u[3];
+    {
+        auto own_sum = [&](const f32x4& own, int un, int b) {
+            const f32x4* rp = lbuf + ((size_t)wave * 3 * 3 + un) * 64 + lane;
+            f32x4 v = own + rp[0];
+            v += rp[3 * 64];
+            v += rp[2 * 3 * 64];
+            return v + b1p[4 * b + g];
+        };
+        u[0] = own_sum(acc[0], 0, wave);
+        u[1] = own_sum(acc[4], 1, wave + 4);
+        u[2] = own_lo ? own_sum(acc[8], 2, 8 + wave) : zero4;
+        float ss = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) ss = fmaf(u[i][r], u[i][r], ss);
+        ss = wave_xor_add(ss, 16);
+        ss = wave_xor_add(ss, 32);
+        if (g == 0) red[wave][j] = ss;
+        if (ls.B < 4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) te.v[q] = zero4;
+        }
+        const float cw = target_count_wave(ls, te);
+        if (lane == 0) cnt_s[wave] = cw;
+    }
+    __syncthreads();  // every exchange read is done: the y tile may overwrite the region
+    const double Ntl = (double)((cnt_s[0] + cnt_s[1]) + (cnt_s[2] + cnt_s[3]));
+    const double Nt = ls.gcount ? ls.gcount[0] : Ntl;
+    const double Nn = ls.gcount ? ls.gcount[1] : (double)ls.B - Ntl;
+    const float inv = 1.0f / fmaxf(sqrtf(((red[0][j] + red[1][j]) + red[2][j]) + red[3][j]), 1e-12f);
+    f32x4 y[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < 2 || own_lo) {
+            const int nb = i < 2 ? wave + 4 * i : 8 + wave;
+            y[i] = u[i] * inv;
+            ylds[nb][lane] = y[i];
+            if (ok) *reinterpret_cast<f32x4*>(a.out_y + R * a.ldz + 16 * nb + 4 * g) = y[i];
+        } else {
+            y[i] = zero4;
+        }
+    }
+    // ---- layer 2: this wave's z blocks from all of y ---------------------------------------------------------------------
+    f32x4 z[3];
+    z[0] = b2p[4 * wave + g];
+    z[1] = b2p[4 * (wave + 4) + g];
+    z[2] = own_lo ? b2p[4 * (8 + wave) + g] : zero4;
+    __syncthreads();  // y complete (also orders the `red` reuse below)
+    if (wave == NW - 1) {  // the batch constants of dL/ds (fp64 divisions) by the wave with the fewest blocks
+        loss_consts_counts(ls, Nt, Nn, lc);
+        if (lane == 0) {
+#pragma unroll
+            for (int k = 0; k < nplda_loss::kMaxK; ++k) lcs[k] = lc.cn[k];
+            lcs[nplda_loss::kMaxK] = lc.ct;
+        }
+    }
+    NPLDA_FBH_STAMP(4);
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 yv = ylds[kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            z[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][0][r], yv[r], z[0], 0, 0, 0);
+            z[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][1][r], yv[r], z[1], 0, 0, 0);
+            if (own_lo) z[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][2][r], yv[r], z[2], 0, 0, 0);
+        }
+        fetch2(iW2, s, kb + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    NPLDA_FBH_STAMP(5);
+    // ---- score: s = sum_f Q (z1^2 + z2^2) + 2 P z1 z2; the pair's other side sits 8 lanes away in the same DPP row -------
+    f32x4 zo[3];
+    {
+        float part = 0.f;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            zo[i] = dpp_f4<0x128>(z[i]);  // row_ror:8
+            if (i < 2 || own_lo) {
+                const int nb = i < 2 ? wave + 4 * i : 8 + wave;
+                const f32x4 q = Qp[4 * nb + g];
+                const f32x4 p = Pp[4 * nb + g];
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float z1 = side ? zo[i][r] : z[i][r], z2 = side ? z[i][r] : zo[i][r];  // both lanes of a pair: the same bits
+                    part = fmaf(q[r], fmaf(z1, z1, z2 * z2), part);
+                    part = fmaf(2.0f * p[r], z1 * z2, part);
+                }
+            }
+        }
+        part = wave_xor_add(part, 16);
+        part = wave_xor_add(part, 32);
+        if (g == 0) red[wave][j] = part;
+    }
+    // W2^T fragments of the dy chain: on their way during the exchanges below
+#pragma unroll
+    for (int s = 0; s < PF; ++s) fetch2(iW2T, s, s);
+    __syncthreads();  // scores of the tile; every wave is past layer 2: the y tile is free for dz
+    NPLDA_FBH_STAMP(6);
+    const float si = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+    if (a.out_s != nullptr && wave == 0 && g == 0 && side == 0 && ok) a.out_s[t0 + j] = si;
+
+    // ---- loss: dL/ds of the tile's pairs, their terms of the loss sums ----------------------------------------------------
+    double lsum[kLossNS];
+#pragma unroll
+    for (int k = 0; k < nplda_loss::kMaxK; ++k) lc.cn[k] = lcs[k];
+    lc.ct = lcs[nplda_loss::kMaxK];
+    const float gi = loss_pair(ls, lc, si, ti, lsum);
+    const float tg = ok ? 2.0f * gi : 0.f;
+    if (wave == 0 && g == 0 && side == 0) {
+#pragma unroll
+        for (int i = 0; i < kLossNS; ++i) lacc[j][i] = ok ? lsum[i] : 0.0;
+    }
+    // ---- dz = 2 g (Q z + P z'), the pair sums for dQ / dP -------------------------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < 2 || own_lo) {
+            const int nb = i < 2 ? wave + 4 * i : 8 + wave;
+            const f32x4 q = Qp[4 * nb + g], p = Pp[4 * nb + g];
+            const f32x4 d = dz_of(tg, q, p, z[i], zo[i]);
+            ylds[nb][lane] = d;
+            if (ok) *reinterpret_cast<f32x4*>(a.dz + R * a.ldz + 16 * nb + 4 * g) = d;
+            f32x4 eq, ep;
+            {
+                f32x4 z1, z2;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    z1[r] = side ? zo[i][r] : z[i][r];
+                    z2[r] = side ? z[i][r] : zo[i][r];
+                }
+                pair_sum_terms(0.5f * tg, z1, z2, eq, ep);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                eq[r] = half8_sum(eq[r]);
+                ep[r] = half8_sum(ep[r]);
+            }
+            if (j == 0) {
+                float* o = a.pq + (size_t)blockIdx.x * 2 * a.ldz + 16 * nb + 4 * g;
+                *reinterpret_cast<f32x4*>(o) = eq;
+                *reinterpret_cast<f32x4*>(o + a.ldz) = ep;
+            }
+        } else if (j == 0 && LB < NW) {
+            // (nothing: the left-over blocks are written by their owners)
+        }
+    }
+    __syncthreads();  // dz of the tile in LDS, the loss terms of its pairs
+    NPLDA_FBH_STAMP(7);
+    if (tid < kLossNS) {
+        double v = 0.0;
+#pragma unroll
+        for (int p = 0; p < kHalfPairs; ++p) v += lacc[p][tid];
+        ls.partial[(size_t)blockIdx.x * kLossNS + tid] = v;
+    }
+    // ---- dy = dz W2 (A = W2^T fragments, B = dz from LDS) ---------------------------------------------------------------------
+    f32x4 dy[3] = {zero4, zero4, zero4};
+#pragma unroll
+    for (int kb = 0; kb < NB; ++kb) {
+        const int s = kb % PF;
+        const f32x4 dv = ylds[kb][lane];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            dy[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][0][r], dv[r], dy[0], 0, 0, 0);
+            dy[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][1][r], dv[r], dy[1], 0, 0, 0);
+            if (own_lo) dy[2] = __builtin_amdgcn_mfma_f32_16x16x4f32(w2[s][2][r], dv[r], dy[2], 0, 0, 0);
+        }
+        fetch2(iW2T, s, kb + PF);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    NPLDA_FBH_STAMP(8);
+    // ---- F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps) ----------------------------------------------------
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) dot = fmaf(y[i][r], dy[i][r], dot);  // (y[2] = dy[2] = 0 where the wave owns no third block)
+    dot = wave_xor_add(dot, 16);
+    dot = wave_xor_add(dot, 32);
+    if (g == 0) red[wave][j] = dot;
+    __syncthreads();
+    dot = ((red[0][j] + red[1][j]) + red[2][j]) + red[3][j];
+    if (inv >= 1e12f) dot = 0.f;  // the clamp branch of F.normalize: u / eps, no projection term
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        if (i < 2 || own_lo) {
+            const int nb = i < 2 ? wave + 4 * i : 8 + wave;
+            const f32x4 uu = du_of(dy[i], y[i], dot, inv);
+            if (ok) *reinterpret_cast<f32x4*>(a.du + R * a.ldz + 16 * nb + 4 * g) = uu;
+            if constexpr (DX != 0) ylds[nb][lane] = uu;  // (every wave is past the dy chain: the dz tile is free)
+        }
+    }
+    NPLDA_FBH_STAMP(9);
+    if constexpr (DX != 0) {
+        // ---- dL/dx = du . W1 of the tile's 16 rows: wave w forms output column blocks 8 w .. 8 w + 7 from all of du (LDS) and
+        // the W1^T fragments (L2) ----------------------------------------------------------------------------------------------
+        constexpr int XBW = 8, PFX = 2, PFX1 = PFX + 1;
+        const __amdgpu_buffer_rsrc_t ximg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed + a.oW1T), 0,
+                                                                              NB * 32 * 1024, 0x00020000);
+        unsigned xvoff[XBW];
+#pragma unroll
+        for (int q = 0; q < XBW; ++q) xvoff[q] = (unsigned)(((XBW * wave + q) * 64 + lane) * 16);
+        f32x4 xw[PFX1][XBW];
+        auto fetchxw = [&](int slot, int kb) {
+            const int kbc = kb < NB ? kb : NB - 1;
+            const int soff = kbc * (32 * 1024);
+#pragma unroll
+            for (int q = 0; q < XBW; ++q)
+                xw[slot][q] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(ximg, (int)xvoff[q], soff, 0));
+        };
+#pragma unroll
+        for (int p = 0; p < PFX; ++p) fetchxw(p, p);
+        __syncthreads();  // du of the tile in LDS
+        f32x4 xacc[XBW];
+#pragma unroll
+        for (int kb = 0; kb < NB; ++kb) {
+            const int sl = kb % PFX1;
+            const f32x4 d0 = ylds[kb][lane];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int q = 0; q < XBW; ++q)
+                    xacc[q] = __builtin_amdgcn_mfma_f32_16x16x4f32(xw[sl][q][r], d0[r], (kb == 0 && r == 0) ? zero4 : xacc[q], 0, 0, 0);
+                if (r == 0 && kb + PFX < NB) fetchxw((kb + PFX) % PFX1, kb + PFX);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        if (ok) {
+            void* dxp = side ? a.dx1 : a.dx0;
+#pragma unroll
+            for (int q = 0; q < XBW; ++q) {
+                const int col = 16 * (XBW * wave + q) + 4 * g;
+                const f32x4 v = xacc[q];
+                if constexpr (DX == 2) {  // round to nearest even, as torch's .to(bfloat16)
+                    unsigned short* dst = reinterpret_cast<unsigned short*>(dxp) + pr * a.lddx + col;
+                    unsigned w[4];
+#pragma unroll
+                    for (int c = 0; c < 4; ++c) {
+                        const unsigned b = __float_as_uint(v[c]);
+                        w[c] = (b & 0x7fffffffu) > 0x7f800000u ? ((b >> 16) | 0x40u) : ((b + 0x7fffu + ((b >> 16) & 1u)) >> 16);
+                    }
+                    typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<u32x2*>(dst) = u32x2{w[0] | (w[1] << 16), w[2] | (w[3] << 16)};
+                } else {
+                    float* dst = reinterpret_cast<float*>(dxp) + pr * a.lddx + col;
+                    *reinterpret_cast<f32x4*>(dst) = v;
+                }
+            }
+        }
+    }
+}
+
+}  // namespace nplda

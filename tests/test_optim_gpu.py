@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from test_train_gpu import NC, model_from, rand_params
+from tests.test_train_gpu import NC, model_from, rand_params
 
 pytestmark = pytest.mark.gpu
 

@@ -405,9 +405,13 @@ def test_fused_train_step_matches_torch_adam(hip_lib, graph, lossname):
 
 
 def _same_step(a, b, D1, what, scale=1.0):
-    """Two tensors left by the one-call step and by the separate launches: the same bits (the small-batch kernels of both
-    paths assign feature blocks to waves the same way, at D = 150 the two left-over blocks by side)."""
-    assert torch.equal(a, b), (what, (a - b).abs().max().item())
+    """Two tensors left by the one-call step and by the separate launches: the same step to rounding.  (Round 5: the one-call
+    step's first kernel works on 8-pair half tiles at the recipe shapes, the separate forward / backward on 16-pair tiles —
+    the cross-wave and cross-pair sums associate differently, so the bits may differ; parity proper is against the fp64
+    oracle and autograd + torch.optim.Adam, test_fused_train_step_matches_torch_adam and the golden trajectories.)"""
+    a, b = a.double(), b.double()
+    tol = 2e-6 + 2e-4 * b.abs()
+    assert bool(((a - b).abs() <= tol).all()), (what, (a - b).abs().max().item())
 
 
 @pytest.mark.parametrize("lossname,B,D", [("SoftCdet", 4096, 150), ("SoftCdet", 1003, 170), ("crossentropy", 250, 150),
