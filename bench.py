@@ -475,10 +475,22 @@ def run_cfg3(args, ctx):
         emu_stats = ops.cohort_stats(zr0, qr0, zc0, qc0, packed, topn=topn).clone()
         del zc0, qc0, zr0, qr0
 
+    prepared_cohort = None
+    if getattr(args, "prepared_cohort", False):
+        # one cohort serves every trial list: embedded and pre-passed ONCE (adaptive_score_normalization.CohortState), outside
+        # the step — the step is then: embed this rank's rows -> statistics -> all-gather -> apply
+        zc_p, qc_p = ops.embed(x_coh, packed)
+        prepared_cohort = (zc_p, qc_p, ops.cohort_prepare(zc_p, qc_p, packed, topn=topn))
+
     def step():
-        (zr, qr), (zc, qc) = ops.embed_pair(x_rows[rlo:rhi], x_coh, packed)  # rows and cohort: one launch
+        if prepared_cohort is not None:
+            zc, qc, prep = prepared_cohort
+            zr, qr = ops.embed(x_rows[rlo:rhi], packed)
+        else:
+            prep = None
+            (zr, qr), (zc, qc) = ops.embed_pair(x_rows[rlo:rhi], x_coh, packed)  # rows and cohort: one launch
         ev["stats"][0].record()
-        local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn)
+        local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topn, prepared=prep)
         ev["stats"][1].record()
         ev["ag"][0].record()
         if ctx.dist is not None:
@@ -548,7 +560,10 @@ def run_cfg3(args, ctx):
         "dtype": "f32 scores, f64 statistics",
         "data": "synthetic",
         "config": {"workload": f"cfg3: cohort {M} x rows {R} ({n_enroll} enroll + {n_test} test) x {T} trials, top-{topn} "
-                               f"lowest, 512->{D}->{D}; rows and trials sharded x{world}, one all-gather of (R, 4) fp64",
+                               f"lowest, 512->{D}->{D}; rows and trials sharded x{world}, one all-gather of (R, 4) fp64" +
+                               ("; the cohort embedded and pre-passed ONCE outside the step (CohortState)"
+                                if prepared_cohort is not None else ""),
+                   "prepared_cohort": prepared_cohort is not None,
                    "cohort": M, "rows": R, "trials": T, "rows_per_gpu": rows_local, "trials_per_gpu": thi - tlo,
                    "parallelism": f"row shard + trial shard x{world}", "backend": ctx.backend if world > 1 else "single process",
                    "cohort_scores_per_s": (rows_local if ctx.emulated else R) * M * args.steps / elapsed, "stats_ms": stats_ms,
@@ -1179,6 +1194,8 @@ def main():
     ap.add_argument("--dp-graph", choices=["auto", "off"], default="auto",
                     help="cfg2 / cfg5 with N > 1: auto = the step's all-reduce captured inside its HIP graph (RCCL), off = eager "
                          "collectives between the step's launches")
+    ap.add_argument("--prepared-cohort", action="store_true",
+                    help="cfg3: the cohort embedded and pre-passed once outside the step (adaptive_score_normalization.CohortState)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", choices=["fp32", "bf16x3"], default="fp32",
                     help="kernel timed as `value`: exact fp32 MFMA (default) or the opt-in split-bf16 kernel")

@@ -296,6 +296,21 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
                            int D2, int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
                            nplda_stream_t stream);
 
+/* A PREPARED cohort.  One cohort serves every trial list scored against it (utils/adaptive_score_normalization.py:27-36 reads
+ * ONE cohort score table for all its trials), but the part of nplda_cohort_stats_f32 that depends on the cohort only — its
+ * second and first moments, folded with P into the covariance image the row thresholds are proposed from — is redone by
+ * every call, and by every rank of a row-sharded call.  nplda_cohort_prepare_f32 leaves it in `state`
+ * (nplda_cohort_state_bytes bytes, 256-byte aligned, caller-owned; 0 = this shape takes the spilling path, which has nothing
+ * to prepare); nplda_cohort_stats_prepared_f32 is nplda_cohort_stats_f32 reading it from there: same statistics, bit for bit.
+ * The state is valid for the (z_coh, q_coh, packed, topn) it was prepared with. */
+size_t nplda_cohort_state_bytes(int64_t M, int topn, int D1, int D2);
+int nplda_cohort_prepare_f32(const float* z_coh, const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0,
+                             int D1, int D2, int topn, void* state, size_t state_bytes, nplda_stream_t stream);
+int nplda_cohort_stats_prepared_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                                    const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1,
+                                    int D2, int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                                    const void* state, size_t state_bytes, nplda_stream_t stream);
+
 /* The row-statistics half alone, on a caller-provided (R, lds) fp32 score matrix (e.g. cohort scores
  * parsed from the TSV the reference consumes, adaptive_score_normalization.py:27-36). */
 int nplda_row_stats_f32(const float* S, int64_t lds, int64_t R, int64_t M, int topn, int select_lowest,

@@ -56,6 +56,11 @@ SIGNATURES = {
     "nplda_cohort_workspace_bytes_ex": (_c_sz, [_c_i64, _c_i64, _c_int, _c_int, _c_int]),
     "nplda_cohort_stats_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int,
                                         _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "nplda_cohort_state_bytes": (_c_sz, [_c_i64, _c_int, _c_int, _c_int]),
+    "nplda_cohort_prepare_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int, _c_int, _c_int, _c_int, _c_vp, _c_sz,
+                                          _c_vp]),
+    "nplda_cohort_stats_prepared_f32": (_c_int, [_c_f32p, _c_f32p, _c_i64, _c_f32p, _c_f32p, _c_i64, _c_i64, _c_vp, _c_int,
+                                                 _c_int, _c_int, _c_int, _c_int, _c_vp, _c_vp, _c_sz, _c_vp, _c_sz, _c_vp]),
     "nplda_row_stats_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_i64, _c_int, _c_int, _c_vp, _c_vp]),
     "nplda_asnorm_apply_f64": (_c_int, [_c_vp, _c_vp, _c_vp, _c_i64, _c_vp, _c_i64, _c_vp, _c_vp]),
     "gb_packed_bytes": (_c_sz, [_c_int, _c_int]),

@@ -24,7 +24,7 @@ import torch
 from . import dist as ndist
 from . import ops
 
-__all__ = ["ASnorm_topN", "normalize_scorefile", "asnorm_scores", "cohort_row_stats"]
+__all__ = ["ASnorm_topN", "normalize_scorefile", "asnorm_scores", "cohort_row_stats", "CohortState"]
 
 ASnorm_topN = 500  # utils/adaptive_score_normalization.py:12
 
@@ -81,32 +81,66 @@ def normalize_scorefile(raw_score_filename, cohort_score_filename, topN=ASnorm_t
     return res
 
 
-def cohort_row_stats(z_rows, q_rows, z_coh, q_coh, packed, topN=ASnorm_topN, select="lowest", group=None):
+def _model_params(model, dev):
+    return [t.detach().float().to(dev) for t in (model.centering_and_LDA.weight, model.centering_and_LDA.bias,
+                                                 model.centering_and_wccn_plda.weight,
+                                                 model.centering_and_wccn_plda.bias, model.P_sqrt, model.Q)]
+
+
+class CohortState:
+    """A cohort made ready ONCE per (model, cohort, top-N) for every trial list scored against it
+    (utils/adaptive_score_normalization.py:27-36 reads one cohort score table for all of its trials): the parameter
+    image, the cohort's embeddings `z_coh`, `q_coh` (utils/models.py:366-370 per cohort utterance) and what
+    nplda_cohort_stats_f32 derives from the cohort alone (Gram matrix, first moments, the covariance image its row
+    thresholds are proposed from: nplda_cohort_prepare_f32).  Without it every `asnorm_scores` call — and every RANK of a
+    row-sharded call — embeds the cohort and redoes that pre-pass: 63 us of the 250 us a rank spends on an eighth of
+    cfg3.  Build with `CohortState.build(model, x_cohort, topN)`; hand it to `asnorm_scores(..., cohort=state)` or
+    `cohort_row_stats(..., prepared=state.prepared)`.  Valid while the model's parameters are unchanged."""
+
+    def __init__(self, packed, z_coh, q_coh, prepared, topN):
+        self.packed, self.z_coh, self.q_coh, self.prepared, self.topN = packed, z_coh, q_coh, prepared, int(topN)
+
+    @classmethod
+    def build(cls, model, x_cohort, topN=ASnorm_topN):
+        dev = x_cohort.device
+        with torch.no_grad():
+            packed = ops.pack_params(*_model_params(model, dev))
+            zc, qc = ops.embed(x_cohort, packed)
+            return cls(packed, zc, qc, ops.cohort_prepare(zc, qc, packed, topn=topN), topN)
+
+
+def cohort_row_stats(z_rows, q_rows, z_coh, q_coh, packed, topN=ASnorm_topN, select="lowest", group=None, prepared=None):
     """(R, 4) float64 statistics of every row against the whole cohort; rows are sharded over the ranks
-    of `group` (each rank needs complete cohort rows for its top-N) and the statistics all-gathered."""
+    of `group` (each rank needs complete cohort rows for its top-N) and the statistics all-gathered.
+    prepared: ops.cohort_prepare(z_coh, q_coh, packed, topN) (or CohortState.prepared) — the cohort-only pre-pass, once."""
     R = z_rows.shape[0]
     rank, ws = ndist.world(group)
     lo, hi = ndist.shard_bounds(R, ws, rank)
-    local = ops.cohort_stats(z_rows[lo:hi], q_rows[lo:hi], z_coh, q_coh, packed, topn=topN, select=select)
+    local = ops.cohort_stats(z_rows[lo:hi], q_rows[lo:hi], z_coh, q_coh, packed, topn=topN, select=select, prepared=prepared)
     return ndist.all_gather_rows(local, R, group)
 
 
-def asnorm_scores(model, x_rows, x_cohort, raw, ie, it, topN=ASnorm_topN, select="lowest", group=None):
+def asnorm_scores(model, x_rows, x_cohort, raw, ie, it, topN=ASnorm_topN, select="lowest", group=None, cohort=None):
     """Device pipeline: x_rows (R, D0) enroll+test x-vectors, x_cohort (M, D0), raw (T,) raw trial scores,
     ie / it (T,) row indices of each trial's enroll / test utterance.  Returns (T, 4) float64 on the device
-    (columns znorm, tnorm, snorm, asnorm1).  With a process group, rows AND trials are sharded."""
+    (columns znorm, tnorm, snorm, asnorm1).  With a process group, rows AND trials are sharded.
+    cohort: a CohortState built once for this (model, x_cohort, topN) — x_cohort is then not touched (may be None)."""
     dev = x_rows.device
-    prm = [t.detach().float().to(dev) for t in (model.centering_and_LDA.weight, model.centering_and_LDA.bias,
-                                                model.centering_and_wccn_plda.weight,
-                                                model.centering_and_wccn_plda.bias, model.P_sqrt, model.Q)]
     with torch.no_grad():
-        packed = ops.pack_params(*prm)
         rank, ws = ndist.world(group)
         R = x_rows.shape[0]
         lo, hi = ndist.shard_bounds(R, ws, rank)
-        # this rank's rows and the (replicated) cohort in ONE embedding launch (nplda_embed_pair_f32)
-        (zr, qr), (zc, qc) = ops.embed_pair(x_rows[lo:hi], x_cohort, packed)
-        local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topN, select=select)
+        if cohort is not None:
+            if cohort.topN != int(topN):
+                raise ValueError("the CohortState was prepared for another top-N")
+            packed, zc, qc = cohort.packed, cohort.z_coh, cohort.q_coh
+            zr, qr = ops.embed(x_rows[lo:hi], packed)
+            local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topN, select=select, prepared=cohort.prepared)
+        else:
+            packed = ops.pack_params(*_model_params(model, dev))
+            # this rank's rows and the (replicated) cohort in ONE embedding launch (nplda_embed_pair_f32)
+            (zr, qr), (zc, qc) = ops.embed_pair(x_rows[lo:hi], x_cohort, packed)
+            local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topN, select=select)
         stats = ndist.all_gather_rows(local, R, group)  # the ONE exchange step: R x 4 doubles
         raw = torch.as_tensor(raw)
         T = raw.shape[0]

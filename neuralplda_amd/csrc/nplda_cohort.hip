@@ -905,10 +905,53 @@ size_t nplda_cohort_fused_min_workspace_bytes(int64_t M, int topn, int D1, int D
     return p.eligible ? fused_workspace_bytes(p, 128, M) : 0;
 }
 
+size_t nplda_cohort_state_bytes(int64_t M, int topn, int D1, int D2) {
+    if (M <= 0 || nplda_kernel_nb(D1, D2) == 0) return 0;
+    const nplda::FusedPlan p = nplda::cohort_fused_plan(M, topn, 16 * nplda_kernel_nb(D1, D2));
+    return p.eligible ? p.fixed_bytes : 0;
+}
+
+int nplda_cohort_prepare_f32(const float* z_coh, const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1,
+                             int D2, int topn, void* state, size_t state_bytes, nplda_stream_t stream) {
+    if (M <= 0 || topn < 1 || M > 0x7ffffff0LL) return NPLDA_EINVAL;
+    if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
+    if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
+    const NpldaLayout L = nplda_layout(D0, D1, D2);
+    if (!z_coh || !q_coh || !packed || !state || ((uintptr_t)state & 255u) != 0) return NPLDA_EINVAL;
+    if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z_coh) || !nplda_aligned16(packed)) return NPLDA_EINVAL;
+    const nplda::FusedPlan plan = nplda::cohort_fused_plan(M, topn, 16 * L.NB);
+    if (!plan.eligible) return NPLDA_EUNSUPPORTED;
+    if (state_bytes < plan.fixed_bytes) return NPLDA_ENOSPC;
+    return nplda::cohort_fused_prepare(plan, z_coh, q_coh, M, ldz, (const float*)packed + L.oP, L.NB, (unsigned char*)state,
+                                       (hipStream_t)stream);
+}
+
+static int cohort_stats_impl(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                             const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1, int D2,
+                             int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                             nplda_stream_t stream, const void* prepared, size_t prepared_bytes);
+
 int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
                            const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1, int D2,
                            int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
                            nplda_stream_t stream) {
+    return cohort_stats_impl(z_rows, q_rows, R, z_coh, q_coh, M, ldz, packed, D0, D1, D2, topn, select_lowest, stats, ws,
+                             ws_bytes, stream, nullptr, 0);
+}
+
+int nplda_cohort_stats_prepared_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                                    const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1, int D2,
+                                    int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                                    const void* state, size_t state_bytes, nplda_stream_t stream) {
+    if (!state || ((uintptr_t)state & 255u) != 0) return NPLDA_EINVAL;
+    return cohort_stats_impl(z_rows, q_rows, R, z_coh, q_coh, M, ldz, packed, D0, D1, D2, topn, select_lowest, stats, ws,
+                             ws_bytes, stream, state, state_bytes);
+}
+
+static int cohort_stats_impl(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
+                             const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1, int D2,
+                             int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
+                             nplda_stream_t stream, const void* prepared, size_t prepared_bytes) {
     if (R < 0 || M < 0 || topn < 1) return NPLDA_EINVAL;
     if (D0 <= 0 || D1 <= 0 || D2 <= 0 || (D0 % 4) != 0) return NPLDA_EINVAL;
     if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
@@ -937,6 +980,9 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
     // Chosen by the shape (M, top-N) alone, and every row is computed independently of its neighbours, so the result of
     // a row does not depend on R, on the row's position or on how the workspace chunks the table.
     const nplda::FusedPlan plan = nplda::cohort_fused_plan(M, topn, 16 * L.NB);
+    // a prepared cohort (nplda_cohort_prepare_f32) belongs to the fused path of exactly this shape and top-N
+    if (prepared && (!plan.eligible || prepared_bytes < plan.fixed_bytes || ws_bytes < fused_workspace_bytes(plan, 128, M)))
+        return NPLDA_EINVAL;
     if (plan.eligible && ws_bytes >= fused_workspace_bytes(plan, 128, M)) {
         const size_t scratch_bytes = (size_t)kFallbackBlocks * lds * sizeof(float);
         long long rows_cap = (long long)((ws_bytes - plan.fixed_bytes - scratch_bytes - 256) / plan.row_bytes) / 128 * 128;
@@ -952,7 +998,7 @@ int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, 
             if (int rc2 = nplda::cohort_fused_run(plan, z_rows + r0 * ldz, q_rows + r0, rc, z_coh, q_coh, M, ldz,
                                                   (const float*)packed + L.oP, L.NB, topn, select_lowest ? 1 : 0,
                                                   stats + 4 * r0, (unsigned char*)ws, rows_cap, r0 == 0, &fail_rows,
-                                                  &nfail, resident, st))
+                                                  &nfail, resident, st, (const unsigned char*)prepared))
                 return rc2;
             FallbackArgs fb;
             fb.zr = z_rows + r0 * ldz; fb.qr = q_rows + r0; fb.zc = z_coh; fb.qc = q_coh; fb.P = (const float*)packed + L.oP;

@@ -18,9 +18,15 @@ struct FusedPlan {
 
 FusedPlan cohort_fused_plan(long long M, int topn, int Mp);
 long long cohort_fused_resident_blocks();
+// prepared: the fixed part of a workspace in which cohort_fused_prepare has left the cohort's moments (a CohortState): the
+// pre-pass is skipped and the covariance image / moment vectors are read from there.
 int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
                      const float* q_coh, long long M, long long ldz, const float* P, int ksteps, int topn, int lowest,
                      double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
-                     unsigned** nfail_out, long long resident, hipStream_t st);
+                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared = nullptr);
+// The cohort-only part of the fused path (Gram matrix + first moments, covariance image folded with P) into `state`
+// (plan.fixed_bytes bytes, 256-byte aligned): what every call on the same (model, cohort) would recompute.
+int cohort_fused_prepare(const FusedPlan& p, const float* z_coh, const float* q_coh, long long M, long long ldz, const float* P,
+                         int ksteps, unsigned char* state, hipStream_t st);
 
 }  // namespace nplda

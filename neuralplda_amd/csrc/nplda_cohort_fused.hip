@@ -796,20 +796,63 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
 
 // Runs the fused path on rows [0, R) (R <= the rows the workspace was planned for).  `fail_rows` / `nfail` (device)
 // receive the rows that need the general path; the caller runs cohort_fallback_kernel on them.
+// the fixed part of a workspace (FusedPlan::fixed_bytes): control block, the pre-pass's scratch and its results
+struct FusedFixed {
+    unsigned* ctl; float* slab; float* ext; float* qz; double* qz64; double* vec64; float* frag; float* vec; unsigned char* end;
+};
+static FusedFixed fused_fixed(unsigned char* ws, int Mp) {
+    FusedFixed f;
+    unsigned char* q = ws;
+    f.ctl = reinterpret_cast<unsigned*>(q); q += 256;
+    f.slab = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * Mp * Mp * 4);
+    f.ext = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * 4 * Mp * 4);
+    f.qz = reinterpret_cast<float*>(q); q += align256((size_t)kQzBlocks * (Mp + 2) * 4);
+    f.qz64 = reinterpret_cast<double*>(q); q += align256((size_t)kQzBlocks * (Mp + 1) * 8);
+    f.vec64 = reinterpret_cast<double*>(q); q += align256((size_t)(Mp + 1) * 8);
+    f.frag = reinterpret_cast<float*>(q); q += align256((size_t)(Mp / 16) * (Mp / 16) * 256 * 4);
+    f.vec = reinterpret_cast<float*>(q); q += align256((size_t)(2 * Mp + 2) * 4);
+    f.end = q;
+    return f;
+}
+
+// cohort moments: second and first moments of the cohort in ONE launch (the first-moment blocks ride along as extra work
+// items), then the centred covariance folded with 2 P into a fragment image
+static int fused_prepass(const FusedFixed& F, const float* z_coh, const float* q_coh, long long M, long long ldz, const float* P,
+                         int Mp, hipStream_t st) {
+    const QzArgs qa = {z_coh, q_coh, M, ldz, Mp, kQzBlocks, F.qz, F.qz64};
+    if (int rc = gram_slabs_launch(z_coh, ldz, M, Mp, kGramSplit, F.slab, F.ext, &qa, st)) return rc;
+    PrepArgs pa = {F.slab, F.ext, F.qz, F.qz64, P, kGramSplit, Mp, M, F.frag, F.vec, F.vec64, F.ctl};
+    // ksplit actually used by gram_slabs_launch: rows per split rounded up -> some trailing slabs may be unwritten
+    {
+        long long rps = (M + kGramSplit - 1) / kGramSplit;
+        rps = (rps + 63) / 64 * 64;
+        pa.ksplit = (int)((M + rps - 1) / rps);
+    }
+    const size_t nfrag = (size_t)(Mp / 16) * (Mp / 16) * 256;
+    hipLaunchKernelGGL(cohort_prep_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, pa);
+    return nplda_launch_status();
+}
+
+int cohort_fused_prepare(const FusedPlan& p, const float* z_coh, const float* q_coh, long long M, long long ldz, const float* P,
+                         int ksteps, unsigned char* state, hipStream_t st) {
+    if (!p.eligible) return NPLDA_EUNSUPPORTED;
+    return fused_prepass(fused_fixed(state, 16 * ksteps), z_coh, q_coh, M, ldz, P, 16 * ksteps, st);
+}
+
 int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
                      const float* q_coh, long long M, long long ldz, const float* P, int ksteps, int topn, int lowest,
                      double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
-                     unsigned** nfail_out, long long resident, hipStream_t st) {
+                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared) {
     const int Mp = 16 * ksteps;
-    unsigned char* q = ws;
-    unsigned* ctl = reinterpret_cast<unsigned*>(q); q += 256;
-    float* slab = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * Mp * Mp * 4);
-    float* ext = reinterpret_cast<float*>(q); q += align256((size_t)kGramSplit * 4 * Mp * 4);
-    float* qz = reinterpret_cast<float*>(q); q += align256((size_t)kQzBlocks * (Mp + 2) * 4);
-    double* qz64 = reinterpret_cast<double*>(q); q += align256((size_t)kQzBlocks * (Mp + 1) * 8);
-    double* vec64 = reinterpret_cast<double*>(q); q += align256((size_t)(Mp + 1) * 8);
-    float* frag = reinterpret_cast<float*>(q); q += align256((size_t)(Mp / 16) * (Mp / 16) * 256 * 4);
-    float* vec = reinterpret_cast<float*>(q); q += align256((size_t)(2 * Mp + 2) * 4);
+    const FusedFixed F = fused_fixed(ws, Mp);
+    unsigned* ctl = F.ctl;
+    unsigned char* q = F.end;
+    // (a prepared cohort: its covariance image and moment vectors are read where cohort_fused_prepare left them)
+    const FusedFixed FP = prepared ? fused_fixed(const_cast<unsigned char*>(prepared), Mp) : F;
+    const double* vec64 = FP.vec64;
+    const float* frag = FP.frag;
+    const float* vec = FP.vec;
+    if (prepared) prepass = false;
     // per-row arrays, sized for rows_cap rows
     double* part = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * (p.nsub / 4) * 8);
     double* mean64 = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * 8);
@@ -823,19 +866,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
 
     if (!prepass && hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NPLDA_EINVAL;  // (the pre-pass zeroes it itself)
     if (prepass) {  // cohort moments: once per call, the cohort does not change between row chunks
-        // second and first moments of the cohort in ONE launch (the first-moment blocks ride along as extra work items)
-        const QzArgs qa = {z_coh, q_coh, M, ldz, Mp, kQzBlocks, qz, qz64};
-        if (int rc = gram_slabs_launch(z_coh, ldz, M, Mp, kGramSplit, slab, ext, &qa, st)) return rc;
-        PrepArgs pa = {slab, ext, qz, qz64, P, kGramSplit, Mp, M, frag, vec, vec64, ctl};
-        // ksplit actually used by gram_slabs_launch: rows per split rounded up -> some trailing slabs may be unwritten
-        {
-            long long rps = (M + kGramSplit - 1) / kGramSplit;
-            rps = (rps + 63) / 64 * 64;
-            pa.ksplit = (int)((M + rps - 1) / rps);
-        }
-        const size_t nfrag = (size_t)(Mp / 16) * (Mp / 16) * 256;
-        hipLaunchKernelGGL(cohort_prep_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, pa);
-        if (int rc = nplda_launch_status()) return rc;
+        if (int rc = fused_prepass(F, z_coh, q_coh, M, ldz, P, Mp, st)) return rc;
     }
     {   // row means and thresholds
         RowThrArgs ra = {z_rows, q_rows, R, ldz, frag, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64,

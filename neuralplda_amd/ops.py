@@ -960,8 +960,42 @@ def gather_pairs_mapped(table, num_map, num1, num2):
 
 # ---- adaptive score normalisation -----------------------------------------------------------------
 
+class PreparedCohort:
+    """What nplda_cohort_stats_f32 derives from the cohort alone (nplda_cohort_prepare_f32), kept for the calls that follow:
+    `state` is None when the shape takes the spilling path (nothing to prepare)."""
+    __slots__ = ("state", "M", "topn", "ldz", "key")
+
+    def __init__(self, state, M, topn, ldz, key):
+        self.state, self.M, self.topn, self.ldz, self.key = state, M, topn, ldz, key
+
+
+def cohort_prepare(z_coh, q_coh, packed, topn=500):
+    """nplda_cohort_prepare_f32: the cohort-only part of cohort_stats (Gram matrix, first moments, the covariance image the
+    row thresholds are proposed from), once per (model, cohort, top-N) -> PreparedCohort for cohort_stats(prepared=...)."""
+    lib = _lib.load()
+    _need_fp32(packed, "cohort_prepare")
+    _require_dev_f32(z_coh, "z_coh")
+    _require_dev_f32(q_coh, "q_coh")
+    if z_coh.stride(0) != packed.ldz:
+        raise ValueError("z_coh must come from embed() (row stride = packed.ldz)")
+    M = z_coh.shape[0]
+    key = (z_coh.data_ptr(), q_coh.data_ptr(), packed.buf.data_ptr(), packed.buf._version if not packed.buf.is_inference() else 0)
+    nb = lib.nplda_cohort_state_bytes(M, int(topn), packed.D1, packed.D2) if M > 0 else 0
+    if nb == 0:
+        return PreparedCohort(None, M, int(topn), packed.ldz, key)
+    state = torch.empty((nb + 255) // 4 + 64, dtype=torch.float32, device=z_coh.device)
+    off = (-state.data_ptr()) % 256 // 4
+    state = state[off:off + (nb + 3) // 4]  # 256-byte aligned view
+    qc = q_coh.contiguous()
+    with _lib.on_device(z_coh.device):
+        code = lib.nplda_cohort_prepare_f32(_lib.ptr(z_coh), _lib.ptr(qc), M, packed.ldz, _lib.ptr(packed.buf), packed.D0,
+                                            packed.D1, packed.D2, int(topn), _lib.ptr(state), nb, _lib.current_stream())
+    _lib.check(code, "nplda_cohort_prepare_f32")
+    return PreparedCohort(state, M, int(topn), packed.ldz, key)
+
+
 def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest", max_ws_bytes=None, force_spill=False,
-                 return_fallback_rows=False):
+                 return_fallback_rows=False, prepared=None):
     """nplda_cohort_stats_f32: (R, 4) float64 rows of (mean, std, mean_top, std_top).  force_spill (tests / A-B timing):
     hand the call a workspace just below the fused path's minimum, so that it materialises the score matrix.
     return_fallback_rows (diagnostics): also return how many rows of the (last chunk of the) fused path were handed to the
@@ -994,12 +1028,22 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
             if wsb < 256 + ((M + 3) // 4 * 4) * 4:
                 raise ValueError("no workspace size selects the spilling path for this shape")
     ws = torch.empty(wsb // 4, dtype=torch.float32, device=dev)
+    use_prep = prepared is not None and prepared.state is not None and not force_spill
+    if prepared is not None and (prepared.M != M or prepared.topn != int(topn) or prepared.ldz != packed.ldz):
+        raise ValueError("prepared cohort does not belong to this cohort table / top-N")
     with _lib.on_device(dev):
-        code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),
-                                          _lib.ptr(q_coh.contiguous()), M, packed.ldz, _lib.ptr(packed.buf), packed.D0,
-                                          packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0,
-                                          _lib.ptr(stats), _lib.ptr(ws), wsb, _lib.current_stream())
-    _lib.check(code, "nplda_cohort_stats_f32")
+        if use_prep:
+            st = prepared.state
+            code = lib.nplda_cohort_stats_prepared_f32(
+                _lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh), _lib.ptr(q_coh.contiguous()), M, packed.ldz,
+                _lib.ptr(packed.buf), packed.D0, packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0, _lib.ptr(stats),
+                _lib.ptr(ws), wsb, _lib.ptr(st), st.numel() * 4, _lib.current_stream())
+        else:
+            code = lib.nplda_cohort_stats_f32(_lib.ptr(z_rows), _lib.ptr(q_rows.contiguous()), R, _lib.ptr(z_coh),
+                                              _lib.ptr(q_coh.contiguous()), M, packed.ldz, _lib.ptr(packed.buf), packed.D0,
+                                              packed.D1, packed.D2, int(topn), 1 if select == "lowest" else 0,
+                                              _lib.ptr(stats), _lib.ptr(ws), wsb, _lib.current_stream())
+    _lib.check(code, "nplda_cohort_stats_prepared_f32" if use_prep else "nplda_cohort_stats_f32")
     if return_fallback_rows:
         fused = lib.nplda_cohort_fused_min_workspace_bytes(M, int(topn), packed.D1, packed.D2)
         return stats, (int(ws.view(torch.int32)[8].item()) if fused and wsb >= fused else None)

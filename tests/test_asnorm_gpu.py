@@ -262,3 +262,43 @@ def test_cohort_stats_shape_sweep(hip_lib):
             C = orc.cohort_scores(orc.extract_plda_embeddings(xr, p, np.float64),
                                   orc.extract_plda_embeddings(xc, p, np.float64), p, np.float64)
             np.testing.assert_allclose(got, orc.cohort_stats(C, topn), atol=2e-5, rtol=2e-5, err_msg=f"R={R} M={M}")
+
+
+def test_prepared_cohort_gives_the_same_statistics(hip_lib):
+    """nplda_cohort_prepare_f32 + nplda_cohort_stats_prepared_f32 (a CohortState: the cohort's pre-pass once per (model,
+    cohort, top-N)) against nplda_cohort_stats_f32: the same kernels on the same inputs — bit-identical statistics — for
+    whole tables, row shards and both selections; asnorm_scores(cohort=state) equals asnorm_scores(x_cohort)."""
+    from neuralplda_amd import adaptive_score_normalization as asn
+    from neuralplda_amd import models, ops
+    from tests.test_train_gpu import NC, model_from, rand_params
+    rng = np.random.default_rng(41)
+    D, R, M = 150, 1500, 6000
+    m = model_from(rand_params(rng, 512, D, D), NC(D1=D, D2=D))
+    xr = torch.from_numpy(rng.standard_normal((R, 512)).astype(np.float32)).cuda()
+    xc = torch.from_numpy(rng.standard_normal((M, 512)).astype(np.float32)).cuda()
+    state = asn.CohortState.build(m, xc, topN=500)
+    assert state.prepared.state is not None  # the fused path's shape: there IS something to prepare
+    packed = state.packed
+    zr, qr = ops.embed(xr, packed)
+    for sel in ("lowest", "highest"):
+        ref = ops.cohort_stats(zr, qr, state.z_coh, state.q_coh, packed, topn=500, select=sel)
+        got = ops.cohort_stats(zr, qr, state.z_coh, state.q_coh, packed, topn=500, select=sel, prepared=state.prepared)
+        assert torch.equal(ref, got)
+        part = ops.cohort_stats(zr[300:900], qr[300:900], state.z_coh, state.q_coh, packed, topn=500, select=sel,
+                                prepared=state.prepared)
+        assert torch.equal(part, ref[300:900])  # a rank's row shard gives exactly the single-GPU rows
+    T = 20000
+    raw = torch.from_numpy(rng.standard_normal(T)).cuda()
+    ie = torch.from_numpy(rng.integers(0, 200, T)).cuda()
+    it = torch.from_numpy(rng.integers(200, R, T)).cuda()
+    a = asn.asnorm_scores(m, xr, xc, raw, ie, it, topN=500)
+    b = asn.asnorm_scores(m, xr, None, raw, ie, it, topN=500, cohort=state)
+    assert torch.equal(a, b)
+    with pytest.raises(ValueError):
+        asn.asnorm_scores(m, xr, None, raw, ie, it, topN=300, cohort=state)
+    # a small cohort takes the spilling path: nothing to prepare, same results
+    small = asn.CohortState.build(m, xc[:1000], topN=100)
+    assert small.prepared.state is None
+    s1 = ops.cohort_stats(zr, qr, small.z_coh, small.q_coh, packed, topn=100)
+    s2 = ops.cohort_stats(zr, qr, small.z_coh, small.q_coh, packed, topn=100, prepared=small.prepared)
+    assert torch.equal(s1, s2)

@@ -27,6 +27,8 @@ def main():
             ("cfg2 strong (4096-pair batch / N)", ["--workload", "cfg2", "--scaling", "strong", "--steps", "300", "--warmup", "30"], "pairs"),
             ("cfg2 weak (4096 pairs per rank)", ["--workload", "cfg2", "--scaling", "weak", "--steps", "300", "--warmup", "30"], "pairs"),
             ("cfg3 (22 000 rows, 2 M trials / N; cohort 10 000 replicated)", ["--workload", "cfg3", "--steps", "20", "--warmup", "3"], "trials"),
+            ("cfg3 with a prepared cohort (CohortState: the cohort embedded and pre-passed once, outside the step)",
+             ["--workload", "cfg3", "--steps", "20", "--warmup", "3", "--prepared-cohort"], "trials"),
             ("cfg5 weak (head step with dL/dx, 4096 bf16 pairs per rank)", ["--workload", "cfg5", "--steps", "300", "--warmup", "30"], "pairs")]
     for title, argv, unit in jobs:
         base = None
