@@ -953,12 +953,18 @@ def run_secondary(args, ctx):
         NC.loss = loss
         return NC
 
+    part = getattr(args, "part", "all")
+    lean = part != "all"  # a PMC pass of ONE kernel family: only that family's headline launches
+
+    def want(p):
+        return part in ("all", p)
+
     # ---- Regime B ---------------------------------------------------------------------------------------------------
     B, N = 1 << 20, 1200000
     rb = {"workload": f"Regime B (SURVEY 8d): {B} index pairs over a pre-embedded {N}-utterance table (VoxCeleb scale; "
                       f"the table is 3x the 256 MB Infinity Cache: NOT cache-resident), nplda_score_indexed_f32",
           "unit": "pairs/s", "bound": "hbm", "peak": HBM_PEAK_TBPS}
-    for D in (150, 170):
+    for D in ((150, 170) if not lean else (args.dim,)) if want("regimeB") else ():
         params, _ = make_params(D, dev)
         packed = ops.pack_params(*params)
         zb = torch.empty(N, packed.ldz, device=dev)
@@ -971,6 +977,9 @@ def run_secondary(args, ctx):
         ms, sc = kernel_ms_of(lambda: ops.score_indexed(zb, qb, j1, j2, packed))
         bpp = 2 * 4 * D + 2 * 4 + 2 * 8 + 4
         ach = B * bpp / (ms * 1e-3) / 1e12
+        if lean:
+            rb[f"d{D}"] = {"value": B / (ms * 1e-3), "kernel_ms": ms, "frac": ach / HBM_PEAK_TBPS}
+            continue
         # the same call on a cache-resident table (100 k utterances, 64 MB)
         ns = 100000
         k1, k2 = j1 % ns, j2 % ns
@@ -987,8 +996,14 @@ def run_secondary(args, ctx):
                                            "frac_of_fp32_mfma_peak": ns * fe / (ms_e * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
                        "checksum_finite": bool(torch.isfinite(sc).all().item())}
         del zb, qb, j1, j2, X
-    out["alt_regimeB"] = rb
+    if want("regimeB"):
+        out["alt_regimeB"] = rb
     torch.cuda.empty_cache()
+    if lean and part not in ("gb", "dplda"):
+        if want("minc"):
+            pass
+        else:
+            return out
 
     # ---- GaussianBackend.forward ------------------------------------------------------------------------------------
     D1 = 170
@@ -1002,26 +1017,27 @@ def run_secondary(args, ctx):
     Bg = 1 << 19
     x1 = torch.randn(Bg, 512, device=dev, generator=gen)
     x2 = torch.randn(Bg, 512, device=dev, generator=gen)
-    ms_g, sg = kernel_ms_of(lambda: ops._gb_call(x1, x2, gpk, True, False)[0], reps=5)
-    # the reference evaluates TWO quadratic forms per pair, -(x - mu_t)' L_t (x - mu_t) + (x - mu_n)' L_n (x - mu_n): 4 (2 D1)^2
-    # FLOP (810 560 per pair with the LDA); algebraically they are ONE, x' (L_n - L_t) x + v' x + c, and that is
-    # what the kernel runs: 2 (2 D1)^2.  `frac` prices the EXECUTED count (a fraction of the matrix pipe's peak); the pair
-    # rate against the reference's count would read above 1.
-    fg_ref = 2 * 2 * 512 * D1 + 4 * (2 * D1) ** 2
-    fg = 2 * 2 * 512 * D1 + 2 * (2 * D1) ** 2
-    ach = Bg * fg / (ms_g * 1e-3) / 1e12
-    out["alt_gb"] = {"workload": f"GaussianBackend.forward (utils/models.py:584-593): {Bg} pairs, 512 -> {D1}, full "
-                                 f"{2 * D1} x {2 * D1} precision matrices (gb_score_pairs_f32)",
-                     "value": Bg / (ms_g * 1e-3), "unit": "pairs/s", "kernel_ms": ms_g, "bound": "mfma", "achieved": ach,
-                     "peak": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "flop_per_pair_algorithmic": fg,
-                     "flop_per_pair_as_the_reference_evaluates_it": fg_ref,
-                     "traffic": _traffic(f"gb_score_D{D1}_B{Bg}"), "checksum_finite": bool(torch.isfinite(sg).all().item())}
+    if want("gb"):
+        ms_g, sg = kernel_ms_of(lambda: ops._gb_call(x1, x2, gpk, True, False)[0], reps=5)
+        # the reference evaluates TWO quadratic forms per pair, -(x - mu_t)' L_t (x - mu_t) + (x - mu_n)' L_n (x - mu_n): 4 (2 D1)^2
+        # FLOP (810 560 per pair with the LDA); algebraically they are ONE, x' (L_n - L_t) x + v' x + c, and that is
+        # what the kernel runs: 2 (2 D1)^2.  `frac` prices the EXECUTED count (a fraction of the matrix pipe's peak); the pair
+        # rate against the reference's count would read above 1.
+        fg_ref = 2 * 2 * 512 * D1 + 4 * (2 * D1) ** 2
+        fg = 2 * 2 * 512 * D1 + 2 * (2 * D1) ** 2
+        ach = Bg * fg / (ms_g * 1e-3) / 1e12
+        out["alt_gb"] = {"workload": f"GaussianBackend.forward (utils/models.py:584-593): {Bg} pairs, 512 -> {D1}, full "
+                                     f"{2 * D1} x {2 * D1} precision matrices (gb_score_pairs_f32)",
+                         "value": Bg / (ms_g * 1e-3), "unit": "pairs/s", "kernel_ms": ms_g, "bound": "mfma", "achieved": ach,
+                         "peak": FP32_MFMA_PEAK_TFLOPS, "frac": ach / FP32_MFMA_PEAK_TFLOPS, "flop_per_pair_algorithmic": fg,
+                         "flop_per_pair_as_the_reference_evaluates_it": fg_ref,
+                         "traffic": _traffic(f"gb_score_D{D1}_B{Bg}"), "checksum_finite": bool(torch.isfinite(sg).all().item())}
 
     # ---- the DPlda recipe step --------------------------------------------------------------------------------------
     dpl = {"workload": "xvector_DPlda_pytorch.py:35-43: DPlda.forward -> loss -> backward -> Adam(1e-4, wd 1e-5) on the linear "
                        "unit and thresholds, LDA frozen (:140-147), 512 -> 170, as ONE graph replay (train.FusedDPldaStep)",
            "unit": "pairs/s", "bound": "mfma", "peak": FP32_MFMA_PEAK_TFLOPS}
-    for Bd, lossname in ((256, "crossentropy"), (2048, "crossentropy"), (2048, "SoftCdet")):
+    for Bd, lossname in ((256, "crossentropy"), (2048, "crossentropy"), (2048, "SoftCdet")) if want("dplda") else ():
         torch.manual_seed(5)
         dp = models.DPlda(NCd(D1, lossname)).to(dev)
         for prm in dp.centering_and_LDA.parameters():
@@ -1029,22 +1045,29 @@ def run_secondary(args, ctx):
         fstep = train.FusedDPldaStep(dp, 1e-4, weight_decay=1e-5, batch_size=Bd, graph=True)
         xa, xb = x1[:Bd].contiguous(), x2[:Bd].contiguous()
         tt = (torch.rand(Bd, device=dev, generator=gen) < 0.1).float()
-        fstep(xa, xb, tt)
+        fstep(xa, xb, tt)  # (captures the graph and leaves the batch in the step's own buffers)
         t_end = time.perf_counter() + 0.05
         while time.perf_counter() < t_end:
             fstep(xa, xb, tt)
-        ms_d, ld = kernel_ms_of(lambda: fstep(xa, xb, tt), reps=100, batches=5, warm=20)
+        ms_c, _ = kernel_ms_of(lambda: fstep(xa, xb, tt), reps=100, batches=5, warm=20)  # + three staging copies
+        # the timed form: the minibatch already sits in the step's input buffers (as for cfg1 / cfg5: inputs resident)
+        ms_d, ld = kernel_ms_of(lambda: fstep(fstep.x1, fstep.x2, fstep.t), reps=100, batches=5, warm=20)
         # forward (LDA both sides + the quadratic form) + the gradient's weighted moments (upper triangle of 2 D1 x 2 D1)
         fd = 2 * 2 * 512 * D1 + 2 * (2 * D1) ** 2 + (2 * D1) * (2 * D1 + 1)
         ach = Bd * fd / (ms_d * 1e-3) / 1e12
         dpl[f"B{Bd}_{'bce' if lossname == 'crossentropy' else 'softcdet'}"] = {
             "value": Bd / (ms_d * 1e-3), "ms_per_step": ms_d, "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS,
-            "flop_per_pair_algorithmic": fd, "launches_per_step": getattr(fstep, "launches_per_step", None),
+            "flop_per_pair_algorithmic": fd, "ms_per_step_with_input_copies": ms_c,
+            "launches_per_step": "6 in one graph replay: quadratic-form image, LDA + normalise + score (paired rows kept), loss, "
+                                 "weighted moments, fold, Adam",
             "final_loss_finite": bool(torch.isfinite(ld if torch.is_tensor(ld) else torch.tensor(ld)).all().item())}
         del fstep, dp
-    out["alt_dplda"] = dpl
+    if want("dplda"):
+        out["alt_dplda"] = dpl
     del x1, x2
     torch.cuda.empty_cache()
+    if not want("minc"):
+        return out
 
     # ---- minc ---------------------------------------------------------------------------------------------------------
     Nm = 10000000
@@ -1194,6 +1217,8 @@ def main():
     ap.add_argument("--dp-graph", choices=["auto", "off"], default="auto",
                     help="cfg2 / cfg5 with N > 1: auto = the step's all-reduce captured inside its HIP graph (RCCL), off = eager "
                          "collectives between the step's launches")
+    ap.add_argument("--part", choices=["all", "regimeB", "gb", "dplda", "minc"], default="all",
+                    help="--workload secondary: one kernel family only, its headline launches only (PMC passes)")
     ap.add_argument("--prepared-cohort", action="store_true",
                     help="cfg3: the cohort embedded and pre-passed once outside the step (adaptive_score_normalization.CohortState)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -1,14 +1,18 @@
 #!/bin/bash
 # Round-end evidence in ONE gpurun call: the driver's bench line, the --workload lines, kernel traces (with the per-launch
 # series of the dominant kernel: the cold start is several launches long), PMC passes of every headline kernel, and
-# profiles/traffic.json REGENERATED from those passes (tools/traffic_from_pmc.py).   usage: round_end_bench.sh <tag, e.g. r04z>
-TAG=${1:-r04z}
+# profiles/traffic.json REGENERATED from those passes (tools/traffic_from_pmc.py).   usage: round_end_bench.sh <tag, e.g. r05z>
+TAG=${1:-r05z}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
 for w in cfg2 cfg3 cfg5; do python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; done
+python bench.py --workload cfg3 --prepared-cohort > $O/bench_cfg3_prepared.json 2>> $O/bench_cfg3.err
+python bench.py --workload cfg2 --batch 2048 > $O/bench_cfg2_b2048.json 2>> $O/bench_cfg2.err
+python bench.py --workload cfg5 --batch 2048 > $O/bench_cfg5_b2048.json 2>> $O/bench_cfg5.err
+python bench.py --workload secondary > $O/extra.json 2> $O/extra.err
 python tools/size_sweep.py 150 > $O/size_sweep.txt 2>&1
 python tools/size_sweep.py 170 >> $O/size_sweep.txt 2>&1
 cd /tmp; export TMPDIR=/tmp
@@ -25,6 +29,9 @@ bash tools/pmc_cmd.sh $TAG/pmc_fwd170 python $R/bench.py --no-cpu-baseline --no-
 bash tools/pmc_cmd.sh $TAG/pmc_cfg2 python $R/bench.py --workload cfg2 --steps 50 --warmup 10
 bash tools/pmc_cmd.sh $TAG/pmc_cfg3 python $R/bench.py --workload cfg3 --steps 10 --warmup 3
 bash tools/pmc_cmd.sh $TAG/pmc_cfg5 python $R/bench.py --workload cfg5 --steps 50 --warmup 10
+bash tools/pmc_cmd.sh $TAG/pmc_regimeB150 python $R/bench.py --workload secondary --part regimeB --dim 150
+bash tools/pmc_cmd.sh $TAG/pmc_regimeB170 python $R/bench.py --workload secondary --part regimeB --dim 170
+bash tools/pmc_cmd.sh $TAG/pmc_gb python $R/bench.py --workload secondary --part gb
 cp $R/profiles/traffic.json $O/traffic.json
 python tools/traffic_from_pmc.py $O/traffic.json \
   score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v3_kernel \
@@ -32,6 +39,9 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   cohort_stats_D150_R22000_M10000=$O/pmc_cfg3:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
+  score_indexed_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel \
+  score_indexed_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel \
+  gb_score_D170_B524288=$O/pmc_gb:nplda_fwd_kernel \
   > $O/traffic.log 2>&1
 tail -3 $O/traffic.log
 tail -c 400 $O/bench.json
