@@ -1058,8 +1058,7 @@ def run_secondary(args, ctx):
         dpl[f"B{Bd}_{'bce' if lossname == 'crossentropy' else 'softcdet'}"] = {
             "value": Bd / (ms_d * 1e-3), "ms_per_step": ms_d, "achieved": ach, "frac": ach / FP32_MFMA_PEAK_TFLOPS,
             "flop_per_pair_algorithmic": fd, "ms_per_step_with_input_copies": ms_c,
-            "launches_per_step": "6 in one graph replay: quadratic-form image, LDA + normalise + score (paired rows kept), loss, "
-                                 "weighted moments, fold, Adam",
+            "launches_per_step": fstep.launches_per_step,
             "final_loss_finite": bool(torch.isfinite(ld if torch.is_tensor(ld) else torch.tensor(ld)).all().item())}
         del fstep, dp
     if want("dplda"):

@@ -384,6 +384,18 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
 int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* dw, float* db,
                          void* workspace, size_t workspace_bytes, nplda_stream_t stream);
 
+/* The tail of the recipe step xvector_DPlda_pytorch.py:35-43 runs (DPlda.forward -> loss -> backward -> Adam on
+ * logistic_regres, the LDA frozen, :140-147) in TWO launches: the weighted moments of the paired rows, then per element of
+ * [logistic_regres.weight | .bias] the gradient fold of nplda_dplda_grad_f32, torch.optim.Adam's update (the arithmetic of
+ * nplda_adam_step_f32; exp_avg / exp_avg_sq: 2 D1^2 + D1 + 1 + K floats each, [weight | bias | thresholds]; step[0] counts
+ * the steps, incremented here) and the store of the new value into the parameter AND into `image`, the quadratic-form image
+ * of gb_pack_dplda_f32 the next forward scores with (NULL: not kept).  K thresholds (SoftCdet; dtheta from the loss call)
+ * take their Adam step in the same launch.  grad_out (optional, 2 D1^2 + D1 + 1): the applied gradient. */
+int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* wlr, float* blr,
+                           float* exp_avg, float* exp_avg_sq, float* const* thetas, const float* dtheta, int K, float* step,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
+                           float* grad_out, void* workspace, size_t workspace_bytes, nplda_stream_t stream);
+
 /* ---- detection-cost sweep (validation metrics) -------------------------------------------------------------------- */
 
 /* NeuralPlda.minc (utils/models.py:406-436) for N scores / labels and K <= 8 betas (HOST array), replacing its

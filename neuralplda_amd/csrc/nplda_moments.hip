@@ -11,6 +11,7 @@
 // class, halved by symmetry), launch latency at training-batch sizes.
 #include <hip/hip_runtime.h>
 
+#include "nplda_adam_math.h"
 #include "nplda_common.h"
 
 namespace {
@@ -31,6 +32,7 @@ struct MomArgs {
     int Np;                // 64 T
     float* slab;           // [class][kgroup][Np][Np]   (upper tiles written)
     float* ext;            // [class][kgroup][Np + 4]   column sums, then the weight sum
+    float* step_bump;      // optional: Adam's step counter, counted here (one thread) for the update kernel of this step
 };
 
 __device__ __forceinline__ void tile_of(int t, int T, int& mt, int& nt) {
@@ -49,6 +51,7 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(const MomArgs a) {
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int i16 = lane & 15, g4 = lane >> 4;
     const int kg = blockIdx.x / a.ntile;
+    if (a.step_bump != nullptr && blockIdx.x == 0 && threadIdx.x == 0) a.step_bump[0] += 1.0f;
     int mt, nt;
     tile_of(blockIdx.x % a.ntile, a.T, mt, nt);
     const int m0 = mt * 64, n0 = nt * 64;
@@ -249,24 +252,66 @@ struct DpldaFoldArgs {
     const float* slab;
     const float* ext;
     int kgroups, Np, D1;
-    float* dw;   // 2 D1^2 + D1
+    float* dw;   // 2 D1^2 + D1   (UPDATE: optional copy of the applied gradient)
     float* db;   // 1
+    // UPDATE form (nplda_dplda_update_f32): the thread that has formed a gradient element goes on to torch.optim.Adam's update
+    // of that parameter (csrc/nplda_adam_math.h: the arithmetic of nplda_adam_step_f32) and stores the new value into the
+    // parameter AND into the quadratic-form image the next forward scores with (gb_pack_dplda_f32's layout) — the fold, the
+    // optimiser and the two pack launches of the recipe step in one
+    float* wlr; float* blr;          // logistic_regres.weight (2 D1^2 + D1), .bias (1)
+    float* m; float* v;              // exp_avg / exp_avg_sq: [wlr | blr | thresholds]
+    const float* step;               // step[0] already counts this step (the moments kernel bumped it)
+    float lr, beta1, beta2, eps, wd;
+    float* image;                    // the GaussianBackend-layout image (may be null)
+    long long oG, ov, oc; int NB;    // its offsets (floats): G fragments, v, c
+    float* theta[4]; const float* dtheta; int K;  // SoftCdet thresholds trained with the unit (K = 0: none)
 };
 
 // One block per 16 x 16 tile of an output block.  Half of the entries a tile needs sit mirrored in the slabs (G21 = G12^T;
 // the lower triangle of G11 / G22 is not computed): read element-wise they are 64 different cache lines per wave-load and
 // the kernel took 21 us.  Here a thread sums ONE entry of the tile as it lies in memory (16 consecutive floats per row)
 // and the mirror is taken through LDS.
+template <bool UPDATE>
 __global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) {
     const int D1 = a.D1, TB = (D1 + 15) / 16;
     const size_t n2 = (size_t)D1 * D1, sst = (size_t)a.Np * a.Np;
     const int tid = threadIdx.x;
     const int b = (int)blockIdx.x;
+    nplda_adam::Consts ac = {};
+    if constexpr (UPDATE) ac = nplda_adam::consts_for(a.step[0], a.lr, a.beta1, a.beta2, a.eps, a.wd);
+    // gradient element e of [wlr | blr] -> Adam -> the parameter; returns the new value
+    auto apply = [&](size_t e, float grad, float* prm) {
+        float m = a.m[e], v = a.v[e];
+        const float pn = nplda_adam::update(prm[0], grad, m, v, ac);
+        prm[0] = pn;
+        a.m[e] = m;
+        a.v[e] = v;
+        return pn;
+    };
     if (b >= 2 * TB * TB) {  // s1 + s2 and sum g: one output per thread, consecutive columns
         const size_t c = (size_t)(b - 2 * TB * TB) * 256 + tid;
         const size_t est = (size_t)a.Np + 4;
-        if (c < (size_t)D1) a.dw[2 * n2 + c] = (float)(slab_sum1(a.ext + c, est, a.kgroups) + slab_sum1(a.ext + D1 + c, est, a.kgroups));
-        else if (c == (size_t)D1) a.db[0] = (float)slab_sum1(a.ext + a.Np, est, a.kgroups);
+        if (c < (size_t)D1) {
+            const float gr = (float)(slab_sum1(a.ext + c, est, a.kgroups) + slab_sum1(a.ext + D1 + c, est, a.kgroups));
+            if (a.dw) a.dw[2 * n2 + c] = gr;
+            if constexpr (UPDATE) {
+                const float pn = apply(2 * n2 + c, gr, a.wlr + 2 * n2 + c);
+                if (a.image) {  // v = [ws; ws] (gb_vc_dplda_kernel)
+                    a.image[a.ov + c] = pn;
+                    a.image[a.ov + 16 * a.NB + c] = pn;
+                }
+            }
+        } else if (c == (size_t)D1) {
+            const float gr = (float)slab_sum1(a.ext + a.Np, est, a.kgroups);
+            if (a.db) a.db[0] = gr;
+            if constexpr (UPDATE) {
+                const float pn = apply(2 * n2 + D1, gr, a.blr);
+                if (a.image) a.image[a.oc] = pn;  // c = the bias
+            }
+        } else if (UPDATE && c > (size_t)D1 && c <= (size_t)D1 + a.K) {  // the thresholds' own Adam step
+            const int k = (int)(c - D1 - 1);
+            apply(2 * n2 + D1 + 1 + k, a.dtheta[k], a.theta[k]);
+        }
         return;
     }
     __shared__ double t1[16][17], t2[16][17];
@@ -295,7 +340,22 @@ __global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) 
         const bool diag = which == 1 && I == J;
         const double v1 = (tr1 || (diag && r > c)) ? t1[c][r] : t1[r][c];
         const double v2 = (tr2 || (diag && r > c)) ? t2[c][r] : t2[r][c];
-        a.dw[(size_t)which * n2 + (size_t)i * D1 + j] = (float)(v1 + v2);
+        const size_t e = (size_t)which * n2 + (size_t)i * D1 + j;
+        const float gr = (float)(v1 + v2);
+        if (a.dw) a.dw[e] = gr;
+        if constexpr (UPDATE) {
+            const float pn = apply(e, gr, a.wlr + e);
+            if (a.image) {
+                // gb_pack_kernel (dplda): block (h_out, h_in) of G at [f][k] is Ww[f][k] on the diagonal (which == 1), Wb[f][k]
+                // off it (which == 0); fragment element (kb, nb, lane, e4) holds f = 16 nb + (lane & 15), k = 16 kb + 4 (lane >> 4) + e4
+                const int nb = i >> 4, kb = j >> 4;
+                const size_t in_blk = ((size_t)(kb * a.NB + nb) * 64 + (size_t)((i & 15) + 16 * ((j & 15) >> 2))) * 4 + (j & 3);
+                const size_t hsz = (size_t)a.NB * a.NB * 256;
+                const int hh0 = which == 1 ? 0 : 1, hh1 = which == 1 ? 3 : 2;  // 2 h_out + h_in
+                a.image[a.oG + hh0 * hsz + in_blk] = pn;
+                a.image[a.oG + hh1 * hsz + in_blk] = pn;
+            }
+        }
     }
 }
 
@@ -360,6 +420,7 @@ int nplda_weighted_moments_f32(const float* x, int64_t B, int64_t ldx, int n, co
     a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
     a.slab = (float*)workspace;
     a.ext = a.slab + p.slab_floats;
+    a.step_bump = nullptr;
     const dim3 grid((unsigned)(p.ntile * p.kgroups));
     if (nc == 2) hipLaunchKernelGGL(moments_kernel<2>, grid, dim3(256), 0, st, a);
     else hipLaunchKernelGGL(moments_kernel<1>, grid, dim3(256), 0, st, a);
@@ -387,12 +448,59 @@ int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, con
     a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
     a.slab = (float*)workspace;
     a.ext = a.slab + p.slab_floats;
+    a.step_bump = nullptr;
     hipLaunchKernelGGL(moments_kernel<1>, dim3((unsigned)(p.ntile * p.kgroups)), dim3(256), 0, st, a);
     if (int rc = nplda_launch_status()) return rc;
-    DpldaFoldArgs f;
+    DpldaFoldArgs f = {};
     f.slab = a.slab; f.ext = a.ext; f.kgroups = p.kgroups; f.Np = p.Np; f.D1 = D1; f.dw = dw; f.db = db;
     const int TB = (D1 + 15) / 16;
-    hipLaunchKernelGGL(dplda_fold_kernel, dim3((unsigned)(2 * TB * TB + (D1 + 1 + 255) / 256)), dim3(256), 0, st, f);
+    hipLaunchKernelGGL(dplda_fold_kernel<false>, dim3((unsigned)(2 * TB * TB + (D1 + 1 + 255) / 256)), dim3(256), 0, st, f);
+    return nplda_launch_status();
+}
+
+int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* wlr, float* blr,
+                           float* exp_avg, float* exp_avg_sq, float* const* thetas, const float* dtheta, int K, float* step,
+                           float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
+                           float* grad_out, void* workspace, size_t workspace_bytes, nplda_stream_t stream) {
+    const int n = 2 * D1;
+    if (B <= 0 || D1 <= 0 || K < 0 || K > 4) return NPLDA_EINVAL;
+    if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
+    if (!paired || !g || !wlr || !blr || !exp_avg || !exp_avg_sq || !step || !workspace) return NPLDA_EINVAL;
+    if (K > 0 && (!thetas || !dtheta)) return NPLDA_EINVAL;
+    if (ld < n || (ld & 3) || !nplda_aligned16(paired) || !nplda_aligned16(workspace)) return NPLDA_EINVAL;
+    const int NB = nplda_kernel_nb(D1, D1);
+    if (image && (NB == 0 || D0 <= 0 || (D0 % 4) != 0 || !nplda_aligned16(image))) return NPLDA_EINVAL;
+    const MomPlan p = mom_plan(B, n);
+    if (workspace_bytes < (p.slab_floats + p.ext_floats) * sizeof(float)) return NPLDA_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    MomArgs a;
+    a.x = paired; a.ldx = ld; a.B = B; a.n = n; a.w0 = g; a.w1 = nullptr;
+    a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
+    a.slab = (float*)workspace;
+    a.ext = a.slab + p.slab_floats;
+    a.step_bump = step;  // the step is counted here: the update kernel below reads t = step[0]
+    hipLaunchKernelGGL(moments_kernel<1>, dim3((unsigned)(p.ntile * p.kgroups)), dim3(256), 0, st, a);
+    if (int rc = nplda_launch_status()) return rc;
+    DpldaFoldArgs f = {};
+    f.slab = a.slab; f.ext = a.ext; f.kgroups = p.kgroups; f.Np = p.Np; f.D1 = D1;
+    f.dw = grad_out; f.db = grad_out ? grad_out + (size_t)2 * D1 * D1 + D1 : nullptr;
+    f.wlr = wlr; f.blr = blr; f.m = exp_avg; f.v = exp_avg_sq; f.step = step;
+    f.lr = lr; f.beta1 = beta1; f.beta2 = beta2; f.eps = eps; f.wd = weight_decay;
+    f.image = (float*)image;
+    if (image) {  // gb_layout(D0, D1) of nplda_gb.hip: [W1 fragments | G | b1 | v | c]
+        const long long KS1 = (D0 + 15) / 16;
+        f.NB = NB;
+        f.oG = KS1 * NB * 256;
+        f.ov = f.oG + 4LL * NB * NB * 256 + (long long)NB * 16;
+        f.oc = f.ov + 2LL * NB * 16;
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!thetas[k]) return NPLDA_EINVAL;
+        f.theta[k] = thetas[k];
+    }
+    f.dtheta = dtheta; f.K = K;
+    const int TB = (D1 + 15) / 16;
+    hipLaunchKernelGGL(dplda_fold_kernel<true>, dim3((unsigned)(2 * TB * TB + (D1 + 1 + K + 255) / 256)), dim3(256), 0, st, f);
     return nplda_launch_status();
 }
 

@@ -1170,8 +1170,9 @@ def quadform_pack(W1, b1, M, v, c):
     return buf, D0, D1
 
 
-def dplda_pack(W1, b1, wlr, blr):
-    """gb_pack_dplda_f32: the quadratic-form image straight from DPlda's parameters (no host sync, no temporaries)."""
+def dplda_pack(W1, b1, wlr, blr, out=None):
+    """gb_pack_dplda_f32: the quadratic-form image straight from DPlda's parameters (no host sync, no temporaries).
+    out: an image returned earlier, refilled in place (its address may be baked into a captured graph)."""
     lib = _lib.load()
     for n, t in (("W1", W1), ("b1", b1), ("wlr", wlr), ("blr", blr)):
         _require_dev_f32(t, n)
@@ -1183,7 +1184,9 @@ def dplda_pack(W1, b1, wlr, blr):
     nbytes = lib.gb_packed_bytes(D0, D1)
     if nbytes == 0:
         raise _lib.NpldaHipError(f"model {D0}->{D1} is outside the compiled kernel set")
-    buf = torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
+    if out is not None and (out[1] != D0 or out[2] != D1 or out[0].numel() * 4 < nbytes or out[0].device != W1.device):
+        out = None
+    buf = out[0] if out is not None else torch.empty(nbytes // 4, dtype=torch.float32, device=W1.device)
     ts = [t.detach().contiguous() for t in (W1, b1, wlr, blr)]
     with _lib.on_device(W1.device):
         code = lib.gb_pack_dplda_f32(*[_lib.ptr(t) for t in ts], D0, D1, _lib.ptr(buf), nbytes, _lib.current_stream())
@@ -1272,6 +1275,38 @@ def dplda_grad(paired, g, D1):
                                         out.data_ptr() + 4 * (out.numel() - 1), _lib.ptr(ws), nbytes, _lib.current_stream())
     _lib.check(code, "nplda_dplda_grad_f32")
     return out[:-1].view(1, -1), out[-1:]
+
+
+def dplda_update(paired, g, wlr, blr, m, v, step, lr, beta1, beta2, eps, wd, thetas=(), dtheta=None, image=None, ws=None,
+                 grad_out=None):
+    """nplda_dplda_update_f32: the tail of DPlda's recipe step in two launches — weighted moments of the paired rows, then per
+    element of [logistic_regres.weight | bias] gradient fold + torch.optim.Adam's update + the new value stored into the
+    parameter and into `image` (the (buf, D0, D1) of dplda_pack the next forward scores with).  m / v: flat moments
+    [weight | bias | thresholds]; step: device [steps taken, scratch]."""
+    import ctypes
+    lib = _lib.load()
+    B, n = paired.shape
+    D1 = n // 2
+    K = len(thetas)
+    if wlr.numel() != 2 * D1 * D1 + D1 or blr.numel() != 1 or m.numel() < wlr.numel() + 1 + K or v.numel() != m.numel():
+        raise ValueError("dplda_update: parameter / moment shapes do not belong to a DPlda of this D1")
+    if paired.stride(1) != 1 or paired.stride(0) % 4 != 0 or paired.data_ptr() % 16 != 0:
+        paired = paired.contiguous()
+    nbytes = lib.nplda_moments_workspace_bytes(B, n)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"paired rows of length {n} are outside the moments kernel")
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=paired.device)
+    gg = g.detach().contiguous()
+    tarr = (ctypes.c_void_p * max(K, 1))(*[t.data_ptr() for t in thetas]) if K else None
+    buf, D0 = (image[0], image[1]) if image is not None else (None, 0)
+    with _lib.on_device(paired.device):
+        code = lib.nplda_dplda_update_f32(_lib.ptr(paired), B, paired.stride(0), D1, _lib.ptr(gg), _lib.ptr(wlr), _lib.ptr(blr),
+                                          _lib.ptr(m), _lib.ptr(v), tarr, _lib.ptr(dtheta) if K else None, K, _lib.ptr(step),
+                                          float(lr), float(beta1), float(beta2), float(eps), float(wd), _lib.ptr(buf), int(D0),
+                                          _lib.ptr(grad_out), _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+    _lib.check(code, "nplda_dplda_update_f32")
+    return ws
 
 
 def weighted_moments(x, w0, w1=None, out=None):

@@ -411,6 +411,10 @@ class FusedTrainStep:
             self._ops.pack_params_into(self._packed, *[q.detach() for q in self.params])
         self._packed_key = key
 
+    def _pre_replay(self, force=False):
+        """Hook in front of a graph replay / capture for steps that carry state derived from the parameters (FusedDPldaStep's
+        quadratic-form image): bring it up to date if something else has touched the parameters."""
+
     def _touched(self):
         """The raw kernels have rewritten the parameters: bump their version counters (autograd's saved-tensor
         checks, the model's packed-image cache); the step's own image was refreshed by the same launch."""
@@ -542,6 +546,7 @@ class FusedTrainStep:
             self._loss_acc.copy_(a0)
         if self._one_call or self._dp_call:
             self._sync_packed()  # the warm-up moved the image along with the parameters: back to the restored values
+        self._pre_replay(force=True)
         graph = torch.cuda.CUDAGraph()
         # with collectives in the step the RCCL watchdog thread polls events while we capture: only this thread's calls
         # may be checked against the capture
@@ -726,6 +731,7 @@ class FusedTrainStep:
             self._capture()
         if self._one_call or self._dp_call:
             self._sync_packed()
+        self._pre_replay()
         # a caller that fills the step's own input buffers (step.x1 / .x2 / .t, e.g. gather_rows(..., out=step.x1)) skips
         # the staging copies: at 4096 x 512 they are 2 x 8 MB, 16 us of a 70 us step
         if x1 is not self.x1:
@@ -954,9 +960,58 @@ class FusedDPldaStep(FusedTrainStep):
             self.t = torch.zeros(batch_size, device=self.dev)
             self.t[::2] = 1
 
+    launches_per_step = None
+
+    def _image(self, force=False):
+        """The quadratic-form image the recipe step scores with: built once (two launches), then kept current by the step's
+        own update kernel; re-packed IN PLACE (its address is baked into the captured graph) when anything else has touched
+        the parameters (version counters)."""
+        mdl = self.model
+        prm = [mdl.centering_and_LDA.weight, mdl.centering_and_LDA.bias] + self.params[:2]
+        key = tuple((q.data_ptr(), q._version) for q in prm)
+        img = getattr(self, "_img", None)
+        if img is None or ((force or key != self._img_key) and not torch.cuda.is_current_stream_capturing()):
+            self._img = self._ops.dplda_pack(*[q.detach() for q in prm], out=img)
+            self._img_key = key
+        return self._img
+
+    def _pre_replay(self, force=False):
+        if getattr(self, "_img", None) is not None:
+            self._image(force=force)
+
+    def _touched(self):
+        super(FusedDPldaStep, self)._touched()
+        if getattr(self, "_img", None) is not None:  # (the step's own launch has refreshed the image with the new values)
+            mdl = self.model
+            prm = [mdl.centering_and_LDA.weight, mdl.centering_and_LDA.bias] + self.params[:2]
+            self._img_key = tuple((q.data_ptr(), q._version) for q in prm)
+
+    def _recipe_step(self, x1, x2, t):
+        """xvector_DPlda_pytorch.py:35-43 with the LDA frozen, on one rank: FOUR launches — LDA + normalise + quadratic-form
+        score (paired rows kept) | loss, dL/ds, dL/dtheta | weighted moments | gradient fold + Adam + parameter and image
+        stores (nplda_dplda_update_f32).  Same arithmetic as the separate calls below (fold and Adam are the same device
+        functions)."""
+        ops = self._ops
+        wlr, blr = (q.detach() for q in self.params[:2])
+        s, paired = ops._gb_call(x1, x2, self._image(), True, True)
+        ths = [th.detach() for th in self.thetas]
+        lths = ths if self.kind == ops.LOSS_SOFTCDET else [self._zero]
+        loss, g, dth, _ = ops.loss_fwd_bwd(s, t, lths, self.betas_loss, self.alpha, self.kind)
+        B = x1.shape[0]
+        self._mws = ops.dplda_update(paired, g, wlr, blr, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
+                                     self.eps, self.wd, thetas=ths, dtheta=dth if ths else None, image=self._img,
+                                     ws=self.__dict__.get("_mws_by_B", {}).get(B))
+        self.__dict__.setdefault("_mws_by_B", {})[B] = self._mws
+        self.launches_per_step = ("4 in one graph replay: LDA + normalise + quadratic-form score | loss + dL/ds | weighted moments | "
+                                  "gradient fold + Adam + parameter and image stores")
+        return loss
+
     def _eager(self, x1, x2, t):
         ops, mdl = self._ops, self.model
         with torch.no_grad():
+            if (not (self.train_lda or self.want_dx) and self.reduce_sums is None and self.reduce_flat is None
+                    and x1.shape[0] > 0 and os.environ.get("NPLDA_DPLDA_SEPARATE", "0") != "1"):
+                return self._recipe_step(x1, x2, t)
             wlr, blr = (q.detach() for q in self.params[:2])
             W1, b1 = mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach()
             packed = ops.dplda_pack(W1, b1, wlr, blr)

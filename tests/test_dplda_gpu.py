@@ -321,3 +321,52 @@ def test_dplda_quadform_image_one_launch(hip_lib, D1):
     out = ops.rows_matmul(x, (frag, K, N), bias=v)
     ref = x.double() @ (M + M.T).double() + v0.double()
     np.testing.assert_allclose(out.cpu().numpy(), ref.cpu().numpy(), atol=2e-4, rtol=1e-5)
+
+
+@pytest.mark.parametrize("graph", [False, True])
+@pytest.mark.parametrize("lossname,D0,D1,B", [("crossentropy", 512, 170, 256), ("SoftCdet", 512, 170, 2048), ("SoftCdet", 128, 40, 100)])
+def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, monkeypatch, graph, lossname, D0, D1, B):
+    """The recipe step of xvector_DPlda_pytorch.py:35-43 as four launches (score | loss | moments | nplda_dplda_update_f32:
+    gradient fold + Adam + parameter and quadratic-form-image stores) against the seven separate launches it replaces
+    (image x 2, score, loss, moments, fold, Adam): the same device functions in the same order -> the same parameter bits
+    after every step, thresholds included; the image the step carries equals a fresh pack of the updated parameters, also
+    after somebody else rewrites a parameter between two steps."""
+    from neuralplda_amd import ops, train
+    rg = np.random.default_rng(21)
+    W1 = (rg.standard_normal((D1, D0)) / np.sqrt(D0)).astype(np.float32)
+    b1 = (0.1 * rg.standard_normal(D1)).astype(np.float32)
+    wlr = (0.05 * rg.standard_normal((1, 2 * D1 * D1 + D1))).astype(np.float32)
+    batches = [(torch.from_numpy(rg.standard_normal((B, D0)).astype(np.float32)).cuda(),
+                torch.from_numpy(rg.standard_normal((B, D0)).astype(np.float32)).cuda(),
+                torch.from_numpy((rg.random(B) < 0.2).astype(np.float32)).cuda()) for _ in range(4)]
+
+    def run(separate):
+        if separate:
+            monkeypatch.setenv("NPLDA_DPLDA_SEPARATE", "1")
+        else:
+            monkeypatch.delenv("NPLDA_DPLDA_SEPARATE", raising=False)
+        m = make(D0, D1, W1, b1, wlr, [0.1])
+        m.lossfn = lossname
+        _freeze_lda(m)
+        step = train.FusedDPldaStep(m, 1e-3, weight_decay=1e-5, batch_size=B, graph=graph)
+        out = []
+        for i, (x1, x2, t) in enumerate(batches):
+            loss = float(step(x1, x2, t))
+            out.append((loss, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+            if not separate:
+                fresh = ops.dplda_pack(m.centering_and_LDA.weight.detach(), m.centering_and_LDA.bias.detach(),
+                                       m.logistic_regres.weight.detach(), m.logistic_regres.bias.detach())
+                assert torch.equal(step._img[0], fresh[0]), i
+            if i == 1:  # an outside write between two steps: the step notices (version counters) and re-packs in place
+                with torch.no_grad():
+                    m.logistic_regres.weight.mul_(0.5)
+        return out, step
+
+    new, step_new = run(False)
+    old, _ = run(True)
+    assert step_new.launches_per_step.startswith("4 ")
+    for i, ((la, sa), (lb, sb)) in enumerate(zip(new, old)):
+        assert la == lb, (i, la, lb)
+        for k in sa:
+            assert torch.equal(sa[k], sb[k]), (i, k, (sa[k] - sb[k]).abs().max().item())
+    assert step_new.step_count[0].item() == 4
