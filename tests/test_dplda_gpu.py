@@ -356,7 +356,9 @@ def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, m
             if not separate:
                 fresh = ops.dplda_pack(m.centering_and_LDA.weight.detach(), m.centering_and_LDA.bias.detach(),
                                        m.logistic_regres.weight.detach(), m.logistic_regres.bias.detach())
-                assert torch.equal(step._img[0], fresh[0]), i
+                nb = {40: 4, 170: 11}[D1]
+                used = fresh[0].numel() - 2 * nb * 256  # (the image ends in a chunk of never-read slack: torch.empty)
+                assert torch.equal(step._img[0][:used], fresh[0][:used]), i
             if i == 1:  # an outside write between two steps: the step notices (version counters) and re-packs in place
                 with torch.no_grad():
                     m.logistic_regres.weight.mul_(0.5)
