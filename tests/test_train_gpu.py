@@ -1102,3 +1102,47 @@ def test_validate_scores_in_kernel_sized_chunks(hip_lib, monkeypatch):
         s = torch.cat([m(X[ia[lo:lo + 10240]], X[ib[lo:lo + 10240]]) for lo in range(0, n, 10240)])
     mc_ref, th_ref = metrics.minc(s, torch.from_numpy(lab).cuda(), nc.beta)
     assert abs(float(mc) - float(mc_ref)) <= 1e-4  # (the arg-min thresholds may sit on different scores where the cost is flat)
+
+
+@pytest.mark.parametrize("lossname", ["SoftCdet", "crossentropy"])
+@pytest.mark.parametrize("D,B", [(150, 2048), (150, 8), (150, 1003), (170, 2048), (170, 333), (150, 4096)])
+def test_one_call_step_gradient_and_loss_against_the_fp64_oracle(hip_lib, lossname, D, B):
+    """nplda_train_step_f32 on its own against the fp64 ORACLE (not against another kernel of this build): the loss, dL/dtheta
+    and the applied flat gradient of one step.  B <= 2048 runs the 8-pair half-tile kernel (nplda_train_fb_half.h: the rows of
+    a pair in one MFMA group, DPP cross terms), 4096 the 16-pair kernel; 8 = one half tile, 1003 / 333 = ragged last tiles.
+    Tolerances: loss 1e-5 relative, gradients 1e-4 of the per-tensor max-abs."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(1000 * D + B)
+    p = rand_params(rng, 512, D, D)
+    prm = [torch.from_numpy(np.ascontiguousarray(a)).cuda() for a in p.tensors()]
+    x1 = rng.standard_normal((B, 512)).astype(np.float32)
+    x2 = rng.standard_normal((B, 512)).astype(np.float32)
+    t = (rng.random(B) < 0.3).astype(np.float32)
+    t[0], t[-1] = 1.0, 0.0  # both classes present
+    kind = ops.LOSS_SOFTCDET if lossname == "SoftCdet" else ops.LOSS_BCE
+    theta = [-0.4, -0.2] if kind == ops.LOSS_SOFTCDET else [0.1]
+    betas, alpha = ([99.0, 199.0], 15.0) if kind == ops.LOSS_SOFTCDET else ([], 0.0)
+    ths = [torch.tensor([v], device="cuda") for v in theta]
+    packed = ops.pack_params(*prm)
+    n = int(sum(q.numel() for q in prm))
+    K = len(ths)
+    m, v, step = torch.zeros(n + K, device="cuda"), torch.zeros(n + K, device="cuda"), torch.zeros(2, device="cuda")
+    out, lbuf = torch.zeros(n + K, device="cuda"), torch.zeros((), device="cuda")
+    ws = ops.train_step_workspace(B, packed)
+    ops.train_step(torch.from_numpy(x1).cuda(), torch.from_numpy(x2).cuda(), torch.from_numpy(t).cuda(), prm, ths, betas, alpha,
+                   kind, m, v, step, 1e-3, 0.9, 0.999, 1e-8, 1e-5, packed, ws, lbuf, grad_out=out)
+    s_ref = orc.forward(x1, x2, p, np.float64)
+    if kind == ops.LOSS_SOFTCDET:
+        L_ref = orc.softcdet(s_ref, t, theta, betas, alpha, np.float64)
+        g_ref, dth_ref = orc.softcdet_grad(s_ref, t, theta, betas, alpha)
+    else:
+        L_ref = orc.crossentropy(s_ref, t, theta[0], np.float64)
+        g_ref, dth_ref = orc.crossentropy_grad(s_ref, t, theta[0])
+        dth_ref = np.atleast_1d(dth_ref)
+    assert abs(lbuf.item() - L_ref) <= 1e-5 * abs(L_ref), (lbuf.item(), L_ref)
+    ref = orc.backward(x1, x2, g_ref, p)
+    got = [a.cpu().numpy() for a in ops.split_flat_grad(out[:n], 512, D, D)]
+    for name, a in zip(("W1", "b1", "W2", "b2", "P_sqrt", "Q"), got):
+        assert relmax(a, ref[name]) <= 1e-4, (name, relmax(a, ref[name]))
+    np.testing.assert_allclose(out[n:].cpu().numpy(), np.asarray(dth_ref, np.float64), rtol=2e-4, atol=1e-7)
+    assert step[0].item() == 1.0

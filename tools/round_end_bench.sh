@@ -32,6 +32,13 @@ bash tools/pmc_cmd.sh $TAG/pmc_cfg5 python $R/bench.py --workload cfg5 --steps 5
 bash tools/pmc_cmd.sh $TAG/pmc_regimeB150 python $R/bench.py --workload secondary --part regimeB --dim 150
 bash tools/pmc_cmd.sh $TAG/pmc_regimeB170 python $R/bench.py --workload secondary --part regimeB --dim 170
 bash tools/pmc_cmd.sh $TAG/pmc_gb python $R/bench.py --workload secondary --part gb
+# the shard shapes of the N > 1 line (alt_cfg1_strong, alt_cfg3): rank N - 1 of N, emulated on this GPU
+# (as plain one-GPU runs of the shard's shape: an --emulate-rank run also computes the other ranks' statistics once, at full size)
+for n in 2 4 8; do
+  bash tools/pmc_traffic.sh $TAG/pmc_cfg1_s$n python $R/bench.py --no-cpu-baseline --no-alt --no-clock-probe --steps 20 --pairs $((1048576 / n))
+  bash tools/pmc_traffic.sh $TAG/pmc_cfg3_s$n python $R/bench.py --workload cfg3 --steps 10 --warmup 3 --no-clock-probe \
+       --enroll $((2000 / n)) --test $((20000 / n)) --trials $((2000000 / n))
+done
 cp $R/profiles/traffic.json $O/traffic.json
 python tools/traffic_from_pmc.py $O/traffic.json \
   score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v3_kernel \
@@ -42,6 +49,11 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   score_indexed_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel \
   score_indexed_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel \
   gb_score_D170_B524288=$O/pmc_gb:nplda_fwd_kernel \
+  score_pairs_D150_B524288=$O/pmc_cfg1_s2:nplda_fwd_v3_kernel score_pairs_D150_B262144=$O/pmc_cfg1_s4:nplda_fwd_v3_kernel \
+  score_pairs_D150_B131072=$O/pmc_cfg1_s8:nplda_fwd_v3_kernel \
+  cohort_stats_D150_R11000_M10000=$O/pmc_cfg3_s2:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R5500_M10000=$O/pmc_cfg3_s4:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R2750_M10000=$O/pmc_cfg3_s8:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
   > $O/traffic.log 2>&1
 tail -3 $O/traffic.log
 tail -c 400 $O/bench.json
