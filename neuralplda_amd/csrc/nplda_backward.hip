@@ -186,14 +186,20 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
     constexpr int WAVES = 8, PFZ = 4;
     __shared__ f32x4 w2t[NB * NB * 64];
     __shared__ f32x4 pqs[WAVES][2][NB * 4];  // per wave: [dQ | dP] partial sums over its tiles, 16 NB floats each
+    // Q and P in LDS (round 5).  As global loads inside the k-block loop they were the YOUNGEST vector-memory operations in
+    // front of their own use: hipcc waited `vmcnt(0)` for them, i.e. for the z prefetches and dz stores issued before them as
+    // well — every k-block drained the memory pipeline and the four-k-block z ring hid one k-block of latency
+    __shared__ f32x4 qps[2][NB * 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), j = lane & 15, g4 = lane >> 4;
     {
         const f32x4* W2T = reinterpret_cast<const f32x4*>(a.packed + a.oW2T);
         for (int i = tid; i < NB * NB * 64; i += WAVES * 64) w2t[i] = W2T[i];
         for (int i = tid; i < WAVES * 2 * NB * 4; i += WAVES * 64) (&pqs[0][0][0])[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (tid < NB * 4) {
+            qps[0][tid] = reinterpret_cast<const f32x4*>(a.packed + a.oQ)[tid];
+            qps[1][tid] = reinterpret_cast<const f32x4*>(a.packed + a.oP)[tid];
+        }
     }
-    const f32x4* Qp = reinterpret_cast<const f32x4*>(a.packed + a.oQ);
-    const f32x4* Pp = reinterpret_cast<const f32x4*>(a.packed + a.oP);
     const float* src = GIVEN ? a.dz : a.z;  // GIVEN: the upstream dL/dz rows are the B operand as they are
     const long long nwt = (a.nA + 15) / 16;  // wave tiles
     auto rows_of = [&](long long wt, long long& rA, long long& rB, bool& okA, bool& okB) {
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
                 dA = zrA[sl];
                 dB = zrB[sl];
             } else {
-                const f32x4 q = Qp[4 * kb + g4], p = Pp[4 * kb + g4];
+                const f32x4 q = qps[0][4 * kb + g4], p = qps[1][4 * kb + g4];
                 dA = dz_of(tg, q, p, zrA[sl], zrB[sl]);
                 dB = dz_of(tg, q, p, zrB[sl], zrA[sl]);
                 if (okA) {
@@ -266,19 +272,28 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // (left free, the scheduler hoists the LDS reads of every k-block to the top: spills)
+            // W2^T fragments two blocks at a time, the NEXT pair read under this pair's 16 MFMAs (round 5: read and waited
+            // for in front of their own MFMAs, every pair opened with an exposed LDS round trip, five per k-block)
+            f32x4 av[2][2];
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+                if (u < NB) av[0][u] = w2t[(kb * NB + u) * 64 + lane];
 #pragma unroll
             for (int nb0 = 0; nb0 < NB; nb0 += 2) {
-                f32x4 av[2];
+                const int cur = (nb0 >> 1) & 1;
+                if (nb0 + 2 < NB) {
 #pragma unroll
-                for (int u = 0; u < 2; ++u)
-                    if (nb0 + u < NB) av[u] = w2t[(kb * NB + nb0 + u) * 64 + lane];
+                    for (int u = 0; u < 2; ++u)
+                        if (nb0 + 2 + u < NB) av[cur ^ 1][u] = w2t[(kb * NB + nb0 + 2 + u) * 64 + lane];
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
                     for (int u = 0; u < 2; ++u) {
                         if (nb0 + u < NB) {
-                            dyA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], dA[r], dyA[nb0 + u], 0, 0, 0);
-                            dyB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], dB[r], dyB[nb0 + u], 0, 0, 0);
+                            dyA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][u][r], dA[r], dyA[nb0 + u], 0, 0, 0);
+                            dyB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[cur][u][r], dB[r], dyB[nb0 + u], 0, 0, 0);
                         }
                     }
                 }
