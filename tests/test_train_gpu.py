@@ -1105,7 +1105,7 @@ def test_validate_scores_in_kernel_sized_chunks(hip_lib, monkeypatch):
 
 
 @pytest.mark.parametrize("lossname", ["SoftCdet", "crossentropy"])
-@pytest.mark.parametrize("D,B", [(150, 2048), (150, 8), (150, 1003), (170, 2048), (170, 333), (150, 4096)])
+@pytest.mark.parametrize("D,B", [(150, 2048), (150, 8), (150, 3), (150, 1003), (170, 2048), (170, 333), (170, 2), (150, 4096)])
 def test_one_call_step_gradient_and_loss_against_the_fp64_oracle(hip_lib, lossname, D, B):
     """nplda_train_step_f32 on its own against the fp64 ORACLE (not against another kernel of this build): the loss, dL/dtheta
     and the applied flat gradient of one step.  B <= 2048 runs the 8-pair half-tile kernel (nplda_train_fb_half.h: the rows of
