@@ -1046,7 +1046,7 @@ WsLayout ws_layout(long long K, const NpldaLayout& L, bool want_dx) {
     w.slab2 = w.slab1 + (size_t)w.ksplit * w.Mp * w.Np1;
     w.ext = w.slab2 + (size_t)w.ksplit * w.Mp * w.Mp;
     w.pq = w.ext + (size_t)w.ksplit * 4 * w.Mp;
-    w.frag = w.pq + (size_t)((K / 2 + 7) / 8) * 2 * w.Mp;  // small-batch pair scoring: K / 2 pairs in blocks of 16 or 8
+    w.frag = w.pq + (size_t)(2 * ((K / 2 + 15) / 16)) * 2 * w.Mp;  // small-batch pair scoring: K / 2 pairs in tiles of 16, or two half tiles each
     w.total = w.frag + (want_dx ? (size_t)L.NB * L.KS1 * 256 : 0);
     return w;
 }
@@ -1059,7 +1059,7 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
                     const float* rn, long long ldz, const float* P_sqrt, float* wsf, const WsLayout& W, float* grad_flat,
                     float* dx0, float* dx1, long long lddx, hipStream_t st, const BwdLoss* ls = nullptr,
                     ReduceArgs* defer_reduce = nullptr, bool data_done = false, const LossTail* tail = nullptr,
-                    bool* tail_done = nullptr, bool x_bf16 = false, int pair_tile = 16) {
+                    bool* tail_done = nullptr, bool x_bf16 = false, int pq_rows = -1) {
     BwdArgs b = {};
     if (ls) {
         if (given || nsplit > 16 * 1024) return NPLDA_EUNSUPPORTED;
@@ -1122,7 +1122,8 @@ int backward_launch(bool given, const float* xa, const float* xb, long long K, l
     wa.nw0 = p1.MT * p1.NT * W.ksplit;
     wa.nw_mm = wa.nw0 + p2.MT * p2.NT * W.ksplit;
     wa.nw = wa.nw_ps = wa.nw_mm + (pair_sums ? W.ksplit : 0);
-    wa.pq = b.pq; wa.nblk = b.nA <= 16 * 1024 ? (int)((b.nA + pair_tile - 1) / pair_tile) : (int)stream_blocks;
+    // (pq_rows: rows of pair sums the data kernel left when it was not one per 16-pair tile — the half-tile kernels)
+    wa.pq = b.pq; wa.nblk = pq_rows >= 0 ? pq_rows : (b.nA <= 16 * 1024 ? (int)((b.nA + 15) / 16) : (int)stream_blocks);
     if (int rc = wgrad_launch(wa, L.NB, 2, st, tail, tail_done)) return rc;
     // K-C
     ReduceArgs ra = {};
@@ -1304,7 +1305,7 @@ struct StepWs { size_t y, z, rn, s, g, partial, xs, bwd, total; long long ldz, l
 static StepWs step_ws(long long B, const NpldaLayout& L, bool rows) {
     StepWs w;
     w.ldz = 16 * L.NB;
-    w.nblk = (int)((B + 7) / 8);  // (room for the half-tile kernel's blocks; the launcher says how many rows are in use)
+    w.nblk = 2 * (int)((B + 15) / 16);  // (room for the half-tile kernels' rows; the launcher says how many are in use)
     auto al = [](size_t v) { return (v + 63) / 64 * 64; };
     w.y = 0;
     w.z = al(w.y + (size_t)2 * B * w.ldz);
@@ -1388,7 +1389,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     const WsLayout W = ws_layout(2 * B, L, false);
     float* bws = wsf + S.bwd;
     bool dx_fused = false, x_direct = false;
-    int pair_tile = 16;
+    int nrows = (int)((B + 15) / 16);  // rows of pair sums / loss partials the first kernel leaves
     {   // forward + loss + data gradients: one kernel (nplda_train_fb_small.h; at the recipe shapes nplda_train_fb_half.h)
         TrainFbArgs fb = {};
         fb.xa = x1; fb.xb = x2; fb.n = B; fb.ldx = ldx; fb.packed = (const float*)packed; fb.D0 = L.D0; fb.KS1 = L.KS1;
@@ -1421,7 +1422,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
         // 512-d x-vectors at NB = 10 / 11, batches of up to one half tile per CU: 8-pair tiles (nplda_train_fb_half.h)
         const HalfSkew skew = half_skew();
         if (k32 && (L.NB == 10 || L.NB == 11) && use_half_tiles(B)) {
-            pair_tile = kHalfPairs;
+            nrows = (int)((B + kHalfPairs - 1) / kHalfPairs);
             const dim3 hgrid((unsigned)((B + kHalfPairs - 1) / kHalfPairs));
 #define NPLDA_LAUNCH_H(NBV)                                                                                                 \
     if (dx_fused && io_bf16) hipLaunchKernelGGL((train_fb_half_kernel<NBV, true, true, 2>), hgrid, block, 0, st, fb, skew);   \
@@ -1449,7 +1450,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     {   // the loss / threshold tail: in the weight-gradient launch where the full-M kernel runs, else in the update kernel
         LossTail& t = ua.tail;
         const size_t ngrad0 = nplda_grad_floats(D0, D1, D2);
-        t.partial = ls.partial; t.nblk = (int)((B + pair_tile - 1) / pair_tile); t.K = nth; t.kind = kind; t.beta = ls.beta; t.alpha = alpha;
+        t.partial = ls.partial; t.nblk = nrows; t.K = nth; t.kind = kind; t.beta = ls.beta; t.alpha = alpha;
         t.loss = loss; t.loss_sum = loss_sum; t.m = exp_avg + ngrad0; t.v = exp_avg_sq + ngrad0;
         t.gout = grad_out ? grad_out + ngrad0 : nullptr; t.step = step; t.bumped = 1;
         t.lr = lr; t.beta1 = beta1; t.beta2 = beta2; t.eps = eps; t.wd = weight_decay;
@@ -1463,7 +1464,7 @@ static int train_step_impl(const float* x1, const float* x2, const int64_t* rows
     const float* wx2 = staged ? wsf + S.xs + (size_t)B * S.ldxs : x2;
     if (int rc = backward_launch(false, wx1, wx2, 2 * B, B, staged ? S.ldxs : ldx, (const float*)packed, L, nullptr,
                                  wsf + S.y, wsf + S.z, wsf + S.rn, S.ldz, params[4], bws, W, grad_out, nullptr, nullptr, 0,
-                                 st, &ls, &ua.r, true, &ua.tail, &tail_done, x_direct, pair_tile))
+                                 st, &ls, &ua.r, true, &ua.tail, &tail_done, x_direct, nrows))
         return rc;
     if (dxa && !dx_fused) {  // dL/dx = du . W1 with the weights the forward used (the update below comes after)
         // (Measured and NOT kept, round 4: this launch on a side stream, forked behind the first kernel and joined in front of

@@ -5,11 +5,14 @@
 #ifndef NPLDA_FBH_STAMPS
 #define NPLDA_FBH_STAMPS 300
 #endif
+#ifndef NPLDA_FBD_STAMPS
+#define NPLDA_FBD_STAMPS 100
+#endif
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
-#include "../neuralplda_amd/csrc/nplda_train_fb_half.h"
+#include "exp_fb_duo_kernel.h"
 
 using namespace nplda;
 
@@ -87,9 +90,54 @@ int main(int argc, char** argv) {
         if (L.NB == 10) hipLaunchKernelGGL((train_fb_half_kernel<10, false>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, 0, fn, sk);
         else hipLaunchKernelGGL((train_fb_half_kernel<11, false>), dim3((unsigned)((B + 7) / 8)), dim3(256), 0, 0, fn, sk);
     };
+    Bufs bd;
+    {
+        Bufs* b = &bd;
+        CK(hipMalloc(&b->y, 2 * B * ldz * 4)); CK(hipMalloc(&b->dz, 2 * B * ldz * 4)); CK(hipMalloc(&b->du, 2 * B * ldz * 4));
+        CK(hipMalloc(&b->pq, ((B + 7) / 8 + 2) * 2 * ldz * 4)); CK(hipMalloc(&b->s, B * 4));
+        CK(hipMalloc(&b->partial, ((B + 7) / 8 + 2) * kLossNS * 8));
+        CK(hipMemset(b->y, 0, 2 * B * ldz * 4)); CK(hipMemset(b->dz, 0, 2 * B * ldz * 4)); CK(hipMemset(b->du, 0, 2 * B * ldz * 4));
+    }
+    const TrainFbArgs fd = args(bd);
+    auto go_duo = [&]() {
+        if (L.NB == 10) hipLaunchKernelGGL((train_fb_duo_kernel<10, false>), dim3((unsigned)((B + 15) / 16)), dim3(512), 0, 0, fd);
+        else hipLaunchKernelGGL((train_fb_duo_kernel<11, false>), dim3((unsigned)((B + 15) / 16)), dim3(512), 0, 0, fd);
+    };
     go_old();
     go_new(HalfSkew{1, 0});
+    go_duo();
     CK(hipDeviceSynchronize());
+    {
+        double r2;
+        printf("D=%d B=%lld  max|duo - old|: y %.3g", D, B, maxdiff(bd.y, bo.y, 2 * B * ldz, &r2)); printf(" (max %.3g)", r2);
+        printf("  dz %.3g", maxdiff(bd.dz, bo.dz, 2 * B * ldz, &r2)); printf(" (max %.3g)", r2);
+        printf("  du %.3g", maxdiff(bd.du, bo.du, 2 * B * ldz, &r2)); printf(" (max %.3g)", r2);
+        printf("  s %.3g", maxdiff(bd.s, bo.s, B, &r2)); printf(" (max %.3g)\n", r2);
+        const size_t no = ((B + 15) / 16), nn = 2 * ((B + 15) / 16);
+        std::vector<float> po(no * 2 * ldz), pn(nn * 2 * ldz);
+        std::vector<double> lo(no * kLossNS), ln(nn * kLossNS);
+        CK(hipMemcpy(po.data(), bo.pq, po.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(pn.data(), bd.pq, pn.size() * 4, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(lo.data(), bo.partial, lo.size() * 8, hipMemcpyDeviceToHost));
+        CK(hipMemcpy(ln.data(), bd.partial, ln.size() * 8, hipMemcpyDeviceToHost));
+        double md = 0, mr = 0;
+        for (int c = 0; c < 2 * ldz; ++c) {
+            if ((c % ldz) >= D) continue;
+            double so = 0, sn = 0;
+            for (size_t b = 0; b < no; ++b) so += po[b * 2 * ldz + c];
+            for (size_t b = 0; b < nn; ++b) sn += pn[b * 2 * ldz + c];
+            md = std::fmax(md, std::fabs(so - sn)); mr = std::fmax(mr, std::fabs(so));
+        }
+        printf("  duo pair sums: max diff %.3g of %.3g;", md, mr);
+        md = 0; mr = 0;
+        for (int c = 0; c < kLossNS; ++c) {
+            double so = 0, sn = 0;
+            for (size_t b = 0; b < no; ++b) so += lo[b * kLossNS + c];
+            for (size_t b = 0; b < nn; ++b) sn += ln[b * kLossNS + c];
+            md = std::fmax(md, std::fabs(so - sn)); mr = std::fmax(mr, std::fabs(so));
+        }
+        printf("  loss sums: max diff %.3g of %.3g\n", md, mr);
+    }
     double r;
     printf("D=%d B=%lld  max|new - old|: y %.3g", D, B, maxdiff(bn.y, bo.y, 2 * B * ldz, &r)); printf(" (max %.3g)", r);
     printf("  dz %.3g", maxdiff(bn.dz, bo.dz, 2 * B * ldz, &r)); printf(" (max %.3g)", r);
@@ -138,7 +186,20 @@ int main(int argc, char** argv) {
         return best;
     };
     printf("16-pair kernel: %.2f us / launch\n", timeit(go_old));
-    const HalfSkew modes[] = {{0, 0}, {1, 0}, {5, 0}, {3, 20}, {3, 60}, {3, 120}};
+    {
+        const float us = timeit(go_duo);
+        unsigned long long st[64];
+        CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_fbd_stamps), sizeof(st)));
+        const unsigned long long t00 = st[0] < st[32] ? st[0] : st[32];
+        printf("16-pair tile by eight waves (duo): %.2f us / launch\n", us);
+        for (int o = 0; o <= 32; o += 32) {
+            auto u = [&](int i) { return (double)(st[o + i] - t00) / 100.0; };
+            printf("      block %3d wave %d: entry %.2f | loads issued %.2f | L1 end %.2f | exchange %.2f | y %.2f | L2 end %.2f | scores %.2f | dz %.2f | "
+                   "dy end %.2f | end %.2f us\n", NPLDA_FBD_STAMPS, o ? 4 : 0, u(0), o ? u(0) : u(1), u(2), u(3), u(4), u(5), u(6), u(7), u(8), u(9));
+        }
+        printf("16-pair kernel again: %.2f us / launch\n", timeit(go_old));
+    }
+    const HalfSkew modes[] = {{0, 0}};
     for (const HalfSkew& sk : modes) {
         const float us = timeit([&]() { go_new(sk); });
         unsigned long long st[64];
