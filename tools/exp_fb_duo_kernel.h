@@ -4,6 +4,9 @@
 // 28.3 at D = 170 (profiles/r05h_exp_duo.txt).  The two waves of a SIMD run the same phase between the same barriers: their
 // serial stretches coincide (exchange -> y 1.4 us, loss + dz 2.1 us — the 16-pair kernel's times, not the lone half tile's
 // 1.0 / 1.65) and their MFMA phases queue behind each other (layer 2 ends at 15.0 us for one wave, 16.6 us for the other).
+// With the halves synchronising SEPARATELY behind the exchange (NPLDA_DUO_SPLIT: a barrier among four waves by an LDS counter
+// and a poll instead of s_barrier — the form tools/exp_fbh.hip builds) they do drift apart, half 0 ends at 20.8 us — and half
+// 1 still at 23.2 us, the launch still takes 26.9 us: the late half needs 12 us for what a lone half tile does in 8.
 //
 // What round 5 measured on the way to this form (profiles/r05b_exp_fbh.txt, design/k06_backward_and_train_step.md "Round 5"):
 // a lone 8-pair half tile (nplda_train_fb_half.h: a pair's x1 and x2 rows in ONE 16-row MFMA group, cross terms by DPP) spends
@@ -69,6 +72,8 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
     constexpr int NW = 4, LB = NB - 8, KSW = 8, PF = 4;
     constexpr int XD = NB == 11 ? 3 : 4;  // x ring (NB = 11: 88 accumulator + 88 weight registers leave room for three sets)
     __shared__ f32x4 lbuf[duo_lds_f4()];
+    __shared__ f32x4 ybuf[2][NB * 64];   // a half's y / dz / du tile: apart from the exchange region, the halves run apart
+    __shared__ unsigned hb[2];           // per-half barrier counters (NPLDA_DUO_SPLIT: the halves synchronise separately)
     __shared__ float red[2][NW][16];
     __shared__ float cnt_s[2][NW];
     __shared__ double lacc[2][kHalfPairs][kLossNS];
@@ -84,7 +89,22 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
     const int g = lane >> 4;
     const int side = j >> 3;
     const bool own_lo = wave < LB;
-    f32x4 (*yl)[64] = reinterpret_cast<f32x4 (*)[64]>(lbuf + half * (NB * 64));  // this half's y / dz / du tile (after the exchange)
+    f32x4 (*yl)[64] = reinterpret_cast<f32x4 (*)[64]>(&ybuf[half][0]);
+    if ((tid & 255) == 0) hb[half] = 0u;
+    unsigned epoch = 0;
+    // a barrier among the four waves of ONE half (LDS counter + poll): the two halves of the block drift apart behind the
+    // exchange, so that one half's serial stretches sit beside the other's MFMA phases
+    auto hbar = [&]() {
+#ifdef NPLDA_DUO_SPLIT
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        epoch += 4;
+        if (lane == 0) __hip_atomic_fetch_add(&hb[half], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        while (__hip_atomic_load(&hb[half], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP) < epoch) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#else
+        __syncthreads();
+#endif
+    };
     const __amdgpu_buffer_rsrc_t prsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.packed), 0, 0x7fffffff, 0x00020000);
     const unsigned lane16 = (unsigned)lane * 16u;
     auto ldw = [&](int soff) {
@@ -272,7 +292,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
         const float cw = target_count_wave_t(ls, te, t256);
         if (lane == 0) cnt_s[half][wave] = cw;
     }
-    __syncthreads();  // every exchange read is done: the y tile may overwrite the region
+    hbar();  // every exchange read is done: the y tile may overwrite the region
     const double Ntl = (double)((cnt_s[half][0] + cnt_s[half][1]) + (cnt_s[half][2] + cnt_s[half][3]));
     const double Nt = ls.gcount ? ls.gcount[0] : Ntl;
     const double Nn = ls.gcount ? ls.gcount[1] : (double)ls.B - Ntl;
@@ -294,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
     z[0] = b2p[4 * wave + g];
     z[1] = b2p[4 * (wave + 4) + g];
     z[2] = own_lo ? b2p[4 * (8 + wave) + g] : zero4;
-    __syncthreads();  // y complete (also orders the `red` reuse below)
+    hbar();  // y complete (also orders the `red` reuse below)
     if (wave == NW - 1) {  // the batch constants of dL/ds (fp64 divisions) by the wave with the fewest blocks
         loss_consts_counts(ls, Nt, Nn, lc);
         if (lane == 0) {
@@ -344,7 +364,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
     // W2^T fragments of the dy chain: on their way during the exchanges below
 #pragma unroll
     for (int s = 0; s < PF; ++s) fetch2(iW2T, s, s);
-    __syncthreads();  // scores of the tile; every wave is past layer 2: the y tile is free for dz
+    hbar();  // scores of the tile; every wave is past layer 2: the y tile is free for dz
     NPLDA_FBD_STAMP(6);
     const float si = ((red[half][0][j] + red[half][1][j]) + red[half][2][j]) + red[half][3][j];
     if (a.out_s != nullptr && wave == 0 && g == 0 && side == 0 && ok) a.out_s[t0 + j] = si;
@@ -393,7 +413,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
             // (nothing: the left-over blocks are written by their owners)
         }
     }
-    __syncthreads();  // dz of the tile in LDS, the loss terms of its pairs
+    hbar();  // dz of the tile in LDS, the loss terms of its pairs
     NPLDA_FBD_STAMP(7);
     if (t256 < kLossNS) {
         double v = 0.0;
@@ -426,7 +446,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
     dot = wave_xor_add(dot, 16);
     dot = wave_xor_add(dot, 32);
     if (g == 0) red[half][wave][j] = dot;
-    __syncthreads();
+    hbar();
     dot = ((red[half][0][j] + red[half][1][j]) + red[half][2][j]) + red[half][3][j];
     if (inv >= 1e12f) dot = 0.f;  // the clamp branch of F.normalize: u / eps, no projection term
 #pragma unroll
@@ -458,7 +478,7 @@ __global__ __launch_bounds__(512, 2) void train_fb_duo_kernel(const TrainFbArgs 
         };
 #pragma unroll
         for (int p = 0; p < PFX; ++p) fetchxw(p, p);
-        __syncthreads();  // du of the tile in LDS
+        hbar();  // du of the tile in LDS
         f32x4 xacc[XBW];
 #pragma unroll
         for (int kb = 0; kb < NB; ++kb) {

@@ -12,6 +12,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <vector>
+#ifndef NPLDA_DUO_JOINT
+#define NPLDA_DUO_SPLIT 1
+#endif
 #include "exp_fb_duo_kernel.h"
 
 using namespace nplda;
