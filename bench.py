@@ -1312,6 +1312,13 @@ def main():
                                      "frac": r170["roofline"]["frac"]}
                 if "stats_ms" in r170["config"]:
                     out[name]["d170"]["stats_ms"] = r170["config"]["stats_ms"]
+                if name in ("alt_cfg2", "alt_cfg5"):
+                    # the batch size of the reference's recipes (conf/voices_config.cfg, sre_config.cfg: batch_size 2048): one 8-pair
+                    # half tile per CU (csrc/nplda_train_fb_half.h) instead of 128 sixteen-pair tiles on half the chip
+                    a4 = argparse.Namespace(**vars(a2))
+                    a4.batch = 2048
+                    r2k = fn(a4, ctx)
+                    out[name]["b2048"] = {"ms_per_step": r2k["ms_per_step"], "value": r2k["value"], "frac": r2k["roofline"]["frac"]}
             except Exception as e:  # an alt object never takes the headline down with it
                 out.setdefault(name, {})["error"] = f"{type(e).__name__}: {e}"
             torch.cuda.empty_cache()
