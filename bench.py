@@ -832,7 +832,8 @@ def run_dropin(args, ctx, B=4096, n_utt=200000, n_valid=1 << 20):
     out = {"workload": f"the reference's literal training-loop body (xvector_NeuralPlda_pytorch.py:35-43) at {B} pairs per "
                        f"batch from a {n_utt}-utterance table, and validate() (:56-83) over {n_valid} trials, both through "
                        f"neuralplda_amd under compat.install(); torch.optim.Adam(lr 1e-4, weight_decay 1e-5) as the driver "
-                       f"creates it (`*_fused_adam`: compat.install(fused_adam=True))", "unit": "ms",
+                       f"creates it (`*_fused_adam`: compat.install(fused_adam=True) — one-launch Adam, backward on the calling "
+                       f"thread; `*_fused_adam_deferred_keyerror`: ... deferred_keyerror=True as well)", "unit": "ms",
            "sampling": "median of >= 15 repetitions of 40 - 60 steps; spread = [min, median, max]"}
     ids = [f"utt{i:07d}" for i in range(n_utt)]
     xmat = rng.standard_normal((n_utt, 512), dtype=np.float32)
@@ -854,8 +855,10 @@ def run_dropin(args, ctx, B=4096, n_utt=200000, n_valid=1 << 20):
             ts.append((time.perf_counter() - t0) / n * 1e3)
         return float(np.median(ts)), [float(min(ts)), float(np.median(ts)), float(max(ts))]
 
-    for fused in (False, True):
-        compat.install(fused_adam=fused)
+    for fused, deferred in ((False, False), (True, False), (True, True)):
+        # (fused_adam=True also runs backward on the calling thread; deferred_keyerror=True is the further opt-in that drops
+        # the loader's per-batch device round trip: compat.install's docstring)
+        compat.install(fused_adam=fused, deferred_keyerror=deferred)
         try:
             from utils.models import NeuralPlda
             from utils import sv_trials_loaders as svl
@@ -894,7 +897,7 @@ def run_dropin(args, ctx, B=4096, n_utt=200000, n_valid=1 << 20):
                     opt.step()
 
                 res = out.setdefault(f"d{D}", {})
-                sfx = "_fused_adam" if fused else ""
+                sfx = ("_fused_adam_deferred_keyerror" if deferred else "_fused_adam") if fused else ""
                 # (interleaved: literal, core, literal, core ... would share the box's noise; two passes each, the lower median
                 # of the two is the figure — a loaded host only ever adds time)
                 lit = min((wall(literal, 40) for _ in range(2)), key=lambda r: r[0])

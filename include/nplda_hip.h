@@ -264,7 +264,8 @@ int nplda_gather_rows_f32(const float* table, int64_t ldt, int64_t N, const int6
  * takes a trial number to its row of the resident (N, ldt) x-vector table (negative: the utterance is not in the table) and
  * out1[r, :] = table[map[num1[r]], :], out2[r, :] = table[map[num2[r]], :] (B rows each, row stride ldo).  A number outside
  * [0, nmap) gives a NaN row and bad[0] |= 1, a number mapped to no row a NaN row and bad[0] |= 2: the caller reads the word
- * back and raises the reference's KeyError (the word is only ever OR-ed into: the caller clears it). */
+ * back and raises the reference's KeyError (the word is only ever OR-ed into, with a system-scope atomic: the caller clears
+ * it, and may keep it in pinned host memory to read it after a stream synchronise without a copy). */
 int nplda_gather_pairs_mapped_f32(const float* table, int64_t ldt, int64_t N, const int64_t* map, int64_t nmap,
                                   const int64_t* num1, const int64_t* num2, int64_t B, int D0, float* out1, float* out2,
                                   int64_t ldo, int32_t* bad, nplda_stream_t stream);

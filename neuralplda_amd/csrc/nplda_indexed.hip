@@ -117,7 +117,8 @@ __global__ __launch_bounds__(kThreads) void gather_pairs_mapped_kernel(const flo
         const bool in_map = num >= 0 && num < nmap;
         const long long i = in_map ? map[num] : -1;
         const bool ok = i >= 0 && i < N;
-        if (!ok && lane == 0) atomicOr(bad, in_map ? 2 : 1);
+        // (system scope: the word may live in pinned host memory, where the caller reads it without a copy)
+        if (!ok && lane == 0) __hip_atomic_fetch_or(bad, in_map ? 2 : 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         const f32x4* src = reinterpret_cast<const f32x4*>(table + (ok ? i : 0) * ldt);
         f32x4* dst = reinterpret_cast<f32x4*>((second ? out2 : out1) + p * ldo);
         for (int c = lane; c < ncol4; c += 64) {

@@ -303,8 +303,9 @@ class _LossFn(torch.autograd.Function):
         need = grad_on and (ctx.needs_input_grad[0] or any(ctx.needs_input_grad[6:]))
         if need and reduce_sums is None and kind != ops.LOSS_HARD_CDET:
             # one rank, training: both loss passes in ONE call (one launch up to 4096 pairs; same bits as the two below)
-            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, ths, betas, alpha, kind)
+            loss, g, dth, _, joint = ops.loss_fwd_bwd(s, t, ths, betas, alpha, kind, want_joint=True)
         else:
+            joint = None
             sums = ops.loss_sums(s, t, ths, alpha, kind)
             if reduce_sums is not None:
                 sums = reduce_sums(sums)
@@ -312,20 +313,31 @@ class _LossFn(torch.autograd.Function):
         ctx.need = need
         ctx.nth = len(thetas)
         if need:
-            ctx.save_for_backward(g, dth, output, *thetas)
+            if joint is not None:
+                ctx.save_for_backward(joint, output, *thetas)
+            else:
+                ctx.save_for_backward(g, dth, output, *thetas)
+            ctx.joint, ctx.B = joint is not None, s.shape[0]
         return loss if loss.device == output.device else loss.to(output.device)
 
     @staticmethod
     def backward(ctx, gl):
         if not ctx.need:
             return (None,) * (6 + ctx.nth)
-        g, dth, output = ctx.saved_tensors[:3]
-        thetas = ctx.saved_tensors[3:]
-        gl = gl.to(g.device)
-        dthg = dth * gl  # (one product for all thresholds, sliced below)
+        if ctx.joint:  # [g | dtheta] in one buffer: one product
+            joint, output = ctx.saved_tensors[:2]
+            thetas = ctx.saved_tensors[2:]
+            if gl.device != joint.device:
+                gl = gl.to(joint.device)
+            gg, dthg = ops.loss_joint_views(joint * gl, ctx.B, ctx.nth)
+        else:
+            g, dth, output = ctx.saved_tensors[:3]
+            thetas = ctx.saved_tensors[3:]
+            gl = gl.to(g.device)
+            gg, dthg = g * gl, dth * gl
         dths = [_back(dthg[k:k + 1], th) if need else None
                 for k, (th, need) in enumerate(zip(thetas, ctx.needs_input_grad[6:]))]
-        return (_back(g * gl, output) if ctx.needs_input_grad[0] else None, None, None, None, None, None) + tuple(dths)
+        return (_back(gg, output) if ctx.needs_input_grad[0] else None, None, None, None, None, None) + tuple(dths)
 
 
 # ---------------------------------------------------------------------------------------------------

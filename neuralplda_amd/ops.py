@@ -4,6 +4,8 @@ Every function takes torch tensors that live on a HIP device, enqueues the kerne
 current stream and returns torch tensors.  No CPU path exists: a CPU tensor is an error here
 (neuralplda_amd.models stages CPU inputs through the device, it never computes on the host).
 """
+import functools
+
 import torch
 
 from . import _lib
@@ -240,6 +242,12 @@ def forward_train(x1, x2, packed):
     return s, (x1, x2, ld1, y, z, rn)
 
 
+@functools.lru_cache(maxsize=64)
+def _backward_sizes(rows, D0, D1, D2, want_dx):
+    lib = _lib.load()
+    return (lib.nplda_grad_floats(D0, D1, D2), lib.nplda_backward_ex_workspace_bytes(rows, D0, D1, D2, want_dx))
+
+
 def backward(saved, g, packed, P_sqrt, want_dx=False):
     """nplda_backward_ex_f32: flat gradient [dW1 | db1 | dW2 | db2 | dP_sqrt | dQ] for dL/ds = g; with want_dx also
     the input gradients -> (flat, dx1, dx2), dx (B, D0) = du . W1."""
@@ -249,9 +257,8 @@ def backward(saved, g, packed, P_sqrt, want_dx=False):
     dev = x1.device
     _require_dev_f32(g, "g")
     g = g.contiguous()
-    n = lib.nplda_grad_floats(packed.D0, packed.D1, packed.D2)
+    n, wsb = _backward_sizes(2 * B, packed.D0, packed.D1, packed.D2, 1 if want_dx else 0)
     flat = torch.empty(n, dtype=torch.float32, device=dev)
-    wsb = lib.nplda_backward_ex_workspace_bytes(2 * B, packed.D0, packed.D1, packed.D2, 1 if want_dx else 0)
     ws = torch.empty(max(wsb // 4, 4), dtype=torch.float32, device=dev)
     ps = P_sqrt.detach().contiguous()
     dx1 = torch.empty((B, packed.D0), dtype=torch.float32, device=dev) if want_dx else None
@@ -415,15 +422,8 @@ def lda_backward(x1, x2, paired, rn, dpaired, W1, want_w=True, want_dx=True):
 
 def split_flat_grad(flat, D0, D1, D2):
     """Views (dW1, db1, dW2, db2, dP_sqrt, dQ) into the flat gradient buffer."""
-    o = 0
-    out = []
-    for shape in ((D1, D0), (D1,), (D2, D1), (D2,), (D2,), (D2,)):
-        n = 1
-        for d in shape:
-            n *= d
-        out.append(flat[o:o + n].view(shape))
-        o += n
-    return tuple(out)
+    w1, b1, w2, b2, ps, q = flat.split_with_sizes((D1 * D0, D1, D2 * D1, D2, D2, D2))  # (one call: six views)
+    return w1.view(D1, D0), b1, w2.view(D2, D1), b2, ps, q
 
 
 def _theta_array(thetas):
@@ -474,8 +474,8 @@ def loss_finish(s, t, thetas, betas, alpha, kind, sums, want_grad=True):
     return loss, g, dth
 
 
-def loss_fwd_bwd(s, t, thetas, betas, alpha, kind):
-    """nplda_loss_fwd_bwd_f32: (loss 0-d tensor, g, dtheta (K,), sums) of an unsharded batch — both loss passes in one
+def loss_fwd_bwd(s, t, thetas, betas, alpha, kind, want_joint=False):
+    """nplda_loss_fwd_bwd_f32: (loss 0-d tensor, g, dtheta (K,), sums[, the buffer g and dtheta live in]) of an unsharded batch — both loss passes in one
     call (one launch up to 4096 pairs), bit-identical to loss_sums + loss_finish."""
     import ctypes
     lib = _lib.load()
@@ -491,15 +491,24 @@ def loss_fwd_bwd(s, t, thetas, betas, alpha, kind):
     dev = s.device
     sums = torch.empty(ns, dtype=torch.float64, device=dev)
     loss = torch.empty((), dtype=torch.float32, device=dev)
-    g = torch.empty_like(s)
-    dth = torch.empty(K, dtype=torch.float32, device=dev)
+    # g and dtheta share a buffer ([g (B) | pad to 4 | dtheta (K)]: loss_joint_views): the backward scales both by the
+    # incoming dL/dloss with ONE product
+    B = s.shape[0]
+    joint = torch.empty(((B + 3) & ~3) + K, dtype=torch.float32, device=dev)
+    g, dth = loss_joint_views(joint, B, K)
     barr = (ctypes.c_float * max(K, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
     with _lib.on_device(dev):
         code = lib.nplda_loss_fwd_bwd_f32(_lib.ptr(s), _lib.ptr(t), s.shape[0], _theta_array(thetas), barr, K,
                                           float(alpha), kind, _lib.ptr(sums), _lib.ptr(loss), _lib.ptr(g),
                                           _lib.ptr(dth), _lib.current_stream())
     _lib.check(code, "nplda_loss_fwd_bwd_f32")
-    return loss, g, dth, sums
+    return (loss, g, dth, sums, joint) if want_joint else (loss, g, dth, sums)
+
+
+def loss_joint_views(joint, B, K):
+    """(g, dtheta) inside loss_fwd_bwd's joint buffer (or a product of it)."""
+    o = (B + 3) & ~3
+    return joint[:B], joint[o:o + K]
 
 
 def pack_params_into(packed, W1, b1, W2, b2, P_sqrt, Q):
@@ -921,12 +930,43 @@ def gather_rows(table, idx, out=None):
 
 
 _BAD_FLAGS = {}
+KEYERROR_DEFERRED = False  # compat.install(lean=True): see gather_pairs_mapped
 
 
-def gather_pairs_mapped(table, num_map, num1, num2):
+def _bad_flag(dev):
+    """The gather kernels' error word of a device: one int32 in PINNED host memory (the kernel ORs into it over the bus,
+    only when a trial number is bad; the host reads it with a load, no copy) -> (tensor, its numpy view)."""
+    hit = _BAD_FLAGS.get(dev)
+    if hit is None:
+        t = torch.zeros(1, dtype=torch.int32).pin_memory()
+        hit = _BAD_FLAGS[dev] = (t, t.numpy())
+    return hit
+
+
+def _raise_bad(view):
+    bad = int(view[0])
+    if bad:
+        view[0] = 0
+        raise KeyError("trial index is outside num_to_id_dict" if bad & 1
+                       else "trial index refers to an utterance that is not in mega_dict")
+
+
+def check_trial_indices(device=None):
+    """Wait for the gathers enqueued so far and raise the KeyError of any bad trial number among them (the deferred mode's
+    explicit check: validate() and the epoch ends call it)."""
+    for dev, (_, view) in list(_BAD_FLAGS.items()):
+        if device is None or torch.device(device) == dev:
+            torch.cuda.current_stream(dev).synchronize()
+            _raise_bad(view)
+
+
+def gather_pairs_mapped(table, num_map, num1, num2, deferred=None):
     """nplda_gather_pairs_mapped_f32: (table[num_map[num1]], table[num_map[num2]]) as two (B, D0) float32 tensors in ONE
-    launch — load_xvec_trials_from_numbatch on the device.  Raises the reference's KeyError (one 4-byte read-back) when a
-    number is outside the map or names an utterance that is not in the table."""
+    launch — load_xvec_trials_from_numbatch on the device.  Raises the reference's KeyError when a number is outside the
+    map or names an utterance that is not in the table: the kernel raises a word in pinned host memory, read after a
+    stream synchronise (no copy).  deferred=True (default: KEYERROR_DEFERRED) skips that synchronise — the host keeps
+    running ahead of the device — and raises for the launches that HAVE finished: the KeyError of a bad batch then surfaces
+    at the next call (or at check_trial_indices()), its rows being NaN in the meantime."""
     lib = _lib.load()
     _require_dev_f32(table, "table")
     if table.dim() != 2 or table.stride(1) != 1 or table.stride(0) % 4 != 0 or table.shape[1] % 4 != 0:
@@ -941,20 +981,21 @@ def gather_pairs_mapped(table, num_map, num1, num2):
     out = torch.empty((2, B, D0), dtype=torch.float32, device=dev)
     if B == 0:
         return out[0], out[1]
-    flag = _BAD_FLAGS.get(dev)
-    if flag is None:
-        flag = _BAD_FLAGS[dev] = torch.zeros(1, dtype=torch.int32, device=dev)
+    flag, view = _bad_flag(dev)
+    if deferred is None:
+        deferred = KEYERROR_DEFERRED
+    if deferred:
+        _raise_bad(view)  # (an earlier batch's)
     with _lib.on_device(dev):  # (the launch goes to the CURRENT device: dev may not be it in a multi-GPU process)
+        st = _lib.current_stream(dev)
         code = lib.nplda_gather_pairs_mapped_f32(table.data_ptr(), table.stride(0), table.shape[0], num_map.data_ptr(),
                                                  num_map.numel(), num1.data_ptr(), num2.data_ptr(), B, D0, out[0].data_ptr(),
-                                                 out[1].data_ptr(), D0, flag.data_ptr(), _lib.current_stream(dev))
+                                                 out[1].data_ptr(), D0, flag.data_ptr(), st)
         _lib.check(code, "nplda_gather_pairs_mapped_f32")
-        bad = int(flag.item())
-        if bad:
-            flag.zero_()
-    if bad:
-        raise KeyError("trial index is outside num_to_id_dict" if bad & 1
-                       else "trial index refers to an utterance that is not in mega_dict")
+        if not deferred:
+            torch.cuda.current_stream(dev).synchronize()
+    if not deferred:
+        _raise_bad(view)
     return out[0], out[1]
 
 

@@ -12,6 +12,7 @@ then leaves torch's own class in charge.
 import ctypes
 
 import torch
+import torch.optim.optimizer as _opt
 
 from . import _lib
 
@@ -88,8 +89,25 @@ class FusedAdam(torch.optim.Optimizer):
                 (ctypes.c_int64 * n)(*[p.numel() for p, _ in live]), n, step.data_ptr())
         return blk
 
-    @torch.no_grad()
+    def zero_grad(self, set_to_none=True):
+        if not set_to_none:
+            return super().zero_grad(set_to_none=False)
+        for group in self.param_groups:  # (what torch's does, without its profiler range and per-device bookkeeping)
+            for p in group["params"]:
+                p.grad = None
+
     def step(self, closure=None):
+        """One launch per <= 12 tensors.  torch wraps every optimiser's step() in a profiler range plus its hook loops
+        (Optimizer.profile_hook_step, ~8 us per call); that wrapper is taken only when a step hook is registered."""
+        if (self._optimizer_step_pre_hooks or self._optimizer_step_post_hooks or _opt._global_optimizer_pre_hooks
+                or _opt._global_optimizer_post_hooks):
+            return self._step_hooked(closure)
+        return self._step(closure)
+
+    step.hooked = True  # (Optimizer.__init__ leaves a step() marked like this alone)
+
+    def _step(self, closure=None):
+        # (no torch op below touches a parameter: raw launches on data_ptr()s; nothing to shield from autograd)
         loss = None
         if closure is not None:
             with torch.enable_grad():
@@ -133,6 +151,8 @@ class FusedAdam(torch.optim.Optimizer):
                 # (models._packed_for) key on the version counter
                 torch.autograd.graph.increment_version(p)
         return loss
+
+    _step_hooked = torch.optim.Optimizer.profile_hook_step(_step)
 
     def load_state_dict(self, state_dict):
         super().load_state_dict(state_dict)

@@ -171,6 +171,10 @@ def _validate_chunk(model):
 def validate(nc, model, device, mega_xvec_dict, num_to_id_dict, data_loader, update_thresholds=False):
     """xvector_NeuralPlda_pytorch.py:56-83 (scores are collected in a list, not by repeated torch.cat)."""
     model.eval()
+    if torch.device(device).type == "cuda":
+        from . import ops as _ops
+        if _ops.KEYERROR_DEFERRED:  # (compat.install(deferred_keyerror=True): the training batches' pending KeyError)
+            _ops.check_trial_indices()
     with torch.no_grad():
         targets, scores = [], []
         device = torch.device(device)

@@ -86,3 +86,77 @@ def test_compat_install_fused_adam_substitutes_and_restores(hip_lib):
     finally:
         compat.uninstall()
     assert torch.optim.Adam is real
+
+
+def test_fused_adam_step_hooks_and_scheduler(hip_lib):
+    """step() skips torch's profiling wrapper unless a hook is registered: hooks still fire, and an LR scheduler (which wraps
+    optimizer.step on the instance) still counts the steps."""
+    from neuralplda_amd.optim import FusedAdam
+    ma, _, rng = _two_models()
+    opt = FusedAdam(ma.parameters(), lr=1e-3, weight_decay=1e-5)
+    sched = torch.optim.lr_scheduler.StepLR(opt, step_size=1, gamma=0.5)
+    x1 = torch.from_numpy(rng.standard_normal((64, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((64, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(64) < 0.2).astype(np.float32)).cuda()
+    fired = []
+    h1 = opt.register_step_pre_hook(lambda o, a, k: fired.append("pre"))
+    h2 = opt.register_step_post_hook(lambda o, a, k: fired.append("post"))
+    w0 = ma.Q.detach().clone()
+    opt.zero_grad()
+    ma.loss(ma(x1, x2), t).backward()
+    opt.step()
+    sched.step()
+    assert fired == ["pre", "post"] and opt.param_groups[0]["lr"] == 5e-4
+    assert not torch.equal(w0, ma.Q.detach())
+    h1.remove()
+    h2.remove()
+    opt.zero_grad()
+    assert all(p.grad is None for p in ma.parameters())
+    ma.loss(ma(x1, x2), t).backward()
+    opt.step()
+    assert fired == ["pre", "post"] and opt.state[ma.Q]["step"].item() == 2.0
+    opt.zero_grad(set_to_none=False)
+    assert float(ma.Q.grad.abs().sum()) == 0.0
+
+
+def test_install_inline_backward_and_deferred_keyerror(hip_lib):
+    """compat.install(fused_adam=True) runs backward on the calling thread (same gradients); deferred_keyerror=True moves the
+    KeyError of a bad trial number to the next loader call / check_trial_indices()."""
+    import neuralplda_amd.compat as compat
+    from neuralplda_amd import ops, sv_trials_loaders as svl
+    ma, mb, rng = _two_models()
+    x1 = torch.from_numpy(rng.standard_normal((300, 512)).astype(np.float32)).cuda()
+    x2 = torch.from_numpy(rng.standard_normal((300, 512)).astype(np.float32)).cuda()
+    t = torch.from_numpy((rng.random(300) < 0.2).astype(np.float32)).cuda()
+    ma.loss(ma(x1, x2), t).backward()
+    was = torch.autograd.is_multithreading_enabled()
+    compat.install(fused_adam=True, deferred_keyerror=True)
+    try:
+        assert not torch.autograd.is_multithreading_enabled() and ops.KEYERROR_DEFERRED
+        mb.loss(mb(x1, x2), t).backward()
+        for pa, pb in zip(ma.parameters(), mb.parameters()):
+            assert (pa.grad is None) == (pb.grad is None)
+            if pa.grad is not None:
+                assert torch.equal(pa.grad, pb.grad)
+        ids = [f"u{i}" for i in range(50)]
+        tab = svl.XvectorTable.from_matrix(ids, rng.standard_normal((50, 512)).astype(np.float32))
+        num_to_id = dict(enumerate(ids))
+        num_to_id[7] = "nobody"
+        good = torch.arange(0, 6).cuda()
+        badn = torch.tensor([1, 7, 3, 4, 5, 6]).cuda()
+        a, b = svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, badn, "cuda")  # returns: the error is pending
+        torch.cuda.synchronize()
+        assert torch.isnan(b[1]).all() and not torch.isnan(b[0]).any() and not torch.isnan(a).any()
+        with pytest.raises(KeyError):
+            svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, good, "cuda")
+        svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, good, "cuda")  # (raised once, then cleared)
+        svl.load_xvec_trials_from_numbatch(tab, num_to_id, badn, good, "cuda")
+        with pytest.raises(KeyError):
+            ops.check_trial_indices()
+    finally:
+        compat.uninstall()
+    assert torch.autograd.is_multithreading_enabled() == was and not ops.KEYERROR_DEFERRED
+    with pytest.raises(KeyError):  # the default: at once
+        svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, badn, "cuda")
+    with pytest.raises(KeyError):  # a number outside the map
+        svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, torch.tensor([1, 2, 3, 4, 5, 99]).cuda(), "cuda")

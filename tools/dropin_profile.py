@@ -19,12 +19,14 @@ import torch  # noqa: E402
 
 def main():
     import neuralplda_amd.compat as compat
-    compat.install()
+    compat.install(fused_adam="--fused-adam" in sys.argv, inline_backward="--inline-backward" in sys.argv,
+                   deferred_keyerror="--deferred" in sys.argv)
     from utils.models import NeuralPlda
     from utils.sv_trials_loaders import load_xvec_trials_from_numbatch
     dev = torch.device("cuda")
-    D = int(sys.argv[1]) if len(sys.argv) > 1 else 150
-    B = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
+    pos = [v for v in sys.argv[1:] if not v.startswith("--")]
+    D = int(pos[0]) if len(pos) > 0 else 150
+    B = int(pos[1]) if len(pos) > 1 else 4096
 
     class NC:
         xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D, D
