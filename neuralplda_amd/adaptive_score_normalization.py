@@ -95,10 +95,24 @@ class CohortState:
     thresholds are proposed from: nplda_cohort_prepare_f32).  Without it every `asnorm_scores` call — and every RANK of a
     row-sharded call — embeds the cohort and redoes that pre-pass: 63 us of the 250 us a rank spends on an eighth of
     cfg3.  Build with `CohortState.build(model, x_cohort, topN)`; hand it to `asnorm_scores(..., cohort=state)` or
-    `cohort_row_stats(..., prepared=state.prepared)`.  Valid while the model's parameters are unchanged."""
+    `cohort_row_stats(..., prepared=state.prepared)`.  Valid while the model's parameters are unchanged (`check(model)`,
+    which `asnorm_scores` calls, raises once they are not)."""
 
-    def __init__(self, packed, z_coh, q_coh, prepared, topN):
+    def __init__(self, packed, z_coh, q_coh, prepared, topN, stamp=None):
         self.packed, self.z_coh, self.q_coh, self.prepared, self.topN = packed, z_coh, q_coh, prepared, int(topN)
+        self.stamp = stamp  # (storage address, autograd version) of the six parameters it was built from
+
+    @staticmethod
+    def _stamp(model):
+        return tuple((t.data_ptr(), t._version) for t in (
+            model.centering_and_LDA.weight, model.centering_and_LDA.bias, model.centering_and_wccn_plda.weight,
+            model.centering_and_wccn_plda.bias, model.P_sqrt, model.Q))
+
+    def check(self, model):
+        """Raise if `model`'s parameters were modified in place (an optimiser step, load_state_dict: the autograd version
+        counters say so) or replaced since build(): the state's image and embeddings are the OLD model's."""
+        if model is not None and self.stamp is not None and self._stamp(model) != self.stamp:
+            raise ValueError("the model's parameters changed since this CohortState was built: build it again")
 
     @classmethod
     def build(cls, model, x_cohort, topN=ASnorm_topN):
@@ -106,7 +120,7 @@ class CohortState:
         with torch.no_grad():
             packed = ops.pack_params(*_model_params(model, dev))
             zc, qc = ops.embed(x_cohort, packed)
-            return cls(packed, zc, qc, ops.cohort_prepare(zc, qc, packed, topn=topN), topN)
+            return cls(packed, zc, qc, ops.cohort_prepare(zc, qc, packed, topn=topN), topN, cls._stamp(model))
 
 
 def cohort_row_stats(z_rows, q_rows, z_coh, q_coh, packed, topN=ASnorm_topN, select="lowest", group=None, prepared=None):
@@ -133,6 +147,7 @@ def asnorm_scores(model, x_rows, x_cohort, raw, ie, it, topN=ASnorm_topN, select
         if cohort is not None:
             if cohort.topN != int(topN):
                 raise ValueError("the CohortState was prepared for another top-N")
+            cohort.check(model)
             packed, zc, qc = cohort.packed, cohort.z_coh, cohort.q_coh
             zr, qr = ops.embed(x_rows[lo:hi], packed)
             local = ops.cohort_stats(zr, qr, zc, qc, packed, topn=topN, select=select, prepared=cohort.prepared)

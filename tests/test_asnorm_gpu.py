@@ -302,3 +302,11 @@ def test_prepared_cohort_gives_the_same_statistics(hip_lib):
     s1 = ops.cohort_stats(zr, qr, small.z_coh, small.q_coh, packed, topn=100)
     s2 = ops.cohort_stats(zr, qr, small.z_coh, small.q_coh, packed, topn=100, prepared=small.prepared)
     assert torch.equal(s1, s2)
+    # a state outlives no parameter change: an in-place update (what an optimiser step is) is noticed
+    with torch.no_grad():
+        m.Q.mul_(1.01)
+    with pytest.raises(ValueError, match="changed since"):
+        asn.asnorm_scores(m, xr, None, raw, ie, it, topN=500, cohort=state)
+    fresh = asn.CohortState.build(m, xc, topN=500)
+    c = asn.asnorm_scores(m, xr, None, raw, ie, it, topN=500, cohort=fresh)
+    assert torch.equal(c, asn.asnorm_scores(m, xr, xc, raw, ie, it, topN=500)) and not torch.equal(a, c)
