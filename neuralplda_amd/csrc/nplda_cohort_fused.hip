@@ -214,6 +214,7 @@ struct FusedArgs {
     unsigned* counts;       // [R][nsub]
     double* part;           // [R][nsub / 4]: sum over the list band's columns of (s - c_r)^2, c_r = the row's mean in fp32
     int nsub;               // nlb * 4 (lane groups)
+    int lrow;               // floats between the list regions of two rows: nsub * ksub + the plan's padding (fused_row_pad)
     int prio;               // static priority 1 for the block's second-dispatched waves (4 .. 7): they lose every VALU
                             // arbitration to the older half otherwise; -0.8 % on the statistics call in interleaved runs
                             // (NPLDA_COHORT_PRIO=0 switches it off for A/B)
@@ -325,7 +326,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             thr[g] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
             qrv[g] = a.qr[rc];
             s2[g] = 0.f;
-            cur[g] = 4u * (unsigned)(((rc * nlb + band_) * a.ksub) * 4 + g4);
+            cur[g] = 4u * (unsigned)(rc * a.lrow + (long long)band_ * a.ksub * 4 + g4);
         }
     };
     auto item_end = [&](long long rb_, int band_) {
@@ -338,7 +339,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 32, 64), __shfl_xor(__double2loint(u2), 32, 64));
             if (row < a.R) {
                 const unsigned sidx = (unsigned)(band_ * 4 + g4);
-                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(((row * nlb + band_) * a.ksub) * 4 + g4)) / 4u;
+                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(row * a.lrow + (long long)band_ * a.ksub * 4 + g4)) / 4u;
                 if (g4 == 0) {
                     a.part[(size_t)row * (a.nsub / 4) + band_] = u2;
                 }
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                 // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
                 long long rc = rb + wave * (16 * RGW) + 16 * g + i16;
                 if (rc >= a.R) rc = a.R - 1;
-                const unsigned lim = 4u * (unsigned)(((rc * nlb + band) * a.ksub + (a.ksub - kSubSlack)) * 4 + g4);
+                const unsigned lim = 4u * (unsigned)(rc * a.lrow + ((long long)band * a.ksub + (a.ksub - kSubSlack)) * 4 + g4);
                 cur[g] = o < lim ? o : lim;
             }
         };
@@ -509,6 +510,7 @@ struct FinishArgs {
     float zhi, fhi;                       // the proposal: t_r = c_r + sgn zhi sd_r, fhi = Phi(zhi) = proposed fraction
     int nsub, nsub_valid, topn, lowest;   // sub-lists [nsub_valid, nsub) belong to bands past the last column tile: never written
     int ksub, cap;                        // cap: keys one row may bring (<= kCandMax); more -> the fail list
+    int lrow;                             // floats between two rows' list regions (FusedArgs::lrow)
     unsigned* nfail; unsigned* fail_rows;
     double* stats;
 };
@@ -559,7 +561,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     }
     // gather the sub-lists (lane = sub-list) into this wave's LDS run as order-preserving keys: element e of sub-list s
     // lands at pre[s] + e — a fixed order
-    const float* lrow = a.lists + (size_t)row * a.nsub * a.ksub;  // [list band][slot][g]: sub-list s = lb 4 + g
+    const float* lrow = a.lists + (size_t)row * a.lrow;  // [list band][slot][g]: sub-list s = lb 4 + g
     // Two groups of 64 sub-lists are fetched together (8 slots of each per batch): with 128 short sub-lists per row
     // (list bands) the gather is a chain of memory round trips, and one batch per group doubled their number.
     auto gather2 = [&](int j0) {
@@ -719,6 +721,20 @@ inline size_t align256(size_t v) { return (v + 255) / 256 * 256; }
 namespace nplda {
 
 // inverse normal CDF (Abramowitz & Stegun 26.2.23), host side
+// Floats of padding behind a row's list region.  Without it two rows' regions are nsub * ksub * 4 B = a power of two
+// apart (32 KB at cfg3) and the lines a block's 256 rows are appending to compete for the same few L2 sets: they were
+// written back half filled and re-opened — 436 MB of L2 write-backs per cfg3 call for 94 MB of candidates.  An odd number of
+// 128-byte lines between rows: 264 - 268 MB for 160 / 224 / 288 / 544 / 1056 / 2080 floats (312 at 32, 343 at 64);
+// tools/exp_rowpad.sh, profiles/r05q_rowpad.txt.  (Times: fused kernel unchanged, select kernel 83 -> 80 us.)
+static int fused_row_pad() {
+    static const int pad = [] {
+        const char* e = getenv("NPLDA_COHORT_ROWPAD");  // (A/B runs)
+        const int v = e ? atoi(e) : 160;
+        return v < 0 ? 0 : (v + 3) / 4 * 4;
+    }();
+    return pad;
+}
+
 static float host_normcdfinv(double p) {
     const bool lower = p < 0.5;
     const double pp = lower ? p : 1.0 - p;
@@ -788,8 +804,9 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256((size_t)kQzBlocks * (Mp + 1) * 8) +
                     align256((size_t)(Mp + 1) * 8) + align256(kb * kb * 256 * 4) +
                     align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
-    p.max_rows = ((1LL << 30) / ((long long)p.nsub * p.ksub)) / 256 * 256;  // 32-bit BYTE offsets into the lists
-    p.row_bytes = 8 + 8 + (size_t)p.nsub * p.ksub * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
+    const long long lrow = (long long)p.nsub * p.ksub + fused_row_pad();
+    p.max_rows = ((1LL << 30) / lrow) / 256 * 256;  // 32-bit BYTE offsets into the lists
+    p.row_bytes = 8 + 8 + (size_t)lrow * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
     p.eligible = true;
     return p;
 }
@@ -856,7 +873,8 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     // per-row arrays, sized for rows_cap rows
     double* part = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * (p.nsub / 4) * 8);
     double* mean64 = reinterpret_cast<double*>(q); q += align256((size_t)rows_cap * 8);
-    float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * p.nsub * p.ksub * 4);
+    const int lrow = p.nsub * p.ksub + fused_row_pad();
+    float* lists = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * lrow * 4);
     unsigned* counts = reinterpret_cast<unsigned*>(q); q += align256((size_t)rows_cap * p.nsub * 4);
     float* crow = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * 4);
     float* trow = reinterpret_cast<float*>(q); q += align256((size_t)rows_cap * 4);
@@ -903,7 +921,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     const int rpb = half_tiles ? 128 : 256;
     fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + rpb - 1) / rpb); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
-    fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub;
+    fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub; fa.lrow = lrow;
     { static const int pr = getenv("NPLDA_COHORT_PRIO") ? atoi(getenv("NPLDA_COHORT_PRIO")) : 1; fa.prio = pr; }
     long long grid = (long long)fa.ny * p.nbands * p.q;  // at most one block per work item
     if (grid > resident) grid = resident;
@@ -928,7 +946,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
 #undef NPLDA_LAUNCH
     if (int rc = nplda_launch_status()) return rc;
-    FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, p.cap, ctl + 8,
+    FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, p.cap, lrow, ctl + 8,
                      fail_rows, stats};
     hipLaunchKernelGGL(cohort_finish_kernel, dim3((unsigned)((R + 3) / 4)), dim3(256), (size_t)p.cap * 16, st, fi);
     return nplda_launch_status();
