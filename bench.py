@@ -980,8 +980,13 @@ def run_secondary(args, ctx):
         ms, sc = kernel_ms_of(lambda: ops.score_indexed(zb, qb, j1, j2, packed))
         bpp = 2 * 4 * D + 2 * 4 + 2 * 8 + 4
         ach = B * bpp / (ms * 1e-3) / 1e12
+        # the same pairs with the self terms formed from the rows (q=None): 8 bytes per pair less to gather
+        ms_self, _ = kernel_ms_of(lambda: ops.score_indexed(zb, None, j1, j2, packed))
+        self_terms = {"value": B / (ms_self * 1e-3), "kernel_ms": ms_self, "bytes_per_pair_algorithmic": bpp - 8,
+                      "frac": B * (bpp - 8) / (ms_self * 1e-3) / 1e12 / HBM_PEAK_TBPS}
         if lean:
-            rb[f"d{D}"] = {"value": B / (ms * 1e-3), "kernel_ms": ms, "frac": ach / HBM_PEAK_TBPS}
+            rb[f"d{D}"] = {"value": B / (ms * 1e-3), "kernel_ms": ms, "frac": ach / HBM_PEAK_TBPS,
+                           "self_terms_from_z": self_terms}
             continue
         # the same call on a cache-resident table (100 k utterances, 64 MB)
         ns = 100000
@@ -997,6 +1002,7 @@ def run_secondary(args, ctx):
                                                      "frac_of_hbm_peak": B * bpp / (ms_s * 1e-3) / 1e12 / HBM_PEAK_TBPS},
                        "embed_100k_utts": {"value": ns / (ms_e * 1e-3), "unit": "utterances/s", "kernel_ms": ms_e,
                                            "frac_of_fp32_mfma_peak": ns * fe / (ms_e * 1e-3) / 1e12 / FP32_MFMA_PEAK_TFLOPS},
+                       "self_terms_from_z": self_terms,
                        "checksum_finite": bool(torch.isfinite(sc).all().item())}
         del zb, qb, j1, j2, X
     if want("regimeB"):

@@ -17,39 +17,77 @@ namespace {
 constexpr int kThreads = 256;
 constexpr int kLPP = 8;  // lanes per pair
 
-__device__ __forceinline__ float group8_sum(float v) {
-    v += __shfl_xor(v, 1, 64);
-    v += __shfl_xor(v, 2, 64);
-    v += __shfl_xor(v, 4, 64);
-    return v;
-}
-
+// 8 lanes per pair, KM float4 columns per lane (sub + 8 k).  What round 5 changed, measured on the 1.2 M-row table
+// (profiles/r05r_indexed.txt):
+//  * a pair's three dependent round trips (its indices -> its rows -> q[i1], q[i2] by lane 0 at the very end) are one now: the
+//    NEXT pair's indices are loaded under this pair's rows, the self terms come with the rows — a wave had its row bytes in
+//    flight for a third of an iteration;
+//  * SELF: q[i] = sum_d Q_d z[i, d]^2 is formed from the row the lane holds anyway instead of being gathered — two scattered
+//    4-byte reads (a 64-byte sector each) per 1 228-byte pair less;
+//  * 2 P and Q are loop invariant: in registers, not re-read per pair; the 8-lane sum on the DPP path (three ds_bpermute
+//    round trips per pair before).
+template <bool SELF, int KM>
 __global__ __launch_bounds__(kThreads) void score_indexed_kernel(const float* __restrict__ z, long long ldz,
                                                                  const float* __restrict__ q, long long N,
                                                                  const long long* __restrict__ i1,
                                                                  const long long* __restrict__ i2, long long B,
-                                                                 const float* __restrict__ P, int ncol4,
-                                                                 float* __restrict__ s) {
+                                                                 const float* __restrict__ P, const float* __restrict__ Q,
+                                                                 int ncol4, float* __restrict__ s) {
     const int sub = threadIdx.x & (kLPP - 1);
     const long long stride = (long long)gridDim.x * (kThreads / kLPP);
-    for (long long p = (long long)blockIdx.x * (kThreads / kLPP) + threadIdx.x / kLPP; p < B; p += stride) {
-        const long long a = i1[p], b = i2[p];
-        const bool ok = a >= 0 && a < N && b >= 0 && b < N;
-        float acc = 0.f;
-        if (ok) {
-            const f32x4* za = reinterpret_cast<const f32x4*>(z + a * ldz);
-            const f32x4* zb = reinterpret_cast<const f32x4*>(z + b * ldz);
-            const f32x4* P4 = reinterpret_cast<const f32x4*>(P);
-            for (int c = sub; c < ncol4; c += kLPP) {
-                const f32x4 va = za[c], vb = zb[c], pp = P4[c];
-                acc = fmaf(pp[0] * va[0], vb[0], acc);
-                acc = fmaf(pp[1] * va[1], vb[1], acc);
-                acc = fmaf(pp[2] * va[2], vb[2], acc);
-                acc = fmaf(pp[3] * va[3], vb[3], acc);
-            }
+    long long p = (long long)blockIdx.x * (kThreads / kLPP) + threadIdx.x / kLPP;
+    int col[KM];
+    f32x4 p2[KM], qq[KM];
+#pragma unroll
+    for (int k = 0; k < KM; ++k) {
+        const int c = sub + kLPP * k;
+        const bool valid = c < ncol4;
+        col[k] = valid ? c : ncol4 - 1;  // (always-valid addresses; the weights of a column past the row are zero)
+        const f32x4 pv = reinterpret_cast<const f32x4*>(P)[col[k]], qv = reinterpret_cast<const f32x4*>(Q)[col[k]];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            p2[k][r] = valid ? 2.0f * pv[r] : 0.f;
+            qq[k][r] = valid && SELF ? qv[r] : 0.f;
         }
-        acc = group8_sum(acc);
-        if (sub == 0) s[p] = ok ? q[a] + q[b] + 2.0f * acc : __builtin_nanf("");
+    }
+    long long a = -1, b = -1;
+    if (p < B) {
+        a = i1[p];
+        b = i2[p];
+    }
+    while (p < B) {
+        const long long pn = p + stride;
+        long long an = -1, bn = -1;
+        if (pn < B) {  // the next pair's indices travel under this pair's rows
+            an = i1[pn];
+            bn = i2[pn];
+        }
+        const bool ok = a >= 0 && a < N && b >= 0 && b < N;
+        const long long ac = ok ? a : 0, bc = ok ? b : 0;
+        const f32x4* za = reinterpret_cast<const f32x4*>(z + ac * ldz);
+        const f32x4* zb = reinterpret_cast<const f32x4*>(z + bc * ldz);
+        float acc = 0.f;
+        if (!SELF) acc = sub == 0 ? q[ac] : (sub == 1 ? q[bc] : 0.f);
+        f32x4 va[KM], vb[KM];
+#pragma unroll
+        for (int k = 0; k < KM; ++k) {
+            va[k] = za[col[k]];
+            vb[k] = zb[col[k]];
+        }
+#pragma unroll
+        for (int k = 0; k < KM; ++k)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                acc = fmaf(p2[k][r] * va[k][r], vb[k][r], acc);
+                if (SELF) acc = fmaf(qq[k][r], fmaf(va[k][r], va[k][r], vb[k][r] * vb[k][r]), acc);
+            }
+        acc += dpp_f32<0xB1>(acc);   // quad_perm [1, 0, 3, 2]
+        acc += dpp_f32<0x4E>(acc);   // quad_perm [2, 3, 0, 1]
+        acc += dpp_f32<0x141>(acc);  // row_half_mirror: the other quad of the pair's eight lanes
+        if (sub == 0) s[p] = ok ? acc : __builtin_nanf("");
+        p = pn;
+        a = an;
+        b = bn;
     }
 }
 
@@ -148,12 +186,28 @@ int nplda_score_indexed_f32(const float* z, int64_t ldz, const float* q, int64_t
     if (!nplda_dims_ok(D0, D1, D2)) return NPLDA_EUNSUPPORTED;
     if (B == 0) return NPLDA_OK;
     const NpldaLayout L = nplda_layout(D0, D1, D2);
-    if (!z || !q || !i1 || !i2 || !packed || !s) return NPLDA_EINVAL;
+    if (!z || !i1 || !i2 || !packed || !s) return NPLDA_EINVAL;  // (q may be null: the self terms then come from z)
     if (ldz < 16 * L.NB || (ldz % 4) != 0 || !nplda_aligned16(z) || !nplda_aligned16(packed)) return NPLDA_EINVAL;
     const float* P = (const float*)packed + L.oP;
-    hipLaunchKernelGGL(score_indexed_kernel, dim3(grid_for(B, kThreads / kLPP)), dim3(kThreads), 0,
-                       (hipStream_t)stream, z, (long long)ldz, q, (long long)N, (const long long*)i1,
-                       (const long long*)i2, (long long)B, P, (D2 + 3) / 4, s);
+    const float* Q = (const float*)packed + L.oQ;
+    const int ncol4 = (D2 + 3) / 4, km = (ncol4 + kLPP - 1) / kLPP;
+    const dim3 grid(grid_for(B, kThreads / kLPP)), block(kThreads);
+#define NPLDA_LAUNCH(SELFV, KMV)                                                                                        \
+    hipLaunchKernelGGL((score_indexed_kernel<SELFV, KMV>), grid, block, 0, (hipStream_t)stream, z, (long long)ldz, q, \
+                       (long long)N, (const long long*)i1, (const long long*)i2, (long long)B, P, Q, ncol4, s)
+#define NPLDA_PICK(SELFV)                        \
+    switch (km) {                                \
+        case 1: NPLDA_LAUNCH(SELFV, 1); break;   \
+        case 2: NPLDA_LAUNCH(SELFV, 2); break;   \
+        case 3: NPLDA_LAUNCH(SELFV, 3); break;   \
+        case 4: NPLDA_LAUNCH(SELFV, 4); break;   \
+        case 5: NPLDA_LAUNCH(SELFV, 5); break;   \
+        case 6: NPLDA_LAUNCH(SELFV, 6); break;   \
+        default: return NPLDA_EUNSUPPORTED;      \
+    }
+    if (q == nullptr) { NPLDA_PICK(true) } else { NPLDA_PICK(false) }
+#undef NPLDA_PICK
+#undef NPLDA_LAUNCH
     return nplda_launch_status();
 }
 

@@ -452,8 +452,8 @@ class NeuralPlda(nn.Module):
         prm = self._params()
         with torch.no_grad():
             packed = _packed_for(self.__dict__.get("_pack_cache"), prm, "fp32")
-            z, q = ops.embed_rows(table, urows, packed)
-            return ops.score_indexed(z, q, j1, j2, packed)
+            z, _ = ops.embed_rows(table, urows, packed)
+            return ops.score_indexed(z, None, j1, j2, packed)  # (self terms from the rows: no scattered q reads)
 
     # -- losses ----------------------------------------------------------------------------------
     def _alpha(self):

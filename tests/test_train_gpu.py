@@ -271,6 +271,28 @@ def test_score_indexed_and_gather(hip_lib, D):
     # out-of-range index -> NaN, not a fault
     bad = ops.score_indexed(z, q, torch.tensor([0, N]), torch.tensor([1, 2]), packed).cpu().numpy()
     assert np.isfinite(bad[0]) and np.isnan(bad[1])
+    # q=None: the self terms formed from the rows themselves — the same scores to the fp32 tolerance
+    s_self = ops.score_indexed(z, None, torch.from_numpy(i1), torch.from_numpy(i2), packed).cpu().numpy()
+    assert np.all(np.abs(s_self - ref) <= 2e-5 + 1e-5 * np.abs(ref))
+    bad = ops.score_indexed(z, None, torch.tensor([0, -1]), torch.tensor([1, 2]), packed).cpu().numpy()
+    assert np.isfinite(bad[0]) and np.isnan(bad[1])
+
+
+@pytest.mark.parametrize("D1,D2", [(16, 16), (40, 24), (100, 70), (128, 128), (160, 160), (192, 180)])
+def test_score_indexed_other_widths(hip_lib, D1, D2):
+    """Every column count of the indexed kernel (1 .. 6 float4 columns per lane), with and without the q table, ragged B."""
+    from neuralplda_amd import ops
+    rng = np.random.default_rng(D1 + D2)
+    p = rand_params(rng, 64, D1, D2)
+    N, B = 300, 1237
+    x = rng.standard_normal((N, 64)).astype(np.float32)
+    i1, i2 = rng.integers(0, N, B), rng.integers(0, N, B)
+    packed = ops.pack_params(*[torch.from_numpy(a).cuda() for a in p.tensors()])
+    z, q = ops.embed(torch.from_numpy(x).cuda(), packed)
+    ref = orc.forward(x[i1], x[i2], p, np.float64)
+    for qq in (q, None):
+        s = ops.score_indexed(z, qq, torch.from_numpy(i1), torch.from_numpy(i2), packed).cpu().numpy()
+        assert np.all(np.abs(s - ref) <= 2e-5 + 1e-5 * np.abs(ref)), (D1, D2, qq is None)
 
 
 def test_cpu_tensors_are_staged_through_the_device(hip_lib):
