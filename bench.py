@@ -983,7 +983,8 @@ def run_secondary(args, ctx):
         # the same pairs with the self terms formed from the rows (q=None): 8 bytes per pair less to gather
         ms_self, _ = kernel_ms_of(lambda: ops.score_indexed(zb, None, j1, j2, packed))
         self_terms = {"value": B / (ms_self * 1e-3), "kernel_ms": ms_self, "bytes_per_pair_algorithmic": bpp - 8,
-                      "frac": B * (bpp - 8) / (ms_self * 1e-3) / 1e12 / HBM_PEAK_TBPS}
+                      "frac": B * (bpp - 8) / (ms_self * 1e-3) / 1e12 / HBM_PEAK_TBPS,
+                      "traffic": _traffic(f"score_indexed_self_D{D}_B{B}_N{N}")}
         if lean:
             rb[f"d{D}"] = {"value": B / (ms * 1e-3), "kernel_ms": ms, "frac": ach / HBM_PEAK_TBPS,
                            "self_terms_from_z": self_terms}

@@ -2,7 +2,7 @@
 # Round-end evidence in ONE gpurun call: the driver's bench line, the --workload lines, kernel traces (with the per-launch
 # series of the dominant kernel: the cold start is several launches long), PMC passes of every headline kernel, and
 # profiles/traffic.json REGENERATED from those passes (tools/traffic_from_pmc.py).   usage: round_end_bench.sh <tag, e.g. r05z>
-TAG=${1:-r05z}
+TAG=${1:-r05s}
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/gpurun_out/$TAG
 mkdir -p $O
@@ -46,8 +46,10 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   cohort_stats_D150_R22000_M10000=$O/pmc_cfg3:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
-  score_indexed_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel \
-  score_indexed_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel \
+  "score_indexed_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel<false" \
+  "score_indexed_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel<false" \
+  "score_indexed_self_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel<true" \
+  "score_indexed_self_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel<true" \
   gb_score_D170_B524288=$O/pmc_gb:nplda_fwd_kernel \
   score_pairs_D150_B524288=$O/pmc_cfg1_s2:nplda_fwd_v3_kernel score_pairs_D150_B262144=$O/pmc_cfg1_s4:nplda_fwd_v3_kernel \
   score_pairs_D150_B131072=$O/pmc_cfg1_s8:nplda_fwd_v3_kernel \
