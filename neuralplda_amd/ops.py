@@ -936,13 +936,13 @@ _BAD_FLAGS = {}
 KEYERROR_DEFERRED = False  # compat.install(lean=True): see gather_pairs_mapped
 
 
-def _bad_flag(dev):
+def _bad_flag(dev, stream=0):
     """The gather kernels' error word of a device: one int32 in PINNED host memory (the kernel ORs into it over the bus,
     only when a trial number is bad; the host reads it with a load, no copy) -> (tensor, its numpy view)."""
-    hit = _BAD_FLAGS.get(dev)
+    hit = _BAD_FLAGS.get((dev, stream))  # (a word per stream: whose launch raised it is then unambiguous)
     if hit is None:
         t = torch.zeros(1, dtype=torch.int32).pin_memory()
-        hit = _BAD_FLAGS[dev] = (t, t.numpy())
+        hit = _BAD_FLAGS[(dev, stream)] = (t, t.numpy())
     return hit
 
 
@@ -957,9 +957,12 @@ def _raise_bad(view):
 def check_trial_indices(device=None):
     """Wait for the gathers enqueued so far and raise the KeyError of any bad trial number among them (the deferred mode's
     explicit check: validate() and the epoch ends call it)."""
-    for dev, (_, view) in list(_BAD_FLAGS.items()):
+    synced = set()
+    for (dev, _), (_, view) in list(_BAD_FLAGS.items()):
         if device is None or torch.device(device) == dev:
-            torch.cuda.current_stream(dev).synchronize()
+            if dev not in synced:
+                torch.cuda.synchronize(dev)  # (every stream of the device: a word per stream)
+                synced.add(dev)
             _raise_bad(view)
 
 
@@ -984,13 +987,13 @@ def gather_pairs_mapped(table, num_map, num1, num2, deferred=None):
     out = torch.empty((2, B, D0), dtype=torch.float32, device=dev)
     if B == 0:
         return out[0], out[1]
-    flag, view = _bad_flag(dev)
     if deferred is None:
         deferred = KEYERROR_DEFERRED
-    if deferred:
-        _raise_bad(view)  # (an earlier batch's)
     with _lib.on_device(dev):  # (the launch goes to the CURRENT device: dev may not be it in a multi-GPU process)
         st = _lib.current_stream(dev)
+        flag, view = _bad_flag(dev, st)
+        if deferred:
+            _raise_bad(view)  # (an earlier batch's)
         code = lib.nplda_gather_pairs_mapped_f32(table.data_ptr(), table.stride(0), table.shape[0], num_map.data_ptr(),
                                                  num_map.numel(), num1.data_ptr(), num2.data_ptr(), B, D0, out[0].data_ptr(),
                                                  out[1].data_ptr(), D0, flag.data_ptr(), st)

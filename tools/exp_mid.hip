@@ -43,12 +43,24 @@ int main(int argc, char** argv) {
     CK(hipDeviceSynchronize());
     if (argc > 3) {  // phase stamps of one block: tools/exp_mid D rounds B
         const long long B = atoll(argv[3]);
+        const bool embed = argc > 4;  // tools/exp_mid D rounds N embed [noq]: the EMBED form on N rows (N / 2 pairs' worth of work)
         FwdArgs m = {};
         m.xa = x1; m.xb = x2; m.n = B; m.ldx = D0; m.packed = packed; m.out_s = s2;
         m.D0 = L.D0; m.KS1 = L.KS1; m.oW2 = L.oW2; m.ob1 = L.ob1; m.ob2 = L.ob2; m.oQ = L.oQ; m.oP = L.oP; m.total = L.total;
+        float* zout = nullptr;
+        if (embed) {
+            CK(hipMalloc(&zout, (size_t)B * 16 * L.NB * 4));
+            m.out_z = zout; m.ldz = 16 * L.NB; m.out_q = argc > 5 ? nullptr : s2; m.out_s = nullptr;
+        }
+        hipEvent_t f0, f1; CK(hipEventCreate(&f0)); CK(hipEventCreate(&f1));
         for (int rep = 0; rep < 4; ++rep) {
-            for (int k = 0; k < 10; ++k) launch_fwd_mid<false>(m, L, 0);
+            for (int k = 0; k < 3; ++k) embed ? launch_fwd_mid<true>(m, L, 0) : launch_fwd_mid<false>(m, L, 0);
+            CK(hipEventRecord(f0, 0));
+            for (int k = 0; k < 10; ++k) embed ? launch_fwd_mid<true>(m, L, 0) : launch_fwd_mid<false>(m, L, 0);
+            CK(hipEventRecord(f1, 0));
             CK(hipDeviceSynchronize());
+            float tms = 0; CK(hipEventElapsedTime(&tms, f0, f1));
+            printf("%s: %.1f us per launch\n", embed ? "EMBED" : "PAIR", tms * 100.0);
             unsigned long long st[32];
             CK(hipMemcpyFromSymbol(st, HIP_SYMBOL(g_mid_stamps), sizeof(st)));
             const char* names[] = {"entry", "prologue loads issued", "step 0 done", "K loop end", "exported", "barrier 1", "reduced + ss",
