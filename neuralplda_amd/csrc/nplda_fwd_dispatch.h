@@ -6,13 +6,16 @@
 #include "nplda_fwd_v2.h"
 #include "nplda_fwd_v3.h"
 #include "nplda_fwd_v5.h"
+#include "nplda_fwd_v6.h"
 #include "nplda_fwd_mid.h"
 
 namespace nplda {
 
 // Product configuration, chosen by interleaved A/B runs of tools/exp_fwd.hip on MI355X
 // (profiles/r01b_*, r01d_*, r01t_*):
-//  * large batches, pair scoring, NB <= 10: the persistent continuous-stream schedule (nplda_fwd_v3.h),
+//  * large batches, pair scoring, D1 = D2 = 150 (round 5): nplda_fwd_v6.h — v5's schedule with the six left-over features
+//    on 4 x 4 x 1 MFMAs instead of a tenth 16-feature block: 0.842 against v3's 0.831;
+//  * large batches, pair scoring, NB <= 10 otherwise: the persistent continuous-stream schedule (nplda_fwd_v3.h),
 //    8 waves/block, one block per CU, 2 k16-steps of weights per barrier, LDS fragments read 4 feature blocks at a
 //    time: 0.82 of the fp32 MFMA peak at D = 150;
 //  * large batches, pair scoring, NB = 11 / 12 (D = 170, the reference's shipped size): the same persistent schedule with
@@ -92,6 +95,33 @@ static inline int launch_fwd_v5(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     return nplda_launch_status();
 }
 
+// pair scoring at D1 = D2 = 150 (the headline shape): nine full blocks on the 16 x 16 MFMA, the six left-over features on
+// 4 x 4 x 1 MFMAs (nplda_fwd_v6.h) — 0.842 against v3's 0.831 of the fp32 MFMA peak at 1 M pairs
+static inline bool fwd_v6_ok(const NpldaLayout& L) { return L.NB == 10 && L.D1 == 150 && L.D2 == 150; }
+template <int XM = 0>
+static inline int launch_fwd_v6(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    constexpr int WAVES = 8;
+    const long long ntiles = (a.n + 16 * WAVES - 1) / (16 * WAVES);
+    if (ntiles > 0x7fffffffLL) return NPLDA_EINVAL;
+    if (!fwd_v6_ok(L)) return NPLDA_EUNSUPPORTED;
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess ||
+        hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
+        cus = 256;
+    const long long blocks = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL((nplda_fwd_v6_kernel<10, 6, WAVES, 4, 3, 3, XM>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a, (int)ntiles);
+    return nplda_launch_status();
+}
+// the streaming pair kernel of a model: v6 at 150 / 150, v3 up to NB = 10 otherwise, v5 at NB = 11 / 12
+template <int XM = 0>
+static inline int launch_fwd_stream(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
+    // NPLDA_FWD_NO_V6=1: the round-4 dispatch (A/B measurements only)
+    static const bool no_v6 = getenv("NPLDA_FWD_NO_V6") != nullptr && getenv("NPLDA_FWD_NO_V6")[0] == '1';
+    if (fwd_v6_ok(L) && !no_v6) return launch_fwd_v6<XM>(a, L, st);
+    if (L.NB <= 10) return launch_fwd_v3<MODE_PAIR, XM>(a, L, st);
+    return launch_fwd_v5<XM>(a, L, st);
+}
+
 template <int MODE>
 static inline int launch_fwd_small(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long per_block = (MODE == MODE_EMBED ? 32 : 16);
@@ -148,10 +178,7 @@ static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st
     if (units <= 256 * 64) return launch_fwd_small<MODE>(a, L, st);  // 4 waves share a 16-pair tile
     // embed / train modes spill in v3 at G = 4; at G = 1 or 2 the embed form fits and was measured: same time as v2
     // (1.2 M rows: 0.72 of the peak either way; the mode is paced by its 0.77 GB of output)
-    if constexpr (MODE == MODE_PAIR) {
-        if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
-        return launch_fwd_v5<0>(a, L, st);
-    }
+    if constexpr (MODE == MODE_PAIR) return launch_fwd_stream<0>(a, L, st);
     return launch_fwd_v2<MODE>(a, L, st);
 }
 
@@ -185,8 +212,7 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
         if (k == FWD_MID) return launch_fwd_mid<false>(a, L, st);
         if (k == FWD_SMALL) return launch_fwd_small<MODE>(a, L, st);
-        if (L.NB <= 10) return launch_fwd_v3<MODE>(a, L, st);
-        return launch_fwd_v5<0>(a, L, st);
+        return launch_fwd_stream<0>(a, L, st);
     }
     if constexpr (MODE == MODE_EMBED) {
         // embedding rows (inference: no saved activations): 32 rows are one tile's worth of work; the balanced-tile kernel
@@ -205,8 +231,7 @@ static inline int launch_fwd_pairs_bf16rows(FwdArgs a, const NpldaLayout& L, hip
     if (pair_kernel_choice(a.n, L, mid_cus()) != FWD_STREAM) return NPLDA_EUNSUPPORTED;
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
-    if (L.NB <= 10) return launch_fwd_v3<MODE_PAIR, 2>(a, L, st);
-    return launch_fwd_v5<2>(a, L, st);
+    return launch_fwd_stream<2>(a, L, st);
 }
 
 // name of the kernel nplda_score_pairs_f32 launches for a batch of n pairs (bench.py labels its roofline object with it)
@@ -214,8 +239,11 @@ static inline const char* pair_kernel_name(long long n, const NpldaLayout& L) {
     switch (pair_kernel_choice(n, L, mid_cus())) {
         case FWD_SMALL: return "nplda_fwd_small_kernel (4 waves share a 16-pair tile, feature-split)";
         case FWD_MID: return "nplda_fwd_mid_kernel (balanced 16-pair tiles, K-split layer 1, groups of 2 tiles)";
-        default: return L.NB <= 10 ? "nplda_fwd_v3_kernel (persistent, 8 waves x 16 pairs, weights through LDS)"
-                                   : "nplda_fwd_v5_kernel (persistent, LDS-DMA weight chunks, layer 2 by output groups)";
+        default:
+            if (fwd_v6_ok(L) && !(getenv("NPLDA_FWD_NO_V6") != nullptr && getenv("NPLDA_FWD_NO_V6")[0] == '1'))
+                return "nplda_fwd_v6_kernel (persistent, 9 feature blocks on 16x16x4 MFMAs + 6 features on 4x4x1 MFMAs)";
+            return L.NB <= 10 ? "nplda_fwd_v3_kernel (persistent, 8 waves x 16 pairs, weights through LDS)"
+                              : "nplda_fwd_v5_kernel (persistent, LDS-DMA weight chunks, layer 2 by output groups)";
     }
 }
 

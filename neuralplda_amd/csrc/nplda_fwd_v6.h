@@ -1,66 +1,49 @@
-// nplda_fwd_v6.h — the persistent pair-scoring schedule of nplda_fwd_v5.h with the PARTIAL feature block on the VALU.
+// nplda_fwd_v6.h — the persistent pair-scoring schedule of nplda_fwd_v5.h with the PARTIAL feature block off the 16x16 MFMA.
 //
-// D = 150 is nine full 16-feature blocks and six features; D = 170 is ten blocks and ten features.  v3 / v5 run the
-// left-over features as one more MFMA block (NB = 10 / 11), i.e. 10 / 16 (6 / 16) of that block's matrix-pipe time
-// multiplies zeros: 1680 MFMAs per 16 rows where 150 features need 1552 (PMC: the kernels execute exactly the padded
-// count, and the matrix pipe is what bounds them).  On CDNA3/4 the vector ALU's packed fp32 FMA (v_pk_fma_f32: two
-// FMAs per lane) has the same peak as the fp32 matrix pipe and runs BESIDE it — a wave's VALU instructions issue in
-// the shadow of its own MFMAs — so the TF left-over features of both layers are computed there:
-//  * the x fragment a lane holds for the MFMAs (row j, columns 16 ks + 4 g + r) is also what the lane needs for a
-//    partial dot product of row j with a tail row of W over the lane's own k values; the tail rows are rows 0 .. TF-1
-//    of the image's last feature block, already in LDS with the chunk (lane group g reads the 16 bytes of row f at
-//    fragment lane 16 g + f: one address per 16 lanes, a broadcast read).  Two pk_fma per (feature, side) and k16-step:
-//    4 TF VALU instructions beside 8 (NB - 1) MFMAs;
+// D = 150 is nine full 16-feature blocks and six features.  v3 / v5 run the left-over features as one more 16 x 16 x 4 MFMA
+// block (NB = 10): 10 / 16 of that block's matrix-pipe time multiplies zeros — 1680 MFMAs per 16 rows where 150 features
+// need 1552 (PMC: the kernels execute exactly the padded count, and the matrix pipe is what bounds them).  Here the TF
+// left-over features of BOTH layers go through v_mfma_f32_4x4x1_16b_f32 — sixteen independent 4 x 4 x 1 products per
+// instruction, two passes instead of eight:
+//  * block (g, j / 4) of the instruction takes lane (j, g)'s element of the x fragment the lane already holds for the
+//    16 x 16 MFMAs as its B operand — rows 4 (j / 4) .. + 3 at the lane group's own k value — and four tail rows of W as A:
+//    fragment lanes 16 g + 4 q + j % 4 of the image's last feature block, already in LDS with the chunk (one more
+//    ds_read_b128 per quad, four addresses per 16 lanes).  One instruction per (quad of features, side, k4-step) leaves, in
+//    lane (j, g), the partial sums over the lane group's k values of features 4 q .. 4 q + 3 for row j;
 //  * the four k-groups' partial sums meet once per tile (v_permlane16/32_swap), get the bias, and are laid out as the
-//    MFMA accumulator block they replace (feature 16 (NB-1) + 4 g + r in lane group g) — norm, layer-2 B operand and
-//    score code then see the block v5 computed, to rounding (a different summation order: parity is against the fp64
-//    oracle at the tolerance of the tests, not against v3's bits);
-//  * layer 2 walks its NB - 1 full output blocks in groups of G2 as v5 does; each group also carries its share of the
-//    TF tail OUTPUT features on the VALU (the group's chunk holds the tail block's segments beside its own), and folds
-//    them into the score in lane group 0.
-// MFMAs per 16 rows: (NB-1) (4 KS1 + 4 NB) = 1512 at D = 150 (v3: 1680), 1720 at D = 170 (v5: 1892).
+//    accumulator block they replace (feature 16 (NB-1) + 4 g + r in lane group g) — norm, layer-2 B operand and score then
+//    see the block v3 computed, to rounding (another summation order: parity is against the fp64 oracle at the tests'
+//    tolerance, not against v3's bits);
+//  * layer 2 walks its NB - 1 full output blocks in groups of G2 as v5 does; group q also carries tail quad q (the group's
+//    chunk holds the tail block's segments beside its own) and folds it into the score in lane group 0.
+// Matrix-pipe time per 16 rows at D = 150: 1512 MFMAs of 8 passes + 336 of 2 (v3: 1680 of 8) = 0.95 of v3's; measured
+// 3.155 against 3.20 ms per 1 M pairs (0.842 against 0.831 of the fp32 MFMA peak, same process: tools/exp_fwd.hip,
+// profiles/r05u_exp_v6_tail.txt).  Measured and NOT kept (same file; the code is in the history, commit 5a1354d): the tail
+// on the vector ALU — v_pk_fma_f32 from broadcast LDS reads (0.823; 0.840 as one burst per k16-step with the reads a step
+// early) and v_fmac_f32 with DPP row-broadcast operands (0.788).  VALU instructions are not free beside MFMAs on this chip:
+// each costs ~2.5 cycles of matrix-pipe time in bursts, 4 - 5 when interleaved, whichever of the SIMD's waves issues it
+// (tools/exp_valu_phase.hip, profiles/r05u_exp_valu_phase.txt), and hipcc unpacks v_pk_fma_f32 it finds in an MFMA's
+// shadow.  With no tail work at all the kernel runs in 2.96 ms (ABL = 1): 0.12 ms is what six features cost at the full
+// blocks' rate, 0.20 ms is what they cost here.  At D = 170 (ten tail features, three quads) the form is level with v5.
 #pragma once
 #include "nplda_fwd_kernel.h"
 
 namespace nplda {
 
-typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ f32x2 pk_fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
-// acc += a * b on both halves, kept packed: hipcc's post-RA pass unpacks v_pk_fma_f32 into two v_fma_f32 when it finds it
-// in an MFMA's shadow (the packed form does not co-issue) — here the instruction COUNT is what costs (every VALU
-// instruction takes ~2.5 cycles of matrix-pipe time whichever wave issues it: tools/exp_valu_phase.hip)
-__device__ __forceinline__ void pk_fma_acc(f32x2& acc, f32x2 a, f32x2 b) {
-    asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b));
-}
-// lane n of every 16-lane row, in all lanes of that row (DPP row_newbcast:n, gfx90a+): an operand modifier of the FMA
-// that consumes it (v_fmac_f32_dpp), not an instruction of its own
-template <int N>
-__device__ __forceinline__ float row_bcast_c(float v) {
-    return __uint_as_float((unsigned)__builtin_amdgcn_update_dpp(0, (int)__float_as_uint(v), 0x150 + N, 0xf, 0xf, true));
-}
-__device__ __forceinline__ float row_bcast(float v, int n) {  // n is a constant after unrolling
-    switch (n) {
-        case 0: return row_bcast_c<0>(v);   case 1: return row_bcast_c<1>(v);   case 2: return row_bcast_c<2>(v);
-        case 3: return row_bcast_c<3>(v);   case 4: return row_bcast_c<4>(v);   case 5: return row_bcast_c<5>(v);
-        case 6: return row_bcast_c<6>(v);   case 7: return row_bcast_c<7>(v);   case 8: return row_bcast_c<8>(v);
-        case 9: return row_bcast_c<9>(v);   case 10: return row_bcast_c<10>(v); case 11: return row_bcast_c<11>(v);
-        case 12: return row_bcast_c<12>(v); case 13: return row_bcast_c<13>(v); case 14: return row_bcast_c<14>(v);
-        default: return row_bcast_c<15>(v);
-    }
-}
-
-template <int NB, int TF, int WAVES, int KPB = 2, int G1 = 3, int G2 = 3, int XM = 0, int ABL = 0, int TM = 1>  // TM: 1 tail rows by DPP row broadcast of the block's own fragment, 0 by broadcast LDS reads + pk_fma; ABL: tools/exp_fwd.hip only (wrong results): 1 no tail work, 2 tail reads but no FMAs
+// ABL (tools/exp_fwd.hip only; results are WRONG when non-zero): 1 = no tail work at all
+template <int NB, int TF, int WAVES, int KPB = 4, int G1 = 3, int G2 = 3, int XM = 0, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(const FwdArgs a, int ntiles) {
-    constexpr int NM = NB - 1;                       // feature blocks on the matrix pipe
-    static_assert(TF >= 1 && TF <= 16 && NM >= 1, "tail features live in the image's last block");
+    constexpr int NM = NB - 1;                       // feature blocks on the 16 x 16 MFMA
+    constexpr int NQ = (TF + 3) / 4;                 // tail features in quads
     constexpr int STEP4 = NB * 64;                   // float4 per k16-step of weights (the image's stride: all NB blocks)
     constexpr int CH1 = STEP4 * KPB;                 // layer-1 chunk
     constexpr int NSEG1 = CH1 / 64;
-    constexpr int NG = (NM + G2 - 1) / G2;           // layer-2 output groups
-    constexpr int TG = (TF + NG - 1) / NG;           // tail output features per group
+    constexpr int NGR = (NM + G1 - 1) / G1;          // MFMA groups of a layer-1 step; tail quad q rides with group q
+    constexpr int NG = (NM + G2 - 1) / G2;           // layer-2 output groups; tail quad q rides with group q
     constexpr int NSEG2 = NB * (G2 + 1);             // a group's chunk: NB k-blocks x (its blocks + the tail block)
     constexpr int CH2 = NSEG2 * 64;
     constexpr int CH = CH1 > CH2 ? CH1 : CH2;
+    static_assert(TF >= 1 && TF <= 16 && NM >= 1 && NQ <= NGR && NQ <= NG, "tail quads ride with the MFMA groups");
     __shared__ f32x4 wbuf[2][CH];
     __shared__ f32x4 cvec[4][NB * 4];
     __shared__ f32x4 sink[64];
@@ -70,6 +53,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15;
     const int g = lane >> 4;
+    const int tl = 16 * g + (j & 3);  // this lane's A operand of the 4x4x1 MFMAs: fragment lane 16 g + 4 q + j % 4 of the tail block
 
     const f32x4* Wall = reinterpret_cast<const f32x4*>(a.packed);
     const long long w2base4 = (long long)(a.oW2 / 4);
@@ -122,8 +106,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
         __builtin_amdgcn_sched_barrier(0);
     };
     // the four k-groups' partial sums of one tail feature -> the full sum in every lane of the row
-    auto kgroups_sum = [&](f32x2 t) {
-        float v = t[0] + t[1];
+    auto kgroups_sum = [&](float v) {
         v = wave_xor_add(v, 16);
         return wave_xor_add(v, 32);
     };
@@ -177,13 +160,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             accA[nb] = b1p[4 * nb + g];
             accB[nb] = accA[nb];
         }
-        f32x2 tA[TF], tB[TF];
-#pragma unroll
-        for (int f = 0; f < TF; ++f) {
-            tA[f] = f32x2{0.f, 0.f};
-            tB[f] = tA[f];
-        }
-        constexpr int NQ = (TF + 3) / 4;  // TM == 2: tail features in quads, one 4x4x1 MFMA (16 blocks) per quad, side and k4-step
         f32x4 qA[NQ], qB[NQ];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
@@ -192,27 +168,23 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
         }
 
         // ---- layer 1 ---------------------------------------------------------------------------------------
-        for (int c = 0; c < NC1; ++c) {
+        // one chunk: the MFMAs read (xc, yc) while (xn, yn) receive the next chunk's rows — the loop below alternates the two
+        // register sets instead of copying the next set over the current one (v5 copies: 16 v_mov per chunk)
+        auto chunk = [&](int c, f32x4 (&xc)[KPB], f32x4 (&yc)[KPB], f32x4 (&xn)[KPB], f32x4 (&yn)[KPB]) {
             const bool more = (c + 1 < NC1);
             f32x4* nxt = wbuf[par ^ 1];
             if (more) dma_l1(c + 1, nxt);
             else dma_l2(0, (G2 < NM ? G2 : NM), nxt);
-            f32x4 xan[KPB], xbn[KPB];
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
-                const int ks = more ? KPB * (c + 1) + s : KPB * c + s;
-                xan[s] = load_xrow<XM>(sa, 16 * ks + 4 * g, D0);
-                xbn[s] = load_xrow<XM>(sb, 16 * ks + 4 * g, D0);
+                const int ks = more ? KPB * (c + 1) + s : KPB * c + s;  // (after the last chunk: a harmless re-read, see v5)
+                xn[s] = load_xrow<XM>(sa, 16 * ks + 4 * g, D0);
+                yn[s] = load_xrow<XM>(sb, 16 * ks + 4 * g, D0);
             }
             const f32x4* w = wbuf[par];
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
                 if (KPB * c + s < KS1) {
-                    constexpr int NGR = (NM + G1 - 1) / G1;          // MFMA groups of a step
-                    static_assert(TM != 2 || (TF + 3) / 4 <= NGR, "a tail quad per MFMA group");
-                    constexpr int TS = (TF + NGR - 1) / NGR;         // tail features dealt with beside each group
-                    f32x4 wtf;
-                    f32x4 wt3[TF];
 #pragma unroll
                     for (int gr = 0; gr < NGR; ++gr) {
                         const int nb0 = gr * G1;
@@ -225,81 +197,38 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
 #pragma unroll
                             for (int u = 0; u < G1; ++u) {
                                 if (nb0 + u < NM) {
-                                    accA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xa[s][r], accA[nb0 + u], 0, 0, 0);
-                                    accB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xb[s][r], accB[nb0 + u], 0, 0, 0);
+                                    accA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xc[s][r], accA[nb0 + u], 0, 0, 0);
+                                    accB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], yc[s][r], accB[nb0 + u], 0, 0, 0);
                                 }
                             }
                         }
-                        if (TM == 3) {
-                            if (gr == 0 && ABL != 1) {  // the step's tail rows are read behind group 0's fragments ...
+                        if (gr < NQ && ABL != 1) {  // tail quad gr beside MFMA group gr
+                            const f32x4 wq = w[s * STEP4 + NM * 64 + tl + 4 * gr];
 #pragma unroll
-                                for (int f = 0; f < TF; ++f) wt3[f] = w[s * STEP4 + NM * 64 + 16 * g + f];
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            if (gr == NGR - 1 && ABL == 0) {  // ... and used in ONE burst behind the step's last MFMA
-                                __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                                for (int f = 0; f < TF; ++f) pk_fma_acc(tA[f], xa[s].xy, wt3[f].xy);
-#pragma unroll
-                                for (int f = 0; f < TF; ++f) pk_fma_acc(tB[f], xb[s].xy, wt3[f].xy);
-#pragma unroll
-                                for (int f = 0; f < TF; ++f) pk_fma_acc(tA[f], xa[s].zw, wt3[f].zw);
-#pragma unroll
-                                for (int f = 0; f < TF; ++f) pk_fma_acc(tB[f], xb[s].zw, wt3[f].zw);
-                                __builtin_amdgcn_sched_barrier(0);
-                            }
-                            if (gr == NGR - 1 && ABL == 2) {
-#pragma unroll
-                                for (int f = 0; f < TF; ++f) asm volatile("" :: "v"(wt3[f]));
-                            }
-                            continue;
-                        }
-                        if (TM == 1 && gr == 0 && ABL != 1) wtf = w[s * STEP4 + NM * 64 + lane];
-                        if (TM == 2 && ABL != 1) {
-                            // quad q beside MFMA group q: block (g, j / 4) of the 4x4x1 MFMA holds rows 4 (j / 4) .. + 3 of the
-                            // x fragment as its B operand and features 4 q .. 4 q + 3 (fragment lanes 16 g + 4 q + j % 4) as A
-                            if (gr < NQ) {
-                                const f32x4 wq = w[s * STEP4 + NM * 64 + 16 * g + 4 * gr + (j & 3)];
-#pragma unroll
-                                for (int r = 0; r < 4; ++r) {
-                                    qA[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xa[s][r], qA[gr], 0, 0, 0);
-                                    qB[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xb[s][r], qB[gr], 0, 0, 0);
-                                }
-                            }
-                            continue;
-                        }
-#pragma unroll
-                        for (int tt = 0; tt < TS; ++tt) {
-                            const int f = gr * TS + tt;
-                            if (f < TF && ABL != 1) {
-                                if (TM == 1) {
-                                    if (ABL == 2) { asm volatile("" :: "v"(wtf)); continue; }
-#pragma unroll
-                                    for (int r = 0; r < 4; ++r) {
-                                        const float wv = row_bcast(wtf[r], f);
-                                        tA[f][0] = fmaf(wv, xa[s][r], tA[f][0]);
-                                        tB[f][0] = fmaf(wv, xb[s][r], tB[f][0]);
-                                    }
-                                    continue;
-                                }
-                                f32x4 wt = w[s * STEP4 + NM * 64 + 16 * g + f];
-                                if (ABL == 2) { asm volatile("" :: "v"(wt)); continue; }
-                                tA[f] = pk_fma2(xa[s].xy, wt.xy, tA[f]);
-                                tB[f] = pk_fma2(xb[s].xy, wt.xy, tB[f]);
-                                tA[f] = pk_fma2(xa[s].zw, wt.zw, tA[f]);
-                                tB[f] = pk_fma2(xb[s].zw, wt.zw, tB[f]);
+                            for (int r = 0; r < 4; ++r) {
+                                qA[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xc[s][r], qA[gr], 0, 0, 0);
+                                qB[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], yc[s][r], qB[gr], 0, 0, 0);
                             }
                         }
                     }
                 }
             }
+            chunk_fence();
+            par ^= 1;
+        };
+        f32x4 xan[KPB], xbn[KPB];
+        int c = 0;
+        for (; c + 1 < NC1; c += 2) {
+            chunk(c, xa, xb, xan, xbn);
+            chunk(c + 1, xan, xbn, xa, xb);
+        }
+        if (c < NC1) {  // an odd chunk count (never at 512-d x-vectors): one more, and the sets change places by copy
+            chunk(c, xa, xb, xan, xbn);
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
                 xa[s] = xan[s];
                 xb[s] = xbn[s];
             }
-            chunk_fence();
-            par ^= 1;
         }
 
         // ---- the tail features join the blocks: sum over the k-groups, bias, accumulator layout ---------------------
@@ -307,13 +236,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             float uA[TF], uB[TF];
 #pragma unroll
             for (int f = 0; f < TF; ++f) {
-                if (TM == 2) {
-                    uA[f] = kgroups_sum(f32x2{qA[f / 4][f % 4], 0.f});
-                    uB[f] = kgroups_sum(f32x2{qB[f / 4][f % 4], 0.f});
-                } else {
-                    uA[f] = kgroups_sum(tA[f]);
-                    uB[f] = kgroups_sum(tB[f]);
-                }
+                uA[f] = kgroups_sum(qA[f / 4][f % 4]);
+                uB[f] = kgroups_sum(qB[f / 4][f % 4]);
             }
             const f32x4 bt = b1p[4 * NM + g];  // zero beyond D1 (the image pads the bias)
             accA[NM] = as_block(uA) + bt;
@@ -342,15 +266,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             }
         }
 
-        // ---- layer 2, output groups of G2 full blocks + TG tail features; the score is folded group by group ----------
+        // ---- layer 2, output groups of G2 full blocks (+ tail quad gi); the score is folded group by group --------------
         float part = 0.f;
 #pragma unroll
         for (int gi = 0; gi < NG; ++gi) {
             const int nb0 = gi * G2;
             const int gc = (NM - nb0) < G2 ? (NM - nb0) : G2;
             const int per = gc + 1;
-            const int f0 = gi * TG;
-            const int fc = (TF - f0) < TG ? (TF - f0 > 0 ? TF - f0 : 0) : TG;
             f32x4 zA[G2], zB[G2];
 #pragma unroll
             for (int u = 0; u < G2; ++u) {
@@ -359,14 +281,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                     zB[u] = zA[u];
                 }
             }
-            f32x2 ztA[TG], ztB[TG];
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                ztA[t] = f32x2{0.f, 0.f};
-                ztB[t] = ztA[t];
-            }
-            static_assert(TM != 2 || (TF + 3) / 4 <= NG, "a tail quad per layer-2 output group");
-            f32x4 zqA = {0.f, 0.f, 0.f, 0.f}, zqB = zqA;  // TM == 2: group gi carries tail quad gi
+            f32x4 zqA = {0.f, 0.f, 0.f, 0.f}, zqB = zqA;
             f32x4* nxt = wbuf[par ^ 1];
             if (gi + 1 < NG) {
                 const int nb1 = nb0 + G2;
@@ -386,13 +301,6 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
 #pragma unroll
                 for (int u = 0; u < G2; ++u)
                     if (u < gc) av[u] = w[(kb * per + u) * 64 + lane];
-                f32x4 wz3[TG];
-                if (TM == 3 && ABL != 1) {
-#pragma unroll
-                    for (int t = 0; t < TG; ++t)
-                        if (t < fc) wz3[t] = w[(kb * per + gc) * 64 + 16 * g + f0 + t];
-                    __builtin_amdgcn_sched_barrier(0);
-                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -403,57 +311,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                         }
                     }
                 }
-                f32x4 wtf;
-                if (TM == 1 && fc > 0 && ABL != 1) wtf = w[(kb * per + gc) * 64 + lane];
-                if (TM == 3) {
-                    if (ABL == 0) {
-                        __builtin_amdgcn_sched_barrier(0);
+                if (gi < NQ && ABL != 1) {
+                    const f32x4 wq = w[(kb * per + gc) * 64 + tl + 4 * gi];
 #pragma unroll
-                        for (int t = 0; t < TG; ++t) if (t < fc) pk_fma_acc(ztA[t], accA[kb].xy, wz3[t].xy);
-#pragma unroll
-                        for (int t = 0; t < TG; ++t) if (t < fc) pk_fma_acc(ztB[t], accB[kb].xy, wz3[t].xy);
-#pragma unroll
-                        for (int t = 0; t < TG; ++t) if (t < fc) pk_fma_acc(ztA[t], accA[kb].zw, wz3[t].zw);
-#pragma unroll
-                        for (int t = 0; t < TG; ++t) if (t < fc) pk_fma_acc(ztB[t], accB[kb].zw, wz3[t].zw);
-                        __builtin_amdgcn_sched_barrier(0);
-                    }
-                    if (ABL == 2) {
-#pragma unroll
-                        for (int t = 0; t < TG; ++t) if (t < fc) asm volatile("" :: "v"(wz3[t]));
-                    }
-                    continue;
-                }
-                if (TM == 2) {
-                    if (gi < NQ && ABL != 1) {
-                        const f32x4 wq = w[(kb * per + gc) * 64 + 16 * g + 4 * gi + (j & 3)];
-#pragma unroll
-                        for (int r = 0; r < 4; ++r) {
-                            zqA = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accA[kb][r], zqA, 0, 0, 0);
-                            zqB = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accB[kb][r], zqB, 0, 0, 0);
-                        }
-                    }
-                    continue;
-                }
-#pragma unroll
-                for (int t = 0; t < TG; ++t) {
-                    if (t < fc && ABL != 1) {
-                        if (TM == 1) {
-                            if (ABL == 2) { asm volatile("" :: "v"(wtf)); continue; }
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) {
-                                const float wv = row_bcast(wtf[r], f0 + t);
-                                ztA[t][0] = fmaf(wv, accA[kb][r], ztA[t][0]);
-                                ztB[t][0] = fmaf(wv, accB[kb][r], ztB[t][0]);
-                            }
-                            continue;
-                        }
-                        f32x4 wt = w[(kb * per + gc) * 64 + 16 * g + f0 + t];
-                        if (ABL == 2) { asm volatile("" :: "v"(wt)); continue; }
-                        ztA[t] = pk_fma2(accA[kb].xy, wt.xy, ztA[t]);
-                        ztB[t] = pk_fma2(accB[kb].xy, wt.xy, ztB[t]);
-                        ztA[t] = pk_fma2(accA[kb].zw, wt.zw, ztA[t]);
-                        ztB[t] = pk_fma2(accB[kb].zw, wt.zw, ztB[t]);
+                    for (int r = 0; r < 4; ++r) {
+                        zqA = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accA[kb][r], zqA, 0, 0, 0);
+                        zqB = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accB[kb][r], zqB, 0, 0, 0);
                     }
                 }
             }
@@ -472,39 +335,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                     }
                 }
             }
-            // the group's tail features: full sums in every lane group, counted once (lane group 0)
-            float tpart = 0.f;
-            if (TM == 2) {
-                if (gi < NQ) {
+            // the group's tail quad: full sums in every lane group, counted once (lane group 0)
+            if (gi < NQ) {
+                float tpart = 0.f;
+                const float* b2s = reinterpret_cast<const float*>(b2p);
+                const float* Qs = reinterpret_cast<const float*>(Qp);
+                const float* Ps = reinterpret_cast<const float*>(Pp);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) {
-                        const int f = 4 * gi + i;
-                        if (f < TF) {
-                            const float* b2s = reinterpret_cast<const float*>(b2p);
-                            const float* Qs = reinterpret_cast<const float*>(Qp);
-                            const float* Ps = reinterpret_cast<const float*>(Pp);
-                            const float z1 = kgroups_sum(f32x2{zqA[i], 0.f}) + b2s[16 * NM + f];
-                            const float z2 = kgroups_sum(f32x2{zqB[i], 0.f}) + b2s[16 * NM + f];
-                            tpart = fmaf(Qs[16 * NM + f], fmaf(z1, z1, z2 * z2), tpart);
-                            tpart = fmaf(2.0f * Ps[16 * NM + f], z1 * z2, tpart);
-                        }
+                for (int i = 0; i < 4; ++i) {
+                    const int f = 4 * gi + i;
+                    if (f < TF) {
+                        const float z1 = kgroups_sum(zqA[i]) + b2s[16 * NM + f];
+                        const float z2 = kgroups_sum(zqB[i]) + b2s[16 * NM + f];
+                        tpart = fmaf(Qs[16 * NM + f], fmaf(z1, z1, z2 * z2), tpart);
+                        tpart = fmaf(2.0f * Ps[16 * NM + f], z1 * z2, tpart);
                     }
                 }
-            } else
-#pragma unroll
-            for (int t = 0; t < TG; ++t) {
-                if (t < fc) {
-                    const int f = f0 + t;
-                    const float* b2s = reinterpret_cast<const float*>(b2p);
-                    const float* Qs = reinterpret_cast<const float*>(Qp);
-                    const float* Ps = reinterpret_cast<const float*>(Pp);
-                    const float z1 = kgroups_sum(ztA[t]) + b2s[16 * NM + f];
-                    const float z2 = kgroups_sum(ztB[t]) + b2s[16 * NM + f];
-                    tpart = fmaf(Qs[16 * NM + f], fmaf(z1, z1, z2 * z2), tpart);
-                    tpart = fmaf(2.0f * Ps[16 * NM + f], z1 * z2, tpart);
-                }
+                part += (g == 0) ? tpart : 0.f;
             }
-            part += (g == 0) ? tpart : 0.f;
         }
         part = wave_xor_add(part, 16);
         part = wave_xor_add(part, 32);

@@ -54,7 +54,7 @@ def test_bench_single_process_contract(hip_lib):
     assert a["flop_per_pair_algorithmic"] == 465120 and a["checksum_finite"]
     assert d["config"]["ranks_in_group"] == 1
     # the kernel label comes from the dispatch actually taken, and the line says which build of the library ran
-    assert d["roofline"]["kernel"].startswith("nplda_fwd_v3_kernel") and a["kernel"].startswith("nplda_fwd_v5_kernel")
+    assert d["roofline"]["kernel"].startswith("nplda_fwd_v6_kernel") and a["kernel"].startswith("nplda_fwd_v5_kernel")
     assert d["lib"]["abi_version"] >= 2 and len(d["lib"]["csrc_sha"]) == 16 and d["lib"]["stale"] is False
     # the other BASELINE configs ride on the default line: training (cfg2), AS-norm (cfg3), the head of the E2E fine-tune (cfg5)
     for k, unit in (("alt_cfg2", "pairs/s"), ("alt_cfg3", "trials/s"), ("alt_cfg5", "pairs/s")):

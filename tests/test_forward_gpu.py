@@ -122,8 +122,10 @@ def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
     st, saved = ops.forward_train(X1, X2, packed)
     # the train-mode forward runs the v2 schedule; pair scoring of this size may run the balanced-tile kernel
     # (nplda_fwd_mid.h: 512-d, D = 145..176), whose layer-1 K sum associates differently: same bits only where the
-    # schedules share the association, the fp32 tolerance everywhere
-    if D0 == 512 and 145 <= D1 <= 176 and D1 == D2:
+    # schedules share the association, the fp32 tolerance everywhere.  At D1 = D2 = 150 the streaming pair kernel is
+    # nplda_fwd_v6.h (round 5): its six left-over features are summed k-group-wise on 4x4x1 MFMAs — tolerance there too
+    # (parity is against the oracle; equality between two of the library's own schedules is a property, kept where it holds)
+    if (D0 == 512 and 145 <= D1 <= 176 and D1 == D2) or (D1 == 150 and D2 == 150):
         assert np.all(np.abs(st.cpu().numpy() - s) <= ATOL + RTOL * np.abs(ref))
     else:
         assert torch.equal(st.cpu(), torch.from_numpy(s))

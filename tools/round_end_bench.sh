@@ -41,7 +41,7 @@ for n in 2 4 8; do
 done
 cp $R/profiles/traffic.json $O/traffic.json
 python tools/traffic_from_pmc.py $O/traffic.json \
-  score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v3_kernel \
+  score_pairs_D150_B1048576=$O/pmc_fwd150:nplda_fwd_v6_kernel \
   score_pairs_D170_B1048576=$O/pmc_fwd170:nplda_fwd_v5_kernel \
   train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
@@ -51,8 +51,8 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   "score_indexed_self_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel<true" \
   "score_indexed_self_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel<true" \
   gb_score_D170_B524288=$O/pmc_gb:nplda_fwd_kernel \
-  score_pairs_D150_B524288=$O/pmc_cfg1_s2:nplda_fwd_v3_kernel score_pairs_D150_B262144=$O/pmc_cfg1_s4:nplda_fwd_v3_kernel \
-  score_pairs_D150_B131072=$O/pmc_cfg1_s8:nplda_fwd_v3_kernel \
+  score_pairs_D150_B524288=$O/pmc_cfg1_s2:nplda_fwd_v6_kernel score_pairs_D150_B262144=$O/pmc_cfg1_s4:nplda_fwd_v6_kernel \
+  score_pairs_D150_B131072=$O/pmc_cfg1_s8:nplda_fwd_v6_kernel \
   cohort_stats_D150_R11000_M10000=$O/pmc_cfg3_s2:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
   cohort_stats_D150_R5500_M10000=$O/pmc_cfg3_s4:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
   cohort_stats_D150_R2750_M10000=$O/pmc_cfg3_s8:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
