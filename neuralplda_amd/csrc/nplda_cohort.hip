@@ -998,7 +998,7 @@ static int cohort_stats_impl(const float* z_rows, const float* q_rows, int64_t R
             if (int rc2 = nplda::cohort_fused_run(plan, z_rows + r0 * ldz, q_rows + r0, rc, z_coh, q_coh, M, ldz,
                                                   (const float*)packed + L.oP, L.NB, topn, select_lowest ? 1 : 0,
                                                   stats + 4 * r0, (unsigned char*)ws, rows_cap, r0 == 0, &fail_rows,
-                                                  &nfail, resident, st, (const unsigned char*)prepared))
+                                                  &nfail, resident, st, (const unsigned char*)prepared, D2))
                 return rc2;
             FallbackArgs fb;
             fb.zr = z_rows + r0 * ldz; fb.qr = q_rows + r0; fb.zc = z_coh; fb.qc = q_coh; fb.P = (const float*)packed + L.oP;

@@ -23,7 +23,8 @@ long long cohort_fused_resident_blocks();
 int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
                      const float* q_coh, long long M, long long ldz, const float* P, int ksteps, int topn, int lowest,
                      double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
-                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared = nullptr);
+                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared = nullptr,
+                     int D2 = 0);  // D2: the embedding dimension (0: unknown — the last k-block runs all four k4-steps)
 // The cohort-only part of the fused path (Gram matrix + first moments, covariance image folded with P) into `state`
 // (plan.fixed_bytes bytes, 256-byte aligned): what every call on the same (model, cohort) would recompute.
 int cohort_fused_prepare(const FusedPlan& p, const float* z_coh, const float* q_coh, long long M, long long ldz, const float* P,

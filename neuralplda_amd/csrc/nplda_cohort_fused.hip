@@ -235,8 +235,16 @@ struct FusedArgs {
 // many work items of half the size, for calls with so few rows that 256-row items leave CUs idle — an 8-way row shard of
 // cfg3 is 11 such tiles for 256 CUs).  A row's lists and sums are formed by the same lanes in the same column order either
 // way: the results do not depend on it, bit for bit.
-template <bool LOWEST, int NB, int RGW = 2>
+// KT: k4-steps of the LAST k16-block (round 5).  D2 = 150 leaves six values there; in the table's column order
+// (k = 16 ks + 4 g4 + r) they sit in lane groups 0 and 1 and still need all four steps.  With KT < 4 both operands take the
+// block as k = 16 (NB - 1) + KT g4 + r, r < KT — the LDS-DMA reads the cohort row's 16 bytes from column 16 (NB - 1) + KT g4
+// (4- / 8-byte aligned: accepted, tools/exp_dma_align.hip), the row operand is loaded to match — and the block runs KT
+// steps: 38 instead of 40 k4-steps at D2 = 150 (KT = 2), 43 instead of 44 at D2 = 170 (KT = 3).  Columns >= D2 are zero in
+// the table on both sides, so nothing is masked.  The scores' last-block terms associate differently from the spilling
+// GEMM's: same values to rounding (tolerance in the tests).
+template <bool LOWEST, int NB, int RGW = 2, int KT = 4>
 __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a) {
+    static_assert(KT >= 2 && KT <= 4, "the k16-step's first two k4-steps always run");
     constexpr int RPB = 8 * 16 * RGW;  // rows of a block's row tile
     constexpr int NF = 4 * NB;  // 1 KiB fragments of a 64-column tile: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..
     __shared__ f32x4 smem[2 * NF * 64 + 2 * 16 + NB * 4 + 2];
@@ -279,7 +287,8 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             const int ks = f >> 2, c = f & 3;
             long long m = (long long)t * 64 + 16 * c + i16;
             if (m >= a.M) m = a.M - 1;
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.zc + m * a.ldz + 16 * ks + 4 * g4),
+            const int col = (KT < 4 && ks == NB - 1) ? 16 * ks + KT * g4 : 16 * ks + 4 * g4;
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.zc + m * a.ldz + col),
                                              (__attribute__((address_space(3))) void*)&tbuf[(buf * NF + f) * 64], 16, 0, 0);
         }
         if (wave == 0) {
@@ -314,6 +323,14 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             const f32x4* zp = reinterpret_cast<const f32x4*>(a.zr + row * a.ldz + 4 * g4);
 #pragma unroll
             for (int ks = 0; ks < NB; ++ks) brow[g][ks] = zp[4 * ks] * p2s[4 * ks + g4];
+            if (KT < 4) {  // the last block in the KT-step order: columns 16 (NB - 1) + KT g4 + r
+                const float* zl = a.zr + row * a.ldz + 16 * (NB - 1) + KT * g4;
+                const float* pl = reinterpret_cast<const float*>(p2s) + 16 * (NB - 1) + KT * g4;
+                f32x4 v = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int r = 0; r < KT; ++r) v[r] = zl[r] * pl[r];
+                brow[g][NB - 1] = v;
+            }
         }
     };
     auto item_state = [&](long long rb_, int band_) {
@@ -396,7 +413,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             }
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int kk = 2; kk < 4; ++kk)
+            for (int kk = 2; kk < (ks == NB - 1 ? KT : 4); ++kk)
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
 #pragma unroll
@@ -859,7 +876,7 @@ int cohort_fused_prepare(const FusedPlan& p, const float* z_coh, const float* q_
 int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
                      const float* q_coh, long long M, long long ldz, const float* P, int ksteps, int topn, int lowest,
                      double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
-                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared) {
+                     unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared, int D2) {
     const int Mp = 16 * ksteps;
     const FusedFixed F = fused_fixed(ws, Mp);
     unsigned* ctl = F.ctl;
@@ -929,22 +946,33 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
         const long long per_xcd = grid / 8 > 0 ? grid / 8 : 1;
         fa.nfull = p.q > 1 ? (int)(fa.ny / per_xcd * per_xcd) : fa.ny;
     }
-#define NPLDA_LAUNCH(NBV)                                                                                                   \
-    if (half_tiles) {                                                                                                       \
-        if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);    \
-        else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1>), dim3((unsigned)grid), dim3(512), 0, st, fa);          \
-    } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
-    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+    // k4-steps of the last k16-block (cohort_fused2_kernel, KT): the instantiated short forms are D2 in 145 .. 152 at NB = 10
+    // (KT = 2: the reference's 150) and D2 in 169 .. 172 at NB = 11 (KT = 3: the shipped 170)
+    const int tail = D2 > 0 ? D2 - 16 * (ksteps - 1) : 16;
+    const int kt = (ksteps == 10 && tail >= 1 && tail <= 8) ? 2 : ((ksteps == 11 && tail >= 9 && tail <= 12) ? 3 : 4);
+    static const bool no_kt = getenv("NPLDA_COHORT_NO_KTAIL") != nullptr && getenv("NPLDA_COHORT_NO_KTAIL")[0] == '1';  // A/B only
+#define NPLDA_LAUNCH_KT(NBV, KTV)                                                                                                   \
+    if (half_tiles) {                                                                                                               \
+        if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);       \
+        else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);             \
+    } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);    \
+    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+#define NPLDA_LAUNCH(NBV) NPLDA_LAUNCH_KT(NBV, 4)
     switch (ksteps) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
         case 8: NPLDA_LAUNCH(8); break;
-        case 10: NPLDA_LAUNCH(10); break;
-        case 11: NPLDA_LAUNCH(11); break;
+        case 10:
+            if (kt == 2 && !no_kt) { NPLDA_LAUNCH_KT(10, 2); } else { NPLDA_LAUNCH(10); }
+            break;
+        case 11:
+            if (kt == 3 && !no_kt) { NPLDA_LAUNCH_KT(11, 3); } else { NPLDA_LAUNCH(11); }
+            break;
         case 12: NPLDA_LAUNCH(12); break;
         default: return NPLDA_EUNSUPPORTED;
     }
 #undef NPLDA_LAUNCH
+#undef NPLDA_LAUNCH_KT
     if (int rc = nplda_launch_status()) return rc;
     FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, p.cap, lrow, ctl + 8,
                      fail_rows, stats};
