@@ -104,7 +104,8 @@ def test_strided_rows(hip_lib):
     np.testing.assert_allclose(s, orc.forward(big[:, :512], big[:, 512:], p, np.float64), atol=ATOL, rtol=RTOL)
 
 
-@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (512, 192, 192), (64, 40, 24), (72, 150, 150)])
+@pytest.mark.parametrize("D0,D1,D2", [(512, 150, 150), (512, 170, 170), (512, 192, 192), (64, 40, 24), (72, 150, 150),
+                                      (144, 150, 150), (16, 150, 150)])  # (nplda_fwd_v6.h: an odd count of layer-1 chunks, one chunk)
 def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
     """Batches above 16 384 pairs take the streaming schedules (v3 persistent for pair scoring at NB <= 10, else v2):
     pair, embed and train modes must agree with the oracle there too (ragged tail included)."""
