@@ -11,8 +11,8 @@
 //    of the image is the order the MFMAs read): no staging registers, no ds_write, and any chunk shape is just a
 //    different list of 1 KB segments — which is what lets layer 2 read W2 group-major out of the k-major image;
 //  * the next tile's first x rows are fetched in the LAST layer-2 chunk, into registers layer 2 does not use.
-// A chunk's x rows are loaded a whole chunk ahead into a second register set and copied at the chunk end, so that
-// the vmcnt(0) the DMA needs before the barrier never waits on a young load.
+// A chunk's x rows are loaded a whole chunk ahead into a second register set (the two sets alternate from chunk to chunk), so
+// that the vmcnt(0) the DMA needs before the barrier never waits on a young load.
 #pragma once
 #include "nplda_fwd_kernel.h"
 
@@ -130,19 +130,21 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
         }
 
         // ---- layer 1 ---------------------------------------------------------------------------------------
-        for (int c = 0; c < NC1; ++c) {
+        // one chunk: the MFMAs read (xc, yc) while (xn, yn) receive the next chunk's rows; the loop below alternates the two
+        // register sets (round 5; before, the next set was copied over the current one: 16 v_mov per chunk, each of them
+        // matrix-pipe time — nplda_fwd_v6.h)
+        auto chunk = [&](int c, f32x4 (&xc)[KPB], f32x4 (&yc)[KPB], f32x4 (&xn)[KPB], f32x4 (&yn)[KPB]) {
             const bool more = (c + 1 < NC1);
             f32x4* nxt = wbuf[par ^ 1];
             if (more) dma_l1(c + 1, nxt);
             else dma_l2(0, (G < NB ? G : NB), 0, KH, nxt);
             // x of the next chunk (after the last chunk: a harmless re-read of the steps just fetched — still in cache;
             // re-reading the tile's FIRST steps instead cost 6 % more HBM fetches, FETCH_SIZE 2.29e6 vs 2.15e6 KB)
-            f32x4 xan[KPB], xbn[KPB];
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
                 const int ks = more ? KPB * (c + 1) + s : KPB * c + s;
-                xan[s] = load_xrow<XM>(sa, 16 * ks + 4 * g, D0);
-                xbn[s] = load_xrow<XM>(sb, 16 * ks + 4 * g, D0);
+                xn[s] = load_xrow<XM>(sa, 16 * ks + 4 * g, D0);
+                yn[s] = load_xrow<XM>(sb, 16 * ks + 4 * g, D0);
             }
             const f32x4* w = wbuf[par];
 #pragma unroll
@@ -159,21 +161,30 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v5_kernel(con
 #pragma unroll
                             for (int u = 0; u < G; ++u) {
                                 if (nb0 + u < NB) {
-                                    accA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xa[s][r], accA[nb0 + u], 0, 0, 0);
-                                    accB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xb[s][r], accB[nb0 + u], 0, 0, 0);
+                                    accA[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], xc[s][r], accA[nb0 + u], 0, 0, 0);
+                                    accB[nb0 + u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[u][r], yc[s][r], accB[nb0 + u], 0, 0, 0);
                                 }
                             }
                         }
                     }
                 }
             }
+            chunk_fence();
+            par ^= 1;
+        };
+        f32x4 xan[KPB], xbn[KPB];
+        int c = 0;
+        for (; c + 1 < NC1; c += 2) {
+            chunk(c, xa, xb, xan, xbn);
+            chunk(c + 1, xan, xbn, xa, xb);
+        }
+        if (c < NC1) {  // an odd chunk count (never at 512-d x-vectors): one more, and the sets change places by copy
+            chunk(c, xa, xb, xan, xbn);
 #pragma unroll
             for (int s = 0; s < KPB; ++s) {
                 xa[s] = xan[s];
                 xb[s] = xbn[s];
             }
-            chunk_fence();
-            par ^= 1;
         }
 
         // ---- F.normalize (utils/models.py:368) ---------------------------------------------------------------
