@@ -5,7 +5,7 @@
 #include <vector>
 #include <cmath>
 #include "../neuralplda_amd/csrc/nplda_fwd_dispatch.h"
-#include "../neuralplda_amd/csrc/nplda_fwd_flex.h"
+#include "exp_flex_kernel.h"
 using namespace nplda;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %s:%d\n", hipGetErrorString(e), __FILE__, __LINE__); exit(1); } } while (0)
 

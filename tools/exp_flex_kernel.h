@@ -1,4 +1,4 @@
-// nplda_fwd_flex.h — pair scoring between one and a few dozen 8-pair row groups per CU, balanced to ONE row group
+// exp_flex_kernel.h (tools/exp_flex.hip; an experiment, NOT part of the library) — pair scoring between one and a few dozen 8-pair row groups per CU, balanced to ONE row group
 // (nplda_fwd_mid.h balances to a 16-pair tile: 10 240 pairs — the validation chunk of xvector_NeuralPlda_pytorch.py:172 —
 // are 2.5 tiles per CU, half the CUs run three; here they are 5 row groups on every CU).
 //
@@ -21,7 +21,7 @@
 // Same arithmetic per element as the other forward kernels; the association of the cross-feature sums differs (per wave,
 // then over waves).  512-d x-vectors (KS1 = 32), NB = 10 / 11, plain (not indexed) pairs.
 #pragma once
-#include "nplda_fwd_kernel.h"
+#include "../neuralplda_amd/csrc/nplda_fwd_kernel.h"
 
 namespace nplda {
 
