@@ -14,7 +14,7 @@ namespace nplda {
 // Product configuration, chosen by interleaved A/B runs of tools/exp_fwd.hip on MI355X
 // (profiles/r01b_*, r01d_*, r01t_*):
 //  * large batches, pair scoring, D1 = D2 = 150 (round 5): nplda_fwd_v6.h — v5's schedule with the six left-over features
-//    on 4 x 4 x 1 MFMAs instead of a tenth 16-feature block: 0.842 against v3's 0.831;
+//    on 4 x 4 x 1 MFMAs instead of a tenth 16-feature block: 0.858 against v3's 0.830;
 //  * large batches, pair scoring, NB <= 10 otherwise: the persistent continuous-stream schedule (nplda_fwd_v3.h),
 //    8 waves/block, one block per CU, 2 k16-steps of weights per barrier, LDS fragments read 4 feature blocks at a
 //    time: 0.82 of the fp32 MFMA peak at D = 150;
@@ -109,7 +109,9 @@ static inline int launch_fwd_v6(FwdArgs a, const NpldaLayout& L, hipStream_t st)
         hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0)
         cus = 256;
     const long long blocks = ntiles < cus ? ntiles : cus;
-    hipLaunchKernelGGL((nplda_fwd_v6_kernel<10, 6, WAVES, 4, 3, 3, XM>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a, (int)ntiles);
+    // (2 k16-steps per fence, layer-1 MFMA groups of 5 + 4 blocks, layer-2 output groups of 3: the best of tools/exp_fwd.hip's
+    // sweep, profiles/r05x_exp_v6_groups.txt)
+    hipLaunchKernelGGL((nplda_fwd_v6_kernel<10, 6, WAVES, 2, 5, 3, XM>), dim3((unsigned)blocks), dim3(WAVES * 64), 0, st, a, (int)ntiles);
     return nplda_launch_status();
 }
 // the streaming pair kernel of a model: v6 at 150 / 150, v3 up to NB = 10 otherwise, v5 at NB = 11 / 12

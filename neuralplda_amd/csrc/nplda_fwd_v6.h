@@ -17,21 +17,23 @@
 //  * layer 2 walks its NB - 1 full output blocks in groups of G2 as v5 does; group q also carries tail quad q (the group's
 //    chunk holds the tail block's segments beside its own) and folds it into the score in lane group 0.
 // Matrix-pipe time per 16 rows at D = 150: 1512 MFMAs of 8 passes + 336 of 2 (v3: 1680 of 8) = 0.95 of v3's; measured
-// 3.155 against 3.20 ms per 1 M pairs (0.842 against 0.831 of the fp32 MFMA peak, same process: tools/exp_fwd.hip,
-// profiles/r05u_exp_v6_tail.txt).  Measured and NOT kept (same file; the code is in the history, commit 5a1354d): the tail
-// on the vector ALU — v_pk_fma_f32 from broadcast LDS reads (0.823; 0.840 as one burst per k16-step with the reads a step
-// early) and v_fmac_f32 with DPP row-broadcast operands (0.788).  VALU instructions are not free beside MFMAs on this chip:
-// each costs ~2.5 cycles of matrix-pipe time in bursts, 4 - 5 when interleaved, whichever of the SIMD's waves issues it
+// 3.09 against 3.19 ms per 1 M pairs (0.858 against 0.832 of the fp32 MFMA peak, same process: tools/exp_fwd.hip,
+// profiles/r05x_exp_v6_groups.txt) with two accumulator chains per (quad, side) — four dependent 4x4x1 MFMAs in a row stall
+// on each other (the first version: 3.155 ms) — 2 k16-steps per fence and layer-1 groups of 5 + 4 blocks.  Measured and NOT
+// kept (profiles/r05u_exp_v6_tail.txt; the code is in the history, commit 5a1354d): the tail on the vector ALU —
+// v_pk_fma_f32 from broadcast LDS reads (0.823; 0.840 as one burst per k16-step with the reads a step early) and
+// v_fmac_f32 with DPP row-broadcast operands (0.788).  VALU instructions are not free beside MFMAs on this chip: each costs
+// ~2.5 cycles of matrix-pipe time in bursts, 4 - 5 when interleaved, whichever of the SIMD's waves issues it
 // (tools/exp_valu_phase.hip, profiles/r05u_exp_valu_phase.txt), and hipcc unpacks v_pk_fma_f32 it finds in an MFMA's
-// shadow.  With no tail work at all the kernel runs in 2.96 ms (ABL = 1): 0.12 ms is what six features cost at the full
-// blocks' rate, 0.20 ms is what they cost here.  At D = 170 (ten tail features, three quads) the form is level with v5.
+// shadow.  With no tail work at all the kernel runs in 2.91 ms (ABL = 1): 0.12 ms is what six features cost at the full
+// blocks' rate, 0.18 ms is what they cost here.  At D = 170 (ten tail features, three quads) the form is behind v5.
 #pragma once
 #include "nplda_fwd_kernel.h"
 
 namespace nplda {
 
 // ABL (tools/exp_fwd.hip only; results are WRONG when non-zero): 1 = no tail work at all
-template <int NB, int TF, int WAVES, int KPB = 4, int G1 = 3, int G2 = 3, int XM = 0, int ABL = 0>
+template <int NB, int TF, int WAVES, int KPB = 2, int G1 = 5, int G2 = 3, int XM = 0, int ABL = 0>
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(const FwdArgs a, int ntiles) {
     constexpr int NM = NB - 1;                       // feature blocks on the 16 x 16 MFMA
     constexpr int NQ = (TF + 3) / 4;                 // tail features in quads
@@ -160,11 +162,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             accA[nb] = b1p[4 * nb + g];
             accB[nb] = accA[nb];
         }
-        f32x4 qA[NQ], qB[NQ];
+        // two accumulators per (quad, side), for the even and the odd k4-steps: four dependent 4x4x1 MFMAs in a row stall on
+        // each other (two passes each, a longer result latency — hipcc separates them by s_nop and keeps them together
+        // wherever the source puts them); with two chains the dependent ones are four instructions apart
+        f32x4 qA[NQ][2], qB[NQ][2];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            qA[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-            qB[q] = qA[q];
+            qA[q][0] = qA[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
+            qB[q][0] = qB[q][1] = qA[q][0];
         }
 
         // ---- layer 1 ---------------------------------------------------------------------------------------
@@ -206,8 +211,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                             const f32x4 wq = w[s * STEP4 + NM * 64 + tl + 4 * gr];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                qA[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xc[s][r], qA[gr], 0, 0, 0);
-                                qB[gr] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], yc[s][r], qB[gr], 0, 0, 0);
+                                qA[gr][r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xc[s][r], qA[gr][r & 1], 0, 0, 0);
+                                qB[gr][r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], yc[s][r], qB[gr][r & 1], 0, 0, 0);
                             }
                         }
                     }
@@ -236,8 +241,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             float uA[TF], uB[TF];
 #pragma unroll
             for (int f = 0; f < TF; ++f) {
-                uA[f] = kgroups_sum(qA[f / 4][f % 4]);
-                uB[f] = kgroups_sum(qB[f / 4][f % 4]);
+                uA[f] = kgroups_sum(qA[f / 4][0][f % 4] + qA[f / 4][1][f % 4]);
+                uB[f] = kgroups_sum(qB[f / 4][0][f % 4] + qB[f / 4][1][f % 4]);
             }
             const f32x4 bt = b1p[4 * NM + g];  // zero beyond D1 (the image pads the bias)
             accA[NM] = as_block(uA) + bt;
@@ -281,7 +286,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                     zB[u] = zA[u];
                 }
             }
-            f32x4 zqA = {0.f, 0.f, 0.f, 0.f}, zqB = zqA;
+            f32x4 zqA[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}}, zqB[2] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};
             f32x4* nxt = wbuf[par ^ 1];
             if (gi + 1 < NG) {
                 const int nb1 = nb0 + G2;
@@ -315,8 +320,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                     const f32x4 wq = w[(kb * per + gc) * 64 + tl + 4 * gi];
 #pragma unroll
                     for (int r = 0; r < 4; ++r) {
-                        zqA = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accA[kb][r], zqA, 0, 0, 0);
-                        zqB = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accB[kb][r], zqB, 0, 0, 0);
+                        zqA[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accA[kb][r], zqA[r & 1], 0, 0, 0);
+                        zqB[r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], accB[kb][r], zqB[r & 1], 0, 0, 0);
                     }
                 }
             }
@@ -345,8 +350,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                 for (int i = 0; i < 4; ++i) {
                     const int f = 4 * gi + i;
                     if (f < TF) {
-                        const float z1 = kgroups_sum(zqA[i]) + b2s[16 * NM + f];
-                        const float z2 = kgroups_sum(zqB[i]) + b2s[16 * NM + f];
+                        const float z1 = kgroups_sum(zqA[0][i] + zqA[1][i]) + b2s[16 * NM + f];
+                        const float z2 = kgroups_sum(zqB[0][i] + zqB[1][i]) + b2s[16 * NM + f];
                         tpart = fmaf(Qs[16 * NM + f], fmaf(z1, z1, z2 * z2), tpart);
                         tpart = fmaf(2.0f * Ps[16 * NM + f], z1 * z2, tpart);
                     }

@@ -150,8 +150,9 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     if (L.NB == 10) {
         vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v5 w8 kpb2 h1", launch_5<10, 8, 2, 4, 1>},
-               {"v6 4x4 kpb4", launch_6<10, 6, 8, 4, 3, 3>}, {"v6 4x4 kpb2", launch_6<10, 6, 8, 2, 3, 3>},
-               {"v6 ABL1 kpb4", launch_6<10, 6, 8, 4, 3, 3, 1>} };
+               {"v6 kpb2 g5/3", launch_6<10, 6, 8, 2, 5, 3>}, {"v6 kpb2 g4/3", launch_6<10, 6, 8, 2, 4, 3>},
+               {"v6 kpb2 g5/4", launch_6<10, 6, 8, 2, 5, 4>}, {"v6 kpb2 g5/2", launch_6<10, 6, 8, 2, 5, 2>},
+               {"v6 kpb2 g3/3", launch_6<10, 6, 8, 2, 3, 3>}, {"v6 ABL1 g5/3", launch_6<10, 6, 8, 2, 5, 3, 1>} };
     } else if (L.NB == 11) {
         vs = { {"v5 w8 kpb2 h1", launch_5<11, 8, 2, 4, 1>}, {"v6 4x4 g4/4", launch_6<11, 10, 8, 2, 4, 4>},
                {"v6 ABL1 g4/4", launch_6<11, 10, 8, 2, 4, 4, 1>} };
