@@ -88,7 +88,7 @@ static inline int launch_fwd_v5(FwdArgs a, const NpldaLayout& L, hipStream_t st)
     const long long blocks = ntiles < cus ? ntiles : cus;
     dim3 grid((unsigned)blocks), block(WAVES * 64);
     switch (L.NB) {
-        case 11: hipLaunchKernelGGL((nplda_fwd_v5_kernel<11, WAVES, 2, 4, 1, XM>), grid, block, 0, st, a, (int)ntiles); break;
+        case 11: hipLaunchKernelGGL((nplda_fwd_v5_kernel<11, WAVES, 2, 6, 1, XM>), grid, block, 0, st, a, (int)ntiles); break;
         case 12: hipLaunchKernelGGL((nplda_fwd_v5_kernel<12, WAVES, 4, 4, 1, XM>), grid, block, 0, st, a, (int)ntiles); break;
         default: return NPLDA_EUNSUPPORTED;
     }

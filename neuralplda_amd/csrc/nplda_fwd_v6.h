@@ -33,7 +33,7 @@
 namespace nplda {
 
 // ABL (tools/exp_fwd.hip only; results are WRONG when non-zero): 1 = no tail work at all
-template <int NB, int TF, int WAVES, int KPB = 2, int G1 = 5, int G2 = 3, int XM = 0, int ABL = 0>
+template <int NB, int TF, int WAVES, int KPB = 2, int G1 = 5, int G2 = 3, int XM = 0, int ABL = 0, int NCH = 2>  // NCH: accumulator chains per (quad, side)
 __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(const FwdArgs a, int ntiles) {
     constexpr int NM = NB - 1;                       // feature blocks on the 16 x 16 MFMA
     constexpr int NQ = (TF + 3) / 4;                 // tail features in quads
@@ -165,11 +165,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
         // two accumulators per (quad, side), for the even and the odd k4-steps: four dependent 4x4x1 MFMAs in a row stall on
         // each other (two passes each, a longer result latency — hipcc separates them by s_nop and keeps them together
         // wherever the source puts them); with two chains the dependent ones are four instructions apart
-        f32x4 qA[NQ][2], qB[NQ][2];
+        f32x4 qA[NQ][NCH], qB[NQ][NCH];
 #pragma unroll
         for (int q = 0; q < NQ; ++q) {
-            qA[q][0] = qA[q][1] = f32x4{0.f, 0.f, 0.f, 0.f};
-            qB[q][0] = qB[q][1] = qA[q][0];
+#pragma unroll
+            for (int h = 0; h < NCH; ++h) {
+                qA[q][h] = f32x4{0.f, 0.f, 0.f, 0.f};
+                qB[q][h] = qA[q][h];
+            }
         }
 
         // ---- layer 1 ---------------------------------------------------------------------------------------
@@ -211,8 +214,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
                             const f32x4 wq = w[s * STEP4 + NM * 64 + tl + 4 * gr];
 #pragma unroll
                             for (int r = 0; r < 4; ++r) {
-                                qA[gr][r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xc[s][r], qA[gr][r & 1], 0, 0, 0);
-                                qB[gr][r & 1] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], yc[s][r], qB[gr][r & 1], 0, 0, 0);
+                                qA[gr][r % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], xc[s][r], qA[gr][r % NCH], 0, 0, 0);
+                                qB[gr][r % NCH] = __builtin_amdgcn_mfma_f32_4x4x1f32(wq[r], yc[s][r], qB[gr][r % NCH], 0, 0, 0);
                             }
                         }
                     }
@@ -241,8 +244,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES / 4) void nplda_fwd_v6_kernel(con
             float uA[TF], uB[TF];
 #pragma unroll
             for (int f = 0; f < TF; ++f) {
-                uA[f] = kgroups_sum(qA[f / 4][0][f % 4] + qA[f / 4][1][f % 4]);
-                uB[f] = kgroups_sum(qB[f / 4][0][f % 4] + qB[f / 4][1][f % 4]);
+                float sa_ = qA[f / 4][0][f % 4], sb_ = qB[f / 4][0][f % 4];
+#pragma unroll
+                for (int h = 1; h < NCH; ++h) {
+                    sa_ += qA[f / 4][h][f % 4];
+                    sb_ += qB[f / 4][h][f % 4];
+                }
+                uA[f] = kgroups_sum(sa_);
+                uB[f] = kgroups_sum(sb_);
             }
             const f32x4 bt = b1p[4 * NM + g];  // zero beyond D1 (the image pads the bias)
             accA[NM] = as_block(uA) + bt;

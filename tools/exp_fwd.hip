@@ -103,13 +103,13 @@ void launch_5(const FwdArgs& a, long long B, hipStream_t st) {
     hipLaunchKernelGGL((nplda_fwd_v5_kernel<NB, WAVES, KPB, G, H>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
 }
 
-template <int NB, int TF, int WAVES, int KPB, int G1, int G2, int ABL = 0>
+template <int NB, int TF, int WAVES, int KPB, int G1, int G2, int ABL = 0, int NCH = 2>
 void launch_6(const FwdArgs& a, long long B, hipStream_t st) {
     const long long per_block = 16 * WAVES;
     const int ntiles = (int)((B + per_block - 1) / per_block);
     int grid = 256;
     if (grid > ntiles) grid = ntiles;
-    hipLaunchKernelGGL((nplda_fwd_v6_kernel<NB, TF, WAVES, KPB, G1, G2, 0, ABL>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
+    hipLaunchKernelGGL((nplda_fwd_v6_kernel<NB, TF, WAVES, KPB, G1, G2, 0, ABL, NCH>), dim3(grid), dim3(WAVES * 64), 0, st, a, ntiles);
 }
 
 int main(int argc, char** argv) {
@@ -150,12 +150,12 @@ int main(int argc, char** argv) {
     std::vector<Variant> vs;
     if (L.NB == 10) {
         vs = { {"v3 w8 kpb2", launch_3<10, 8, false, 2, 1>}, {"v5 w8 kpb2 h1", launch_5<10, 8, 2, 4, 1>},
-               {"v6 kpb2 g5/3", launch_6<10, 6, 8, 2, 5, 3>}, {"v6 kpb2 g4/3", launch_6<10, 6, 8, 2, 4, 3>},
-               {"v6 kpb2 g5/4", launch_6<10, 6, 8, 2, 5, 4>}, {"v6 kpb2 g5/2", launch_6<10, 6, 8, 2, 5, 2>},
-               {"v6 kpb2 g3/3", launch_6<10, 6, 8, 2, 3, 3>}, {"v6 ABL1 g5/3", launch_6<10, 6, 8, 2, 5, 3, 1>} };
+               {"v6 g5/3 2 chains", launch_6<10, 6, 8, 2, 5, 3>}, {"v6 g5/3 4 chains", launch_6<10, 6, 8, 2, 5, 3, 0, 4>},
+               {"v6 g5/3 1 chain", launch_6<10, 6, 8, 2, 5, 3, 0, 1>}, {"v6 ABL1 g5/3", launch_6<10, 6, 8, 2, 5, 3, 1>} };
     } else if (L.NB == 11) {
-        vs = { {"v5 w8 kpb2 h1", launch_5<11, 8, 2, 4, 1>}, {"v6 4x4 g4/4", launch_6<11, 10, 8, 2, 4, 4>},
-               {"v6 ABL1 g4/4", launch_6<11, 10, 8, 2, 4, 4, 1>} };
+        vs = { {"v5 kpb2 g4", launch_5<11, 8, 2, 4, 1>}, {"v5 kpb2 g3", launch_5<11, 8, 2, 3, 1>},
+               {"v5 kpb2 g5", launch_5<11, 8, 2, 5, 1>}, {"v5 kpb2 g6", launch_5<11, 8, 2, 6, 1>},
+               {"v5 kpb4 g4", launch_5<11, 8, 4, 4, 1>}, {"v6 4x4 g4/4", launch_6<11, 10, 8, 2, 4, 4>} };
     } else if (L.NB == 8) {
         vs = { {"v3 w8 kpb2 nb8", launch_3<8, 8, false, 2, 1>}, {"v5 w8 kpb2 nb8", launch_5<8, 8, 2>} };
     } else {
