@@ -158,17 +158,23 @@ static inline int mid_cus() {
 }
 template <bool EMBED = false>
 static inline int launch_fwd_mid(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
-    const long long n16 = EMBED ? (a.n + 31) / 32 : (a.n + 15) / 16;  // tiles: 16 pairs, or 32 embedding rows
+    const long long nh = EMBED ? (a.n + 15) / 16 : (a.n + 7) / 8;  // HALF tiles: 8 pairs, or 16 embedding rows
     const int cus = mid_cus();
-    const long long grid = n16 < cus ? n16 : cus;
-    const long long c = (n16 + grid - 1) / grid;
-    const long long r = n16 - grid * (c - 1);
+    // one block per CU; with fewer than two halves per CU, as many blocks as whole tiles (a lone half tile costs 0.7 of a tile)
+    long long grid = (nh + 1) / 2 < cus ? (nh + 1) / 2 : cus;
+    if (grid < 1) grid = 1;
+    const long long c = (nh + grid - 1) / grid;
+    const long long r = nh - grid * (c - 1);
     if (c > 0x7fffffffLL) return NPLDA_EINVAL;
+    const bool half = !(r == grid && (c & 1) == 0);  // some block ends on an odd half tile
+#define NPLDA_LAUNCH(NBV, HV) \
+    hipLaunchKernelGGL((nplda_fwd_mid_kernel<NBV, EMBED, HV>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r)
     switch (L.NB) {
-        case 10: hipLaunchKernelGGL((nplda_fwd_mid_kernel<10, EMBED>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
-        case 11: hipLaunchKernelGGL((nplda_fwd_mid_kernel<11, EMBED>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r); break;
+        case 10: if (half) { NPLDA_LAUNCH(10, true); } else { NPLDA_LAUNCH(10, false); } break;
+        case 11: if (half) { NPLDA_LAUNCH(11, true); } else { NPLDA_LAUNCH(11, false); } break;
         default: return NPLDA_EUNSUPPORTED;
     }
+#undef NPLDA_LAUNCH
     return nplda_launch_status();
 }
 
@@ -198,9 +204,9 @@ static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus)
     static const bool no_mid = getenv("NPLDA_FWD_NO_MID") != nullptr && getenv("NPLDA_FWD_NO_MID")[0] == '1';
     const bool mid_ok = !no_mid && (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
     if (!mid_ok) return n <= 64LL * cus ? FWD_SMALL : FWD_STREAM;
-    const long long c = ((n + 15) / 16 + cus - 1) / cus;
+    const long long ch = ((n + 7) / 8 + cus - 1) / cus;  // half tiles on the busiest CU (a trailing half costs ~0.7 of a tile)
     const long long rounds = ((n + 127) / 128 + cus - 1) / cus;
-    const long long t_mid = 40 + c * (L.NB == 10 ? 133 : 168);
+    const long long t_mid = 40 + (ch / 2) * (L.NB == 10 ? 133 : 168) + (ch & 1) * (L.NB == 10 ? 93 : 118);
     const long long t_stream = 50 + rounds * (L.NB == 10 ? 1000 : 1150);
     return t_mid < t_stream ? FWD_MID : FWD_STREAM;
 }

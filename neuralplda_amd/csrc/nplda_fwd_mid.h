@@ -40,12 +40,15 @@ __device__ unsigned long long g_mid_stamps[32];
 template <int NB, int T>
 struct MidCfg {
     static_assert(NB == 10 || NB == 11, "mid kernel: D = 145..176");
-    static_assert(T == 1 || T == 2, "groups of one or two tiles");
-    static constexpr int RG = 2 * T;                   // row groups of a group: (tile, side)
+    static_assert(T == 0 || T == 1 || T == 2, "groups of one or two tiles, or a trailing HALF tile (T = 0)");
+    // T = 0 (round 5): one row group of 16 rows — in pair mode the x1 rows of 8 pairs in lanes j < 8 and their x2 rows in
+    // lanes j >= 8 (the half tile of nplda_train_fb_half.h: a pair's two embeddings meet by a DPP row rotation), in embed
+    // mode 16 consecutive rows.  A block's range is counted in such halves, so the grid balances to 8 pairs / 16 rows.
+    static constexpr int RG = T == 0 ? 1 : 2 * T;      // row groups of a group: (tile, side)
     static constexpr int LB = NB - 8;                  // left-over blocks (blocks 0..7 go two to a wave, whole)
     // own left-over units of a wave: LS block slots x LR row groups (in the wave's permuted index space: a = 8 + i, rho < LR)
     static constexpr int LS = (NB == 11 && T == 2) ? 3 : 1;
-    static constexpr int LR = (NB == 10) ? T : (T == 2 ? 1 : 2);
+    static constexpr int LR = T == 0 ? 1 : ((NB == 10) ? T : (T == 2 ? 1 : 2));
     static constexpr int UW = 2 * RG + LS * LR;        // units (f32x4 accumulators) a wave owns
     // the two sides of a left-over unit sit in two waves (w, w ^ 1): their z meet through LDS for the score
     static constexpr bool XCH = (NB == 10 && T == 1) || (NB == 11 && T == 2);
@@ -54,6 +57,7 @@ struct MidCfg {
 // wave-uniform index maps (all arguments and results live in SGPRs); T may be a run-time value (the NEXT group's size)
 template <int NB>
 __device__ __forceinline__ int mid_swz(int T, int w) {
+    if (T == 0) return 0;
     if constexpr (NB == 10) return T == 2 ? 2 * (w & 1) : (w & 1);
     else return T == 2 ? w : 0;
 }
@@ -61,6 +65,8 @@ template <int NB>
 __device__ __forceinline__ int mid_blk(int T, int a, int w) {  // accumulator slot a of wave w holds feature block ...
     if (a < 8) return (a & 4) | ((a + w) & 3);
     const int i = a - 8;
+    // T = 0: the LB left-over blocks x one row group are LB units: wave w < LB owns block 8 + w in its slot 8
+    if (T == 0) return 8 + (i + w) % (NB - 8);
     if constexpr (NB == 10) return 8 + ((i + (w >> 1)) & 1);
     else return T == 2 ? 8 + i : 8 + (w < 3 ? (i + w) % 3 : i);
 }
@@ -78,14 +84,21 @@ struct MidAddr {
     const float* xr[4];
     unsigned voff[NB];  // byte offset of this lane's 16 bytes of slot a's fragment inside a k16-step of the image
 };
-// EMBED: the rows are single rows of ONE table (a.xa); a "tile" is 32 consecutive rows, its two "sides" the two halves
-template <int NB, bool EMBED = false>
-__device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int T, int wave, int lane, MidAddr<NB>& A) {
+// EMBED: the rows are single rows of ONE table (a.xa); a "tile" is 32 consecutive rows, its two "sides" the two halves.
+// A group starts at HALF tile h0 (8 pairs / 16 embedding rows each): pair 8 h0 / row 16 h0.
+template <int NB, bool EMBED = false, bool HALF = true>  // HALF = false: T is never 0 (the checks fold away)
+__device__ __forceinline__ void mid_addr(const FwdArgs& a, long long h0, int Tin, int wave, int lane, MidAddr<NB>& A) {
+    const int T = (!HALF && Tin == 0) ? 1 : Tin;
+    if (!HALF) __builtin_assume(T != 0);
     const int swz = mid_swz<NB>(T, wave);
+    const int rgm = T == 0 ? 0 : 2 * T - 1;
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) {
-        const int rg = (rho & (2 * T - 1)) ^ swz;  // T = 1: slots 2, 3 repeat 0, 1 (loaded, never used)
-        long long row = EMBED ? (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + (lane & 15) : (tile0 + (rg >> 1)) * 16 + (lane & 15);
+        const int rg = (rho & rgm) ^ swz;  // T = 1: slots 2, 3 repeat 0, 1 (loaded, never used); T = 0: all repeat 0
+        // pair mode, T = 0: lanes j < 8 hold the x1 rows of pairs 8 h0 + j, lanes j >= 8 the x2 rows of the same pairs
+        const int side = T == 0 ? ((lane >> 3) & 1) : (rg & 1);
+        long long row = EMBED ? h0 * 16 + 16 * rg + (lane & 15)
+                              : (T == 0 ? h0 * 8 + (lane & 7) : h0 * 8 + (rg >> 1) * 16 + (lane & 15));
         if (row >= a.n) row = a.n - 1;
         if (EMBED) {
             if (a.ia != nullptr) {  // rows named by index (nplda_embed_rows_f32): one table, the gather folded in
@@ -99,10 +112,10 @@ __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long tile0, int 
             continue;
         }
         if (a.ia != nullptr) {  // indexed pairs: the pair's row of the x-vector table (one dependent load per group, a group ahead)
-            row = ((rg & 1) ? a.ib : a.ia)[row];
+            row = (side ? a.ib : a.ia)[row];
             row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
         }
-        A.xr[rho] = ((rg & 1) ? a.xb : a.xa) + row * a.ldx + 4 * (lane >> 4) + 32 * wave;  // k16-steps 2 w, 2 w + 1 (+ 8 m)
+        A.xr[rho] = (side ? a.xb : a.xa) + row * a.ldx + 4 * (lane >> 4) + 32 * wave;  // k16-steps 2 w, 2 w + 1 (+ 8 m)
     }
 #pragma unroll
     for (int s = 0; s < NB; ++s) A.voff[s] = (unsigned)(mid_blk<NB>(T, s, wave) * 64 + lane) * 16u;
@@ -128,10 +141,10 @@ __device__ __forceinline__ void mid_fetchx(const MidAddr<NB>& A, MidRing<NB>& R,
     R.xf[i & 3][rho] = *reinterpret_cast<const f32x4*>(A.xr[rho] + 16 * (8 * (i >> 1) + (i & 1)));
 }
 
-// One group of T tiles starting at 16-pair tile `tile0`; the next group (TN tiles from tile_n; the block's last group names
-// itself) gets its first loads from here.  LDS: red (the exchange of the layer-1 partial sums; reused as the y tiles of
+// One group of T tiles (T = 0: one half tile) starting at half tile `tile0` (8 pairs / 16 embedding rows per half); the next
+// group (TN tiles from half tile tile_n; the block's last group names itself) gets its first loads from here.  LDS: red (the exchange of the layer-1 partial sums; reused as the y tiles of
 // layer 2), ssb / scb (row norms, scores), zx (left-over z of the other side), cv (b1, b2, Q, P).
-template <int NB, int T, bool EMBED = false>
+template <int NB, int T, bool EMBED = false, bool HALF = true>
 __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int TN, long long tile_n, MidRing<NB>& R,
                                           int wave, int lane, f32x4* red, float (*ssb)[4][16], float (*scb)[2][16],
                                           f32x4 (*zx)[3][64], const f32x4* cv) {
@@ -150,10 +163,11 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
 
     NPLDA_MSTAMP(0);
     MidAddr<NB> A, AN;
-    mid_addr<NB, EMBED>(a, tile0, T, wave, lane, A);
-    mid_addr<NB, EMBED>(a, tile_n, TN, wave, lane, AN);
-    bool lo_valid = true;  // NB = 11, T = 1: wave 3 owns no left-over block
+    mid_addr<NB, EMBED, HALF>(a, tile0, T, wave, lane, A);
+    mid_addr<NB, EMBED, HALF>(a, tile_n, TN, wave, lane, AN);
+    bool lo_valid = true;  // NB = 11, T = 1: wave 3 owns no left-over block; T = 0: the LB left-over units go to waves 0 .. LB - 1
     if constexpr (NB == 11 && T == 1) lo_valid = wave < 3;
+    if constexpr (T == 0) lo_valid = wave < NB - 8;
     // where unit (slot s, row group rho) of this wave's partial sums goes: wave v, index u, red[v][(src - v - 1) & 3][u]
     auto export_unit = [&](int s, int rho, const f32x4& val) {
         const bool own_static = s < 8 ? (s & 3) == 0 : ((s - 8) < LS && rho < LR);
@@ -164,6 +178,9 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         if (s < 8) {
             v = b & 3;
             u = (b >> 2) * RG + (rg ^ mid_swz<NB>(T, v));
+        } else if constexpr (T == 0) {
+            v = b - 8;
+            u = 2 * RG;
         } else if constexpr (NB == 10) {
             v = 2 * (b - 8) + (T == 2 ? (rg >> 1) : rg);
             u = 2 * RG + (T == 2 ? (rg & 1) : 0);
@@ -189,7 +206,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         if (q < RG) {
             if (i + 3 < KSW) mid_fetchx<NB>(A, R, i + 3, q);
             else mid_fetchx<NB>(AN, R, i + 3 - KSW, q);
-        } else if (T == 1 && q < 4 && i + 3 >= KSW) {
+        } else if (T <= 1 && q < 4 && i + 3 >= KSW) {
             mid_fetchx<NB>(AN, R, i + 3 - KSW, q);  // the next group may have four row groups
         } else if (q >= NB && q < 2 * NB) {
             R.wf[(i + 1) & 1][q - NB] = mid_ldw(img, i + 1 < KSW ? A.voff[q - NB] : AN.voff[q - NB], wnext);
@@ -301,7 +318,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
     // such a chain is paid in full) — and the row groups' values cross the 16-lane rows by ds_bpermute
     float inv_l;
     {
-        const int rgl = g & (RG - 1);
+        const int rgl = g & (RG - 1);  // (RG = 1: every lane group forms row group 0's value)
         inv_l = 1.0f / fmaxf(sqrtf(((ssb[0][rgl][j] + ssb[1][rgl][j]) + ssb[2][rgl][j]) + ssb[3][rgl][j]), 1e-12f);
     }
 #pragma unroll
@@ -373,7 +390,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         for (int rho = 0; rho < RG; ++rho) qp[rho] = 0.f;
         auto out_unit = [&](const f32x4& z, int b, int rho, bool valid) {
             const int rg = rho ^ swz;
-            const long long row = (tile0 + (rg >> 1)) * 32 + 16 * (rg & 1) + j;
+            const long long row = tile0 * 16 + 16 * rg + j;
             if (valid && row < a.n) *reinterpret_cast<f32x4*>(a.out_z + row * a.ldz + 16 * b + 4 * g) = z;
             if (valid) {
                 const f32x4 q = Qp[4 * b + g];
@@ -398,7 +415,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
             }
             __syncthreads();
             if (wave < RG && g == 0) {
-                const long long row = (tile0 + (wave >> 1)) * 32 + 16 * (wave & 1) + j;
+                const long long row = tile0 * 16 + 16 * wave + j;
                 if (row < a.n) a.out_q[row] = ((ssb[0][wave][j] + ssb[1][wave][j]) + ssb[2][wave][j]) + ssb[3][wave][j];
             }
         }
@@ -417,7 +434,32 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         }
         return part;
     };
-    float part[T];
+    if constexpr (T == 0) {
+        // the half tile: a pair's z1 sits in lane j < 8, its z2 in lane j + 8 of the same registers (DPP row_ror:8 swaps them;
+        // the term is symmetric, lanes j >= 8 form the same value)
+        auto half = [&](const f32x4& z, int b) {
+            f32x4 zo;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) zo[r] = dpp_f32<0x128>(z[r]);
+            return term(z, zo, b);
+        };
+        float ph = half(zF[0][0], blk(0)) + half(zF[1][0], blk(4));
+        if (lo_valid) {
+#pragma unroll
+            for (int i = 0; i < LS; ++i) ph += half(zL[i][0], blk(8 + i));
+        }
+        ph = wave_xor_add(ph, 16);
+        ph = wave_xor_add(ph, 32);
+        if (g == 0) scb[wave][0][j] = ph;
+        __syncthreads();
+        if (wave == 0 && g == 0 && j < 8) {
+            const long long row = tile0 * 8 + j;
+            if (row < a.n) a.out_s[row] = ((scb[0][0][j] + scb[1][0][j]) + scb[2][0][j]) + scb[3][0][j];
+        }
+        NPLDA_MSTAMP(10);
+        return;
+    }
+    float part[T > 0 ? T : 1];
 #pragma unroll
     for (int t = 0; t < T; ++t)
         part[t] = term(zF[0][2 * t], zF[0][2 * t + 1], blk(0)) + term(zF[1][2 * t], zF[1][2 * t + 1], blk(4));
@@ -434,7 +476,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         // both sides of the left-over units are here: (rho 0, rho 1) of tile' 0
         if (lo_valid) {
 #pragma unroll
-            for (int i = 0; i < LS; ++i) part[0] += term(zL[i][0], zL[i][1], blk(8 + i));
+            for (int i = 0; i < LS; ++i) part[0] += term(zL[i][0], zL[i][LR > 1 ? 1 : 0], blk(8 + i));
         }
     }
 #pragma unroll
@@ -445,15 +487,19 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
     }
     __syncthreads();
     if (wave < T && g == 0) {
-        const long long row = (tile0 + wave) * 16 + j;
+        const long long row = tile0 * 8 + wave * 16 + j;
         if (row < a.n) a.out_s[row] = ((scb[0][wave][j] + scb[1][wave][j]) + scb[2][wave][j]) + scb[3][wave][j];
     }
     NPLDA_MSTAMP(10);
 }
 
-// Block b works on the contiguous tile range [start, start + k): k = c for the first r blocks, c - 1 for the rest
-// (c = ceil(n16 / grid), r = n16 - grid (c - 1)) — pairs of tiles as T = 2 groups, an odd last tile as a T = 1 group.
-template <int NB, bool EMBED = false>
+// Block b works on the contiguous range of HALF tiles [start, start + k): k = c for the first r blocks, c - 1 for the rest
+// (c = ceil(nh / grid), r = nh - grid (c - 1), nh = halves of 8 pairs / 16 rows) — four halves as a T = 2 group, two as a
+// T = 1 group, an odd last half as a T = 0 group: the grid balances to half a tile (round 5; to a whole tile before: 10 240
+// pairs — 2.5 tiles per CU — ran three tiles on half the CUs).
+// HALF = false: every block's count is even (the host checks) — the T = 0 group is not instantiated, and the kernel is the
+// round-4 one (with it in, the compiler's register assignment for the shared rings costs the even sizes ~1 %).
+template <int NB, bool EMBED = false, bool HALF = true>
 __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, int c, int r) {
     constexpr int UWM = MidCfg<NB, 2>::UW > MidCfg<NB, 1>::UW ? MidCfg<NB, 2>::UW : MidCfg<NB, 1>::UW;
     __shared__ f32x4 red[4 * 3 * UWM * 64];
@@ -465,12 +511,13 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int b = blockIdx.x;
     int k = b < r ? c : c - 1;
-    long long tile = b < r ? (long long)b * c : (long long)r * c + (long long)(b - r) * (c - 1);
+    long long h = b < r ? (long long)b * c : (long long)r * c + (long long)(b - r) * (c - 1);
+    auto group_t = [](int kk) { return kk >= 4 ? 2 : (kk >= 2 ? 1 : 0); };  // the next group of a remaining count of halves
     // the first group's first loads (x steps 0 .. 2, weights step 0)
     MidRing<NB> R;
     {
         MidAddr<NB> A0;
-        mid_addr<NB, EMBED>(a, tile, k >= 2 ? 2 : 1, wave, lane, A0);
+        mid_addr<NB, EMBED, HALF>(a, h, group_t(k), wave, lane, A0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -484,11 +531,20 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
         const size_t o = v == 0 ? a.ob1 : (v == 1 ? a.ob2 : (v == 2 ? a.oQ : a.oP));
         cv[i] = reinterpret_cast<const f32x4*>(a.packed + o)[e];
     }
-    for (; k >= 2; k -= 2, tile += 2) {
-        const int TN = k >= 4 ? 2 : (k == 3 ? 1 : 2);  // the last group names itself: a harmless re-read of its own first rows
-        mid_group<NB, 2, EMBED>(a, tile, TN, k >= 3 ? tile + 2 : tile, R, wave, lane, red, ssb, scb, zx, cv);
+    // (the block's last group names itself as its successor: a harmless re-read of its own first rows)
+    for (; k >= 4; k -= 4, h += 4) {
+        const bool more = k > 4;
+        mid_group<NB, 2, EMBED, HALF>(a, h, more ? group_t(k - 4) : 2, more ? h + 4 : h, R, wave, lane, red, ssb, scb, zx, cv);
     }
-    if (k == 1) mid_group<NB, 1, EMBED>(a, tile, 1, tile, R, wave, lane, red, ssb, scb, zx, cv);
+    if (k >= 2) {
+        const bool more = k > 2;
+        mid_group<NB, 1, EMBED, HALF>(a, h, more ? 0 : 1, more ? h + 2 : h, R, wave, lane, red, ssb, scb, zx, cv);
+        k -= 2;
+        h += 2;
+    }
+    if constexpr (HALF) {
+        if (k == 1) mid_group<NB, 0, EMBED, true>(a, h, 0, h, R, wave, lane, red, ssb, scb, zx, cv);
+    }
 }
 
 }  // namespace nplda

@@ -141,12 +141,12 @@ def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
 
 
 @pytest.mark.parametrize("D", [150, 160, 170])
-@pytest.mark.parametrize("B", [4097, 4112, 8192, 12289, 16384, 16385, 20480, 24577, 40000, 100001])
+@pytest.mark.parametrize("B", [4097, 4112, 6145, 8192, 10240, 10247, 12289, 16384, 16385, 20480, 24577, 40000, 100001])
 def test_mid_regime_batches_match_oracle(hip_lib, D, B):
     """The batch sizes between one 16-pair tile per CU and full streaming rounds — validate()'s 5 x batch_size = 20 480
     pairs (xvector_NeuralPlda_pytorch.py:125), the 10 240-pair score-file chunks, any 8-way shard of a modest list — take
-    the balanced-tile kernel (nplda_fwd_mid.h): contiguous tile ranges per block, T = 2 groups with an odd T = 1 tail,
-    blocks with c and c - 1 tiles, a ragged last tile.  Every score against the fp64 oracle, determinism, and independence of
+    the balanced-tile kernel (nplda_fwd_mid.h): contiguous ranges of HALF tiles per block (round 5), T = 2 groups with a T = 1
+    and / or a half-tile (8 pairs, x1 | x2 rows in one MFMA operand) tail, blocks with c and c - 1 halves, a ragged last tile.  Every score against the fp64 oracle, determinism, and independence of
     a pair's score from its position in the batch (to the last bits)."""
     from neuralplda_amd import _lib, ops
     rng = np.random.default_rng(31 * D + B)
@@ -330,7 +330,7 @@ def test_score_pairs_rows_equals_gather_then_score(hip_lib, D, B):
 
 
 @pytest.mark.parametrize("D", [150, 170])
-@pytest.mark.parametrize("N", [8193, 10000, 22000, 40001, 100003])
+@pytest.mark.parametrize("N", [8193, 10000, 12304, 22000, 40001, 100003])  # (12 304 = 769 half tiles of 16 rows)
 def test_mid_regime_embedding_rows_match_oracle(hip_lib, D, N):
     """extract_plda_embeddings at the row counts of cfg3 (10 000 cohort utterances, 22 000 enroll / test ids) and of a
     score file's distinct utterances: the balanced-tile kernel's embedding mode (32 rows per tile, odd tile counts, a ragged
