@@ -160,8 +160,9 @@ template <bool EMBED = false>
 static inline int launch_fwd_mid(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
     const long long nh = EMBED ? (a.n + 15) / 16 : (a.n + 7) / 8;  // HALF tiles: 8 pairs, or 16 embedding rows
     const int cus = mid_cus();
-    // one block per CU; with fewer than two halves per CU, as many blocks as whole tiles (a lone half tile costs 0.7 of a tile)
-    long long grid = (nh + 1) / 2 < cus ? (nh + 1) / 2 : cus;
+    // one block per CU; up to one half per CU every block takes ONE half tile (a lone half costs ~8 us + launch where a whole
+    // tile costs ~13); above that at least a whole tile per block
+    long long grid = nh <= cus ? nh : ((nh + 1) / 2 < cus ? (nh + 1) / 2 : cus);
     if (grid < 1) grid = 1;
     const long long c = (nh + grid - 1) / grid;
     const long long r = nh - grid * (c - 1);
@@ -199,10 +200,15 @@ static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st
 // The two are compared by these measured costs (tenths of a microsecond; both scale with the shader clock alike).
 enum { FWD_SMALL = 0, FWD_MID = 1, FWD_STREAM = 2 };
 static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus) {
-    if (n <= 16LL * cus) return FWD_SMALL;
     // NPLDA_FWD_NO_MID=1: the round-2 dispatch (A/B measurements only: tools/validate_e2e.py)
     static const bool no_mid = getenv("NPLDA_FWD_NO_MID") != nullptr && getenv("NPLDA_FWD_NO_MID")[0] == '1';
     const bool mid_ok = !no_mid && (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
+    // up to ONE half tile (8 pairs) per CU: the balanced-tile kernel with a lone T = 0 group per block — 12 us against the
+    // small-batch kernel's 16.6 (round 5: half the rows per CU; tools/ab_small_mid.py).  NPLDA_FWD_SMALL_MAX=<pairs> moves the
+    // small-batch kernel's upper bound (A/B measurements).
+    static const long long small_max = getenv("NPLDA_FWD_SMALL_MAX") ? atoll(getenv("NPLDA_FWD_SMALL_MAX")) : -1;
+    if (mid_ok && small_max < 0 && n <= 8LL * cus) return FWD_MID;
+    if (n <= (small_max >= 0 ? small_max : 16LL * cus)) return FWD_SMALL;
     if (!mid_ok) return n <= 64LL * cus ? FWD_SMALL : FWD_STREAM;
     const long long ch = ((n + 7) / 8 + cus - 1) / cus;  // half tiles on the busiest CU (a trailing half costs ~0.7 of a tile)
     const long long rounds = ((n + 127) / 128 + cus - 1) / cus;

@@ -76,7 +76,8 @@ def test_embed_backward_matches_oracle(hip_lib, D0, D1, D2, N):
     zref = orc.extract_plda_embeddings(x, p, np.float64)
     np.testing.assert_allclose(z[:, :D2].cpu().numpy(), zref, atol=5e-6, rtol=1e-5)
     z_plain, _ = ops.embed(cu(x), packed, want_q=False)
-    if D0 == 512 and 145 <= D1 <= 176 and D1 == D2 and N > 8192:  # plain rows of this count take the balanced-tile kernel
+    # plain rows of these counts take the balanced-tile kernel (round 5: also up to one 16-row half tile per CU, as lone halves)
+    if D0 == 512 and 145 <= D1 <= 176 and D1 == D2 and (N > 8192 or N <= 4096):
         np.testing.assert_allclose(z.cpu().numpy(), z_plain.cpu().numpy(), atol=2e-6, rtol=1e-5)
     else:
         assert torch.equal(z, z_plain)  # the saving variant computes the same bits
