@@ -20,11 +20,11 @@ def _check(line, steps, warmup, with_cpu):
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None
     assert d["dtype"] == "f32" and d["data"] == "synthetic" and "workload" in d["config"] and "model" not in d["config"]
     B = d["config"]["pairs_per_gpu_per_step"]
-    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - B / (d["ms_per_step"] * 1e-3)) <= 1e-5 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and r["peak"] == 157.3
-    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9 and 0.3 < r["frac"] < 1.0
-    assert abs(r["achieved"] - B * r["flop_per_pair_algorithmic"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-6 * r["achieved"]
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-6 and 0.3 < r["frac"] < 1.0
+    assert abs(r["achieved"] - B * r["flop_per_pair_algorithmic"] / (r["kernel_ms"] * 1e-3) / 1e12) < 1e-5 * r["achieved"]
     assert r["traffic"] is None or r["traffic"] > 0
     assert 1000.0 < r["sclk_mhz_under_kernel"] < 2600.0 and r["frac_at_measured_clock"] >= r["frac"] * 0.9
     assert r["kernel_ms"] <= d["ms_per_step"] * 1.02  # the kernel fits inside the step the wall clock saw
@@ -50,8 +50,8 @@ def test_bench_single_process_contract(hip_lib):
     d = _check(lines[0], 4, 1, True)
     assert "alt_bf16x3" in d and d["alt_bf16x3"]["max_abs_diff_vs_fp32_scores"] < 2e-5
     a = d["alt_d170"]  # the reference's shipped shape rides on the same line
-    assert a["bound"] == "mfma" and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-9 and 0.3 < a["frac"] < 1.0
-    assert a["flop_per_pair_algorithmic"] == 465120 and a["checksum_finite"]
+    assert a["bound"] == "mfma" and abs(a["frac"] - a["achieved"] / a["peak"]) < 1e-6 and 0.3 < a["frac"] < 1.0
+    assert a["flop_per_pair_algorithmic"] == 465120
     assert d["config"]["ranks_in_group"] == 1
     # the kernel label comes from the dispatch actually taken, and the line says which build of the library ran
     assert d["roofline"]["kernel"].startswith("nplda_fwd_v6_kernel") and a["kernel"].startswith("nplda_fwd_v5_kernel")
@@ -64,6 +64,18 @@ def test_bench_single_process_contract(hip_lib):
         assert o["roofline"]["bound"] == "mfma" and 0 < o["roofline"]["frac"] < 1
         assert o["d170"]["ms_per_step"] > 0 and 0 < o["d170"]["frac"] < 1  # the reference's shipped shape beside it
     assert d["alt_cfg2"]["ms_per_step"] < 0.2 and d["alt_cfg3"]["stats_ms"] <= 1.0 and d["alt_cfg5"]["ms_per_step"] < 0.3
+    # the line fits the ~8 KB of stdout tail the driver keeps, and ends with the objects that are read first; the prose
+    # and the full-precision figures are in the detail file it names
+    assert len(lines[0]) <= 7000, len(lines[0])
+    assert list(d)[-6:] == ["cpu_baseline", "alt_d170", "alt_cfg5", "alt_cfg3", "alt_cfg2", "roofline"]
+    full = json.load(open(os.path.join(ROOT, d["detail"])))
+    assert full["alt_cfg3"]["workload"].startswith("cfg3: cohort 10000 x rows 22000") and "sample" in full["cpu_baseline"]
+    assert abs(full["value"] - d["value"]) <= 1e-6 * d["value"] and full["alt_d170"]["checksum_finite"]
+    for k in ("alt_dropin", "alt_regimeB", "alt_gb", "alt_dplda", "alt_minc"):
+        assert k in d and "error" not in d[k] and k in full, k
+
+
+from tests.test_bench_line_cpu import test_line_fits_the_driver_tail  # noqa: E402,F401  (also run on the GPU box)
 
 
 def test_bench_torchrun_one_rank(hip_lib):
@@ -103,7 +115,7 @@ def test_bench_gpus_flag_launches_the_ranks_itself(hip_lib):
         per_gpu = d["config"]["pairs_per_gpu_per_step"]
         assert per_gpu == (65536 if scaling == "weak" else 32768)
         total = 2 * per_gpu if scaling == "weak" else 65536
-        assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+        assert abs(d["value"] - total / (d["ms_per_step"] * 1e-3)) <= 1e-5 * d["value"]
 
 
 def test_bench_cfg3_single_and_two_rank_dry_run(hip_lib):
@@ -115,7 +127,7 @@ def test_bench_cfg3_single_and_two_rank_dry_run(hip_lib):
     d1 = json.loads(lines[0])
     assert d1["n_gpus"] == 1 and d1["unit"] == "trials/s" and d1["config"]["rows_per_gpu"] == 2000
     assert d1["roofline"]["bound"] == "mfma" and d1["roofline"]["kernel_ms"] > 0
-    assert abs(d1["value"] - 100000 / (d1["ms_per_step"] * 1e-3)) <= 1e-6 * d1["value"]
+    assert abs(d1["value"] - 100000 / (d1["ms_per_step"] * 1e-3)) <= 1e-5 * d1["value"]
     assert d1["config"]["stats_ms"] + d1["config"]["allgather_ms"] + d1["config"]["apply_ms"] <= d1["ms_per_step"] * 1.5
     out, lines = _run(["--gpus", "2"] + small, env={"NPLDA_BENCH_BACKEND": "gloo"})
     assert out.returncode == 0, out.stderr[-2000:]
@@ -144,7 +156,7 @@ def test_bench_cfg2_single_and_two_rank_dry_run(hip_lib):
     d1 = json.loads(lines[0])
     assert d1["n_gpus"] == 1 and d1["unit"] == "pairs/s" and d1["config"]["global_batch"] == 4096
     assert d1["config"]["graph_replay"] is True and d1["roofline"]["bound"] == "mfma"
-    assert abs(d1["value"] - 4096 / (d1["ms_per_step"] * 1e-3)) <= 1e-6 * d1["value"]
+    assert abs(d1["value"] - 4096 / (d1["ms_per_step"] * 1e-3)) <= 1e-5 * d1["value"]
     assert d1["ms_per_step"] < 0.5 and np.isfinite(d1["config"]["final_loss"])
     out, lines = _run(["--gpus", "2", "--scaling", "strong"] + small, env={"NPLDA_BENCH_BACKEND": "gloo"})
     assert out.returncode == 0, out.stderr[-2000:]
@@ -160,7 +172,7 @@ def test_bench_emulate_rank_lines(hip_lib):
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["config"]["emulated_rank"] == "3/8" and "NOT a scaling" in d["config"]["note"]
     assert d["scaling"] == "strong" and d["config"]["pairs_per_gpu_per_step"] == (1 << 20) // 8 and "cpu_baseline" not in d
-    assert abs(d["value"] - 131072 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    assert abs(d["value"] - 131072 / (d["ms_per_step"] * 1e-3)) <= 1e-5 * d["value"]
     out, lines = _run(["--workload", "cfg3", "--emulate-rank", "7/8", "--steps", "2", "--warmup", "1"])
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(lines[0])
@@ -188,7 +200,7 @@ def test_bench_cfg5_line(hip_lib):
     assert out.returncode == 0, out.stderr[-2000:]
     d = json.loads(lines[0])
     assert d["unit"] == "pairs/s" and d["config"]["global_batch"] == 4096 and d["dtype"].startswith("bf16")
-    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"] and d["ms_per_step"] < 0.3
+    assert abs(d["value"] - 4096 / (d["ms_per_step"] * 1e-3)) <= 1e-5 * d["value"] and d["ms_per_step"] < 0.3
     assert d["roofline"]["flop_per_pair_algorithmic"] == 2 * 398400 + 2 * 2 * 150 * 150 + 2 * 2 * 512 * 150
 
 
@@ -212,7 +224,7 @@ def test_driver_scale_command_carries_the_collective_workloads(hip_lib):
     assert d["config"]["pairs_per_gpu_per_step"] == 1 << 20 and "cpu_baseline" not in d
     s = d["alt_cfg1_strong"]
     assert s["scaling"] == "strong" and s["n_gpus"] == 2 and s["pairs_per_gpu_per_step"] == 1 << 19
-    assert abs(s["value"] - (1 << 20) / (s["ms_per_step"] * 1e-3)) <= 1e-6 * s["value"]
+    assert abs(s["value"] - (1 << 20) / (s["ms_per_step"] * 1e-3)) <= 1e-5 * s["value"]
     a3 = d["alt_cfg3"]
     assert a3["ranks_in_group"] == 2 and a3["rows_per_gpu"] == 11000 and a3["trials_per_gpu"] == 1000000
     assert a3["allgather_bytes"] == 2 * 11000 * 32 and "all_gather_into_tensor" in a3["collective"]
@@ -221,7 +233,7 @@ def test_driver_scale_command_carries_the_collective_workloads(hip_lib):
     assert a2["ranks_in_group"] == 2 and a2["global_batch"] == 8192 and a2["pairs_per_gpu_per_step"] == 4096
     assert a2["scaling"] == "weak" and a2["mode"] == "eager collectives" and a2["graph_replay"] is False
     assert list(a2["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]
-    assert abs(a2["value"] - 8192 / (a2["ms_per_step"] * 1e-3)) <= 1e-6 * a2["value"]
+    assert abs(a2["value"] - 8192 / (a2["ms_per_step"] * 1e-3)) <= 1e-5 * a2["value"]
     a5 = d["alt_cfg5"]
     assert a5["ranks_in_group"] == 2 and a5["global_batch"] == 8192 and "eager collectives" in a5["mode"]
     assert list(a5["collective_bytes_per_step"]) == ["one_allreduce_flat_gradient_and_loss_sums"]

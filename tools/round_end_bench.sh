@@ -8,6 +8,7 @@ O=$R/gpurun_out/$TAG
 mkdir -p $O
 cd $R
 python bench.py > $O/bench.json 2> $O/bench.err
+cp $R/gpurun_out/bench_detail.json $O/bench_detail.json  # the line's full-precision objects + prose (bench.emit)
 for w in cfg2 cfg3 cfg5; do python bench.py --workload $w > $O/bench_$w.json 2> $O/bench_$w.err; done
 python bench.py --workload cfg3 --prepared-cohort > $O/bench_cfg3_prepared.json 2>> $O/bench_cfg3.err
 python bench.py --workload cfg2 --batch 2048 > $O/bench_cfg2_b2048.json 2>> $O/bench_cfg2.err
