@@ -956,7 +956,9 @@ def _raise_bad(view):
 
 def check_trial_indices(device=None):
     """Wait for the gathers enqueued so far and raise the KeyError of any bad trial number among them (the deferred mode's
-    explicit check: validate() and the epoch ends call it)."""
+    explicit check: validate() and train() at the end of every epoch call it).  In deferred mode the step on a bad batch is
+    NOT recoverable: its rows are NaN, so the loss, the gradients and — after the optimiser's step — every parameter are NaN
+    by the time the KeyError surfaces; the error says which run to throw away, it does not save it."""
     synced = set()
     for (dev, _), (_, view) in list(_BAD_FLAGS.items()):
         if device is None or torch.device(device) == dev:
@@ -1016,6 +1018,15 @@ class PreparedCohort:
         self.state, self.M, self.topn, self.ldz, self.key = state, M, topn, ldz, key
 
 
+def _cohort_key(z_coh, q_coh, packed):
+    """What a PreparedCohort was derived from: the cohort's embedding tables and the packed model image (addresses +
+    in-place versions).  cohort_stats(prepared=...) recomputes it: a state prepared for ANOTHER cohort or model of the same
+    size would otherwise feed its first moments and covariance image into this call's row means and thresholds."""
+    def ver(t):
+        return 0 if t.is_inference() else t._version
+    return (z_coh.data_ptr(), ver(z_coh), q_coh.data_ptr(), ver(q_coh), packed.buf.data_ptr(), ver(packed.buf))
+
+
 def cohort_prepare(z_coh, q_coh, packed, topn=500):
     """nplda_cohort_prepare_f32: the cohort-only part of cohort_stats (Gram matrix, first moments, the covariance image the
     row thresholds are proposed from), once per (model, cohort, top-N) -> PreparedCohort for cohort_stats(prepared=...)."""
@@ -1026,7 +1037,7 @@ def cohort_prepare(z_coh, q_coh, packed, topn=500):
     if z_coh.stride(0) != packed.ldz:
         raise ValueError("z_coh must come from embed() (row stride = packed.ldz)")
     M = z_coh.shape[0]
-    key = (z_coh.data_ptr(), q_coh.data_ptr(), packed.buf.data_ptr(), packed.buf._version if not packed.buf.is_inference() else 0)
+    key = _cohort_key(z_coh, q_coh, packed)
     nb = lib.nplda_cohort_state_bytes(M, int(topn), packed.D1, packed.D2) if M > 0 else 0
     if nb == 0:
         return PreparedCohort(None, M, int(topn), packed.ldz, key)
@@ -1078,6 +1089,9 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
     use_prep = prepared is not None and prepared.state is not None and not force_spill
     if prepared is not None and (prepared.M != M or prepared.topn != int(topn) or prepared.ldz != packed.ldz):
         raise ValueError("prepared cohort does not belong to this cohort table / top-N")
+    if prepared is not None and prepared.key != _cohort_key(z_coh, q_coh, packed):
+        raise ValueError("prepared cohort was derived from other cohort tables / another model image (or they were "
+                         "modified since): call cohort_prepare() again")
     with _lib.on_device(dev):
         if use_prep:
             st = prepared.state

@@ -34,6 +34,10 @@ class FusedAdam(torch.optim.Optimizer):
             for p in g["params"]:
                 if not (p.is_cuda and p.dtype == torch.float32 and p.is_contiguous()):
                     raise ValueError("FusedAdam needs contiguous float32 parameters on a HIP device")
+            # a group's moments and step counters live in flat buffers on ONE device and every launch of the group runs
+            # there (_init_group): a group that spans devices would hand the kernel wrong-device pointers
+            if len({p.device for p in g["params"]}) > 1:
+                raise ValueError("FusedAdam: the parameters of one group must live on one device")
         self._lib = _lib.load()
         self._plans = {}  # group index -> pre-marshalled launch blocks
 
@@ -113,6 +117,8 @@ class FusedAdam(torch.optim.Optimizer):
             with torch.enable_grad():
                 loss = closure()
         for gi, group in enumerate(self.param_groups):
+            if not group["params"]:
+                continue  # (an empty group: nothing to plan, nothing to step)
             plan = self._plans.get(gi)
             if plan is None:
                 plan = self._plans[gi] = self._init_group(group)
@@ -169,7 +175,10 @@ def adam_factory(real_adam):
 
         def __new__(cls, params, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0, amsgrad=False, **kw):
             params = list(params)
-            plain = (not amsgrad and not any(kw.get(k) for k in ("maximize", "capturable", "differentiable", "fused", "foreach"))
+            # an ALLOW-list: FusedAdam only when every further keyword sits at torch's default (False / None).  Anything
+            # else — `decoupled_weight_decay=True` (AdamW-style decay, which FusedAdam's L2 decay is not), a keyword a
+            # later torch adds — goes to torch's own Adam with the keyword intact; this patch is process-wide.
+            plain = (not amsgrad and all(v is None or v is False for v in kw.values())
                      and not torch.is_tensor(lr) and len(params) > 0 and all(torch.is_tensor(p) for p in params)
                      and all(p.is_cuda and p.dtype == torch.float32 and p.is_contiguous() for p in params)
                      and len({p.device for p in params}) == 1)

@@ -74,6 +74,12 @@ def _read_trials(f, id_to_num_dict, strip_ext_col2):
     return (torch.from_numpy(x1.copy()), torch.from_numpy(x2.copy()), torch.from_numpy(l.copy()), rows - len(x1))
 
 
+def _tensor_version(t):
+    """A tensor's in-place version counter, 0 for an inference tensor (which has none: reading `_version` raises, and it
+    cannot be modified in place outside inference mode either) — the guard ops.cohort_prepare uses."""
+    return 0 if t.is_inference() else t._version
+
+
 def _seed_broadcaster(device, group=None):
     """seed -> rank 0's seed (one 8-byte broadcast on `group`); None when there is nothing to synchronise with."""
     import torch.distributed as dist
@@ -143,15 +149,18 @@ class TrialLoader(DataLoader):
             if num_to_row is not None:
                 # (the mapped columns of a resident list are kept: the mapping is two index launches and two
                 # synchronising min() read-backs per call, and validate() walks the same list every epoch)
-                mkey = (key if device.type == "cuda" else None, num_to_row.data_ptr(), num_to_row._version, num_to_row.numel())
+                # (an inference tensor has no version counter — it cannot be written in place outside inference mode
+                # either; the cache holds the map itself and compares with `is`, so a freed map's address reused by
+                # another tensor can never hit)
+                mkey = (key if device.type == "cuda" else None, _tensor_version(num_to_row), num_to_row.numel())
                 mc = getattr(self, "_dev_columns_mapped", None)
-                if mc is not None and mkey[0] is not None and mc[0] == mkey:
+                if mc is not None and mkey[0] is not None and mc[0] == mkey and mc[3] is num_to_row:
                     return n, mc[1], mc[2], el
                 e1, e2 = num_to_row[e1.long()], num_to_row[e2.long()]
                 if n and (int(e1.min()) < 0 or int(e2.min()) < 0):
                     raise KeyError("trial index refers to an utterance that is not in mega_dict")
                 if mkey[0] is not None:
-                    self._dev_columns_mapped = (mkey, e1, e2)
+                    self._dev_columns_mapped = (mkey, e1, e2, num_to_row)
             return n, e1, e2, el
         perm = torch.randperm(n, generator=gen)
         if device.type == "cuda":
@@ -213,11 +222,11 @@ class TrialLoader(DataLoader):
         n, e1, e2, el = self.device_columns(device, num_to_row)
         resident = torch.device(device).type == "cuda" and getattr(self, "_dev_columns", None) is not None
         key = (self._dev_columns[0] if resident else None, None if num_to_row is None else
-               (num_to_row.data_ptr(), num_to_row._version, num_to_row.numel()))
+               (_tensor_version(num_to_row), num_to_row.numel()))
         cache = getattr(self, "_dev_distinct", None)
-        if cache is None or cache[0] != key or key[0] is None:
+        if cache is None or cache[0] != key or key[0] is None or cache[4] is not num_to_row:
             urows, inv = torch.unique(torch.cat([e1.long(), e2.long()]), return_inverse=True)
-            cache = self._dev_distinct = (key, urows, inv[:n].contiguous(), inv[n:].contiguous())
+            cache = self._dev_distinct = (key, urows, inv[:n].contiguous(), inv[n:].contiguous(), num_to_row)
         return n, e1, e2, el, cache[1], cache[2], cache[3]
 
     def device_batches(self, device, num_to_row=None, pack=False, permute=True, shard=None, group=None):

@@ -119,6 +119,12 @@ def train(nc, model, device, train_loader, mega_xvec_dict, num_to_id_dict, optim
         if batch_idx % nc.log_interval == 0:
             _log_train(nc, epoch, batch_idx, len(data1), train_loader, step_fn.pop_loss_mean() if fused else losses)
             losses = []
+    if device.type == "cuda":
+        from . import ops as _ops
+        if _ops.KEYERROR_DEFERRED:
+            # compat.install(deferred_keyerror=True): the epoch's last batches have no "next loader call" to surface a bad
+            # trial number — the end of the epoch is that call (ops.check_trial_indices: one synchronise per epoch)
+            _ops.check_trial_indices(device)
 
 
 def _device_table(mega_xvec_dict, num_to_id_dict, device):

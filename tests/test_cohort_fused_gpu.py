@@ -138,3 +138,20 @@ def test_row_tile_size_does_not_change_a_row(hip_lib):
     for lo, hi in ((0, 300), (1000, 3750), (6399, 6400), (5000, 5129)):
         part = ops.cohort_stats(zr[lo:hi].contiguous(), qr[lo:hi].contiguous(), zc, qc, packed, topn=500)  # 128-row tiles
         assert torch.equal(part, big[lo:hi]), (lo, hi)
+
+
+def test_prepared_cohort_is_bound_to_its_cohort_and_model(hip_lib):
+    """ADVICE r5: a PreparedCohort carries the first moments and the covariance image of ONE cohort under ONE model image;
+    cohort_stats(prepared=...) must refuse a state prepared for another cohort / model of the same size (its statistics
+    would be silently wrong) and a cohort table modified in place since."""
+    ops, packed, zr, qr, zc, qc, C = setup(150, 300, 10000, 11)
+    prep = ops.cohort_prepare(zc, qc, packed, topn=500)
+    a = ops.cohort_stats(zr, qr, zc, qc, packed, topn=500, prepared=prep)
+    b = ops.cohort_stats(zr, qr, zc, qc, packed, topn=500)
+    assert torch.allclose(a, b, rtol=1e-12, atol=0)
+    zc2, qc2 = zc.clone(), qc.clone()  # same size, another table
+    with pytest.raises(ValueError):
+        ops.cohort_stats(zr, qr, zc2, qc2, packed, topn=500, prepared=prep)
+    zc.mul_(1.0)  # in-place write: the version moves
+    with pytest.raises(ValueError):
+        ops.cohort_stats(zr, qr, zc, qc, packed, topn=500, prepared=prep)

@@ -160,3 +160,35 @@ def test_install_inline_backward_and_deferred_keyerror(hip_lib):
         svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, badn, "cuda")
     with pytest.raises(KeyError):  # a number outside the map
         svl.load_xvec_trials_from_numbatch(tab, num_to_id, good, torch.tensor([1, 2, 3, 4, 5, 99]).cuda(), "cuda")
+
+
+def test_adam_factory_allow_list_and_group_checks(hip_lib):
+    """compat.install(fused_adam=True) must hand any non-default keyword to torch's own Adam —
+    `decoupled_weight_decay=True` is AdamW-style decay, FusedAdam's is L2 — and FusedAdam refuses a group spanning devices
+    and steps over an empty group."""
+    import neuralplda_amd.compat as compat
+    from neuralplda_amd.optim import FusedAdam
+    real = torch.optim.Adam
+    m, _, _ = _two_models()
+    compat.install(fused_adam=True)
+    try:
+        import torch.optim as optim
+        o = optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5, decoupled_weight_decay=True)
+        assert isinstance(o, real) and not isinstance(o, FusedAdam) and o.defaults["decoupled_weight_decay"] is True
+        o = optim.Adam(m.parameters(), lr=1e-4, weight_decay=1e-5, decoupled_weight_decay=False, foreach=None, fused=None)
+        assert isinstance(o, FusedAdam)  # every extra keyword at its default: still ours
+        o = optim.Adam(m.parameters(), lr=1e-4, foreach=True)
+        assert isinstance(o, real) and not isinstance(o, FusedAdam)
+    finally:
+        compat.uninstall()
+    # an empty group is skipped (torch itself refuses an empty parameter LIST, not an empty added group)
+    opt = FusedAdam(m.parameters(), lr=1e-3)
+    opt.param_groups.append(dict(params=[], lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0))
+    for p in m.parameters():
+        p.grad = torch.ones_like(p)
+    opt.step()
+    if torch.cuda.device_count() > 1:
+        a = torch.nn.Parameter(torch.zeros(4, device="cuda:0"))
+        b = torch.nn.Parameter(torch.zeros(4, device="cuda:1"))
+        with pytest.raises(ValueError):
+            FusedAdam([a, b], lr=1e-3)

@@ -133,3 +133,39 @@ def test_validate_with_a_dplda_model(hip_lib):
     mc_ref, th_ref = metrics.minc(s, torch.from_numpy(lab).cuda(), nc.beta)
     assert float(mc) == float(mc_ref)  # the same batches through the same kernels
     assert [float(dp.threshold[bb].detach()) for bb in dp.beta] == [float(th_ref[bb]) for bb in nc.beta]
+
+
+def test_validate_first_run_under_inference_mode_in_a_fresh_process(hip_lib):
+    """the loader's mapped-column / distinct-row caches keyed on `num_to_row._version`, which an INFERENCE tensor
+    does not have — a validate() whose first call (the one that builds the row map) runs under torch.inference_mode() raised
+    RuntimeError.  Fresh process: nothing is cached yet.  The second call (outside inference mode, a NEW map object for the
+    same dict) must not hit columns cached for the first one's map by address."""
+    import os, subprocess, sys, textwrap
+    code = textwrap.dedent("""
+        import contextlib, io
+        import numpy as np, torch
+        from neuralplda_amd import train
+        from tests.test_validate_gpu import _speaker_set
+        from tests.test_train_gpu import NC, model_from, rand_params
+        rng = np.random.default_rng(5)
+        mega, num_to_id, loader, mat, a, b, lab = _speaker_set(rng, 3000, 20000)
+        nc = NC(D1=150, D2=150)
+        m = model_from(rand_params(rng, 512, 150, 150), nc, thetas=[-0.5, -0.3])
+        dev = torch.device("cuda")
+        with torch.inference_mode(), contextlib.redirect_stdout(io.StringIO()):
+            r1 = train.validate(nc, m, dev, mega, num_to_id, loader)
+            n, e1, e2, el = loader.device_columns(dev, train._device_table(mega, num_to_id, dev)[1])
+            assert train._device_table(mega, num_to_id, dev)[1].is_inference()
+        with contextlib.redirect_stdout(io.StringIO()):
+            r2 = train.validate(nc, m, dev, mega, num_to_id, loader)
+        assert r1 == r2, (r1, r2)
+        # a different map of the same size must never be served the first map's cached columns
+        other = torch.arange(3000, device=dev).flip(0).contiguous()
+        n2, f1, f2, _ = loader.device_columns(dev, other)
+        assert torch.equal(f1, 2999 - e1.long()) and torch.equal(f2, 2999 - e2.long())
+        print("validate ok", r1)
+    """)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "validate ok" in r.stdout
