@@ -1089,7 +1089,7 @@ def cohort_stats(z_rows, q_rows, z_coh, q_coh, packed, topn=500, select="lowest"
     use_prep = prepared is not None and prepared.state is not None and not force_spill
     if prepared is not None and (prepared.M != M or prepared.topn != int(topn) or prepared.ldz != packed.ldz):
         raise ValueError("prepared cohort does not belong to this cohort table / top-N")
-    if prepared is not None and prepared.key != _cohort_key(z_coh, q_coh, packed):
+    if use_prep and prepared.key != _cohort_key(z_coh, q_coh, packed):  # (state None: nothing was derived, nothing to mismatch)
         raise ValueError("prepared cohort was derived from other cohort tables / another model image (or they were "
                          "modified since): call cohort_prepare() again")
     with _lib.on_device(dev):
