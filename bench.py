@@ -1112,21 +1112,22 @@ _DROP_SUBSTR = ("spread", "launch_ms_after_1s_idle", "sampling", "note", "valida
 _SHED_ORDER = ("alt_dropin", "alt_minc", "alt_bf16x3", "alt_gb", "alt_regimeB", "alt_dplda", "alt_cfg1_strong")
 
 
-def _slim(v, top=False):
+def _slim(v, cut=True):
+    """7 significant digits; with `cut` also: prose keys dropped, strings cut at 72 characters, lists of > 4 dropped."""
     if isinstance(v, bool) or v is None or isinstance(v, int):
         return v
     if isinstance(v, float):
         return float(f"{v:.7g}") if np.isfinite(v) else None
     if isinstance(v, str):
-        return v if len(v) <= 72 or top else v[:69] + "..."
+        return v if len(v) <= 72 or not cut else v[:69] + "..."
     if isinstance(v, (list, tuple)):
-        return [_slim(x) for x in v] if len(v) <= 4 else None
+        return [_slim(x, cut) for x in v] if len(v) <= 4 or not cut else None
     if isinstance(v, dict):
         o = {}
         for k, x in v.items():
-            if any(sub in k for sub in _DROP_SUBSTR):
+            if cut and any(sub in k for sub in _DROP_SUBSTR):
                 continue
-            y = _slim(x)
+            y = _slim(x, cut)
             if y is None and x is not None:
                 continue
             o[k] = y
@@ -1184,19 +1185,27 @@ def emit(out):
         det = os.path.relpath(detail_path(), ROOT)
     except OSError as e:
         det = f"not written: {e}"
-    line = {}
-    for k, v in out.items():
-        if k in _LAST_KEYS:
-            continue
-        line[k] = _slim(v)
-        if k == "config" and isinstance(v.get("workload"), str):
-            line[k]["workload"] = v["workload"]  # the contract's own description of the workload stays whole
-    line["detail"] = det
-    for k in _LAST_KEYS:
-        if k in out:
-            line[k] = _slim(out[k])
-    if isinstance(out.get("cpu_baseline"), dict) and "sample_short" in out["cpu_baseline"]:
-        line["cpu_baseline"]["sample"] = line["cpu_baseline"].pop("sample_short")  # (the long form: the detail file)
+    def assemble(cut):
+        line = {}
+        for k, v in out.items():
+            if k in _LAST_KEYS:
+                continue
+            line[k] = _slim(v, cut)
+            if k == "config" and isinstance(v.get("workload"), str):
+                line[k]["workload"] = v["workload"]  # the contract's own description of the workload stays whole
+        line["detail"] = det
+        for k in _LAST_KEYS:
+            if k in out:
+                line[k] = _slim(out[k], cut)
+        if isinstance(out.get("cpu_baseline"), dict) and "sample_short" in out["cpu_baseline"]:
+            s_short = line["cpu_baseline"].pop("sample_short")
+            if cut:
+                line["cpu_baseline"]["sample"] = s_short  # (the long form: the detail file)
+        return line
+
+    line = assemble(False)  # stage 0: everything, 7 significant digits (a --workload / --emulate-rank line is small)
+    if len(json.dumps(line)) > LINE_LIMIT:
+        line = assemble(True)
     if len(json.dumps(line)) > LINE_LIMIT:
         # stage 1: the alt objects keep their figures and lose what the headline / the detail file already says
         for k in [k for k in line if k.startswith("alt_")]:

@@ -37,6 +37,14 @@ int gram_slabs_launch(const float* Z, long long ldz, long long rows, int Mp, int
                       const QzArgs* qz, hipStream_t st);
 }  // namespace nplda
 
+#ifdef NPLDA_COHORT_ABLATE
+static unsigned long long* g_cf_stamps = nullptr;
+extern "C" __attribute__((visibility("default"))) int nplda_cohort_debug_stamps(unsigned long long* host_out) {
+    if (!g_cf_stamps) return -1;
+    return (int)hipMemcpy(host_out, g_cf_stamps, 2 * 64 * 8 * sizeof(unsigned long long), hipMemcpyDeviceToHost);
+}
+#endif
+
 namespace {
 
 constexpr int kSubSlack = 17;     // a sub-list of ksub slots counts as overflowed at ksub - 17 (one tile appends <= 16 to it)
@@ -218,6 +226,10 @@ struct FusedArgs {
     int prio;               // static priority 1 for the block's second-dispatched waves (4 .. 7): they lose every VALU
                             // arbitration to the older half otherwise; -0.8 % on the statistics call in interleaved runs
                             // (NPLDA_COHORT_PRIO=0 switches it off for A/B)
+#ifdef NPLDA_COHORT_ABLATE  // tools/exp_cohort.sh only: timing ablations (results are then garbage) and per-tile cycle stamps
+    int abl;                // 1: no epilogue, 2: no MFMA loop, 4: no end-of-tile barrier, 8: no tile DMA after the first
+    unsigned long long* stamps;  // [2 waves (0 and NW / 2)][64 tiles][8]
+#endif
     int q, ksub, nfull;     // list bands per band, slots per sub-list; row tiles [0, nfull) are handed out as whole bands,
                             // the rest one list band at a time (the tail of the work queue in quarters)
 };
@@ -242,10 +254,11 @@ struct FusedArgs {
 // steps: 38 instead of 40 k4-steps at D2 = 150 (KT = 2), 43 instead of 44 at D2 = 170 (KT = 3).  Columns >= D2 are zero in
 // the table on both sides, so nothing is masked.  The scores' last-block terms associate differently from the spilling
 // GEMM's: same values to rounding (tolerance in the tests).
-template <bool LOWEST, int NB, int RGW = 2, int KT = 4>
-__global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a) {
+template <bool LOWEST, int NB, int RGW = 2, int KT = 4, int NW = 8>
+__global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedArgs a) {
     static_assert(KT >= 2 && KT <= 4, "the k16-step's first two k4-steps always run");
-    constexpr int RPB = 8 * 16 * RGW;  // rows of a block's row tile
+    static_assert(NW == 8 || NW == 16, "two or four waves per SIMD");
+    constexpr int RPB = NW * 16 * RGW;  // rows of a block's row tile
     constexpr int NF = 4 * NB;  // 1 KiB fragments of a 64-column tile: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..
     __shared__ f32x4 smem[2 * NF * 64 + 2 * 16 + NB * 4 + 2];
     f32x4* tbuf = smem;
@@ -281,9 +294,49 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         }
         return true;
     };
-    // LDS-DMA of the 64-column tile `t` into buffer `buf`: wave w fills fragments w, w + 8, ...
+    // LDS-DMA of the 64-column tile `t` into buffer `buf`: wave w fills fragments w, w + NW, ...  The source address of lane
+    // (i16, g4) for fragment (ks, c) of tile t is zc + (64 t + 16 c + i16) ldz + col(ks, g4): everything but the 64 t ldz term
+    // is fixed per lane and fragment — kept as byte offsets in NFW registers, the tile term is a scalar base (the per-tile
+    // 64-bit address arithmetic was 19 VALU instructions per fragment, 95 per tile and wave: matrix-pipe time, see above).
+    // Only the cohort's LAST tile, when M is not a multiple of 64, clamps rows and takes the general form.
+    // WHO issues it: ONE half of the block (waves [NW / 2, NW)), at the top of the tile.  The CU's address unit takes ~50
+    // cycles per DMA instruction (64 lanes x 16 bytes from 16 rows); with every wave issuing its pieces at the top of the
+    // tile, BOTH waves of a SIMD stood in that queue and the matrix pipe idled 1.1 k cycles per tile before the first loop
+    // (cycle stamps: tools/exp_cohort_stamps.py, profiles/r06*_stamps.txt).  Now the other half starts its MFMA loop at once;
+    // the issuing half's pieces go out beside that loop (it would be waiting for the pipe anyway), its own loop follows.
+    // (Issued BEHIND the loop instead: 25.3 k cycles per tile against 23.9 k — the second epilogue of the tile then runs
+    // twice as long.)
+    constexpr int NWD = NW / 2;                       // waves that issue the DMA
+    constexpr int NFW = (NF + NWD - 1) / NWD;
+    const bool dma_wave = wave >= NW - NWD;
+    const int dw = wave - (NW - NWD);
+    unsigned doff[NFW];
+#pragma unroll
+    for (int j = 0; j < NFW; ++j) {
+        const int f = (dma_wave ? dw : 0) + NWD * j, ks = f >> 2, c = f & 3;
+        const int col = (KT < 4 && ks == NB - 1) ? 16 * ks + KT * g4 : 16 * ks + 4 * g4;
+        doff[j] = 4u * (unsigned)((long long)(16 * c + i16) * a.ldz + col);
+    }
+    const unsigned qoff = 4u * (unsigned)lane;
     auto tile_in = [&](int t, int buf) {
-        for (int f = wave; f < NF; f += 8) {
+        if (!dma_wave) return;
+        if ((long long)t * 64 + 64 <= a.M) {
+            const char* sb = reinterpret_cast<const char*>(a.zc) + (size_t)t * 64 * (size_t)a.ldz * 4;
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) {
+                const int f = dw + NWD * j;
+                if (f < NF)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(sb + doff[j]),
+                                                     (__attribute__((address_space(3))) void*)&tbuf[(buf * NF + f) * 64], 16, 0, 0);
+            }
+            if (dw == 0) {
+                const char* qb = reinterpret_cast<const char*>(a.qc) + (size_t)t * 256;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(qb + qoff),
+                                                 (__attribute__((address_space(3))) void*)&qms[buf * 64], 4, 0, 0);
+            }
+            return;
+        }
+        for (int f = dw; f < NF; f += NWD) {
             const int ks = f >> 2, c = f & 3;
             long long m = (long long)t * 64 + 16 * c + i16;
             if (m >= a.M) m = a.M - 1;
@@ -291,7 +344,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.zc + m * a.ldz + col),
                                              (__attribute__((address_space(3))) void*)&tbuf[(buf * NF + f) * 64], 16, 0, 0);
         }
-        if (wave == 0) {
+        if (dw == 0) {
             long long m = (long long)t * 64 + lane;
             if (m >= a.M) m = a.M - 1;
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.qc + m),
@@ -299,7 +352,19 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         }
     };
 
-    if (a.prio && wave >= 4) __builtin_amdgcn_s_setprio(1);
+#ifdef NPLDA_COHORT_ABLATE
+    const int abl = a.abl;
+    int stamp_tile = 0;
+    const bool stamper = blockIdx.x == 8 && lane == 0 && (wave == 0 || wave == NW / 2);
+#define NPLDA_CF_STAMP(i)                                                                                              \
+    do {                                                                                                               \
+        if (stamper && stamp_tile < 64) a.stamps[((wave ? 1 : 0) * 64 + stamp_tile) * 8 + (i)] = __builtin_readcyclecounter(); \
+    } while (0)
+#else
+    constexpr int abl = 0;
+#define NPLDA_CF_STAMP(i) do { } while (0)
+#endif
+    if (a.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
     long long rb = 0, nrb = 0;
     int band = 0, lbn = 0, t = 0, t1 = 0, nlb0 = 0, nlbn = 0;  // `band`: the list band being filled; the item ends at lbn
     if (tid == 0) nxt_s[0] = atomicAdd(a.ctr + xcd, 1u);
@@ -313,8 +378,13 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
 
     // per-lane state of a work item: the lane's two rows (wave's row group A / B, row i16), their operand fragments
     f32x4 brow[RGW][NB];
-    float cen[RGW], thr[RGW], qrv[RGW], s2[RGW];
-    unsigned cur[RGW];
+    // kq = q_r - c_r and thc = t_r - c_r: the epilogue forms the CENTRED score d = acc + (q_m + kq) (= s - c_r to rounding),
+    // squares it, compares it with thc and appends IT — the select kernel adds c_r back in fp64.  (Every VALU instruction of
+    // this kernel costs matrix-pipe time — on a SIMD fp32 MFMAs and VALU instructions do not overlap, whichever wave issues
+    // them: tools/exp_mfma_yield.hip, profiles/r06e_mfma_yield.txt — so the uncentred score is never formed: 4 instructions
+    // per accumulator block less.)
+    float kq[RGW], thc[RGW], s2[RGW];
+    unsigned cur[RGW], lim[RGW];
     auto item_rows = [&](long long rb_) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
@@ -333,17 +403,45 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             }
         }
     };
-    auto item_state = [&](long long rb_, int band_) {
+    // Per-lane state in two layers.  Per ITEM (a row tile): kq, thc and the byte offset of the row's list region — loaded
+    // once per item, and for the NEXT item already at the top of this item's last tile (next_consts: the loads ride under
+    // that tile's MFMA loop).  Per LIST BAND: the sum of squares, the append cursor and its limit.  (Cycle stamps: a tile that
+    // ended a list band took 28 k cycles instead of 25 k — the row constants were re-loaded from memory at every list band.
+    // A tile that ends an ITEM takes 43 - 48 k: 256 blocks pull 164 KB of row operands each at about the same time, 42 MB
+    // against HBM / the memory-side cache; warming the L2 a tile ahead does not help — an XCD's 32 row tiles are 5.2 MB, more
+    // than its L2 — and neither does staggering the queue so that blocks change items at different times: both measured,
+    // r06j / r06k.)
+    unsigned rowbase[RGW];
+    float nraw[RGW][3];
+    auto next_consts = [&](long long rb_) {
+#pragma unroll
+        for (int g = 0; g < RGW; ++g) {
+            long long rc = rb_ + wave * (16 * RGW) + 16 * g + i16;
+            if (rc >= a.R) rc = a.R - 1;
+            nraw[g][0] = a.crow[rc];
+            nraw[g][1] = a.trow[rc];
+            nraw[g][2] = a.qr[rc];
+        }
+    };
+    auto take_consts = [&](long long rb_) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             const long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
             const bool ok = row < a.R;
             const long long rc = ok ? row : a.R - 1;
-            cen[g] = a.crow[rc];
-            thr[g] = ok ? a.trow[rc] : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
-            qrv[g] = a.qr[rc];
+            const float cen = nraw[g][0];
+            kq[g] = nraw[g][2] - cen;
+            thc[g] = ok ? nraw[g][1] - cen : (LOWEST ? -__builtin_inff() : __builtin_inff());  // rows past the table never append
+            rowbase[g] = 4u * (unsigned)(rc * a.lrow + g4);
+        }
+    };
+    auto band_state = [&](int band_) {
+#pragma unroll
+        for (int g = 0; g < RGW; ++g) {
             s2[g] = 0.f;
-            cur[g] = 4u * (unsigned)(rc * a.lrow + (long long)band_ * a.ksub * 4 + g4);
+            cur[g] = rowbase[g] + 16u * (unsigned)(band_ * a.ksub);
+            // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
+            lim[g] = cur[g] + 16u * (unsigned)(a.ksub - kSubSlack);
         }
     };
     auto item_end = [&](long long rb_, int band_) {
@@ -356,7 +454,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             u2 += __hiloint2double(__shfl_xor(__double2hiint(u2), 32, 64), __shfl_xor(__double2loint(u2), 32, 64));
             if (row < a.R) {
                 const unsigned sidx = (unsigned)(band_ * 4 + g4);
-                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] / 4u - (unsigned)(row * a.lrow + (long long)band_ * a.ksub * 4 + g4)) / 4u;
+                a.counts[(size_t)row * a.nsub + sidx] = (cur[g] - rowbase[g]) / 16u - (unsigned)(band_ * a.ksub);
                 if (g4 == 0) {
                     a.part[(size_t)row * (a.nsub / 4) + band_] = u2;
                 }
@@ -365,7 +463,9 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
     };
 
     item_rows(rb);
-    item_state(rb, band);
+    next_consts(rb);
+    take_consts(rb);
+    band_state(band);
     tile_in(t, 0);
     __syncthreads();  // (drains the DMA: it is a pending LDS write)
     int buf = 0;
@@ -377,12 +477,17 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         const bool last_of_item = last_tile && band + 1 == lbn;
         bool have_next = true;
         // next tile into the other buffer: of this item (its list bands are contiguous), or the first of the next one
-        if (!last_of_item) {
-            tile_in(t + 1, buf ^ 1);
-        } else {
+        NPLDA_CF_STAMP(0);
+        int tnext = t + 1;
+        if (last_of_item) {
             have_next = decode(__builtin_amdgcn_readfirstlane((int)nxt_s[npar]), nrb, nlb0, nlbn);
-            if (have_next) tile_in(lb_tile(nlb0), buf ^ 1);
+            tnext = have_next ? lb_tile(nlb0) : -1;
+            if (have_next) next_consts(nrb);
         }
+        // next tile into the other buffer (all waves left it at the previous barrier): of this item (its list bands are
+        // contiguous), or the first of the next one
+        if (tnext >= 0 && !(abl & 8)) tile_in(tnext, buf ^ 1);
+        NPLDA_CF_STAMP(1);
         f32x4 acc[RGW][4];
 #pragma unroll
         for (int g = 0; g < RGW; ++g)
@@ -396,6 +501,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         f32x4 af[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) af[0][c] = tb[c * 64];
+        if (!(abl & 2))
 #pragma unroll
         for (int ks = 0; ks < NB; ++ks) {
 #pragma unroll
@@ -407,7 +513,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                         acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[g][ks][kk], acc[g][c], 0, 0, 0);
                 }
             __builtin_amdgcn_sched_barrier(0);
-            if (ks + 1 < NB) {
+            if (ks + 1 < NB && !(abl & 256)) {
 #pragma unroll
                 for (int c = 0; c < 4; ++c) af[(ks + 1) & 1][c] = tb[((ks + 1) * 4 + c) * 64];
             }
@@ -426,6 +532,7 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         // wave's MFMAs: ~13 cycles each, 29.6 k cycles per tile against 23.4 k for the MFMA loops alone.  Forcing the
         // phases together with a barrier at this point gives the same tile time (24.6 k + 4.6 k) and a kernel 2 % slower.)
         // the operand rows of the NEXT item are fetched here, under the epilogue of this item's last tile
+        NPLDA_CF_STAMP(2);
         if (last_of_item && have_next) item_rows(nrb);
 
         // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
@@ -436,14 +543,14 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
             for (int g = 0; g < RGW; ++g) {
-                const float c0 = cen[g], th = thr[g], qr_ = qrv[g];
+                const float th = thc[g], kq_ = kq[g];
                 f32x2 pq2 = {s2[g], 0.f};
                 unsigned o = cur[g];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const f32x4 qmv = *reinterpret_cast<const f32x4*>(qm_s + 16 * c);
-                    f32x4 s4 = acc[g][c] + (qmv + qr_);   // the score, same bits as the spilling kernel
-                    f32x4 d4 = s4 - c0;                     // centred on the row's analytic mean
+                    f32x4 d4 = acc[g][c] + (qmv + kq_);   // the score centred on the row's analytic mean (fp32 rounding of it)
+                    f32x4 s4 = d4;                          // what is compared and appended
                     if (MASKED) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r) {
@@ -464,33 +571,78 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                     // epilogue got 2 k cycles per tile shorter, but the lists tripled, the kernel as a whole did not
                     // get faster and the select kernel had to re-filter: 1.10 ms against 1.04 ms for the pipeline.)
                     unsigned long long sv, k0, k1, k2, k3;
+#if defined(NPLDA_EPI_VARIANT) && NPLDA_EPI_VARIANT == 1   // experiment: compares and cursors, no stores
+#define NPLDA_ST(o_, v_)
+#else
+#define NPLDA_ST(o_, v_) "global_store_dword " o_ ", " v_ ", %[base]\n\t"
+#endif
+#if defined(NPLDA_EPI_VARIANT) && NPLDA_EPI_VARIANT == 2   // experiment: sums only
+#define NPLDA_APPEND4(CMP) asm volatile("" : [o] "+v"(o) : [th] "v"(th), [s0] "v"(s4[0]), [s1] "v"(s4[1]), [s2] "v"(s4[2]), [s3] "v"(s4[3]) : "memory")
+#else
 #define NPLDA_APPEND4(CMP)                                                                                         \
     asm volatile(CMP " %[k0], %[s0], %[th]\n\t" CMP " %[k1], %[s1], %[th]\n\t" CMP " %[k2], %[s2], %[th]\n\t"       \
                  CMP " %[k3], %[s3], %[th]\n\t"                                                                    \
                  "s_mov_b64 %[sv], exec\n\t"                                                                       \
-                 "s_mov_b64 exec, %[k0]\n\tglobal_store_dword %[o], %[s0], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
-                 "s_mov_b64 exec, %[k1]\n\tglobal_store_dword %[o], %[s1], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
-                 "s_mov_b64 exec, %[k2]\n\tglobal_store_dword %[o], %[s2], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
-                 "s_mov_b64 exec, %[k3]\n\tglobal_store_dword %[o], %[s3], %[base]\n\tv_add_u32 %[o], %[o], %[st]\n\t" \
+                 "s_mov_b64 exec, %[k0]\n\t" NPLDA_ST("%[o]", "%[s0]") "v_add_u32 %[o], %[o], %[st]\n\t"                     \
+                 "s_mov_b64 exec, %[k1]\n\t" NPLDA_ST("%[o]", "%[s1]") "v_add_u32 %[o], %[o], %[st]\n\t"                     \
+                 "s_mov_b64 exec, %[k2]\n\t" NPLDA_ST("%[o]", "%[s2]") "v_add_u32 %[o], %[o], %[st]\n\t"                     \
+                 "s_mov_b64 exec, %[k3]\n\t" NPLDA_ST("%[o]", "%[s3]") "v_add_u32 %[o], %[o], %[st]\n\t"                     \
                  "s_mov_b64 exec, %[sv]"                                                                            \
                  : [o] "+v"(o), [sv] "=&s"(sv), [k0] "=&s"(k0), [k1] "=&s"(k1), [k2] "=&s"(k2), [k3] "=&s"(k3)       \
                  : [th] "v"(th), [s0] "v"(s4[0]), [s1] "v"(s4[1]), [s2] "v"(s4[2]), [s3] "v"(s4[3]), [base] "s"(lbase), \
                    [st] "s"(stride_b)                                                                               \
                  : "memory")
+#endif
                     if (LOWEST) NPLDA_APPEND4("v_cmp_le_f32");
                     else NPLDA_APPEND4("v_cmp_ge_f32");
 #undef NPLDA_APPEND4
+#undef NPLDA_ST
                 }
                 s2[g] = pq2[0] + pq2[1];
-                // at most ksub - kSubSlack entries stay (the select kernel treats that count as an overflow)
-                long long rc = rb + wave * (16 * RGW) + 16 * g + i16;
-                if (rc >= a.R) rc = a.R - 1;
-                const unsigned lim = 4u * (unsigned)(rc * a.lrow + ((long long)band * a.ksub + (a.ksub - kSubSlack)) * 4 + g4);
-                cur[g] = o < lim ? o : lim;
+                cur[g] = o < lim[g] ? o : lim[g];
             }
         };
-        if (m0 + 64 > a.M) epilogue(std::true_type{});
+#ifdef NPLDA_COHORT_ABLATE
+        if (abl & (16 | 32 | 64 | 128)) {  // synthetic epilogues: what the partner of an MFMA loop gets issued
+            float v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = acc[0][i & 3][0] + (float)i;
+            const float aa = kq[0], bb = thc[0];
+            if (abl & 16) {  // 256 VALU, ONE dependent chain
+#pragma unroll
+                for (int i = 0; i < 256; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[0]) : "v"(aa), "v"(bb));
+            }
+            if (abl & 32) {  // 256 VALU, eight independent chains
+#pragma unroll
+                for (int i = 0; i < 256; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i & 7]) : "v"(aa), "v"(bb));
+            }
+            if (abl & 64) {  // 256 VALU, two chains
+#pragma unroll
+                for (int i = 0; i < 256; ++i) asm volatile("v_fmac_f32 %0, %1, %2" : "+v"(v[i & 1]) : "v"(aa), "v"(bb));
+            }
+            if (abl & 128) {  // 64 x (SALU exec write + VALU under it)
+                unsigned long long sv;
+                asm volatile("s_mov_b64 %0, exec" : "=s"(sv));
+#pragma unroll
+                for (int i = 0; i < 64; ++i)
+                    asm volatile("s_mov_b64 exec, %1\n\tv_fmac_f32 %0, %2, %3" : "+v"(v[i & 7]) : "s"(sv), "v"(aa), "v"(bb));
+            }
+            float sink = 0.f;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) sink += v[i];
+            if (sink == 1.2345e30f) s2[0] += sink;
+        } else
+#endif
+        if (abl & 1) {  // (keeps the accumulators alive)
+            float sink = 0.f;
+#pragma unroll
+            for (int g = 0; g < RGW; ++g)
+#pragma unroll
+                for (int c = 0; c < 4; ++c) sink += acc[g][c][0] + acc[g][c][1] + acc[g][c][2] + acc[g][c][3];
+            if (sink == 1.2345e30f) s2[0] += sink;
+        } else if (m0 + 64 > a.M) epilogue(std::true_type{});
         else epilogue(std::false_type{});
+        NPLDA_CF_STAMP(3);
 
         if (last_tile) {
             item_end(rb, band);
@@ -498,11 +650,12 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
                 ++band;
                 ++t;
                 t1 = lb_tile(band + 1);
-                item_state(rb, band);
+                band_state(band);
             } else {
                 if (!have_next) break;
                 rb = nrb; band = nlb0; lbn = nlbn; t = lb_tile(band); t1 = lb_tile(band + 1);
-                item_state(rb, band);
+                take_consts(rb);
+                band_state(band);
                 npar ^= 1;
                 if (tid == 0) nxt_s[npar] = atomicAdd(a.ctr + xcd, 1u);  // visible after the barrier below; read >= 1 tile later
             }
@@ -511,8 +664,18 @@ __global__ __launch_bounds__(512, 1) void cohort_fused2_kernel(const FusedArgs a
         }
         // end of tile: this wave's part of the next tile has landed (and its appends are out), then everybody's; nobody
         // still reads the buffer the tile after next will overwrite
-        __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-        __builtin_amdgcn_s_barrier();
+        NPLDA_CF_STAMP(4);
+        // The DMA pieces are older than the tile's 16 RGW append instructions (exec-masked stores count whatever their mask),
+        // and vector memory operations retire in order: on a plain tile vmcnt(16 RGW) says "my pieces have landed" without
+        // waiting for the appends to be acknowledged.  Tiles that end a list band also load / store per-row state: vmcnt(0).
+        if (last_tile || (abl & (1 | 1024))) __builtin_amdgcn_s_waitcnt(0x0070);      // vmcnt(0) lgkmcnt(0)
+        else __builtin_amdgcn_s_waitcnt(RGW == 2 ? 0x8070 : 0x4070);                  // vmcnt(32 | 16) lgkmcnt(0)
+        NPLDA_CF_STAMP(5);
+        if (!(abl & 4)) __builtin_amdgcn_s_barrier();
+        NPLDA_CF_STAMP(6);
+#ifdef NPLDA_COHORT_ABLATE
+        ++stamp_tile;
+#endif
         buf ^= 1;
     }
 }
@@ -642,7 +805,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     // fixed order) and the bisection runs on four registers per lane.  The counts decide; a miss takes the full search.
     unsigned rank = (unsigned)N;
     {
-        const float c = c_row, t = t_row;
+        const float c = 0.f, t = t_row - c_row;  // the lists hold CENTRED scores s - c_r (cohort_fused2_kernel's epilogue)
         const float sgn = a.lowest ? 1.f : -1.f;
         const float sd = (t - c) / (sgn * a.zhi);
         const float q = a.fhi * (float)N / (float)total;
@@ -697,7 +860,7 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
     for (int j = 0; j < kCandMax / 64; ++j) {
         if (j < J && k[j] < tkey) {
             const float w = key2f(k[j]);
-            const double v = (double)(a.lowest ? w : -w);  // the raw score behind the ordered key
+            const double v = (double)(a.lowest ? w : -w);  // the centred score behind the ordered key
             t1 += v;
             t2 += v * v;
             ++nless;
@@ -715,18 +878,18 @@ __global__ __launch_bounds__(256) void cohort_finish_kernel(const FinishArgs a) 
         const double mw = mean_s - (double)c_row;
         double var = d2 / n - mw * mw;
         if (var < 0.0) var = 0.0;
-        double tv = (double)key2f(tkey);           // the threshold in ordered space -> raw score
+        double tv = (double)key2f(tkey);           // the threshold in ordered space -> centred score
         if (!a.lowest) tv = -tv;
         const double ties = nn - (double)nless;
         t1 += ties * tv;
         t2 += ties * tv * tv;
-        const double mt = t1 / nn;
+        const double mt = t1 / nn;                 // of the centred scores: the top-N mean is c_r + mt, their variance is vt
         double vt = t2 / nn - mt * mt;
         if (vt < 0.0) vt = 0.0;
         double* o = a.stats + row * 4;
         o[0] = mean_s;
         o[1] = sqrt(var);
-        o[2] = mt;
+        o[2] = (double)c_row + mt;
         o[3] = sqrt(vt);
     }
 }
@@ -940,6 +1103,16 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
     fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub; fa.lrow = lrow;
     { static const int pr = getenv("NPLDA_COHORT_PRIO") ? atoi(getenv("NPLDA_COHORT_PRIO")) : 1; fa.prio = pr; }
+#ifdef NPLDA_COHORT_ABLATE
+    {
+        static unsigned long long* dstamps = nullptr;
+        if (!dstamps) (void)hipMalloc(&dstamps, 2 * 64 * 8 * sizeof(unsigned long long));
+        (void)hipMemsetAsync(dstamps, 0, 2 * 64 * 8 * sizeof(unsigned long long), st);
+        fa.abl = getenv("NPLDA_COHORT_ABL") ? atoi(getenv("NPLDA_COHORT_ABL")) : 0;
+        fa.stamps = dstamps;
+        g_cf_stamps = dstamps;
+    }
+#endif
     long long grid = (long long)fa.ny * p.nbands * p.q;  // at most one block per work item
     if (grid > resident) grid = resident;
     {   // whole-band items for as many row tiles as fill complete rounds of an XCD's blocks, the rest in list bands
@@ -951,8 +1124,17 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     const int tail = D2 > 0 ? D2 - 16 * (ksteps - 1) : 16;
     const int kt = (ksteps == 10 && tail >= 1 && tail <= 8) ? 2 : ((ksteps == 11 && tail >= 9 && tail <= 12) ? 3 : 4);
     static const bool no_kt = getenv("NPLDA_COHORT_NO_KTAIL") != nullptr && getenv("NPLDA_COHORT_NO_KTAIL")[0] == '1';  // A/B only
+    // four waves per SIMD (NW = 16: a wave owns ONE 16-row group, the block the same 256 rows; 128 VGPRs per wave): while one
+    // wave's MFMA loop has the matrix pipe, three partners — not one — work through their epilogues in the issue slots it leaves
+    static const int nw_env = getenv("NPLDA_COHORT_NW") ? atoi(getenv("NPLDA_COHORT_NW")) : 8;
+    const bool nw16 = nw_env == 16 && !half_tiles && (ksteps == 10 || ksteps == 11);
 #define NPLDA_LAUNCH_KT(NBV, KTV)                                                                                                   \
-    if (half_tiles) {                                                                                                               \
+    if (nw16) {                                                                                                                     \
+        if constexpr (NBV == 10 || NBV == 11) {                                                                                     \
+            if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1, KTV, 16>), dim3((unsigned)grid), dim3(1024), 0, st, fa);  \
+            else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1, KTV, 16>), dim3((unsigned)grid), dim3(1024), 0, st, fa);        \
+        }                                                                                                                           \
+    } else if (half_tiles) {                                                                                                               \
         if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);       \
         else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);             \
     } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);    \
