@@ -204,3 +204,80 @@ def test_shard_bounds_cover_everything():
     assert nd.world() == (0, 1)
     t = torch.arange(4.0)
     assert nd.allreduce_sum_(t) is t and nd.sharded_apply(lambda lo, hi: torch.arange(lo, hi), 5).tolist() == [0, 1, 2, 3, 4]
+
+
+def _worker_short_last(rank, world, port, tmp):
+    """World size 4 with n = 9 units: chunks of ceil(9 / 4) = 3 -> shards [0, 3) [3, 6) [6, 9) and an EMPTY shard on the last
+    rank, for all three partitionings of SURVEY 8(e): the trial list, the AS-norm rows, the training minibatch."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    from neuralplda_amd import dist as nd
+    nd.init("gloo")
+    try:
+        rng = np.random.default_rng(3)
+        p = _params(rng)
+        n = 9
+        lo, hi = nd.shard_bounds(n, world, rank)
+        assert (lo, hi) == [(0, 3), (3, 6), (6, 9), (9, 9)][rank]
+        # ---- 1. scoring: the last rank scores nothing and still takes part in the all-gather ------------------------------
+        x = rng.standard_normal((40, 64)).astype(np.float32)
+        i1, i2 = rng.integers(0, 40, n), rng.integers(0, 40, n)
+        full = orc.forward(x[i1], x[i2], p)
+
+        def score(lo_, hi_):
+            if hi_ == lo_:
+                return torch.empty(0, dtype=torch.float32)
+            return torch.from_numpy(orc.forward(x[i1[lo_:hi_]], x[i2[lo_:hi_]], p))
+
+        got = nd.sharded_apply(score, n)
+        np.testing.assert_array_equal(got.numpy(), full)
+        assert nd.sharded_apply(score, n, gather=False).shape == (hi - lo,)
+        # ---- 2. AS-norm: 9 rows, the last rank holds none; ONE all-gather of (9, 4) statistics, then trial shards ----------
+        R, M = 9, 60
+        zr = orc.extract_plda_embeddings(rng.standard_normal((R, 64)).astype(np.float32), p)
+        zc = orc.extract_plda_embeddings(rng.standard_normal((M, 64)).astype(np.float32), p)
+        stats_full = orc.cohort_stats(orc.cohort_scores(zr, zc, p), topn=10)
+        if hi > lo:
+            local = torch.from_numpy(orc.cohort_stats(orc.cohort_scores(zr[lo:hi], zc, p), topn=10))
+        else:
+            local = torch.empty((0, 4), dtype=torch.float64)
+        stats = nd.all_gather_rows(local, R)
+        np.testing.assert_allclose(stats.numpy(), stats_full, rtol=1e-12)
+        # ---- 3. data-parallel SoftCdet on a 9-pair minibatch: the empty shard contributes zeros to both all-reduces --------
+        B = 9
+        x1 = rng.standard_normal((B, 64)).astype(np.float32)
+        x2 = rng.standard_normal((B, 64)).astype(np.float32)
+        t = np.asarray([1, 0, 0, 1, 0, 0, 0, 1, 0], dtype=np.float64)
+        theta, beta, alpha = [-0.5, -0.3], [99.0, 199.0], 15.0
+        s_full = orc.forward(x1, x2, p, np.float64)
+        g_full, dth_full = orc.softcdet_grad(s_full, t, theta, beta, alpha)
+        grads_full = orc.backward(x1, x2, g_full, p)
+        sx1, sx2, st = (v.numpy() for v in nd.shard_batch((torch.from_numpy(x1), torch.from_numpy(x2), torch.from_numpy(t))))
+        assert sx1.shape[0] == hi - lo
+        keys = ("W1", "b1", "W2", "b2", "P_sqrt", "Q")
+        if hi > lo:
+            s_loc = orc.forward(sx1, sx2, p, np.float64)
+            own = _softcdet_sums(s_loc, st, theta, alpha)
+        else:
+            own = np.zeros(2 + 4 * len(theta))
+        sums = nd.allreduce_sum_(torch.from_numpy(own)).numpy()
+        np.testing.assert_allclose(sums, _softcdet_sums(s_full, t, theta, alpha), rtol=1e-12)
+        if hi > lo:
+            g_loc, _ = orc.softcdet_grad(s_loc, st, theta, beta, alpha, nt=sums[0], nn=sums[1])
+            np.testing.assert_allclose(g_loc, g_full[lo:hi], rtol=1e-12)
+            gl = orc.backward(sx1, sx2, g_loc, p)
+            flat = np.concatenate([gl[k].ravel() for k in keys])
+        else:
+            flat = np.zeros(sum(grads_full[k].size for k in keys))
+        flat = nd.allreduce_sum_(torch.from_numpy(flat)).numpy()
+        np.testing.assert_allclose(flat, np.concatenate([grads_full[k].ravel() for k in keys]), rtol=1e-9, atol=1e-14)
+        open(os.path.join(tmp, f"ok{rank}"), "w").write("ok")
+    finally:
+        torch.distributed.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_world_size_4_gloo_with_an_empty_last_shard(tmp_path):
+    world = 4
+    port = _free_port()
+    mp.spawn(_worker_short_last, args=(world, port, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
