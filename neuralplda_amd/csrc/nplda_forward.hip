@@ -65,7 +65,7 @@ int nplda_score_pairs_rows_f32(const float* table, int64_t N, int64_t ldt, const
     const NpldaLayout L = nplda_layout(D0, D1, D2);
     // only where nplda_score_pairs_f32 would run the balanced-tile kernel itself: the fused form then gives the same bits as
     // gather + score (validate()'s device-resident pass equals its generic loop); elsewhere: gather + nplda_score_pairs_f32
-    if (pair_kernel_choice(B, L, mid_cus()) != FWD_MID) return NPLDA_EUNSUPPORTED;
+    if (pair_kernel_choice(B, L, mid_cus()) != FWD_MID) return NPLDA_EUNSUPPORTED;  // (same kernel as nplda_score_pairs_f32: same bits)
     FwdArgs a = {};
     a.xa = table; a.xb = table; a.n = B; a.ldx = ldt; a.packed = (const float*)packed; a.out_s = s;
     a.ia = (const long long*)rows1; a.ib = (const long long*)rows2; a.ntab = N;
@@ -116,7 +116,7 @@ int nplda_embed_rows_f32(const float* table, int64_t N, int64_t ldt, const int64
     const NpldaLayout L = nplda_layout(D0, D1, D2);
     if (!rows_ok(z, ldz, 16 * L.NB)) return NPLDA_EINVAL;
     const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32 &&
-                        pair_kernel_choice((U + 1) / 2, L, mid_cus()) == FWD_MID;
+                        pair_kernel_choice((U + 1) / 2, L, mid_cus(), nullptr, false) == FWD_MID;
     if (!mid_ok) return NPLDA_EUNSUPPORTED;
     FwdArgs a = {};
     a.xa = table; a.xb = table; a.n = U; a.ldx = ldt; a.packed = (const float*)packed;
@@ -139,7 +139,7 @@ int nplda_embed_pair_f32(const float* xa, int64_t Na, const float* xb, int64_t N
     const long long N = Na + Nb;
     // one launch where the balanced-tile kernel embeds (its row addressing takes the second table); two otherwise
     const bool mid_ok = (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32 &&
-                        pair_kernel_choice((N + 1) / 2, L, mid_cus()) == FWD_MID;
+                        pair_kernel_choice((N + 1) / 2, L, mid_cus(), nullptr, false) == FWD_MID;
     if (!mid_ok) {
         if (int rc = nplda_embed_f32(xa, Na, ldx, packed, D0, D1, D2, z, ldz, q, stream)) return rc;
         return nplda_embed_f32(xb, Nb, ldx, packed, D0, D1, D2, z + Na * ldz, ldz, q ? q + Na : nullptr, stream);

@@ -198,8 +198,15 @@ static inline int launch_fwd_old(FwdArgs a, const NpldaLayout& L, hipStream_t st
 //  * the mid kernel (nplda_fwd_mid.h; 512-d x-vectors, NB = 10 / 11) balances 16-pair tiles to within one tile per CU at
 //    ~13.3 / 16.8 us per tile — 6 to 25 % more per pair than a FULL streaming round, far less than a part-filled one.
 // The two are compared by these measured costs (tenths of a microsecond; both scale with the shader clock alike).
-enum { FWD_SMALL = 0, FWD_MID = 1, FWD_STREAM = 2 };
-static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus) {
+//  * (round 6) FWD_SPLIT: the streaming kernel for the FULL rounds of the persistent grid, the remainder — less than one round —
+//    by whichever of the other kernels it would take alone, as a second launch on the same stream: a batch just past a
+//    multiple of 128 pairs x CUs no longer pays the mid kernel's per-tile rate on all of it (100 000 pairs: three full rounds
+//    + 1 696 pairs; profiles/r06*_size_sweep.txt).
+enum { FWD_SMALL = 0, FWD_MID = 1, FWD_STREAM = 2, FWD_SPLIT = 3 };
+static inline long long pair_split_point(long long n, int cus) { return (n / 128 / cus) * 128 * cus; }  // pairs in full rounds
+static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus, long long* cost = nullptr, bool allow_split = true) {
+    long long dummy;
+    if (!cost) cost = &dummy;
     // NPLDA_FWD_NO_MID=1: the round-2 dispatch (A/B measurements only: tools/validate_e2e.py)
     static const bool no_mid = getenv("NPLDA_FWD_NO_MID") != nullptr && getenv("NPLDA_FWD_NO_MID")[0] == '1';
     const bool mid_ok = !no_mid && (L.NB == 10 || L.NB == 11) && L.D0 == 512 && L.KS1 == 32;
@@ -207,14 +214,32 @@ static inline int pair_kernel_choice(long long n, const NpldaLayout& L, int cus)
     // small-batch kernel's 16.6 (round 5: half the rows per CU; tools/ab_small_mid.py).  NPLDA_FWD_SMALL_MAX=<pairs> moves the
     // small-batch kernel's upper bound (A/B measurements).
     static const long long small_max = getenv("NPLDA_FWD_SMALL_MAX") ? atoll(getenv("NPLDA_FWD_SMALL_MAX")) : -1;
+    const long long round_cost = L.NB == 10 ? 1000 : 1150;
+    *cost = 120;
     if (mid_ok && small_max < 0 && n <= 8LL * cus) return FWD_MID;
+    *cost = 190;
     if (n <= (small_max >= 0 ? small_max : 16LL * cus)) return FWD_SMALL;
+    const long long rounds = ((n + 127) / 128 + cus - 1) / cus;
+    const long long t_stream = 50 + rounds * round_cost;
+    *cost = n <= 64LL * cus ? 190 * ((n + 16LL * cus - 1) / (16LL * cus)) : t_stream;
     if (!mid_ok) return n <= 64LL * cus ? FWD_SMALL : FWD_STREAM;
     const long long ch = ((n + 7) / 8 + cus - 1) / cus;  // half tiles on the busiest CU (a trailing half costs ~0.7 of a tile)
-    const long long rounds = ((n + 127) / 128 + cus - 1) / cus;
     const long long t_mid = 40 + (ch / 2) * (L.NB == 10 ? 133 : 168) + (ch & 1) * (L.NB == 10 ? 93 : 118);
-    const long long t_stream = 50 + rounds * (L.NB == 10 ? 1000 : 1150);
-    return t_mid < t_stream ? FWD_MID : FWD_STREAM;
+    int best = t_mid < t_stream ? FWD_MID : FWD_STREAM;
+    *cost = t_mid < t_stream ? t_mid : t_stream;
+    // NPLDA_FWD_NO_SPLIT=1: the round-5 dispatch (A/B measurements only)
+    static const bool no_split = getenv("NPLDA_FWD_NO_SPLIT") != nullptr && getenv("NPLDA_FWD_NO_SPLIT")[0] == '1';
+    const long long full = pair_split_point(n, cus);
+    if (allow_split && !no_split && full > 0 && full < n) {
+        long long t_rem = 0;
+        pair_kernel_choice(n - full, L, cus, &t_rem, false);
+        const long long t_split = 50 + (full / 128 / cus) * round_cost + t_rem;
+        if (t_split + 30 < *cost) {  // (3 us of margin: a second launch is not free)
+            *cost = t_split;
+            best = FWD_SPLIT;
+        }
+    }
+    return best;
 }
 
 template <int MODE>
@@ -226,12 +251,23 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
         a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
         if (k == FWD_MID) return launch_fwd_mid<false>(a, L, st);
         if (k == FWD_SMALL) return launch_fwd_small<MODE>(a, L, st);
+        if (k == FWD_SPLIT && a.ia == nullptr && a.ib == nullptr) {
+            const long long full = pair_split_point(a.n, cus);
+            FwdArgs b = a;  // the remainder: rows [full, n) of both sides, scores [full, n)
+            b.xa += full * a.ldx; b.xb += full * a.ldx; b.out_s += full; b.n = a.n - full;
+            a.n = full;
+            if (int rc = launch_fwd_stream<0>(a, L, st)) return rc;
+            const int kr = pair_kernel_choice(b.n, L, cus, nullptr, false);
+            if (kr == FWD_MID) return launch_fwd_mid<false>(b, L, st);
+            if (kr == FWD_SMALL) return launch_fwd_small<MODE>(b, L, st);
+            return launch_fwd_stream<0>(b, L, st);
+        }
         return launch_fwd_stream<0>(a, L, st);
     }
     if constexpr (MODE == MODE_EMBED) {
         // embedding rows (inference: no saved activations): 32 rows are one tile's worth of work; the balanced-tile kernel
         // between one tile per CU and the streaming sizes (10 000 cohort + 22 000 enroll / test rows of cfg3: 116 -> 60 us)
-        if (a.out_y == nullptr && pair_kernel_choice((a.n + 1) / 2, L, mid_cus()) == FWD_MID) {
+        if (a.out_y == nullptr && pair_kernel_choice((a.n + 1) / 2, L, mid_cus(), nullptr, false) == FWD_MID) {
             a.D0 = L.D0; a.KS1 = L.KS1;
             a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
             return launch_fwd_mid<true>(a, L, st);
@@ -242,7 +278,10 @@ static inline int launch_fwd(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
 
 // bf16 rows (load_xrow, XM = 2): the streaming kernels only — below their sizes a conversion pass costs next to nothing
 static inline int launch_fwd_pairs_bf16rows(FwdArgs a, const NpldaLayout& L, hipStream_t st) {
-    if (pair_kernel_choice(a.n, L, mid_cus()) != FWD_STREAM) return NPLDA_EUNSUPPORTED;
+    // (a batch the fp32 call would split — full rounds streamed, the remainder on the balanced-tile kernel — is streamed whole
+    // here: the balanced-tile kernel does not read bf16 rows)
+    const int k = pair_kernel_choice(a.n, L, mid_cus());
+    if (k != FWD_STREAM && k != FWD_SPLIT) return NPLDA_EUNSUPPORTED;
     a.D0 = L.D0; a.KS1 = L.KS1;
     a.oW2 = L.oW2; a.ob1 = L.ob1; a.ob2 = L.ob2; a.oQ = L.oQ; a.oP = L.oP; a.total = L.total;
     return launch_fwd_stream<2>(a, L, st);
@@ -251,6 +290,8 @@ static inline int launch_fwd_pairs_bf16rows(FwdArgs a, const NpldaLayout& L, hip
 // name of the kernel nplda_score_pairs_f32 launches for a batch of n pairs (bench.py labels its roofline object with it)
 static inline const char* pair_kernel_name(long long n, const NpldaLayout& L) {
     switch (pair_kernel_choice(n, L, mid_cus())) {
+        case FWD_SPLIT:  // (labelled by the kernel that carries the full rounds)
+            return pair_kernel_name(pair_split_point(n, mid_cus()), L);
         case FWD_SMALL: return "nplda_fwd_small_kernel (4 waves share a 16-pair tile, feature-split)";
         case FWD_MID: return "nplda_fwd_mid_kernel (balanced 16-pair tiles, K-split layer 1, groups of 2 tiles)";
         default:

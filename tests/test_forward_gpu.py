@@ -352,6 +352,21 @@ def test_mid_regime_embedding_rows_match_oracle(hip_lib, D, N):
     assert np.array_equal(z2.cpu().numpy(), z)  # deterministic, and q is optional
 
 
+def _same_scores(s_b, s_f, B):
+    """bf16 rows widened in registers against the fp32 call on the widened rows: the SAME kernel -> the same bits.  Since
+    round 6 the fp32 call hands the pairs past the last FULL round of the persistent grid (128 pairs x CUs) to the
+    balanced-tile kernel (csrc/nplda_fwd_dispatch.h: FWD_SPLIT) while the bf16 entry point streams them all: bit equality on
+    the full rounds, the SURVEY 8(c) tolerance on the remainder (another summation order)."""
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    full = B // (128 * cus) * (128 * cus)
+    if full == 0 or full == B:
+        assert torch.equal(s_b, s_f), B
+        return
+    assert torch.equal(s_b[:full], s_f[:full]), B
+    d = (s_b[full:] - s_f[full:]).abs()
+    assert bool((d <= 2e-5 + 1e-5 * s_f[full:].abs()).all()), (B, float(d.max()))
+
+
 @pytest.mark.parametrize("D1", [150, 170])
 def test_bf16_rows_are_scored_without_an_fp32_copy(hip_lib, D1):
     """nplda_score_pairs_bf16rows_f32 (streaming kernels, bf16 rows widened in registers): the scores of
@@ -367,25 +382,25 @@ def test_bf16_rows_are_scored_without_an_fp32_copy(hip_lib, D1):
         x2 = torch.from_numpy(rng.standard_normal((B, 512)).astype(np.float32)).cuda().bfloat16()
         s_b = ops.score_pairs(x1, x2, packed)
         s_f = ops.score_pairs(x1.float(), x2.float(), packed)
-        assert torch.equal(s_b, s_f), B
+        _same_scores(s_b, s_f, B)
         name = lib.nplda_score_pairs_kernel_name(B, 512, D1, D1).decode()
         out = torch.empty(B, device="cuda")
         code = lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr(), x2.data_ptr(), B, 512, _lib.ptr(packed.buf), 512, D1, D1,
                                                   _lib.ptr(out), _lib.current_stream())
         assert (code == 0) == ("persistent" in name), (B, name, code)  # the entry point itself: streaming sizes only
         if code == 0:
-            assert torch.equal(out, s_f)
+            _same_scores(out, s_f, B)
     # a strided view (every other row of a wider buffer) and the module's inference path
     big = torch.from_numpy(rng.standard_normal((2 * 140000, 512)).astype(np.float32)).cuda().bfloat16()
     v1, v2 = big[0::2], big[1::2]
-    assert torch.equal(ops.score_pairs(v1, v2, packed), ops.score_pairs(v1.float(), v2.float(), packed))
+    _same_scores(ops.score_pairs(v1, v2, packed), ops.score_pairs(v1.float(), v2.float(), packed), 140000)
 
     class NC:
         xvector_dim, layer1_LDA_dim, layer2_PLDA_spkfactor_dim = 512, D1, D1
         beta, alpha, device, loss = [99.0], 15.0, "cuda", "SoftCdet"
     m = models.NeuralPlda(NC()).cuda()
     with torch.no_grad():
-        assert torch.equal(m(v1, v2), m(v1.float(), v2.float()))
+        _same_scores(m(v1, v2), m(v1.float(), v2.float()), 140000)
     # misaligned rows are refused by the entry point (the wrapper widens instead)
     assert lib.nplda_score_pairs_bf16rows_f32(x1.data_ptr() + 2, x2.data_ptr(), 1, 512, _lib.ptr(packed.buf), 512, D1, D1,
                                               _lib.ptr(out), _lib.current_stream()) != 0

@@ -12,8 +12,8 @@ dev = torch.device("cuda:0")
 prm, _ = bench.make_params(D, dev)
 pk = ops.pack_params(*prm)
 f = bench.algorithmic_flops_per_pair(512, D, D)
-for B in (4096, 8192, 10240, 12288, 16384, 16385, 20000, 20480, 24577, 32768, 40000, 49152, 65536, 100000, 131072, 200000, 262144,
-          524288, 1048576):
+for B in (4096, 8192, 10240, 12288, 16384, 16385, 20000, 20480, 24577, 32768, 40000, 49152, 65536, 70000, 81920, 100000, 131072,
+          150000, 200000, 262144, 300000, 524288, 1048576):
     x1 = torch.randn(B, 512, device=dev); x2 = torch.randn(B, 512, device=dev)
     ms, _ = bench.kernel_ms_of(lambda: ops.score_pairs(x1, x2, pk), reps=20)
     name = _lib.load().nplda_score_pairs_kernel_name(B, 512, D, D).decode().split(" ")[0]
