@@ -393,11 +393,15 @@ int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, con
  * nplda_adam_step_f32; exp_avg / exp_avg_sq: 2 D1^2 + D1 + 1 + K floats each, [weight | bias | thresholds]; step[0] counts
  * the steps, incremented here) and the store of the new value into the parameter AND into `image`, the quadratic-form image
  * of gb_pack_dplda_f32 the next forward scores with (NULL: not kept).  K thresholds (SoftCdet; dtheta from the loss call)
- * take their Adam step in the same launch.  grad_out (optional, 2 D1^2 + D1 + 1): the applied gradient. */
+ * take their Adam step in the same launch.  grad_out (optional, 2 D1^2 + D1 + 1): the applied gradient.
+ * loss / loss_sum (optional, ABI 4): loss_sum[0] += loss[0], the device-side running sum behind the progress line of
+ * xvector_DPlda_pytorch.py:44-50 (mean of the losses since the previous line) — one launch less per step than adding it
+ * from the host side. */
 int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* wlr, float* blr,
                            float* exp_avg, float* exp_avg_sq, float* const* thetas, const float* dtheta, int K, float* step,
                            float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
-                           float* grad_out, void* workspace, size_t workspace_bytes, nplda_stream_t stream);
+                           float* grad_out, const float* loss, double* loss_sum, void* workspace, size_t workspace_bytes,
+                           nplda_stream_t stream);
 
 /* ---- detection-cost sweep (validation metrics) -------------------------------------------------------------------- */
 

@@ -7,7 +7,7 @@
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-#define NPLDA_ABI_VERSION 3  // 3: the parameter image carries a W1^T fragment copy (dx = du . W1); 2: cohort control block, two-word Adam step
+#define NPLDA_ABI_VERSION 4  // 4: nplda_dplda_update_f32 takes loss / loss_sum; 3: the parameter image carries a W1^T fragment copy (dx = du . W1); 2: cohort control block, two-word Adam step
 #define NPLDA_MAX_NB 12            // 12 x 16 = 192 features per layer
 #define NPLDA_MAX_DIM (NPLDA_MAX_NB * 16)
 

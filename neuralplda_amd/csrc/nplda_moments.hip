@@ -265,6 +265,7 @@ struct DpldaFoldArgs {
     float* image;                    // the GaussianBackend-layout image (may be null)
     long long oG, ov, oc; int NB;    // its offsets (floats): G fragments, v, c
     float* theta[4]; const float* dtheta; int K;  // SoftCdet thresholds trained with the unit (K = 0: none)
+    const float* loss; double* loss_sum;          // optional: loss_sum[0] += loss[0] (the training log's running sum; by the bias thread)
 };
 
 // One block per 16 x 16 tile of an output block.  Half of the entries a tile needs sit mirrored in the slabs (G21 = G12^T;
@@ -307,6 +308,7 @@ __global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) 
             if constexpr (UPDATE) {
                 const float pn = apply(2 * n2 + D1, gr, a.blr);
                 if (a.image) a.image[a.oc] = pn;  // c = the bias
+                if (a.loss_sum && a.loss) a.loss_sum[0] += (double)a.loss[0];
             }
         } else if (UPDATE && c > (size_t)D1 && c <= (size_t)D1 + a.K) {  // the thresholds' own Adam step
             const int k = (int)(c - D1 - 1);
@@ -461,9 +463,11 @@ int nplda_dplda_grad_f32(const float* paired, int64_t B, int64_t ld, int D1, con
 int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* wlr, float* blr,
                            float* exp_avg, float* exp_avg_sq, float* const* thetas, const float* dtheta, int K, float* step,
                            float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
-                           float* grad_out, void* workspace, size_t workspace_bytes, nplda_stream_t stream) {
+                           float* grad_out, const float* loss, double* loss_sum, void* workspace, size_t workspace_bytes,
+                           nplda_stream_t stream) {
     const int n = 2 * D1;
     if (B <= 0 || D1 <= 0 || K < 0 || K > 4) return NPLDA_EINVAL;
+    if (loss_sum && !loss) return NPLDA_EINVAL;
     if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
     if (!paired || !g || !wlr || !blr || !exp_avg || !exp_avg_sq || !step || !workspace) return NPLDA_EINVAL;
     if (K > 0 && (!thetas || !dtheta)) return NPLDA_EINVAL;
@@ -486,6 +490,7 @@ int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, c
     f.dw = grad_out; f.db = grad_out ? grad_out + (size_t)2 * D1 * D1 + D1 : nullptr;
     f.wlr = wlr; f.blr = blr; f.m = exp_avg; f.v = exp_avg_sq; f.step = step;
     f.lr = lr; f.beta1 = beta1; f.beta2 = beta2; f.eps = eps; f.wd = weight_decay;
+    f.loss = loss; f.loss_sum = loss_sum;
     f.image = (float*)image;
     if (image) {  // gb_layout(D0, D1) of nplda_gb.hip: [W1 fragments | G | b1 | v | c]
         const long long KS1 = (D0 + 15) / 16;

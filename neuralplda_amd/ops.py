@@ -1339,14 +1339,17 @@ def dplda_grad(paired, g, D1):
 
 
 def dplda_update(paired, g, wlr, blr, m, v, step, lr, beta1, beta2, eps, wd, thetas=(), dtheta=None, image=None, ws=None,
-                 grad_out=None):
+                 grad_out=None, loss=None, loss_sum=None):
     """nplda_dplda_update_f32: the tail of DPlda's recipe step in two launches — weighted moments of the paired rows, then per
     element of [logistic_regres.weight | bias] gradient fold + torch.optim.Adam's update + the new value stored into the
     parameter and into `image` (the (buf, D0, D1) of dplda_pack the next forward scores with).  m / v: flat moments
-    [weight | bias | thresholds]; step: device [steps taken, scratch]."""
+    [weight | bias | thresholds]; step: device [steps taken, scratch].  loss / loss_sum: optional 0-d float32 / (1,) float64
+    device tensors, loss_sum += loss inside the update launch."""
     import ctypes
     lib = _lib.load()
     B, n = paired.shape
+    if loss_sum is not None and (loss is None or loss.dtype != torch.float32 or loss_sum.dtype != torch.float64):
+        raise ValueError("dplda_update: loss must be float32 and loss_sum float64")
     D1 = n // 2
     K = len(thetas)
     if wlr.numel() != 2 * D1 * D1 + D1 or blr.numel() != 1 or m.numel() < wlr.numel() + 1 + K or v.numel() != m.numel():
@@ -1365,7 +1368,8 @@ def dplda_update(paired, g, wlr, blr, m, v, step, lr, beta1, beta2, eps, wd, the
         code = lib.nplda_dplda_update_f32(_lib.ptr(paired), B, paired.stride(0), D1, _lib.ptr(gg), _lib.ptr(wlr), _lib.ptr(blr),
                                           _lib.ptr(m), _lib.ptr(v), tarr, _lib.ptr(dtheta) if K else None, K, _lib.ptr(step),
                                           float(lr), float(beta1), float(beta2), float(eps), float(wd), _lib.ptr(buf), int(D0),
-                                          _lib.ptr(grad_out), _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
+                                          _lib.ptr(grad_out), _lib.ptr(loss) if loss_sum is not None else None,
+                                          _lib.ptr(loss_sum), _lib.ptr(ws), ws.numel() * 4, _lib.current_stream())
     _lib.check(code, "nplda_dplda_update_f32")
     return ws
 

@@ -399,6 +399,8 @@ class FusedTrainStep:
         self._acc_n += 1
         if isinstance(loss, tuple):  # (loss, dx1, dx2) of a step that also returns input gradients
             loss = loss[0]
+        if self.__dict__.get("_acc_in_kernel", False):  # (FusedDPldaStep's recipe step: nplda_dplda_update_f32 added it)
+            return
         if not ((self._one_call and 0 < B <= 16384) or (self._dp_call and B <= 16384)):
             self._acc().add_(loss.detach().reshape(1))
 
@@ -1010,7 +1012,8 @@ class FusedDPldaStep(FusedTrainStep):
         B = x1.shape[0]
         self._mws = ops.dplda_update(paired, g, wlr, blr, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
                                      self.eps, self.wd, thetas=ths, dtheta=dth if ths else None, image=self._img,
-                                     ws=self.__dict__.get("_mws_by_B", {}).get(B))
+                                     ws=self.__dict__.get("_mws_by_B", {}).get(B), loss=loss, loss_sum=self._acc())
+        self._acc_in_kernel = True  # (the update launch adds the step's loss to the running sum: _account leaves it alone)
         self.__dict__.setdefault("_mws_by_B", {})[B] = self._mws
         self.launches_per_step = ("4 in one graph replay: LDA + normalise + quadratic-form score | loss + dL/ds | weighted moments | "
                                   "gradient fold + Adam + parameter and image stores")
@@ -1022,6 +1025,7 @@ class FusedDPldaStep(FusedTrainStep):
             if (not (self.train_lda or self.want_dx) and self.reduce_sums is None and self.reduce_flat is None
                     and x1.shape[0] > 0 and os.environ.get("NPLDA_DPLDA_SEPARATE", "0") != "1"):
                 return self._recipe_step(x1, x2, t)
+            self._acc_in_kernel = False
             wlr, blr = (q.detach() for q in self.params[:2])
             W1, b1 = mdl.centering_and_LDA.weight.detach(), mdl.centering_and_LDA.bias.detach()
             packed = ops.dplda_pack(W1, b1, wlr, blr)

@@ -353,6 +353,9 @@ def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, m
         for i, (x1, x2, t) in enumerate(batches):
             loss = float(step(x1, x2, t))
             out.append((loss, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+            if i == 2:  # the progress line's mean of the losses since the previous line: the update launch keeps the sum (ABI 4)
+                mean3 = step.pop_loss_mean()
+                assert abs(mean3 - float(np.mean([o[0] for o in out]))) <= 1e-6 * abs(mean3), (separate, mean3)
             if not separate:
                 fresh = ops.dplda_pack(m.centering_and_LDA.weight.detach(), m.centering_and_LDA.bias.detach(),
                                        m.logistic_regres.weight.detach(), m.logistic_regres.bias.detach())
@@ -372,3 +375,4 @@ def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, m
         for k in sa:
             assert torch.equal(sa[k], sb[k]), (i, k, (sa[k] - sb[k]).abs().max().item())
     assert step_new.step_count[0].item() == 4
+    assert abs(step_new.pop_loss_mean() - new[3][0]) <= 1e-6 * abs(new[3][0])  # (one step since the pop after the third)

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(hip_lib):
     for name in declared:
         assert hasattr(hip_lib, name), name
     # argument-free entry points work without a GPU
-    assert hip_lib.nplda_abi_version() == 3
+    assert hip_lib.nplda_abi_version() == 4
     assert hip_lib.nplda_max_dim() == 192
     assert hip_lib.nplda_padded_dim(150, 150) == 160 and hip_lib.nplda_padded_dim(170, 170) == 176
     assert hip_lib.nplda_packed_bytes(512, 150, 150) > 0 and hip_lib.nplda_packed_bytes(512, 500, 500) == 0
