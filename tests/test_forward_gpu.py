@@ -141,7 +141,10 @@ def test_large_batch_kernel_variant(hip_lib, D0, D1, D2):
 
 
 @pytest.mark.parametrize("D", [150, 160, 170])
-@pytest.mark.parametrize("B", [4097, 4112, 6145, 8192, 10240, 10247, 12289, 16384, 16385, 20480, 24577, 40000, 100001])
+@pytest.mark.parametrize("B", [4097, 4112, 6145, 8192, 10240, 10247, 12289, 16384, 16385, 20480, 24577, 40000, 100001,
+                               # round 6, FWD_SPLIT: full rounds of the persistent grid (32 768 pairs on 256 CUs) by the streaming
+                               # kernel + a remainder of 1 pair / lone half tiles / the small-batch kernel's / the mid kernel's size
+                               65537, 67000, 98304 + 3000, 70000])
 def test_mid_regime_batches_match_oracle(hip_lib, D, B):
     """The batch sizes between one 16-pair tile per CU and full streaming rounds — validate()'s 5 x batch_size = 20 480
     pairs (xvector_NeuralPlda_pytorch.py:125), the 10 240-pair score-file chunks, any 8-way shard of a modest list — take
