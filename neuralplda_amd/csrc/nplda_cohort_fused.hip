@@ -410,7 +410,10 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     // A tile that ends an ITEM takes 43 - 48 k: 256 blocks pull 164 KB of row operands each at about the same time, 42 MB
     // against HBM / the memory-side cache; warming the L2 a tile ahead does not help — an XCD's 32 row tiles are 5.2 MB, more
     // than its L2 — and neither does staggering the queue so that blocks change items at different times: both measured,
-    // r06j / r06k.)
+    // r06j / r06k.  With the row loads left out (ablation 4096) such a tile takes 28 k: the loads are the cost.  Loading the
+    // raw rows behind the loop and multiplying by 2 P only at the top of the next tile — so that the epilogue, the barrier
+    // and the partner's loop lie between load and first use — moved the wait without shortening it: 34 - 40 k, and the
+    // plain tiles got 0.5 k slower: r06q, not kept.)
     unsigned rowbase[RGW];
     float nraw[RGW][3];
     auto next_consts = [&](long long rb_) {
@@ -533,7 +536,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         // phases together with a barrier at this point gives the same tile time (24.6 k + 4.6 k) and a kernel 2 % slower.)
         // the operand rows of the NEXT item are fetched here, under the epilogue of this item's last tile
         NPLDA_CF_STAMP(2);
-        if (last_of_item && have_next) item_rows(nrb);
+        if (last_of_item && have_next && !(abl & 4096)) item_rows(nrb);  // (abl 4096: keeps the old rows — timing only)
 
         // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
         const long long m0 = (long long)t * 64;

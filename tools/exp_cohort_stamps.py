@@ -57,6 +57,10 @@ if rc == 0 and st[0, 5, 0] > 0:
         per = np.array([st[w, k + 1, 0] - st[w, k, 0] for k in tiles], dtype=np.float64)
         print(f"wave {'0' if w == 0 else 'NW/2'}: tile period median {np.median(per):8.0f} cycles; phases (median): " +
               ", ".join(f"{n} {np.median(d[:, i]):7.0f}" for i, n in enumerate(names)))
+    # tiles that end an item / a list band stand out by their period: the longest periods of the stamped block
+    for w in (0,):
+        per = sorted(((int(st[w, k + 1, 0] - st[w, k, 0]), k) for k in range(2, 62) if st[w, k + 1, 0] > 0 and st[w, k, 0] > 0), reverse=True)
+        print("longest tile periods (cycles, tile): " + ", ".join(f"{p_}@{k}" for p_, k in per[:6]) + f"; median {per[len(per) // 2][0]}")
     if os.environ.get("STAMP_RAW"):
         base = st[0, 8, 0]
         for k in range(8, 20):
