@@ -144,6 +144,7 @@ struct RowThrArgs {
     float zhi, sgn;
     float* crow; float* trow; double* mean64;
     int ntiles;           // tiles of 128 rows (8 waves x 16)
+    unsigned* ctl_zero;   // a prepared cohort (no pre-pass to do it): the call's 64-word control block, zeroed by block 0 here
 };
 
 template <int NB>
@@ -152,6 +153,7 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int j = lane & 15, g = lane >> 4;
     constexpr int Mp = 16 * NB;
+    if (a.ctl_zero != nullptr && blockIdx.x == 0 && tid < 64) a.ctl_zero[tid] = 0u;
     for (int i = tid; i < NB * (NB + 1) / 2 * 64; i += 512) cimg[i] = reinterpret_cast<const f32x4*>(a.frag)[i];
     __syncthreads();
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
@@ -1065,13 +1067,15 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     *fail_rows_out = fail_rows;
     *nfail_out = ctl + 8;
 
-    if (!prepass && hipMemsetAsync(ctl, 0, 256, st) != hipSuccess) return NPLDA_EINVAL;  // (the pre-pass zeroes it itself)
+    // (the control block — work-item counters, fail count — is zeroed by the pre-pass, or, with a prepared cohort, by the
+    // row-threshold kernel below: a hipMemsetAsync in front cost a launch, and as a memset NODE of a captured graph it let a
+    // replayed AS-norm step fault — tools/exp_cfg3_graph.py, round 6)
     if (prepass) {  // cohort moments: once per call, the cohort does not change between row chunks
         if (int rc = fused_prepass(F, z_coh, q_coh, M, ldz, P, Mp, st)) return rc;
     }
     {   // row means and thresholds
         RowThrArgs ra = {z_rows, q_rows, R, ldz, frag, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64,
-                         (int)((R + 127) / 128)};
+                         (int)((R + 127) / 128), prepass ? nullptr : ctl};
         const unsigned grid = (unsigned)(ra.ntiles < resident ? ra.ntiles : resident);
         const size_t shm = (size_t)ksteps * (ksteps + 1) / 2 * 1024;
 #define NPLDA_LAUNCH(NBV)                                                                                             \
