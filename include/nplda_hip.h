@@ -403,6 +403,20 @@ int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, c
                            float* grad_out, const float* loss, double* loss_sum, void* workspace, size_t workspace_bytes,
                            nplda_stream_t stream);
 
+/* nplda_dplda_update_f32 with the LOSS inside its first launch (round 6): the weights of the moments are dL/ds_i of
+ * utils/models.py:384-399's loss (kind 0 = SoftCdet with loss_K thresholds `loss_theta` and HOST betas, 1 = BCE with
+ * loss_theta[0]), formed by the moments blocks from (s, t) with the device functions of nplda_loss_fwd_bwd_f32, and ONE more
+ * block of that launch is the loss kernel itself: `sums` (nplda_loss_nsums doubles), `loss`, `dtheta` (and dL/ds into g_out
+ * when it is not NULL) come out exactly as nplda_loss_fwd_bwd_f32 gives them.  The step xvector_DPlda_pytorch.py:35-43 runs
+ * is then THREE launches: score | moments + loss | fold + Adam.  B <= 4096, s / t 16-byte aligned (else
+ * NPLDA_EUNSUPPORTED: run the two calls).  `thetas` (K, may be 0): the thresholds that take their Adam step from `dtheta`. */
+int nplda_dplda_update_loss_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* s, const float* t, int kind,
+                                const float* const* loss_theta, const float* beta, int loss_K, float alpha, double* sums,
+                                float* loss, float* dtheta, float* g_out, float* wlr, float* blr, float* exp_avg,
+                                float* exp_avg_sq, float* const* thetas, int K, float* step, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, void* image, int D0, float* grad_out, double* loss_sum,
+                                void* workspace, size_t workspace_bytes, nplda_stream_t stream);
+
 /* ---- detection-cost sweep (validation metrics) -------------------------------------------------------------------- */
 
 /* NeuralPlda.minc (utils/models.py:406-436) for N scores / labels and K <= 8 betas (HOST array), replacing its

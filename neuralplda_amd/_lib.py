@@ -158,6 +158,11 @@ SIGNATURES = {
     "nplda_dplda_update_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
                                         ctypes.POINTER(ctypes.c_void_p), _c_f32p, _c_int, _c_vp] + [ctypes.c_float] * 5 +
                                [_c_vp, _c_int, _c_f32p, _c_f32p, _c_vp, _c_vp, _c_sz, _c_vp]),
+    "nplda_dplda_update_loss_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_f32p, _c_f32p, _c_int,
+                                             ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_float), _c_int, ctypes.c_float,
+                                             _c_vp, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p, _c_f32p,
+                                             ctypes.POINTER(ctypes.c_void_p), _c_int, _c_vp] + [ctypes.c_float] * 5 +
+                                    [_c_vp, _c_int, _c_f32p, _c_vp, _c_vp, _c_sz, _c_vp]),
     "nplda_rows_matmul_f32": (_c_int, [_c_f32p, _c_i64, _c_i64, _c_int, _c_vp, _c_int, _c_f32p, _c_f32p, _c_f32p,
                                        _c_i64, _c_vp]),
     "nplda_normalize_bwd_paired_f32": (_c_int, [_c_f32p, _c_i64, _c_f32p, _c_i64, _c_f32p, _c_i64, _c_int, _c_f32p,

@@ -13,6 +13,7 @@
 
 #include "nplda_adam_math.h"
 #include "nplda_common.h"
+#include "nplda_loss_single.h"
 
 namespace {
 
@@ -33,6 +34,12 @@ struct MomArgs {
     float* slab;           // [class][kgroup][Np][Np]   (upper tiles written)
     float* ext;            // [class][kgroup][Np + 4]   column sums, then the weight sum
     float* step_bump;      // optional: Adam's step counter, counted here (one thread) for the update kernel of this step
+    // LOSS != 0 (nplda_dplda_update_loss_f32): the weights are dL/ds_i of the loss, formed HERE from (score, target) by the
+    // device functions of the loss kernels — and one more block at the end of the grid is the loss kernel itself (sums, loss,
+    // dL/dtheta; nplda_loss_single.h): DPlda's recipe step needs no loss launch between its forward and this one
+    const float* ls; const float* lt;      // scores, targets (B each, 16-byte aligned, B <= kSingleBlockMax)
+    nplda_loss::ThetaPtrs lth; nplda_loss::BetaVals lbeta; float lalpha;
+    double* lsums; float* lloss; float* ldtheta; float* lg;  // outputs of the loss block (lg: optional dL/ds)
 };
 
 __device__ __forceinline__ void tile_of(int t, int T, int& mt, int& nt) {
@@ -43,8 +50,29 @@ __device__ __forceinline__ void tile_of(int t, int T, int& mt, int& nt) {
     nt = mt + t;
 }
 
-template <int NC>
+// LOSS: 0 = weights from w0 / w1; 1 = BCE; 1 + K = SoftCdet with K thresholds (see MomArgs)
+template <int NC, int LOSS = 0>
 __global__ __launch_bounds__(256, 2) void moments_kernel(const MomArgs a) {
+    static_assert(LOSS == 0 || NC == 1, "inline loss weights: one class");
+    constexpr int LK = LOSS > 1 ? LOSS - 1 : 1;
+    float ltheta[LK], lcn[LK], lct = 0.f, linvN = 0.f;
+    if constexpr (LOSS != 0) {
+        if (blockIdx.x == gridDim.x - 1) {  // the loss block (block-uniform)
+            if constexpr (LOSS == 1) nplda_loss::loss_fused_bce_body(a.ls, a.lt, a.B, a.lth, a.lsums, a.lloss, a.lg, a.ldtheta);
+            else nplda_loss::loss_fused_softcdet_body<LK>(a.ls, a.lt, a.B, a.lth, a.lbeta, a.lalpha, a.lsums, a.lloss, a.lg, a.ldtheta);
+            return;
+        }
+        // the batch constants of dL/ds: the label counts by the loss block's own summation pattern (the same per-thread
+        // partial sums in the same order: the same N_t, N_n to the last bit, soft labels included)
+        __shared__ double ltot[2];
+        double lacc[2] = {0.0, 0.0};
+        nplda_loss::sums_single_block(a.ls, a.lt, a.B, [&](float, float ti) { lacc[0] += ti; lacc[1] += 1.0f - ti; });
+        nplda_loss::block_totals<2>(lacc, ltot, nullptr);
+#pragma unroll
+        for (int k = 0; k < LK; ++k) ltheta[k] = a.lth.p[k][0];
+        if constexpr (LOSS == 1) linvN = (float)(1.0 / (ltot[0] + ltot[1]));
+        else nplda_loss::softcdet_consts<LK>(ltot[0], ltot[1], a.lbeta, a.lalpha, lcn, lct);
+    }
     __shared__ f32x4 red[4][16 * 64];  // [wave][(ca*4+cb)*64 + lane]  (64 KB), reused per class
     __shared__ f32x4 rede[4][NC][16];
     __shared__ float redc[4][NC];
@@ -92,7 +120,13 @@ __global__ __launch_bounds__(256, 2) void moments_kernel(const MomArgs a) {
         const f32x4 vb = *reinterpret_cast<const f32x4*>(X + rc * ldx + ncol);
         f.xa = mval ? va : zero4;
         f.xb = nval ? vb : zero4;
-        const float w0 = W0[rc];
+        // (LOSS != 0: dL/ds_i formed HERE, at load time, as in the first form of this kernel — formed at the point of use, with
+        // the batch constants computed behind the first operand loads, the step was 1 us shorter and SoftCdet's weights differed
+        // from the loss kernel's in their last bit: the same expression compiled in another context)
+        float w0;
+        if constexpr (LOSS == 0) w0 = W0[rc];
+        else if constexpr (LOSS == 1) w0 = nplda_loss::bce_gi(a.ls[rc], a.lt[rc], ltheta[0], linvN);
+        else w0 = nplda_loss::softcdet_gi<LK>(a.ls[rc], a.lt[rc], ltheta, lcn, lct, a.lalpha);
         f.w[0] = ok ? w0 : 0.f;
         if (NC == 2) {
             const float w1 = W1[rc];
@@ -389,6 +423,87 @@ MomPlan mom_plan(long long B, int n) {
 
 }  // namespace
 
+// kind < 0: the weights are `g` (nplda_dplda_update_f32); kind 0 / 1 (SoftCdet / BCE): they are formed inside the moments launch
+// from (ls, lt) and the loss block rides in it (nplda_dplda_update_loss_f32)
+struct DpldaLossIn {
+    int kind, K;
+    const float* s; const float* t; const float* const* theta; const float* beta; float alpha;
+    double* sums; float* loss; float* dtheta; float* g_out;
+};
+static int dplda_update_impl(const float* paired, int64_t B, int64_t ld, int D1, const float* g, float* wlr, float* blr,
+                             float* exp_avg, float* exp_avg_sq, float* const* thetas, const float* dtheta, int K, float* step,
+                             float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
+                             float* grad_out, const float* loss, double* loss_sum, void* workspace, size_t workspace_bytes,
+                             const DpldaLossIn* li, nplda_stream_t stream) {
+    const int n = 2 * D1;
+    if (B <= 0 || D1 <= 0 || K < 0 || K > 4) return NPLDA_EINVAL;
+    if (loss_sum && !loss) return NPLDA_EINVAL;
+    if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
+    if (!paired || (!g && !li) || !wlr || !blr || !exp_avg || !exp_avg_sq || !step || !workspace) return NPLDA_EINVAL;
+    if (K > 0 && (!thetas || !dtheta)) return NPLDA_EINVAL;
+    if (ld < n || (ld & 3) || !nplda_aligned16(paired) || !nplda_aligned16(workspace)) return NPLDA_EINVAL;
+    const int NB = nplda_kernel_nb(D1, D1);
+    if (image && (NB == 0 || D0 <= 0 || (D0 % 4) != 0 || !nplda_aligned16(image))) return NPLDA_EINVAL;
+    const MomPlan p = mom_plan(B, n);
+    if (workspace_bytes < (p.slab_floats + p.ext_floats) * sizeof(float)) return NPLDA_ENOSPC;
+    hipStream_t st = (hipStream_t)stream;
+    MomArgs a = {};
+    a.x = paired; a.ldx = ld; a.B = B; a.n = n; a.w0 = g; a.w1 = nullptr;
+    a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
+    a.slab = (float*)workspace;
+    a.ext = a.slab + p.slab_floats;
+    a.step_bump = step;  // the step is counted here: the update kernel below reads t = step[0]
+    const unsigned mgrid = (unsigned)(p.ntile * p.kgroups);
+    if (!li) {
+        hipLaunchKernelGGL(moments_kernel<1>, dim3(mgrid), dim3(256), 0, st, a);
+    } else {
+        const int LK = li->kind == 1 ? 1 : li->K;
+        if ((li->kind != 0 && li->kind != 1) || LK < 1 || LK > nplda_loss::kMaxK) return NPLDA_EINVAL;
+        if (!li->s || !li->t || !li->theta || !li->sums || !li->loss || !li->dtheta || (li->kind == 0 && !li->beta)) return NPLDA_EINVAL;
+        if (B > nplda_loss::kSingleBlockMax || !nplda_aligned16(li->s) || !nplda_aligned16(li->t) ||
+            (li->g_out && !nplda_aligned16(li->g_out)))
+            return NPLDA_EUNSUPPORTED;  // (the caller runs nplda_loss_fwd_bwd_f32 + nplda_dplda_update_f32 instead)
+        a.ls = li->s; a.lt = li->t; a.lalpha = li->alpha;
+        a.lsums = li->sums; a.lloss = li->loss; a.ldtheta = li->dtheta; a.lg = li->g_out;
+        for (int k = 0; k < LK; ++k) {
+            if (!li->theta[k]) return NPLDA_EINVAL;
+            a.lth.p[k] = li->theta[k];
+            if (li->kind == 0) a.lbeta.b[k] = li->beta[k];  // beta is a HOST array (config constants)
+        }
+        const dim3 grid(mgrid + 1), block(256);  // + the loss block
+        if (li->kind == 1) hipLaunchKernelGGL((moments_kernel<1, 1>), grid, block, 0, st, a);
+        else switch (LK) {
+            case 1: hipLaunchKernelGGL((moments_kernel<1, 2>), grid, block, 0, st, a); break;
+            case 2: hipLaunchKernelGGL((moments_kernel<1, 3>), grid, block, 0, st, a); break;
+            case 3: hipLaunchKernelGGL((moments_kernel<1, 4>), grid, block, 0, st, a); break;
+            default: hipLaunchKernelGGL((moments_kernel<1, 5>), grid, block, 0, st, a); break;
+        }
+    }
+    if (int rc = nplda_launch_status()) return rc;
+    DpldaFoldArgs f = {};
+    f.slab = a.slab; f.ext = a.ext; f.kgroups = p.kgroups; f.Np = p.Np; f.D1 = D1;
+    f.dw = grad_out; f.db = grad_out ? grad_out + (size_t)2 * D1 * D1 + D1 : nullptr;
+    f.wlr = wlr; f.blr = blr; f.m = exp_avg; f.v = exp_avg_sq; f.step = step;
+    f.lr = lr; f.beta1 = beta1; f.beta2 = beta2; f.eps = eps; f.wd = weight_decay;
+    f.loss = loss; f.loss_sum = loss_sum;
+    f.image = (float*)image;
+    if (image) {  // gb_layout(D0, D1) of nplda_gb.hip: [W1 fragments | G | b1 | v | c]
+        const long long KS1 = (D0 + 15) / 16;
+        f.NB = NB;
+        f.oG = KS1 * NB * 256;
+        f.ov = f.oG + 4LL * NB * NB * 256 + (long long)NB * 16;
+        f.oc = f.ov + 2LL * NB * 16;
+    }
+    for (int k = 0; k < K; ++k) {
+        if (!thetas[k]) return NPLDA_EINVAL;
+        f.theta[k] = thetas[k];
+    }
+    f.dtheta = dtheta; f.K = K;
+    const int TB = (D1 + 15) / 16;
+    hipLaunchKernelGGL(dplda_fold_kernel<true>, dim3((unsigned)(2 * TB * TB + (D1 + 1 + K + 255) / 256)), dim3(256), 0, st, f);
+    return nplda_launch_status();
+}
+
 extern "C" {
 
 size_t nplda_moments_workspace_bytes(int64_t B, int n) {
@@ -465,48 +580,20 @@ int nplda_dplda_update_f32(const float* paired, int64_t B, int64_t ld, int D1, c
                            float lr, float beta1, float beta2, float eps, float weight_decay, void* image, int D0,
                            float* grad_out, const float* loss, double* loss_sum, void* workspace, size_t workspace_bytes,
                            nplda_stream_t stream) {
-    const int n = 2 * D1;
-    if (B <= 0 || D1 <= 0 || K < 0 || K > 4) return NPLDA_EINVAL;
-    if (loss_sum && !loss) return NPLDA_EINVAL;
-    if (n > kMaxN || (n & 3)) return NPLDA_EUNSUPPORTED;
-    if (!paired || !g || !wlr || !blr || !exp_avg || !exp_avg_sq || !step || !workspace) return NPLDA_EINVAL;
-    if (K > 0 && (!thetas || !dtheta)) return NPLDA_EINVAL;
-    if (ld < n || (ld & 3) || !nplda_aligned16(paired) || !nplda_aligned16(workspace)) return NPLDA_EINVAL;
-    const int NB = nplda_kernel_nb(D1, D1);
-    if (image && (NB == 0 || D0 <= 0 || (D0 % 4) != 0 || !nplda_aligned16(image))) return NPLDA_EINVAL;
-    const MomPlan p = mom_plan(B, n);
-    if (workspace_bytes < (p.slab_floats + p.ext_floats) * sizeof(float)) return NPLDA_ENOSPC;
-    hipStream_t st = (hipStream_t)stream;
-    MomArgs a;
-    a.x = paired; a.ldx = ld; a.B = B; a.n = n; a.w0 = g; a.w1 = nullptr;
-    a.T = p.T; a.ntile = p.ntile; a.kgroups = p.kgroups; a.rows_per_group = p.rows_per_group; a.Np = p.Np;
-    a.slab = (float*)workspace;
-    a.ext = a.slab + p.slab_floats;
-    a.step_bump = step;  // the step is counted here: the update kernel below reads t = step[0]
-    hipLaunchKernelGGL(moments_kernel<1>, dim3((unsigned)(p.ntile * p.kgroups)), dim3(256), 0, st, a);
-    if (int rc = nplda_launch_status()) return rc;
-    DpldaFoldArgs f = {};
-    f.slab = a.slab; f.ext = a.ext; f.kgroups = p.kgroups; f.Np = p.Np; f.D1 = D1;
-    f.dw = grad_out; f.db = grad_out ? grad_out + (size_t)2 * D1 * D1 + D1 : nullptr;
-    f.wlr = wlr; f.blr = blr; f.m = exp_avg; f.v = exp_avg_sq; f.step = step;
-    f.lr = lr; f.beta1 = beta1; f.beta2 = beta2; f.eps = eps; f.wd = weight_decay;
-    f.loss = loss; f.loss_sum = loss_sum;
-    f.image = (float*)image;
-    if (image) {  // gb_layout(D0, D1) of nplda_gb.hip: [W1 fragments | G | b1 | v | c]
-        const long long KS1 = (D0 + 15) / 16;
-        f.NB = NB;
-        f.oG = KS1 * NB * 256;
-        f.ov = f.oG + 4LL * NB * NB * 256 + (long long)NB * 16;
-        f.oc = f.ov + 2LL * NB * 16;
-    }
-    for (int k = 0; k < K; ++k) {
-        if (!thetas[k]) return NPLDA_EINVAL;
-        f.theta[k] = thetas[k];
-    }
-    f.dtheta = dtheta; f.K = K;
-    const int TB = (D1 + 15) / 16;
-    hipLaunchKernelGGL(dplda_fold_kernel<true>, dim3((unsigned)(2 * TB * TB + (D1 + 1 + K + 255) / 256)), dim3(256), 0, st, f);
-    return nplda_launch_status();
+    if (!g) return NPLDA_EINVAL;
+    return dplda_update_impl(paired, B, ld, D1, g, wlr, blr, exp_avg, exp_avg_sq, thetas, dtheta, K, step, lr, beta1, beta2, eps,
+                             weight_decay, image, D0, grad_out, loss, loss_sum, workspace, workspace_bytes, nullptr, stream);
+}
+
+int nplda_dplda_update_loss_f32(const float* paired, int64_t B, int64_t ld, int D1, const float* s, const float* t, int kind,
+                                const float* const* loss_theta, const float* beta, int loss_K, float alpha, double* sums,
+                                float* loss, float* dtheta, float* g_out, float* wlr, float* blr, float* exp_avg,
+                                float* exp_avg_sq, float* const* thetas, int K, float* step, float lr, float beta1, float beta2,
+                                float eps, float weight_decay, void* image, int D0, float* grad_out, double* loss_sum,
+                                void* workspace, size_t workspace_bytes, nplda_stream_t stream) {
+    const DpldaLossIn li = {kind, loss_K, s, t, loss_theta, beta, alpha, sums, loss, dtheta, g_out};
+    return dplda_update_impl(paired, B, ld, D1, nullptr, wlr, blr, exp_avg, exp_avg_sq, thetas, dtheta, K, step, lr, beta1, beta2,
+                             eps, weight_decay, image, D0, grad_out, loss, loss_sum, workspace, workspace_bytes, &li, stream);
 }
 
 }  // extern "C"

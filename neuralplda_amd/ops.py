@@ -1374,6 +1374,52 @@ def dplda_update(paired, g, wlr, blr, m, v, step, lr, beta1, beta2, eps, wd, the
     return ws
 
 
+def dplda_update_loss(paired, s, t, loss_thetas, betas, alpha, kind, wlr, blr, m, v, step, lr, beta1, beta2, eps, wd, thetas=(),
+                      image=None, ws=None, grad_out=None, loss_sum=None):
+    """nplda_dplda_update_loss_f32: dplda_update with the loss inside its first launch — the moments blocks form dL/ds_i from
+    (s, t) themselves, one more block of that launch is the loss kernel (loss, dL/dtheta).  Returns (loss, dtheta, ws), or None
+    when the batch is outside the one-block loss (B > 4096 / unaligned): the caller runs loss_fwd_bwd + dplda_update."""
+    import ctypes
+    lib = _lib.load()
+    B, n = paired.shape
+    D1 = n // 2
+    K, LK = len(thetas), len(loss_thetas)
+    if wlr.numel() != 2 * D1 * D1 + D1 or blr.numel() != 1 or m.numel() < wlr.numel() + 1 + K or v.numel() != m.numel():
+        raise ValueError("dplda_update_loss: parameter / moment shapes do not belong to a DPlda of this D1")
+    _require_dev_f32(s, "output")
+    _require_dev_f32(t, "target")
+    if s.shape != (B,) or t.shape != (B,):
+        raise ValueError("output and target must be (B,) tensors")
+    if B > 4096 or not s.is_contiguous() or not t.is_contiguous() or s.data_ptr() % 16 or t.data_ptr() % 16:
+        return None
+    if paired.stride(1) != 1 or paired.stride(0) % 4 != 0 or paired.data_ptr() % 16 != 0:
+        paired = paired.contiguous()
+    ns = lib.nplda_loss_nsums(LK, kind)
+    if ns == 0 or kind == LOSS_HARD_CDET:
+        raise _lib.NpldaHipError("dplda_update_loss: unsupported loss kind / number of thresholds")
+    nbytes = lib.nplda_moments_workspace_bytes(B, n)
+    if nbytes == 0:
+        raise _lib.NpldaHipError(f"paired rows of length {n} are outside the moments kernel")
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty(nbytes // 4, dtype=torch.float32, device=paired.device)
+    dev = paired.device
+    sums = torch.empty(ns, dtype=torch.float64, device=dev)
+    loss = torch.empty((), dtype=torch.float32, device=dev)
+    dth = torch.empty(max(LK, 1), dtype=torch.float32, device=dev)
+    barr = (ctypes.c_float * max(LK, 1))(*[float(b) for b in betas]) if kind != LOSS_BCE else None
+    tarr = (ctypes.c_void_p * max(K, 1))(*[x.data_ptr() for x in thetas]) if K else None
+    buf, D0 = (image[0], image[1]) if image is not None else (None, 0)
+    with _lib.on_device(dev):
+        code = lib.nplda_dplda_update_loss_f32(_lib.ptr(paired), B, paired.stride(0), D1, _lib.ptr(s), _lib.ptr(t), kind,
+                                               _theta_array(loss_thetas), barr, LK, float(alpha), _lib.ptr(sums), _lib.ptr(loss),
+                                               _lib.ptr(dth), None, _lib.ptr(wlr), _lib.ptr(blr), _lib.ptr(m), _lib.ptr(v), tarr, K,
+                                               _lib.ptr(step), float(lr), float(beta1), float(beta2), float(eps), float(wd),
+                                               _lib.ptr(buf), int(D0), _lib.ptr(grad_out), _lib.ptr(loss_sum), _lib.ptr(ws),
+                                               ws.numel() * 4, _lib.current_stream())
+    _lib.check(code, "nplda_dplda_update_loss_f32")
+    return loss, dth, ws
+
+
 def weighted_moments(x, w0, w1=None, out=None):
     """nplda_weighted_moments_f32: x (B, n) fp32, w0/w1 (B,) fp32 -> (cnt (nc,), sum (nc, n), sq (nc, n, n)) doubles,
     nc = 2 if w1 is given else 1.  `out` = a previous result to accumulate into (streamed batches)."""

@@ -999,24 +999,37 @@ class FusedDPldaStep(FusedTrainStep):
             self._img_key = tuple((q.data_ptr(), q._version) for q in prm)
 
     def _recipe_step(self, x1, x2, t):
-        """xvector_DPlda_pytorch.py:35-43 with the LDA frozen, on one rank: FOUR launches — LDA + normalise + quadratic-form
-        score (paired rows kept) | loss, dL/ds, dL/dtheta | weighted moments | gradient fold + Adam + parameter and image
-        stores (nplda_dplda_update_f32).  Same arithmetic as the separate calls below (fold and Adam are the same device
+        """xvector_DPlda_pytorch.py:35-43 with the LDA frozen, on one rank: THREE launches up to 4096 pairs — LDA + normalise +
+        quadratic-form score (paired rows kept) | weighted moments, their weights dL/ds_i formed inline, + the loss block (loss,
+        dL/dtheta) | gradient fold + Adam + parameter and image stores (nplda_dplda_update_loss_f32) — four above that (the loss
+        as a launch of its own).  Same arithmetic as the separate calls below (loss, fold and Adam are the same device
         functions)."""
         ops = self._ops
         wlr, blr = (q.detach() for q in self.params[:2])
         s, paired = ops._gb_call(x1, x2, self._image(), True, True)
         ths = [th.detach() for th in self.thetas]
         lths = ths if self.kind == ops.LOSS_SOFTCDET else [self._zero]
-        loss, g, dth, _ = ops.loss_fwd_bwd(s, t, lths, self.betas_loss, self.alpha, self.kind)
         B = x1.shape[0]
-        self._mws = ops.dplda_update(paired, g, wlr, blr, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
-                                     self.eps, self.wd, thetas=ths, dtheta=dth if ths else None, image=self._img,
-                                     ws=self.__dict__.get("_mws_by_B", {}).get(B), loss=loss, loss_sum=self._acc())
-        self._acc_in_kernel = True  # (the update launch adds the step's loss to the running sum: _account leaves it alone)
+        ws0 = self.__dict__.get("_mws_by_B", {}).get(B)
+        # THREE launches where the batch fits the one-block loss (<= 4096 pairs): the loss rides in the moments launch
+        fused = None
+        if os.environ.get("NPLDA_DPLDA_LOSS_LAUNCH", "0") != "1":
+            fused = ops.dplda_update_loss(paired, s, t, lths, self.betas_loss, self.alpha, self.kind, wlr, blr, self.m, self.v,
+                                          self.step_count, self.lr, self.betas[0], self.betas[1], self.eps, self.wd, thetas=ths,
+                                          image=self._img, ws=ws0, loss_sum=self._acc())
+        if fused is not None:
+            loss, _, self._mws = fused
+            self.launches_per_step = ("3 in one graph replay: LDA + normalise + quadratic-form score | weighted moments with dL/ds "
+                                      "formed inline + the loss block | gradient fold + Adam + parameter and image stores")
+        else:
+            loss, g, dth, _ = ops.loss_fwd_bwd(s, t, lths, self.betas_loss, self.alpha, self.kind)
+            self._mws = ops.dplda_update(paired, g, wlr, blr, self.m, self.v, self.step_count, self.lr, self.betas[0], self.betas[1],
+                                         self.eps, self.wd, thetas=ths, dtheta=dth if ths else None, image=self._img, ws=ws0,
+                                         loss=loss, loss_sum=self._acc())
+            self.launches_per_step = ("4 in one graph replay: LDA + normalise + quadratic-form score | loss + dL/ds | weighted "
+                                      "moments | gradient fold + Adam + parameter and image stores")
         self.__dict__.setdefault("_mws_by_B", {})[B] = self._mws
-        self.launches_per_step = ("4 in one graph replay: LDA + normalise + quadratic-form score | loss + dL/ds | weighted moments | "
-                                  "gradient fold + Adam + parameter and image stores")
+        self._acc_in_kernel = True  # (the update launch adds the step's loss to the running sum: _account leaves it alone)
         return loss
 
     def _eager(self, x1, x2, t):

@@ -324,7 +324,8 @@ def test_dplda_quadform_image_one_launch(hip_lib, D1):
 
 
 @pytest.mark.parametrize("graph", [False, True])
-@pytest.mark.parametrize("lossname,D0,D1,B", [("crossentropy", 512, 170, 256), ("SoftCdet", 512, 170, 2048), ("SoftCdet", 128, 40, 100)])
+@pytest.mark.parametrize("lossname,D0,D1,B", [("crossentropy", 512, 170, 256), ("SoftCdet", 512, 170, 2048), ("SoftCdet", 128, 40, 100),
+                                               ("crossentropy", 128, 40, 4100), ("SoftCdet", 128, 40, 4096)])
 def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, monkeypatch, graph, lossname, D0, D1, B):
     """The recipe step of xvector_DPlda_pytorch.py:35-43 as four launches (score | loss | moments | nplda_dplda_update_f32:
     gradient fold + Adam + parameter and quadratic-form-image stores) against the seven separate launches it replaces
@@ -369,7 +370,8 @@ def test_dplda_recipe_step_in_four_launches_equals_the_separate_calls(hip_lib, m
 
     new, step_new = run(False)
     old, _ = run(True)
-    assert step_new.launches_per_step.startswith("4 ")
+    # (round 6: the loss rides in the moments launch up to 4096 pairs: three launches; a launch of its own above that)
+    assert step_new.launches_per_step.startswith("3 " if B <= 4096 else "4 ")
     for i, ((la, sa), (lb, sb)) in enumerate(zip(new, old)):
         assert la == lb, (i, la, lb)
         for k in sa:
