@@ -48,3 +48,15 @@ def test_register_budget_of_the_cohort_gemm():
     res = _resources("nplda_cohort.hip")
     gemm = [v for k, v in res.items() if "cohort_gemm_kernel" in k]
     assert len(gemm) == 1 and gemm[0]["Occupancy"] >= 3 and gemm[0]["ScratchSize"] == 0
+
+
+def test_register_budget_of_the_fused_cohort_kernel():
+    """cohort_fused2_kernel, the forms the library launches by default (8 waves per block, RGW = 2 for full row tiles, RGW = 1
+    for calls with few rows): one 512-thread block per CU = two waves per SIMD = at most 256 registers, and NO scratch — a spill
+    inside the 304-MFMA tile loop is paid in matrix-pipe time (round 6: every VALU / memory instruction is).  The 16-wave forms
+    (NPLDA_COHORT_NW=16, 128 registers) are opt-in and may spill a few bytes."""
+    res = _resources("nplda_cohort_fused.hip")
+    fused = {k: v for k, v in res.items() if "cohort_fused2_kernel" in k and "ELi8EEEvNS_9FusedArgsE" in k}
+    assert len(fused) >= 8, sorted(res)
+    for k, v in fused.items():
+        assert v["ScratchSize"] == 0 and v["VGPRs"] + v["AGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)
