@@ -47,7 +47,11 @@ __global__ __launch_bounds__(256, 2) void nplda_fwd_small_kernel(const FwdArgs a
     constexpr int HS = NBF;                    // the half slot (HALF only)
     // 512-d pairs at the recipe sizes: layer 1 split over the waves by K (nplda_l1_ksplit.h), its LDS exchange region reused
     // for the y tiles
-    constexpr bool KSPLIT = KS1C == 32 && (NB == 10 || NB == 11) && (MODE == MODE_PAIR || MODE == MODE_TRAIN);
+    // (round 6: also the GaussianBackend / DPlda mode at NB = 11 — the reference's shipped D1 = 170; its layer 1 is the same GEMM
+    // on the same image layout.  At NB = 10 the K-split hands back the two left-over blocks split by SIDE, which only the pair
+    // modes' HALF slot takes)
+    constexpr bool KSPLIT = KS1C == 32 && (((NB == 10 || NB == 11) && (MODE == MODE_PAIR || MODE == MODE_TRAIN)) ||
+                                           (NB == 11 && MODE == MODE_GB));
     __shared__ f32x4 lbuf[KSPLIT ? l1k_lds_f4(NB) : 2 * NB * 64];
     f32x4 (*ylds)[NB][64] = reinterpret_cast<f32x4 (*)[NB][64]>(lbuf);  // normalised layer-1 output, accumulator layout
     __shared__ float red[NW][2][16];         // cross-wave partials (norms, then scores)

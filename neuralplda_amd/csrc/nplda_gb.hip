@@ -6,6 +6,7 @@
 // (B x 2 D1)(2 D1 x 2 D1) GEMMs of the reference collapse to one — S = x^T (L_n - L_t) x + x^T v + c —
 // evaluated as four chained fp32-MFMA block GEMMs straight from the layer-1 accumulators (kernel:
 // MODE_GB in nplda_fwd_kernel.h).  v and c are computed in fp64 when the image is packed.
+#include <cstdlib>
 #include "nplda_fwd_dispatch.h"
 
 namespace {
@@ -173,15 +174,23 @@ int launch_gb_small(FwdArgs a, const GbLayout& L, hipStream_t st) {
     const long long blocks = (a.n + 15) / 16;
     dim3 grid((unsigned)blocks), block(256);
 #define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE_GB>), grid, block, 0, st, a)
+    // 512-d x-vectors (KS1 = 32) at the recipe sizes: the fully unrolled K loop, as the NeuralPlda modes have had it since round 2
+    // (nplda_fwd_small.h: a loop whose loads cross the back-edge gets an s_waitcnt vmcnt(0) at its head — the prefetch ring
+    // drained every four k16-steps).  NPLDA_GB_NO_UNROLL=1: the rolled loop (A/B runs).
+    static const bool no_unroll = getenv("NPLDA_GB_NO_UNROLL") != nullptr && getenv("NPLDA_GB_NO_UNROLL")[0] == '1';
+#define NPLDA_LAUNCH32(NBV)                                                                                                \
+    if (L.KS1 == 32 && a.D0 == 512 && !no_unroll) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE_GB, 32>), grid, block, 0, st, a); \
+    else NPLDA_LAUNCH(NBV)
     switch (L.NB) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
         case 8: NPLDA_LAUNCH(8); break;
-        case 10: NPLDA_LAUNCH(10); break;
-        case 11: NPLDA_LAUNCH(11); break;
+        case 10: NPLDA_LAUNCH32(10); break;
+        case 11: NPLDA_LAUNCH32(11); break;
         case 12: NPLDA_LAUNCH(12); break;
         default: return NPLDA_EUNSUPPORTED;
     }
+#undef NPLDA_LAUNCH32
 #undef NPLDA_LAUNCH
     return nplda_launch_status();
 }
