@@ -10,6 +10,7 @@
 // fp64 reduction over the k-groups -> bitwise deterministic.  Bound: MFMA at large B (2 n^2 flop per row and
 // class, halved by symmetry), launch latency at training-batch sizes.
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 
 #include "nplda_adam_math.h"
 #include "nplda_common.h"
@@ -408,7 +409,12 @@ MomPlan mom_plan(long long B, int n) {
     p.ntile = p.T * (p.T + 1) / 2;
     long long kg = 512 / p.ntile;  // ~2 blocks per CU in one wave of blocks
     if (kg < 1) kg = 1;
-    const long long maxkg = (B + 15) / 16;
+    // at least 64 rows per k-group (16 per wave: four k4-steps) — NPLDA_MOM_MIN_ROWS for A/B runs.  With 16 (one k4-step per
+    // wave) a 256-row batch was 16 k-groups x 21 tiles = 336 blocks that each staged 64 KB through LDS and wrote a 16 KB slab
+    // tile for four MFMAs' worth of rows, and the fold kernel summed 16 slabs per element (round 6: 13.4 + 8.9 us)
+    static const long long min_rows = getenv("NPLDA_MOM_MIN_ROWS") ? atoll(getenv("NPLDA_MOM_MIN_ROWS")) : 64;
+    const long long mr = min_rows < 16 ? 16 : min_rows;
+    const long long maxkg = (B + mr - 1) / mr;
     if (kg > maxkg) kg = maxkg < 1 ? 1 : maxkg;
     long long rpg = (B + kg - 1) / kg;
     rpg = (rpg + 15) / 16 * 16;
