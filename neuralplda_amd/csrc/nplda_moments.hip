@@ -355,6 +355,18 @@ __global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) 
     const int which = b / (TB * TB);  // 0: G12 + G21, 1: G11 + G22
     const int I = (b % (TB * TB)) / TB, J = b % TB;
     const int r = tid >> 4, c = tid & 15;
+    // the element this thread will update: its parameter and moments are asked for NOW, next to the slab loads — fetched
+    // inside apply(), behind the slab sums and the barrier, they were a second memory round trip of an 8.5 us kernel
+    float pre_p = 0.f, pre_m = 0.f, pre_v = 0.f;
+    {
+        const int i0 = 16 * I + r, j0 = 16 * J + c;
+        if (UPDATE && i0 < D1 && j0 < D1) {
+            const size_t e0 = (size_t)which * n2 + (size_t)i0 * D1 + j0;
+            pre_p = a.wlr[e0];
+            pre_m = a.m[e0];
+            pre_v = a.v[e0];
+        }
+    }
     // source tiles (row block, column block in units of 16 inside a D1 x D1 block; row / column offsets of that block)
     const bool tr1 = which == 1 && I > J;        // G11 tile below the diagonal: its mirror image, transposed
     const int rb1 = tr1 ? J : I, cb1 = tr1 ? I : J;
@@ -381,7 +393,11 @@ __global__ __launch_bounds__(256) void dplda_fold_kernel(const DpldaFoldArgs a) 
         const float gr = (float)(v1 + v2);
         if (a.dw) a.dw[e] = gr;
         if constexpr (UPDATE) {
-            const float pn = apply(e, gr, a.wlr + e);
+            float m = pre_m, v = pre_v;  // (apply() with the three loads taken at the top)
+            const float pn = nplda_adam::update(pre_p, gr, m, v, ac);
+            a.wlr[e] = pn;
+            a.m[e] = m;
+            a.v[e] = v;
             if (a.image) {
                 // gb_pack_kernel (dplda): block (h_out, h_in) of G at [f][k] is Ww[f][k] on the diagonal (which == 1), Wb[f][k]
                 // off it (which == 0); fragment element (kb, nb, lane, e4) holds f = 16 nb + (lane & 15), k = 16 kb + 4 (lane >> 4) + e4
