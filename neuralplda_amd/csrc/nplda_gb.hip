@@ -8,6 +8,7 @@
 // MODE_GB in nplda_fwd_kernel.h).  v and c are computed in fp64 when the image is packed.
 #include <cstdlib>
 #include "nplda_fwd_dispatch.h"
+#include "nplda_gb_half.h"
 
 namespace {
 
@@ -139,7 +140,8 @@ __global__ __launch_bounds__(512) void gb_vc_dplda_kernel(const float* __restric
     }
     if (threadIdx.x == 0) {
         out[L.oc] = blr[0];
-        out[L.oc + 1] = out[L.oc + 2] = out[L.oc + 3] = 0.f;
+        out[L.oc + 1] = 1.0f;  // block-symmetric image (G00 = G11, G01 = G10, v0 = v1): nplda_gb_half.h takes ONE pass
+        out[L.oc + 2] = out[L.oc + 3] = 0.f;
     }
 }
 
@@ -171,6 +173,25 @@ int launch_gb(FwdArgs a, const GbLayout& L, hipStream_t st) {
 
 // batches of <= 16 384 pairs: the feature-split schedule (4 waves share a 16-pair tile), as for NeuralPlda
 int launch_gb_small(FwdArgs a, const GbLayout& L, hipStream_t st) {
+    // up to ONE 8-pair half tile per CU: nplda_gb_half.h (both sides of a pair in one MFMA row group: half the layer-1 MFMAs
+    // per block, twice the blocks; NPLDA_GB_NO_HALF=1: the 16-pair tiles, A/B runs)
+    static const bool no_half = getenv("NPLDA_GB_NO_HALF") != nullptr && getenv("NPLDA_GB_NO_HALF")[0] == '1';
+    if (!no_half && a.n <= 8LL * mid_cus() && (L.NB == 10 || L.NB == 11 || L.NB == 2 || L.NB == 4 || L.NB == 8 || L.NB == 12)) {
+        dim3 hgrid((unsigned)((a.n + 7) / 8)), hblock(256);
+#define NPLDA_LAUNCH_H(NBV)                                                                                              \
+    if (L.KS1 == 32 && a.D0 == 512) hipLaunchKernelGGL((nplda_gb_half_kernel<NBV, 32>), hgrid, hblock, 0, st, a);        \
+    else hipLaunchKernelGGL((nplda_gb_half_kernel<NBV, 0>), hgrid, hblock, 0, st, a)
+        switch (L.NB) {
+            case 2: NPLDA_LAUNCH_H(2); break;
+            case 4: NPLDA_LAUNCH_H(4); break;
+            case 8: NPLDA_LAUNCH_H(8); break;
+            case 10: NPLDA_LAUNCH_H(10); break;
+            case 11: NPLDA_LAUNCH_H(11); break;
+            default: NPLDA_LAUNCH_H(12); break;
+        }
+#undef NPLDA_LAUNCH_H
+        return nplda_launch_status();
+    }
     const long long blocks = (a.n + 15) / 16;
     dim3 grid((unsigned)blocks), block(256);
 #define NPLDA_LAUNCH(NBV) hipLaunchKernelGGL((nplda_fwd_small_kernel<NBV, MODE_GB>), grid, block, 0, st, a)
