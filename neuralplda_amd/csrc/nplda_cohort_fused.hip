@@ -143,7 +143,9 @@ struct RowThrArgs {
     const double* vec64;
     float zhi, sgn;
     float* crow; float* trow; double* mean64;
-    int ntiles;           // tiles of 128 rows (8 waves x 16)
+    int ntiles;           // tiles of 16 wpt rows
+    int wpt;              // waves of a block that take a 16-row group (8: 128-row tiles; fewer for calls with few rows, so that
+                          // a 2 750-row shard is 86 blocks instead of 22 — the other waves only help to load the image)
     unsigned* ctl_zero;   // a prepared cohort (no pre-pass to do it): the call's 64-word control block, zeroed by block 0 here
 };
 
@@ -157,8 +159,8 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
     for (int i = tid; i < NB * (NB + 1) / 2 * 64; i += 512) cimg[i] = reinterpret_cast<const f32x4*>(a.frag)[i];
     __syncthreads();
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-        const long long r0 = ((long long)tile * 8 + wave) * 16;
-        if (r0 >= a.R) continue;  // wave-uniform
+        const long long r0 = ((long long)tile * a.wpt + wave) * 16;
+        if (wave >= a.wpt || r0 >= a.R) continue;  // wave-uniform
         const long long row = r0 + j < a.R ? r0 + j : a.R - 1;
         const float* zp = a.zr + row * a.ldz + 4 * g;
         f32x4 zf[NB], acc[NB];
@@ -1074,8 +1076,11 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
         if (int rc = fused_prepass(F, z_coh, q_coh, M, ldz, P, Mp, st)) return rc;
     }
     {   // row means and thresholds
+        // rows per block: 128, or fewer (down to 32) when 128-row tiles would leave most CUs without a block
+        int wpt = 8;
+        while (wpt > 2 && (R + 16 * wpt - 1) / (16 * wpt) < resident / 2) wpt >>= 1;
         RowThrArgs ra = {z_rows, q_rows, R, ldz, frag, vec, vec64, p.zhi, lowest ? 1.0f : -1.0f, crow, trow, mean64,
-                         (int)((R + 127) / 128), prepass ? nullptr : ctl};
+                         (int)((R + 16 * wpt - 1) / (16 * wpt)), wpt, prepass ? nullptr : ctl};
         const unsigned grid = (unsigned)(ra.ntiles < resident ? ra.ntiles : resident);
         const size_t shm = (size_t)ksteps * (ksteps + 1) / 2 * 1024;
 #define NPLDA_LAUNCH(NBV)                                                                                             \
