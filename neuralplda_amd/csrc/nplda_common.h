@@ -71,6 +71,22 @@ static inline int nplda_launch_status() {
 
 static inline bool nplda_aligned16(const void* p) { return (((uintptr_t)p) & 15u) == 0; }
 
+// An MFMA accumulator fragment of a (16 features x 16 rows) block has lane 16 g + j on row j, features 4 g .. 4 g + 3: stored
+// as it is, CONSECUTIVE lanes write 16 bytes to sixteen different rows, and a CU gets 15 B / clk out of such stores where
+// pieces of 64 contiguous bytes per four lanes get 29 - 43 (tools/exp_store_patterns.hip, round 6).  This moves the rows to
+// the lane's high bits — lane L receives row L >> 2, features 4 (L & 3) .. — by four ds_bpermute (the LDS crossbar, no memory);
+// the caller stores the result at row (L >> 2), column 16 b + 4 (L & 3).  All 64 lanes must be active.
+// (Component by component: written as a loop over z[r] of a const reference hipcc 7.2 permuted z[0] four times.)
+__device__ __forceinline__ f32x4 frag_rows_to_high_lanes(const f32x4& z, int lane) {
+    const int src4 = 4 * (16 * (lane & 3) + (lane >> 2));
+    f32x4 t;
+    t.x = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(z.x)));
+    t.y = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(z.y)));
+    t.z = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(z.z)));
+    t.w = __int_as_float(__builtin_amdgcn_ds_bpermute(src4, __float_as_int(z.w)));
+    return t;
+}
+
 // v + (v of lane ^ mask).  For mask = 16 / 32 (whole rows of 16 lanes: the MFMA k-groups) gfx950 exchanges rows on the
 // VALU: v_permlane16_swap(a, b) swaps the odd rows of a with the even rows of b, v_permlane32_swap the upper half of a
 // with the lower half of b; with a = b = v the two results are (own, partner) in some order, and the sum is bit-identical

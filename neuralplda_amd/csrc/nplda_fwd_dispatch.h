@@ -168,13 +168,16 @@ static inline int launch_fwd_mid(FwdArgs a, const NpldaLayout& L, hipStream_t st
     const long long r = nh - grid * (c - 1);
     if (c > 0x7fffffffLL) return NPLDA_EINVAL;
     const bool half = !(r == grid && (c & 1) == 0);  // some block ends on an odd half tile
-#define NPLDA_LAUNCH(NBV, HV) \
-    hipLaunchKernelGGL((nplda_fwd_mid_kernel<NBV, EMBED, HV>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r)
+    const bool idx = a.ia != nullptr;  // rows through an index: a kernel of its own (mid_addr)
+#define NPLDA_LAUNCH(NBV, HV, IV) \
+    hipLaunchKernelGGL((nplda_fwd_mid_kernel<NBV, EMBED, HV, IV>), dim3((unsigned)grid), dim3(256), 0, st, a, (int)c, (int)r)
+#define NPLDA_LAUNCH_H(NBV, HV) do { if (idx) { NPLDA_LAUNCH(NBV, HV, true); } else { NPLDA_LAUNCH(NBV, HV, false); } } while (0)
     switch (L.NB) {
-        case 10: if (half) { NPLDA_LAUNCH(10, true); } else { NPLDA_LAUNCH(10, false); } break;
-        case 11: if (half) { NPLDA_LAUNCH(11, true); } else { NPLDA_LAUNCH(11, false); } break;
+        case 10: if (half) NPLDA_LAUNCH_H(10, true); else NPLDA_LAUNCH_H(10, false); break;
+        case 11: if (half) NPLDA_LAUNCH_H(11, true); else NPLDA_LAUNCH_H(11, false); break;
         default: return NPLDA_EUNSUPPORTED;
     }
+#undef NPLDA_LAUNCH_H
 #undef NPLDA_LAUNCH
     return nplda_launch_status();
 }

@@ -86,36 +86,48 @@ struct MidAddr {
 };
 // EMBED: the rows are single rows of ONE table (a.xa); a "tile" is 32 consecutive rows, its two "sides" the two halves.
 // A group starts at HALF tile h0 (8 pairs / 16 embedding rows each): pair 8 h0 / row 16 h0.
-template <int NB, bool EMBED = false, bool HALF = true>  // HALF = false: T is never 0 (the checks fold away)
+// IDX: the rows are named through a.ia / a.ib.  A template parameter, not a test of the pointers: as a (uniform) branch around
+// each index load the compiler's wait placement at the joins made every group wait for the stores and loads in flight —
+// 4.5 k cycles of an embedding group's 73 k, ~1 k of a pair group's (round 6, tools/exp_mid.hip).
+template <int NB, bool EMBED = false, bool HALF = true, bool IDX = false>  // HALF = false: T is never 0 (the checks fold away)
 __device__ __forceinline__ void mid_addr(const FwdArgs& a, long long h0, int Tin, int wave, int lane, MidAddr<NB>& A) {
     const int T = (!HALF && Tin == 0) ? 1 : Tin;
     if (!HALF) __builtin_assume(T != 0);
     const int swz = mid_swz<NB>(T, wave);
     const int rgm = T == 0 ? 0 : 2 * T - 1;
+    long long rows[4];
+    int sides[4];
 #pragma unroll
     for (int rho = 0; rho < 4; ++rho) {
         const int rg = (rho & rgm) ^ swz;  // T = 1: slots 2, 3 repeat 0, 1 (loaded, never used); T = 0: all repeat 0
         // pair mode, T = 0: lanes j < 8 hold the x1 rows of pairs 8 h0 + j, lanes j >= 8 the x2 rows of the same pairs
-        const int side = T == 0 ? ((lane >> 3) & 1) : (rg & 1);
-        long long row = EMBED ? h0 * 16 + 16 * rg + (lane & 15)
-                              : (T == 0 ? h0 * 8 + (lane & 7) : h0 * 8 + (rg >> 1) * 16 + (lane & 15));
-        if (row >= a.n) row = a.n - 1;
+        sides[rho] = T == 0 ? ((lane >> 3) & 1) : (rg & 1);
+        const long long row = EMBED ? h0 * 16 + 16 * rg + (lane & 15)
+                                    : (T == 0 ? h0 * 8 + (lane & 7) : h0 * 8 + (rg >> 1) * 16 + (lane & 15));
+        rows[rho] = row >= a.n ? a.n - 1 : row;
+    }
+    if constexpr (IDX) {
+        // rows named by index (nplda_embed_rows_f32: one table; indexed pairs: the pair's rows of the x-vector table) — the
+        // group's index loads leave together, one wait for all of them
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) rows[rho] = (EMBED || !sides[rho] ? a.ia : a.ib)[rows[rho]];
+#pragma unroll
+        for (int rho = 0; rho < 4; ++rho) rows[rho] = rows[rho] < 0 ? 0 : (rows[rho] < a.ntab ? rows[rho] : a.ntab - 1);
+    }
+#pragma unroll
+    for (int rho = 0; rho < 4; ++rho) {
+        const long long row = rows[rho];
         if (EMBED) {
-            if (a.ia != nullptr) {  // rows named by index (nplda_embed_rows_f32): one table, the gather folded in
-                row = a.ia[row];
-                row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
-                A.xr[rho] = a.xa + row * a.ldx + 4 * (lane >> 4) + 32 * wave;
-                continue;
-            }
-            const bool second = a.nsplit > 0 && row >= a.nsplit;  // two-table form: the row's own table
-            A.xr[rho] = (second ? a.xb : a.xa) + (second ? row - a.nsplit : row) * a.ldx + 4 * (lane >> 4) + 32 * wave;
-            continue;
+            // two-table form: the row's own table — as a byte distance added to ONE base (a per-lane choice between the two
+            // pointer FIELDS is compiled as an indexed read of a scratch copy of them: 16 scratch loads and vmcnt(0) waits
+            // per group, round 6)
+            const bool second = !IDX && a.nsplit > 0 && row >= a.nsplit;
+            const long long dxb = reinterpret_cast<const char*>(a.xb) - reinterpret_cast<const char*>(a.xa);
+            const float* pr = a.xa + (second ? row - a.nsplit : row) * a.ldx + 4 * (lane >> 4) + 32 * wave;
+            A.xr[rho] = reinterpret_cast<const float*>(reinterpret_cast<const char*>(pr) + (second ? dxb : 0LL));
+        } else {
+            A.xr[rho] = (sides[rho] ? a.xb : a.xa) + row * a.ldx + 4 * (lane >> 4) + 32 * wave;  // k16-steps 2 w, 2 w + 1 (+ 8 m)
         }
-        if (a.ia != nullptr) {  // indexed pairs: the pair's row of the x-vector table (one dependent load per group, a group ahead)
-            row = (side ? a.ib : a.ia)[row];
-            row = row < 0 ? 0 : (row < a.ntab ? row : a.ntab - 1);
-        }
-        A.xr[rho] = (side ? a.xb : a.xa) + row * a.ldx + 4 * (lane >> 4) + 32 * wave;  // k16-steps 2 w, 2 w + 1 (+ 8 m)
     }
 #pragma unroll
     for (int s = 0; s < NB; ++s) A.voff[s] = (unsigned)(mid_blk<NB>(T, s, wave) * 64 + lane) * 16u;
@@ -144,7 +156,7 @@ __device__ __forceinline__ void mid_fetchx(const MidAddr<NB>& A, MidRing<NB>& R,
 // One group of T tiles (T = 0: one half tile) starting at half tile `tile0` (8 pairs / 16 embedding rows per half); the next
 // group (TN tiles from half tile tile_n; the block's last group names itself) gets its first loads from here.  LDS: red (the exchange of the layer-1 partial sums; reused as the y tiles of
 // layer 2), ssb / scb (row norms, scores), zx (left-over z of the other side), cv (b1, b2, Q, P).
-template <int NB, int T, bool EMBED = false, bool HALF = true>
+template <int NB, int T, bool EMBED = false, bool HALF = true, bool IDX = false>
 __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int TN, long long tile_n, MidRing<NB>& R,
                                           int wave, int lane, f32x4* red, float (*ssb)[4][16], float (*scb)[2][16],
                                           f32x4 (*zx)[3][64], const f32x4* cv) {
@@ -163,8 +175,10 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
 
     NPLDA_MSTAMP(0);
     MidAddr<NB> A, AN;
-    mid_addr<NB, EMBED, HALF>(a, tile0, T, wave, lane, A);
-    mid_addr<NB, EMBED, HALF>(a, tile_n, TN, wave, lane, AN);
+    mid_addr<NB, EMBED, HALF, IDX>(a, tile0, T, wave, lane, A);
+    NPLDA_MSTAMP(11);
+    mid_addr<NB, EMBED, HALF, IDX>(a, tile_n, TN, wave, lane, AN);
+    NPLDA_MSTAMP(12);
     bool lo_valid = true;  // NB = 11, T = 1: wave 3 owns no left-over block; T = 0: the LB left-over units go to waves 0 .. LB - 1
     if constexpr (NB == 11 && T == 1) lo_valid = wave < 3;
     if constexpr (T == 0) lo_valid = wave < NB - 8;
@@ -388,10 +402,22 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         float qp[RG];
 #pragma unroll
         for (int rho = 0; rho < RG; ++rho) qp[rho] = 0.f;
+        // z leaves in 64-byte pieces per four lanes (frag_rows_to_high_lanes, nplda_common.h): in the accumulator's own lane
+        // order a block's 40 KB of z took 2.1 k cycles to issue, 1.5 k this way (tools/exp_mid.hip)
+#ifndef NPLDA_MID_TSTORE_NB11
+#define NPLDA_MID_TSTORE_NB11 1
+#endif
+        constexpr bool TSTORE = NB == 10 || NPLDA_MID_TSTORE_NB11 != 0;
         auto out_unit = [&](const f32x4& z, int b, int rho, bool valid) {
             const int rg = rho ^ swz;
-            const long long row = tile0 * 16 + 16 * rg + j;
-            if (valid && row < a.n) *reinterpret_cast<f32x4*>(a.out_z + row * a.ldz + 16 * b + 4 * g) = z;
+            if constexpr (TSTORE) {
+                const f32x4 zt = frag_rows_to_high_lanes(z, lane);
+                const long long srow = tile0 * 16 + 16 * rg + (lane >> 2);
+                if (valid && srow < a.n) *reinterpret_cast<f32x4*>(a.out_z + srow * a.ldz + 16 * b + 4 * (lane & 3)) = zt;
+            } else {
+                const long long row = tile0 * 16 + 16 * rg + j;
+                if (valid && row < a.n) *reinterpret_cast<f32x4*>(a.out_z + row * a.ldz + 16 * b + 4 * g) = z;
+            }
             if (valid) {
                 const f32x4 q = Qp[4 * b + g];
 #pragma unroll
@@ -406,6 +432,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
         for (int i = 0; i < LS; ++i)
 #pragma unroll
             for (int rho = 0; rho < LR; ++rho) out_unit(zL[i][rho], blk(8 + i), rho, lo_valid);
+        NPLDA_MSTAMP(13);
         if (a.out_q != nullptr) {
 #pragma unroll
             for (int rho = 0; rho < RG; ++rho) {
@@ -499,7 +526,7 @@ __device__ __forceinline__ void mid_group(const FwdArgs& a, long long tile0, int
 // pairs — 2.5 tiles per CU — ran three tiles on half the CUs).
 // HALF = false: every block's count is even (the host checks) — the T = 0 group is not instantiated, and the kernel is the
 // round-4 one (with it in, the compiler's register assignment for the shared rings costs the even sizes ~1 %).
-template <int NB, bool EMBED = false, bool HALF = true>
+template <int NB, bool EMBED = false, bool HALF = true, bool IDX = false>
 __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, int c, int r) {
     constexpr int UWM = MidCfg<NB, 2>::UW > MidCfg<NB, 1>::UW ? MidCfg<NB, 2>::UW : MidCfg<NB, 1>::UW;
     __shared__ f32x4 red[4 * 3 * UWM * 64];
@@ -517,7 +544,7 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
     MidRing<NB> R;
     {
         MidAddr<NB> A0;
-        mid_addr<NB, EMBED, HALF>(a, h, group_t(k), wave, lane, A0);
+        mid_addr<NB, EMBED, HALF, IDX>(a, h, group_t(k), wave, lane, A0);
 #pragma unroll
         for (int i = 0; i < 3; ++i)
 #pragma unroll
@@ -534,16 +561,16 @@ __global__ __launch_bounds__(256, 1) void nplda_fwd_mid_kernel(const FwdArgs a, 
     // (the block's last group names itself as its successor: a harmless re-read of its own first rows)
     for (; k >= 4; k -= 4, h += 4) {
         const bool more = k > 4;
-        mid_group<NB, 2, EMBED, HALF>(a, h, more ? group_t(k - 4) : 2, more ? h + 4 : h, R, wave, lane, red, ssb, scb, zx, cv);
+        mid_group<NB, 2, EMBED, HALF, IDX>(a, h, more ? group_t(k - 4) : 2, more ? h + 4 : h, R, wave, lane, red, ssb, scb, zx, cv);
     }
     if (k >= 2) {
         const bool more = k > 2;
-        mid_group<NB, 1, EMBED, HALF>(a, h, more ? 0 : 1, more ? h + 2 : h, R, wave, lane, red, ssb, scb, zx, cv);
+        mid_group<NB, 1, EMBED, HALF, IDX>(a, h, more ? 0 : 1, more ? h + 2 : h, R, wave, lane, red, ssb, scb, zx, cv);
         k -= 2;
         h += 2;
     }
     if constexpr (HALF) {
-        if (k == 1) mid_group<NB, 0, EMBED, true>(a, h, 0, h, R, wave, lane, red, ssb, scb, zx, cv);
+        if (k == 1) mid_group<NB, 0, EMBED, true, IDX>(a, h, 0, h, R, wave, lane, red, ssb, scb, zx, cv);
     }
 }
 

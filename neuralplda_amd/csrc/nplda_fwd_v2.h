@@ -274,6 +274,8 @@ __global__ __launch_bounds__(WAVES * 64, 2) void nplda_fwd_v2_kernel(const FwdAr
                 qa = fmaf(q[r] * zA[nb][r], zA[nb][r], qa);
                 qb = fmaf(q[r] * zB[nb][r], zB[nb][r], qb);
             }
+            // (rows moved to the lanes' high bits for 64-byte pieces — nplda_common.h — measured here and no faster: with two
+            // blocks per CU the stores drain under the other block's MFMAs; round 6)
             if (okA) *reinterpret_cast<f32x4*>(a.out_z + rowA * a.ldz + 16 * nb + 4 * g) = zA[nb];
             if (okB) *reinterpret_cast<f32x4*>(a.out_z + rowB * a.ldz + 16 * nb + 4 * g) = zB[nb];
         }

@@ -139,7 +139,6 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
 #pragma unroll
     for (int i = 0; i < KSW - 1; ++i) {
         const int wnext = mid_w1_step<NB>(i + 1, wave);
-        stage_step(i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
@@ -149,13 +148,17 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
                     acc[s][rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i & 1][s][r], xf[i % XD][rho][r],
                                                                        (i == 0 && r == 0) ? zero4 : acc[s][rho], 0, 0, 0);
                 refill(i, r * NB + s, wnext);
+                // The staged copies leave BEHIND the step's refills.  vmcnt counts stores and loads in one order: issued in
+                // front of them (at the head of the step, as until round 6), the stores had to be acknowledged before the
+                // step's last weight fragment counted as arrived — 18 MFMAs later; here the next wait that covers them is
+                // the next step's last fragment, ~58 MFMAs on.
+                if (r == 2 && s == 0) stage_step(i);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
     }
     {   // the last step block-major: a block's sums are final after its 4 RG MFMAs and leave for LDS under the next block's
         constexpr int i = KSW - 1;
-        stage_step(i);
 #pragma unroll
         for (int s = 0; s < NB; ++s) {
 #pragma unroll
@@ -163,6 +166,7 @@ __device__ __forceinline__ int l1_ksplit_tile(const float* packed, size_t image_
 #pragma unroll
                 for (int rho = 0; rho < RG; ++rho)
                     acc[s][rho] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i & 1][s][r], xf[i % XD][rho][r], acc[s][rho], 0, 0, 0);
+            if (s == NB - 1) stage_step(i);  // (nothing waits on the memory counter again before the exchange)
             if (s > 0) {
 #pragma unroll
                 for (int rho = 0; rho < RG; ++rho) export_unit(s - 1, rho, acc[s - 1][rho]);

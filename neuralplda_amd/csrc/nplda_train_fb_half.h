@@ -183,13 +183,13 @@ __global__ __launch_bounds__(256, 2) void train_fb_half_kernel(const TrainFbArgs
 #pragma unroll
     for (int i = 0; i < KSW - 1; ++i) {
         const int wnext = w1step(i + 1);
-        stage_step(i);
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
 #pragma unroll
             for (int s = 0; s < NB; ++s) {
                 acc[s] = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[i & 1][s][r], xf[i % XD][r], (i == 0 && r == 0) ? zero4 : acc[s], 0, 0, 0);
                 refill(i, r * NB + s, wnext);
+                if (r == 2 && s == 0) stage_step(i);  // behind the step's refills: nplda_l1_ksplit.h
                 __builtin_amdgcn_sched_barrier(0);
             }
         }

@@ -333,11 +333,13 @@ def test_score_pairs_rows_equals_gather_then_score(hip_lib, D, B):
 
 
 @pytest.mark.parametrize("D", [150, 170])
-@pytest.mark.parametrize("N", [8193, 10000, 12304, 22000, 40001, 100003])  # (12 304 = 769 half tiles of 16 rows)
+@pytest.mark.parametrize("N", [17, 200, 1000, 4095, 8193, 10000, 12304, 22000, 40001, 100003])  # (12 304 = 769 half tiles of 16 rows)
 def test_mid_regime_embedding_rows_match_oracle(hip_lib, D, N):
     """extract_plda_embeddings at the row counts of cfg3 (10 000 cohort utterances, 22 000 enroll / test ids) and of a
     score file's distinct utterances: the balanced-tile kernel's embedding mode (32 rows per tile, odd tile counts, a ragged
-    last tile) — z, the zero padding columns and the self term q against the fp64 oracle."""
+    last tile) — z, the zero padding columns and the self term q against the fp64 oracle.  (Round 6: the kernel moves every
+    accumulator fragment's rows to the lanes' high bits before it stores z — 64-byte pieces per four lanes; the small row counts
+    run it on lone half tiles and one- and two-tile groups.)"""
     from neuralplda_amd import ops
     rng = np.random.default_rng(N + D)
     p = rand_params(rng, 512, D, D)
@@ -345,7 +347,7 @@ def test_mid_regime_embedding_rows_match_oracle(hip_lib, D, N):
     packed = ops.pack_params(*to_dev(p))
     z, q = ops.embed(torch.from_numpy(x).cuda(), packed)
     z, q = z.cpu().numpy(), q.cpu().numpy()
-    sel = np.unique(np.concatenate([rng.choice(N, 3000, replace=False), np.arange(64), np.arange(N - 64, N)]))
+    sel = np.unique(np.concatenate([rng.choice(N, min(3000, N), replace=False), np.arange(min(64, N)), np.arange(max(N - 64, 0), N)]))
     zr = orc.extract_plda_embeddings(x[sel], p, np.float64)
     assert z.shape == (N, packed.ldz)
     np.testing.assert_allclose(z[sel][:, :D], zr, atol=2e-6, rtol=1e-5)

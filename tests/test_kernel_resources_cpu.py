@@ -60,3 +60,15 @@ def test_register_budget_of_the_fused_cohort_kernel():
     assert len(fused) >= 8, sorted(res)
     for k, v in fused.items():
         assert v["ScratchSize"] == 0 and v["VGPRs"] + v["AGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)
+
+
+def test_balanced_tile_kernels_keep_their_row_pointers_out_of_scratch():
+    """nplda_fwd_mid_kernel at NB = 10 (D = 150), all eight forms (pair / embed, half tiles or not, rows by index or not): no
+    scratch.  Round 6: the embedding form chose a row's table with `second ? a.xb : a.xa` on two pointer FIELDS of the by-value
+    argument struct; hipcc compiled that as an indexed read of a scratch copy of the struct — sixteen scratch loads, each with
+    an s_waitcnt vmcnt(0), at the head of every group (csrc/nplda_fwd_mid.h, mid_addr)."""
+    res = _resources("nplda_forward.hip")
+    mid = {k: v for k, v in res.items() if "nplda_fwd_mid_kernelILi10E" in k}
+    assert len(mid) == 8, sorted(k for k in res if "mid_kernel" in k)
+    for k, v in mid.items():
+        assert v["ScratchSize"] == 0, (k, v)

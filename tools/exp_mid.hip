@@ -68,6 +68,7 @@ int main(int argc, char** argv) {
             printf("B=%lld last group of the middle block (us since group entry / cycles):\n", B);
             for (int i = 1; i <= 10; ++i)
                 printf("  %-22s %7.2f us  %8llu cyc  (+%6llu)\n", names[i], (st[i] - st[0]) / 100.0, st[16 + i] - st[16], st[16 + i] - st[16 + i - 1]);
+            printf("  addr A %llu, addr next %llu (cycles since entry); z stores issued +%llu after layer 2\n", st[16 + 11] - st[16], st[16 + 12] - st[16], st[16 + 13] - st[16 + 9]);
             printf("  clock over the group: %.0f MHz\n", (double)(st[26] - st[16]) / ((st[10] - st[0]) / 100.0));
         }
         return 0;
