@@ -202,32 +202,66 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
     }
     const float* src = GIVEN ? a.dz : a.z;  // GIVEN: the upstream dL/dz rows are the B operand as they are
     const long long nwt = (a.nA + 15) / 16;  // wave tiles
-    auto rows_of = [&](long long wt, long long& rA, long long& rB, bool& okA, bool& okB) {
-        const long long t0 = wt * 16;
-        okA = t0 + j < a.nA;
-        okB = t0 + j < a.nB;
-        rA = okA ? t0 + j : a.nA - 1;
-        rB = a.offB + (okB ? t0 + j : (a.nB > 0 ? a.nB - 1 : 0));
+    // A tile's rows as a UNIFORM first row per side (element offsets eA / eB: scalar registers) and this lane's byte offset
+    // inside the tile (vA / vB: one 32-bit register per side) — every load and store below is base (SGPR pair) + offset
+    // (VGPR) + immediate.  As 64-bit per-lane pointers (z, dz, y, du, each for two sides and two tiles) the addresses took
+    // 20+ registers of a kernel that runs at the 256-register limit: hipcc spilled five of them AND the uniform array bases
+    // (held in vector registers), and each of the eight reloads per tile was followed by s_waitcnt vmcnt(0) — the memory
+    // counter is in order, so every reload drained the z ring and the dz stores in flight (round 6).
+    struct TileRows {
+        long long eA, eB;
+        unsigned vA, vB, rA4, rB4;
+        bool okA, okB;
+    };
+    auto sgpr64 = [](long long v) {
+        const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)v);
+        const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)((unsigned long long)v >> 32));
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    auto rows_of = [&](long long wt_, TileRows& T) {
+        const long long t0 = sgpr64(wt_ * 16);
+        const long long lastB = a.nB > 0 ? a.nB - 1 : 0;
+        const long long b0 = t0 < a.nB ? t0 : lastB;  // the tile's first row of the B side (rows past nB repeat the last one)
+        T.okA = t0 + j < a.nA;
+        T.okB = t0 + j < a.nB;
+        const int jA = T.okA ? j : (int)(a.nA - 1 - t0);
+        const int jB = T.okB ? j : (int)(lastB - b0);
+        T.eA = sgpr64(t0 * a.ldz);
+        T.eB = sgpr64((a.offB + b0) * a.ldz);
+        T.vA = (unsigned)(jA * (int)a.ldz + 4 * g4) * 4u;
+        T.vB = (unsigned)(jB * (int)a.ldz + 4 * g4) * 4u;
+        T.rA4 = (unsigned)jA * 4u;  // the row's own scalar (rn, g): rn + t0 is rn + eA / ldz
+        T.rB4 = (unsigned)jB * 4u;
+    };
+    // (the lane offset is made opaque at every use: left visible, hipcc forms base + offset ONCE per array as a 64-bit vector
+    // add, keeps the sums — the per-lane pointers again — and the loads lose the scalar-base form)
+    auto ld4 = [](const float* arr, long long e, unsigned v, int imm) {
+        asm volatile("" : "+v"(v));
+        return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(arr + e) + v + imm);
+    };
+    auto st4 = [](float* arr, long long e, unsigned v, int imm, const f32x4& x) {
+        asm volatile("" : "+v"(v));
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(arr + e) + v + imm) = x;
     };
     long long wt = (long long)blockIdx.x * WAVES + wave;
     const long long stride = (long long)gridDim.x * WAVES;
-    long long rA, rB;
-    bool okA, okB;
-    rows_of(wt < nwt ? wt : nwt - 1, rA, rB, okA, okB);
+    TileRows T;
+    rows_of(wt < nwt ? wt : nwt - 1, T);
     f32x4 zrA[PFZ], zrB[PFZ];
-    auto fetchz = [&](int slot, long long ra, long long rb, int kb) {
-        zrA[slot] = *reinterpret_cast<const f32x4*>(src + ra * a.ldz + 16 * kb + 4 * g4);
-        zrB[slot] = *reinterpret_cast<const f32x4*>(src + rb * a.ldz + 16 * kb + 4 * g4);
+    auto fetchz = [&](int slot, const TileRows& R, int kb) {
+        zrA[slot] = ld4(src, R.eA, R.vA, 64 * kb);
+        zrB[slot] = ld4(src, R.eB, R.vB, 64 * kb);
     };
 #pragma unroll
-    for (int s = 0; s < PFZ; ++s) fetchz(s, rA, rB, s);
+    for (int s = 0; s < PFZ; ++s) fetchz(s, T, s);
     __syncthreads();  // the weights are in LDS
 
     for (; wt < nwt; wt += stride) {
-        long long rA_n, rB_n;
-        bool okA_n, okB_n;
-        rows_of(wt + stride < nwt ? wt + stride : wt, rA_n, rB_n, okA_n, okB_n);
-        const float tg = GIVEN ? 0.f : 2.0f * (okA ? a.g[rA] : 0.f);
+        TileRows Tn;
+        rows_of(wt + stride < nwt ? wt + stride : wt, Tn);
+        const long long t0 = sgpr64(wt * 16);
+        const long long b0r = sgpr64(a.offB + (t0 < a.nB ? t0 : (a.nB > 0 ? a.nB - 1 : 0)));
+        const float tg = GIVEN ? 0.f : 2.0f * (T.okA ? *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.g + t0) + T.rA4) : 0.f);
         f32x4 dyA[NB], dyB[NB], yA[NB], yB[NB];
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -245,9 +279,9 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
                 const f32x4 q = qps[0][4 * kb + g4], p = qps[1][4 * kb + g4];
                 dA = dz_of(tg, q, p, zrA[sl], zrB[sl]);
                 dB = dz_of(tg, q, p, zrB[sl], zrA[sl]);
-                if (okA) {
-                    *reinterpret_cast<f32x4*>(a.dz + rA * a.ldz + 16 * kb + 4 * g4) = dA;
-                    *reinterpret_cast<f32x4*>(a.dz + rB * a.ldz + 16 * kb + 4 * g4) = dB;
+                if (T.okA) {
+                    st4(a.dz, T.eA, T.vA, 64 * kb, dA);
+                    st4(a.dz, T.eB, T.vB, 64 * kb, dB);
                 }
                 f32x4 eq, ep;
                 pair_sum_terms(0.5f * tg, zrA[sl], zrB[sl], eq, ep);
@@ -262,13 +296,13 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
                 }
             }
             // refill the slot: k-block kb + PFZ of this tile, or the first k-blocks of the wave's next tile
-            if (kb + PFZ < NB) fetchz(sl, rA, rB, kb + PFZ);
-            else fetchz(sl, rA_n, rB_n, kb + PFZ - NB);
+            if (kb + PFZ < NB) fetchz(sl, T, kb + PFZ);
+            else fetchz(sl, Tn, kb + PFZ - NB);
             if (kb >= NB - 2) {  // y under the last MFMAs: half of the blocks each
 #pragma unroll
                 for (int nb = (kb == NB - 2 ? 0 : NB / 2); nb < (kb == NB - 2 ? NB / 2 : NB); ++nb) {
-                    yA[nb] = *reinterpret_cast<const f32x4*>(a.y + rA * a.ldz + 16 * nb + 4 * g4);
-                    yB[nb] = *reinterpret_cast<const f32x4*>(a.y + rB * a.ldz + 16 * nb + 4 * g4);
+                    yA[nb] = ld4(a.y, T.eA, T.vA, 64 * nb);
+                    yB[nb] = ld4(a.y, T.eB, T.vB, 64 * nb);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);  // (left free, the scheduler hoists the LDS reads of every k-block to the top: spills)
@@ -301,7 +335,8 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
             }
         }
         // F.normalize backward: du = (dy - y (y . dy)) / max(||u||, eps); clamp branch: du = dy / eps
-        const float rnA = a.rn[rA], rnB = a.rn[rB];
+        const float rnA = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.rn + t0) + T.rA4);
+        const float rnB = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.rn + b0r) + T.rB4);
         float dotA = 0.f, dotB = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
@@ -317,10 +352,10 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
         if (rnB >= 1e12f) dotB = 0.f;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            if (okA) *reinterpret_cast<f32x4*>(a.du + rA * a.ldz + 16 * nb + 4 * g4) = (dyA[nb] - yA[nb] * dotA) * rnA;
-            if (okB) *reinterpret_cast<f32x4*>(a.du + rB * a.ldz + 16 * nb + 4 * g4) = (dyB[nb] - yB[nb] * dotB) * rnB;
+            if (T.okA) st4(a.du, T.eA, T.vA, 64 * nb, (dyA[nb] - yA[nb] * dotA) * rnA);
+            if (T.okB) st4(a.du, T.eB, T.vB, 64 * nb, (dyB[nb] - yB[nb] * dotB) * rnB);
         }
-        rA = rA_n; rB = rB_n; okA = okA_n; okB = okB_n;
+        T = Tn;
         // the next tile's k-block i was fetched into slot (NB - PFZ + i) % PFZ (the slot that was free): back to slot i
         if constexpr (NB % PFZ != 0) {
             f32x4 tA[PFZ], tB[PFZ];

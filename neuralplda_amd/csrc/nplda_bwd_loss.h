@@ -27,10 +27,14 @@ struct BwdLoss {
 // What a pair's loss step needs besides its score and target, in three parts so that a kernel can place each where it
 // is free: the thresholds (global loads — early), the batch constants of dL/ds (fp64 divisions — once the counts are
 // known), the pair itself.
+// (theta / cn are VECTOR values, not arrays: the K = 1 .. 4 branches of loss_consts_counts write cn[0 .. K - 1], hipcc merged
+// their tails into one store at a run-time offset and with that the struct lived in scratch — a scratch store, four scratch
+// loads and an s_waitcnt vmcnt(0) in front of the counts' way to LDS, in every training kernel; round 6.)
+static_assert(nplda_loss::kMaxK == 4, "PairLossConsts holds the thresholds' constants in float4 values");
 struct PairLossConsts {
-    float theta[nplda_loss::kMaxK];
-    float cn[nplda_loss::kMaxK];  // SoftCdet: beta_k alpha / (N_n K);  BCE: cn[0] = 1 / N
-    float ct;                     // SoftCdet: -alpha / (N_t K)
+    f32x4 theta;
+    f32x4 cn;   // SoftCdet: beta_k alpha / (N_n K);  BCE: cn[0] = 1 / N
+    float ct;   // SoftCdet: -alpha / (N_t K)
 };
 
 __device__ __forceinline__ void loss_consts_theta(const BwdLoss& L, PairLossConsts& c) {

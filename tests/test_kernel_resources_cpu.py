@@ -41,6 +41,18 @@ def test_register_budgets_of_the_training_kernels():
     assert small, "the training-mode small forward is instantiated in this translation unit"
     for k, v in small.items():
         assert v["AGPRs"] == 0 and v["ScratchSize"] == 0, (k, v)
+    # round 6: the one-kernel training steps at D = 150 and the streaming data gradient keep NOTHING in scratch.  (Until then
+    # every training kernel had a 20-byte scratch object — the loss constants, written at a run-time offset by merged branch
+    # tails — and the streaming data gradient spilled five 64-bit row pointers it reloaded, with an s_waitcnt vmcnt(0) each,
+    # eight times per tile.)
+    fb = {k: v for k, v in res.items() if "train_fb_small_kernelILi10E" in k or "train_fb_half_kernelILi10E" in k}
+    assert len(fb) >= 10, sorted(res)
+    for k, v in fb.items():
+        assert v["ScratchSize"] == 0, (k, v)
+    stream = {k: v for k, v in res.items() if "bwd_data_stream_kernelILi10E" in k}
+    assert len(stream) == 2
+    for k, v in stream.items():
+        assert v["ScratchSize"] == 0 and v["Occupancy"] >= 2, (k, v)
 
 
 def test_register_budget_of_the_cohort_gemm():
