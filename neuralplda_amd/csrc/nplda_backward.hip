@@ -1030,8 +1030,10 @@ __global__ __launch_bounds__(256) void train_update_kernel(const UpdateArgs a) {
             a.m[idx] = m;
             a.v[idx] = v;
             *pp[e4] = pn;
+#ifndef NPLDA_EXP_NO_IMAGE_STORES  // (tools/trace_update.sh: what the scattered image stores cost)
             a.packed[pk0[e4]] = which[e4] ? pn * pn : pn;  // P = P_sqrt^2 (utils/models.py:373)
             if (pk1[e4] != (size_t)-1) a.packed[pk1[e4]] = pn;
+#endif
         }
     } else {
         __shared__ double tail_smem[(kLossTailSmem + 7) / 8];
