@@ -389,16 +389,35 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     // per accumulator block less.)
     float kq[RGW], thc[RGW], s2[RGW];
     unsigned cur[RGW], lim[RGW];
+    // ALL of an item's row loads are on their way before the first one is waited for (BATCH): left to itself hipcc fetched each
+    // fragment into one 4-register temporary — load, s_waitcnt vmcnt(0), multiply, next load — twenty dependent round trips,
+    // the 14 k cycles by which a tile that ends an item was longer than one that does not (round 6: seen in the ISA after the
+    // same pattern turned up in nplda_fwd_mid.h; the round's stamps had put it down to the memory system).  D >= 173 with two
+    // row groups sits at 255 registers and spills in that form: it keeps the compiler's order.
+    constexpr bool BATCH = RGW == 1 || NB <= 10 || (NB == 11 && KT < 4);
     auto item_rows = [&](long long rb_) {
+        const float* zrow[RGW];
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
             if (row >= a.R) row = a.R - 1;
-            const f32x4* zp = reinterpret_cast<const f32x4*>(a.zr + row * a.ldz + 4 * g4);
+            zrow[g] = a.zr + row * a.ldz;
+            const f32x4* zp = reinterpret_cast<const f32x4*>(zrow[g] + 4 * g4);
 #pragma unroll
-            for (int ks = 0; ks < NB; ++ks) brow[g][ks] = zp[4 * ks] * p2s[4 * ks + g4];
+            for (int ks = 0; ks < NB; ++ks) {
+                if constexpr (BATCH) brow[g][ks] = zp[4 * ks];
+                else brow[g][ks] = zp[4 * ks] * p2s[4 * ks + g4];
+            }
+        }
+        if constexpr (BATCH) __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int g = 0; g < RGW; ++g) {
+            if constexpr (BATCH) {
+#pragma unroll
+                for (int ks = 0; ks < NB; ++ks) brow[g][ks] *= p2s[4 * ks + g4];
+            }
             if (KT < 4) {  // the last block in the KT-step order: columns 16 (NB - 1) + KT g4 + r
-                const float* zl = a.zr + row * a.ldz + 16 * (NB - 1) + KT * g4;
+                const float* zl = zrow[g] + 16 * (NB - 1) + KT * g4;
                 const float* pl = reinterpret_cast<const float*>(p2s) + 16 * (NB - 1) + KT * g4;
                 f32x4 v = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
