@@ -156,7 +156,14 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
     const int j = lane & 15, g = lane >> 4;
     constexpr int Mp = 16 * NB;
     if (a.ctl_zero != nullptr && blockIdx.x == 0 && tid < 64) a.ctl_zero[tid] = 0u;
+    // v = 4 P cov(z, q) and the fp64 cohort mean through LDS as well: as global loads in the epilogue they were thirty
+    // load - s_waitcnt vmcnt(0) - use round trips per 16-row group (hipcc threads them through the MFMA loop one at a time; the
+    // memory counter is in order, an LDS read has its own) — round 6
+    __shared__ float vlin_s[Mp];
+    __shared__ double vec64_s[Mp + 1];
     for (int i = tid; i < NB * (NB + 1) / 2 * 64; i += 512) cimg[i] = reinterpret_cast<const f32x4*>(a.frag)[i];
+    for (int i = tid; i < Mp; i += 512) vlin_s[i] = a.vec[Mp + i];
+    for (int i = tid; i <= Mp; i += 512) vec64_s[i] = a.vec64[i];
     __syncthreads();
     for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
         const long long r0 = ((long long)tile * a.wpt + wave) * 16;
@@ -183,12 +190,12 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
         double mu = 0.0;  // the mean is an OUTPUT (stats[.][0]): fp64 on the fp64 cohort mean
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(a.vec + Mp + 16 * nb + 4 * g);
+            const f32x4 v = *reinterpret_cast<const f32x4*>(vlin_s + 16 * nb + 4 * g);
 #pragma unroll
             for (int r = 0; r < 4; ++r) {
                 quad = fmaf(zf[nb][r], acc[nb][r], quad);
                 lin = fmaf(zf[nb][r], v[r], lin);
-                mu = fma((double)zf[nb][r], a.vec64[16 * nb + 4 * g + r], mu);
+                mu = fma((double)zf[nb][r], vec64_s[16 * nb + 4 * g + r], mu);
             }
         }
         quad = wave_xor_add(quad, 16); quad = wave_xor_add(quad, 32);
@@ -196,7 +203,7 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
         mu += __hiloint2double(__shfl_xor(__double2hiint(mu), 16, 64), __shfl_xor(__double2loint(mu), 16, 64));
         mu += __hiloint2double(__shfl_xor(__double2hiint(mu), 32, 64), __shfl_xor(__double2loint(mu), 32, 64));
         if (g == 0 && r0 + j < a.R) {
-            const double m64 = (double)a.qr[row] + a.vec64[Mp] + mu;
+            const double m64 = (double)a.qr[row] + vec64_s[Mp] + mu;
             a.mean64[row] = m64;
             const float mean = (float)m64;
             const float var = a.vec[2 * Mp + 1] + lin + quad;

@@ -16,7 +16,7 @@ for rep in 1 2; do
     if [ -n "$lib" ]; then cp $R/tools/$lib $R/neuralplda_amd/libnplda_hip.so; else cp /tmp/libnplda_hip_product.so $R/neuralplda_amd/libnplda_hip.so; fi
     env $cfg rocprofv3 --kernel-trace -d /tmp/ab_$i -- python $R/tools/asnorm_profile.py fused ${DIM:-150} > /tmp/ab_$i.log 2>&1
     echo "== rep $rep [$cfg] $(grep cohort_stats /tmp/ab_$i.log)" >> $O/ab.txt
-    python $R/tools/rocpd_summary.py --drop-first /tmp/ab_$i/*/*.db | grep -E "fused2|finish|calls" | cut -c1-175 >> $O/ab.txt
+    python $R/tools/rocpd_summary.py --drop-first /tmp/ab_$i/*/*.db | grep -E "fused2|finish|rowthr|calls" | cut -c1-175 >> $O/ab.txt
   done
 done
 cp /tmp/libnplda_hip_product.so $R/neuralplda_amd/libnplda_hip.so
