@@ -50,7 +50,12 @@ __device__ __forceinline__ void chunk_store(f32x4* dst, const f32x4 (&st)[NSLOT]
 #pragma unroll
     for (int i = 0; i < NSLOT; ++i) {
         const int idx = tid + THREADS * i;
-        if (idx < CH) dst[idx] = st[i];
+        // The staged value is "used" here, outside the predicate: with its only use inside `if (idx < CH)` hipcc SINKS the
+        // (unconditional) load of the last, partly filled slot into that branch — load, s_waitcnt vmcnt(0), ds_write in front of
+        // every stage's barrier, an exposed L2 round trip per k16-step (round 6: the GaussianBackend forward's ISA).
+        f32x4 v = st[i];
+        asm volatile("" : "+v"(v));
+        if (idx < CH) dst[idx] = v;
     }
 }
 
