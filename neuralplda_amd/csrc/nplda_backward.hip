@@ -235,17 +235,14 @@ __global__ __launch_bounds__(512, 2) void bwd_data_stream_kernel(const BwdArgs a
     };
     // (the lane offset is made opaque at every use: left visible, hipcc forms base + offset ONCE per array as a 64-bit vector
     // add, keeps the sums — the per-lane pointers again — and the loads lose the scalar-base form)
-    // (NB >= 11 keeps the accumulators of a wider tile: there the copy of the offset each opaque use costs is not paid back —
-    // D = 170 measured 0.7 % slower with it — and the compiler's own address arithmetic stays)
-#ifndef NPLDA_BWD_STREAM_OPAQUE_MAXNB
-#define NPLDA_BWD_STREAM_OPAQUE_MAXNB 10
-#endif
+    // (for every NB: with the offsets left visible at NB = 11 — where the v_mov per use is not paid back by fewer spills, D = 170
+    // is 0.7 % slower than round 5 — the backward is 3.6 % slower still: profiles/r06gn_backward_nb11_ab.txt)
     auto ld4 = [](const float* arr, long long e, unsigned v, int imm) {
-        if constexpr (NB <= NPLDA_BWD_STREAM_OPAQUE_MAXNB) asm volatile("" : "+v"(v));
+        asm volatile("" : "+v"(v));
         return *reinterpret_cast<const f32x4*>(reinterpret_cast<const char*>(arr + e) + v + imm);
     };
     auto st4 = [](float* arr, long long e, unsigned v, int imm, const f32x4& x) {
-        if constexpr (NB <= NPLDA_BWD_STREAM_OPAQUE_MAXNB) asm volatile("" : "+v"(v));
+        asm volatile("" : "+v"(v));
         *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(arr + e) + v + imm) = x;
     };
     long long wt = (long long)blockIdx.x * WAVES + wave;
