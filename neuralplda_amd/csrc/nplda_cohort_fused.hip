@@ -54,6 +54,63 @@ constexpr int kGramSplit = 16;    // k-groups of the cohort Gram matrix
 constexpr int kQzBlocks = 64;
 
 // ------------------------------------------------------------------------------------------------------------------
+// split form of the fused GEMM (round 6): fp32 operands as three bf16 pieces, six v_mfma_f32_16x16x32_bf16 passes
+// ------------------------------------------------------------------------------------------------------------------
+// gfx950 has no TF32, and its fp32-input MFMA runs at 1/16 of the bf16 rate.  v = h + m + l with h = bf16(v),
+// m = bf16(v - h), l = bf16(v - h - m) (the residuals are exact in fp32; |m| <= 2^-9 |v|, |l| <= 2^-18 |v|, what is left of v
+// is below 2^-27 |v|), and a product x y is taken as hh + hm + mh + hl + lh + mm — each bf16 x bf16 product is exact in the
+// MFMA's fp32 accumulate, the dropped terms (ml, lm, ll) are below 2^-26 |x y|: the same products to fp32 rounding, in 6 x 16
+// cycles per 16 x 16 x 32 block instead of 8 x 32.  The cohort is split ONCE (cohort_split_kernel, into the fragment order
+// the tile DMA wants: a tile's fragment is 1 KiB contiguous), a row tile's operands when the item is taken.
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+__host__ __device__ constexpr int split_ksteps(int Mp) { return (Mp + 31) / 32; }
+__host__ __device__ constexpr size_t split_tile_bytes(int Mp) { return (size_t)12 * split_ksteps(Mp) * 1024; }
+
+__device__ __forceinline__ void split3(float v, __bf16& h, __bf16& m, __bf16& l) {
+    h = (__bf16)v;
+    const float r1 = v - (float)h;
+    m = (__bf16)r1;
+    const float r2 = r1 - (float)m;
+    l = (__bf16)r2;
+}
+__device__ __forceinline__ void split3x8(const f32x4 lo, const f32x4 hi, bf16x8& H, bf16x8& M, bf16x8& L) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        __bf16 h, m, l;
+        split3(e < 4 ? lo[e] : hi[e - 4], h, m, l);
+        H[e] = h; M[e] = m; L[e] = l;
+    }
+}
+
+struct SplitArgs {
+    const float* zc; long long M, ldz; int Mp; unsigned char* img;  // [tiles of 64 columns][ks][c][piece][lane][8 bf16]
+};
+// one thread per (tile, ks, c, lane): eight values of one cohort row -> three 16-byte pieces.  Rows past M and columns past Mp
+// are zero (the last tile needs no clamped addressing in the fused kernel; its columns are masked in the epilogue as before).
+__global__ __launch_bounds__(256) void cohort_split_kernel(const SplitArgs a) {
+    const int NK = split_ksteps(a.Mp);
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long nt64 = (a.M + 63) / 64;
+    if (idx >= nt64 * NK * 4 * 64) return;
+    const int lane = (int)(idx & 63), c = (int)((idx >> 6) & 3);
+    const long long rest = idx >> 8;
+    const int ks = (int)(rest % NK);
+    const long long t = rest / NK;
+    const long long m = t * 64 + 16 * c + (lane & 15);
+    const int k0 = 32 * ks + 8 * (lane >> 4);
+    f32x4 lo = {0.f, 0.f, 0.f, 0.f}, hi = lo;
+    if (m < a.M) {
+        const float* zp = a.zc + m * a.ldz + k0;
+        if (k0 < a.Mp) lo = *reinterpret_cast<const f32x4*>(zp);
+        if (k0 + 4 < a.Mp) hi = *reinterpret_cast<const f32x4*>(zp + 4);
+    }
+    bf16x8 H, Mm, L;
+    split3x8(lo, hi, H, Mm, L);
+    bf16x8* out = reinterpret_cast<bf16x8*>(a.img + (size_t)t * split_tile_bytes(a.Mp)) + (size_t)((ks * 4 + c) * 3) * 64 + lane;
+    out[0] = H; out[64] = Mm; out[128] = L;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // pre-pass
 // ------------------------------------------------------------------------------------------------------------------
 
@@ -219,6 +276,7 @@ __global__ __launch_bounds__(512, 1) void cohort_rowthr_kernel(const RowThrArgs 
 // ------------------------------------------------------------------------------------------------------------------
 struct FusedArgs {
     const float* zr; const float* qr; const float* zc; const float* qc; const float* P;
+    const unsigned char* zc3;     // the cohort as three bf16 pieces in fragment order (cohort_split_kernel); SPLIT kernels only
     long long R, M, ldz;
     int ksteps, nbands, ny, nx;   // nbands: a multiple of 8; band b -> XCD b % 8, column tiles [b nx / nbands, (b + 1) nx / nbands)
     unsigned* ctr;          // 8 work-item counters (one per XCD), zero at launch
@@ -265,12 +323,16 @@ struct FusedArgs {
 // steps: 38 instead of 40 k4-steps at D2 = 150 (KT = 2), 43 instead of 44 at D2 = 170 (KT = 3).  Columns >= D2 are zero in
 // the table on both sides, so nothing is masked.  The scores' last-block terms associate differently from the spilling
 // GEMM's: same values to rounding (tolerance in the tests).
-template <bool LOWEST, int NB, int RGW = 2, int KT = 4, int NW = 8>
+template <bool LOWEST, int NB, int RGW = 2, int KT = 4, int NW = 8, bool SPLIT = false>
 __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedArgs a) {
     static_assert(KT >= 2 && KT <= 4, "the k16-step's first two k4-steps always run");
     static_assert(NW == 8 || NW == 16, "two or four waves per SIMD");
+    static_assert(!SPLIT || (KT == 4 && NW == 8), "the split form has no short last block and two waves per SIMD");
     constexpr int RPB = NW * 16 * RGW;  // rows of a block's row tile
-    constexpr int NF = 4 * NB;  // 1 KiB fragments of a 64-column tile: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..
+    constexpr int NK = split_ksteps(16 * NB);  // SPLIT: k32-steps
+    // 1 KiB fragments of a 64-column tile.  fp32: [ks][c], lane (i16, g4) = column 16 c + i16, k 16 ks + 4 g4 ..;
+    // SPLIT: [ks][c][piece], lane (i16, g4) = column 16 c + i16, eight bf16 of k 32 ks + 8 g4 ..
+    constexpr int NF = SPLIT ? 12 * NK : 4 * NB;
     __shared__ f32x4 smem[2 * NF * 64 + 2 * 16 + NB * 4 + 2];
     f32x4* tbuf = smem;
     float* qms = reinterpret_cast<float*>(smem + 2 * NF * 64);                 // q_m of the two buffered tiles
@@ -331,6 +393,25 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     const unsigned qoff = 4u * (unsigned)lane;
     auto tile_in = [&](int t, int buf) {
         if (!dma_wave) return;
+        if constexpr (SPLIT) {
+            // the split image is in fragment order: fragment f of tile t is the 1 KiB at (t NF + f) 1024 — a scalar base and ONE
+            // lane offset for all of them, and every DMA instruction reads whole lines
+            const char* sb = reinterpret_cast<const char*>(a.zc3) + (size_t)t * (NF * 1024);
+#pragma unroll
+            for (int j = 0; j < NFW; ++j) {
+                const int f = dw + NWD * j;
+                if (f < NF)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((sb + f * 1024) + 4 * qoff),
+                                                     (__attribute__((address_space(3))) void*)&tbuf[(buf * NF + f) * 64], 16, 0, 0);
+            }
+            if (dw == 0) {
+                long long m = (long long)t * 64 + lane;
+                if (m >= a.M) m = a.M - 1;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(a.qc + m),
+                                                 (__attribute__((address_space(3))) void*)&qms[buf * 64], 4, 0, 0);
+            }
+            return;
+        }
         if ((long long)t * 64 + 64 <= a.M) {
             const char* sb = reinterpret_cast<const char*>(a.zc) + (size_t)t * 64 * (size_t)a.ldz * 4;
 #pragma unroll
@@ -388,7 +469,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     int npar = 1;                                          // which word holds the next item's slot
 
     // per-lane state of a work item: the lane's two rows (wave's row group A / B, row i16), their operand fragments
-    f32x4 brow[RGW][NB];
+    f32x4 brow[RGW][SPLIT ? 1 : NB];
+    bf16x8 brow3[RGW][SPLIT ? NK : 1][3];   // SPLIT: (2 P z_r) in three bf16 pieces, lane (i16, g4): row i16, k 32 ks + 8 g4 ..
     // kq = q_r - c_r and thc = t_r - c_r: the epilogue forms the CENTRED score d = acc + (q_m + kq) (= s - c_r to rounding),
     // squares it, compares it with thc and appends IT — the select kernel adds c_r back in fp64.  (Every VALU instruction of
     // this kernel costs matrix-pipe time — on a SIMD fp32 MFMAs and VALU instructions do not overlap, whichever wave issues
@@ -403,6 +485,31 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     // row groups sits at 255 registers and spills in that form: it keeps the compiler's order.
     constexpr bool BATCH = RGW == 1 || NB <= 10 || (NB == 11 && KT < 4);
     auto item_rows = [&](long long rb_) {
+        if constexpr (SPLIT) {
+            const float* p2f = reinterpret_cast<const float*>(p2s);
+#pragma unroll
+            for (int g = 0; g < RGW; ++g) {
+                long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
+                if (row >= a.R) row = a.R - 1;
+                const float* zp = a.zr + row * a.ldz + 8 * g4;
+                f32x4 raw[NK][2];
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {   // (columns past 16 NB: not part of the table's contract — zero pieces)
+                    const bool in = 32 * ks + 16 < 16 * NB || g4 < 2;
+                    raw[ks][0] = in ? *reinterpret_cast<const f32x4*>(zp + 32 * ks) : f32x4{0.f, 0.f, 0.f, 0.f};
+                    raw[ks][1] = in ? *reinterpret_cast<const f32x4*>(zp + 32 * ks + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                __builtin_amdgcn_sched_barrier(0);   // all of a row group's loads in flight before the first wait
+#pragma unroll
+                for (int ks = 0; ks < NK; ++ks) {
+                    const bool in = 32 * ks + 16 < 16 * NB || g4 < 2;
+                    const int kc = in ? 32 * ks + 8 * g4 : 0;
+                    const f32x4 p0 = *reinterpret_cast<const f32x4*>(p2f + kc), p1 = *reinterpret_cast<const f32x4*>(p2f + kc + 4);
+                    split3x8(raw[ks][0] * p0, raw[ks][1] * p1, brow3[g][ks][0], brow3[g][ks][1], brow3[g][ks][2]);
+                }
+            }
+            return;
+        }
         const float* zrow[RGW];
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
@@ -531,6 +638,42 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         // pinned by scheduling barriers: hipcc otherwise sinks them to just before their use, and it waits lgkmcnt(0)
         // there).  The two waves of a SIMD run this loop in step, so an LDS round trip that is not covered by 16 MFMAs
         // stalls the matrix pipe for both at once (measured: the loop alone ran at 0.77 of the pipe's rate).
+        if constexpr (SPLIT) {
+            // A step is one k32-block of CG column groups: 3 CG fragment reads feed 6 CG RGW MFMAs (four independent
+            // accumulator chains: a 16x16x32 MFMA issues every 16 cycles, its result is ready ~2.5 issue slots later).  Small
+            // terms first: mm, hl, lh, hm, mh, hh.  The next step's fragments are read in the middle of this step's MFMAs.
+            constexpr int CG = 4 / RGW, SPK = 4 / CG, NSTEP = NK * SPK;
+            const bf16x8* tb3 = reinterpret_cast<const bf16x8*>(tb);
+            bf16x8 af3[2][CG][3];
+#pragma unroll
+            for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                for (int p = 0; p < 3; ++p) af3[0][cc][p] = tb3[(cc * 3 + p) * 64];
+            if (!(abl & 2))
+#pragma unroll
+            for (int s = 0; s < NSTEP; ++s) {
+                const int ks = s / SPK, c0 = (s % SPK) * CG;
+#define NPLDA_CF_PASS(PA, PB)                                                                                          \
+    _Pragma("unroll") for (int cc = 0; cc < CG; ++cc) _Pragma("unroll") for (int g = 0; g < RGW; ++g)                 \
+        acc[g][c0 + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[s & 1][cc][PA], brow3[g][ks][PB], acc[g][c0 + cc], 0, 0, 0)
+                NPLDA_CF_PASS(1, 1);
+                NPLDA_CF_PASS(0, 2);
+                NPLDA_CF_PASS(2, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (s + 1 < NSTEP) {
+                    const int ks1 = (s + 1) / SPK, c1 = ((s + 1) % SPK) * CG;
+#pragma unroll
+                    for (int cc = 0; cc < CG; ++cc)
+#pragma unroll
+                        for (int p = 0; p < 3; ++p) af3[(s + 1) & 1][cc][p] = tb3[((ks1 * 4 + c1 + cc) * 3 + p) * 64];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                NPLDA_CF_PASS(0, 1);
+                NPLDA_CF_PASS(1, 0);
+                NPLDA_CF_PASS(0, 0);
+#undef NPLDA_CF_PASS
+            }
+        } else {
         f32x4 af[2][4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) af[0][c] = tb[c * 64];
@@ -559,6 +702,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
                     for (int g = 0; g < RGW; ++g)
                         acc[g][c] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[ks & 1][c][kk], brow[g][ks][kk], acc[g][c], 0, 0, 0);
                 }
+        }
         }
         // (No barrier here.  Cycle stamps show the two waves of a SIMD falling into alternation — one in its MFMA loop while
         // the other works through its epilogue, whose VALU instructions then find issue slots only between the other
@@ -939,6 +1083,13 @@ namespace nplda {
 // written back half filled and re-opened — 436 MB of L2 write-backs per cfg3 call for 94 MB of candidates.  An odd number of
 // 128-byte lines between rows: 264 - 268 MB for 160 / 224 / 288 / 544 / 1056 / 2080 floats (312 at 32, 343 at 64);
 // tools/exp_rowpad.sh, profiles/r05q_rowpad.txt.  (Times: fused kernel unchanged, select kernel 83 -> 80 us.)
+// The split form of the fused kernel (three bf16 pieces, six passes) serves the two shipped dimensions' block counts;
+// NPLDA_COHORT_SPLIT=0 keeps the fp32-input MFMA form (A/B runs).
+static bool split_enabled(int ksteps) {
+    static const bool on = !(getenv("NPLDA_COHORT_SPLIT") && getenv("NPLDA_COHORT_SPLIT")[0] == '0');
+    return on && (ksteps == 10 || ksteps == 11);
+}
+
 static int fused_row_pad() {
     static const int pad = [] {
         const char* e = getenv("NPLDA_COHORT_ROWPAD");  // (A/B runs)
@@ -1016,7 +1167,8 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     p.fixed_bytes = 256 + align256((size_t)kGramSplit * Mp * Mp * 4) + align256((size_t)kGramSplit * 4 * Mp * 4) +
                     align256((size_t)kQzBlocks * (Mp + 2) * 4) + align256((size_t)kQzBlocks * (Mp + 1) * 8) +
                     align256((size_t)(Mp + 1) * 8) + align256(kb * kb * 256 * 4) +
-                    align256((size_t)(2 * Mp + 2) * 4) + 8 * 256;  // + the alignment slack of the per-row arrays
+                    align256((size_t)(2 * Mp + 2) * 4) + 8 * 256 +  // + the alignment slack of the per-row arrays
+                    align256((size_t)((M + 63) / 64) * split_tile_bytes(Mp));  // the cohort's split image (cohort_split_kernel)
     const long long lrow = (long long)p.nsub * p.ksub + fused_row_pad();
     p.max_rows = ((1LL << 30) / lrow) / 256 * 256;  // 32-bit BYTE offsets into the lists
     p.row_bytes = 8 + 8 + (size_t)lrow * 4 + (size_t)p.nsub * 4 + (size_t)(p.nsub / 4) * 8 + 4;
@@ -1028,9 +1180,11 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
 // receive the rows that need the general path; the caller runs cohort_fallback_kernel on them.
 // the fixed part of a workspace (FusedPlan::fixed_bytes): control block, the pre-pass's scratch and its results
 struct FusedFixed {
-    unsigned* ctl; float* slab; float* ext; float* qz; double* qz64; double* vec64; float* frag; float* vec; unsigned char* end;
+    unsigned* ctl; float* slab; float* ext; float* qz; double* qz64; double* vec64; float* frag; float* vec;
+    unsigned char* img;   // the cohort's split image: ceil(M / 64) tiles of split_tile_bytes(Mp)
+    unsigned char* end;
 };
-static FusedFixed fused_fixed(unsigned char* ws, int Mp) {
+static FusedFixed fused_fixed(unsigned char* ws, int Mp, long long M) {
     FusedFixed f;
     unsigned char* q = ws;
     f.ctl = reinterpret_cast<unsigned*>(q); q += 256;
@@ -1041,6 +1195,7 @@ static FusedFixed fused_fixed(unsigned char* ws, int Mp) {
     f.vec64 = reinterpret_cast<double*>(q); q += align256((size_t)(Mp + 1) * 8);
     f.frag = reinterpret_cast<float*>(q); q += align256((size_t)(Mp / 16) * (Mp / 16) * 256 * 4);
     f.vec = reinterpret_cast<float*>(q); q += align256((size_t)(2 * Mp + 2) * 4);
+    f.img = q; q += align256((size_t)((M + 63) / 64) * split_tile_bytes(Mp));
     f.end = q;
     return f;
 }
@@ -1060,13 +1215,18 @@ static int fused_prepass(const FusedFixed& F, const float* z_coh, const float* q
     }
     const size_t nfrag = (size_t)(Mp / 16) * (Mp / 16) * 256;
     hipLaunchKernelGGL(cohort_prep_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, pa);
+    if (split_enabled(Mp / 16)) {  // the cohort in three bf16 pieces, fragment order (what the split fused kernel streams)
+        const SplitArgs sa = {z_coh, M, ldz, Mp, F.img};
+        const long long nthr = (M + 63) / 64 * split_ksteps(Mp) * 256;
+        hipLaunchKernelGGL(cohort_split_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, sa);
+    }
     return nplda_launch_status();
 }
 
 int cohort_fused_prepare(const FusedPlan& p, const float* z_coh, const float* q_coh, long long M, long long ldz, const float* P,
                          int ksteps, unsigned char* state, hipStream_t st) {
     if (!p.eligible) return NPLDA_EUNSUPPORTED;
-    return fused_prepass(fused_fixed(state, 16 * ksteps), z_coh, q_coh, M, ldz, P, 16 * ksteps, st);
+    return fused_prepass(fused_fixed(state, 16 * ksteps, M), z_coh, q_coh, M, ldz, P, 16 * ksteps, st);
 }
 
 int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_rows, long long R, const float* z_coh,
@@ -1074,11 +1234,11 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
                      double* stats, unsigned char* ws, long long rows_cap, bool prepass, unsigned** fail_rows_out,
                      unsigned** nfail_out, long long resident, hipStream_t st, const unsigned char* prepared, int D2) {
     const int Mp = 16 * ksteps;
-    const FusedFixed F = fused_fixed(ws, Mp);
+    const FusedFixed F = fused_fixed(ws, Mp, M);
     unsigned* ctl = F.ctl;
     unsigned char* q = F.end;
     // (a prepared cohort: its covariance image and moment vectors are read where cohort_fused_prepare left them)
-    const FusedFixed FP = prepared ? fused_fixed(const_cast<unsigned char*>(prepared), Mp) : F;
+    const FusedFixed FP = prepared ? fused_fixed(const_cast<unsigned char*>(prepared), Mp, M) : F;
     const double* vec64 = FP.vec64;
     const float* frag = FP.frag;
     const float* vec = FP.vec;
@@ -1131,6 +1291,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
 
     FusedArgs fa = {};
     fa.zr = z_rows; fa.qr = q_rows; fa.zc = z_coh; fa.qc = q_coh; fa.P = P;
+    fa.zc3 = FP.img;
     // Row tiles of 256 rows — or of 128 when the call has so few rows that 256-row items would leave most CUs idle in the
     // last round (fewer than three items per resident block: an 8-way row shard of cfg3 is 11 tiles x 32 list bands for
     // 256 CUs, 1.4 items each; as 22 x 32 half-size items the slowest CU carries 7.5 tile-units instead of 10).  Same
@@ -1178,6 +1339,15 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa);    \
     else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2, KTV>), dim3((unsigned)grid), dim3(512), 0, st, fa)
 #define NPLDA_LAUNCH(NBV) NPLDA_LAUNCH_KT(NBV, 4)
+#define NPLDA_LAUNCH_SPLIT(NBV)                                                                                                      \
+    if (half_tiles) {                                                                                                                \
+        if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 1, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa);  \
+        else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa);        \
+    } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
+    else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa)
+    if (split_enabled(ksteps)) {
+        if (ksteps == 10) { NPLDA_LAUNCH_SPLIT(10); } else { NPLDA_LAUNCH_SPLIT(11); }
+    } else
     switch (ksteps) {
         case 2: NPLDA_LAUNCH(2); break;
         case 4: NPLDA_LAUNCH(4); break;
@@ -1193,6 +1363,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     }
 #undef NPLDA_LAUNCH
 #undef NPLDA_LAUNCH_KT
+#undef NPLDA_LAUNCH_SPLIT
     if (int rc = nplda_launch_status()) return rc;
     FinishArgs fi = {lists, counts, part, crow, mean64, R, M, trow, p.zhi, p.fhi, p.nsub, p.nsub, topn, lowest, p.ksub, p.cap, lrow, ctl + 8,
                      fail_rows, stats};
