@@ -391,11 +391,15 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         doff[j] = 4u * (unsigned)((long long)(16 * c + i16) * a.ldz + col);
     }
     const unsigned qoff = 4u * (unsigned)lane;
-    auto tile_in = [&](int t, int buf) {
+    // (The lambdas of this kernel are always_inline: they capture the register arrays by reference, and ONE that hipcc decides
+    // not to inline puts brow3 / acc into scratch — seen in the ABLATE build of an experiment: 480 bytes of scratch, 10 x the time.)
+    auto tile_in = [&](int t, int buf) __attribute__((always_inline)) {
         if (!dma_wave) return;
         if constexpr (SPLIT) {
             // the split image is in fragment order: fragment f of tile t is the 1 KiB at (t NF + f) 1024 — a scalar base and ONE
-            // lane offset for all of them, and every DMA instruction reads whole lines
+            // lane offset for all of them, and every DMA instruction reads whole lines.  (Who issues them does not matter to the
+            // tile's time — the first half taking 3 / 5 / 7 / 10 of the 15 fragments per wave in front of its loop:
+            // 400 - 415 us in every setting, profiles/r06h_split_dma_share_ab.txt — as in the fp32 form it is the second half.)
             const char* sb = reinterpret_cast<const char*>(a.zc3) + (size_t)t * (NF * 1024);
 #pragma unroll
             for (int j = 0; j < NFW; ++j) {
@@ -484,7 +488,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     // same pattern turned up in nplda_fwd_mid.h; the round's stamps had put it down to the memory system).  D >= 173 with two
     // row groups sits at 255 registers and spills in that form: it keeps the compiler's order.
     constexpr bool BATCH = RGW == 1 || NB <= 10 || (NB == 11 && KT < 4);
-    auto item_rows = [&](long long rb_) {
+    auto item_rows = [&](long long rb_) __attribute__((always_inline)) {
         if constexpr (SPLIT) {
             const float* p2f = reinterpret_cast<const float*>(p2s);
 #pragma unroll
@@ -553,7 +557,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     // plain tiles got 0.5 k slower: r06q, not kept.)
     unsigned rowbase[RGW];
     float nraw[RGW][3];
-    auto next_consts = [&](long long rb_) {
+    auto next_consts = [&](long long rb_) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             long long rc = rb_ + wave * (16 * RGW) + 16 * g + i16;
@@ -563,7 +567,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
             nraw[g][2] = a.qr[rc];
         }
     };
-    auto take_consts = [&](long long rb_) {
+    auto take_consts = [&](long long rb_) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             const long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
@@ -575,7 +579,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
             rowbase[g] = 4u * (unsigned)(rc * a.lrow + g4);
         }
     };
-    auto band_state = [&](int band_) {
+    auto band_state = [&](int band_) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             s2[g] = 0.f;
@@ -584,7 +588,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
             lim[g] = cur[g] + 16u * (unsigned)(a.ksub - kSubSlack);
         }
     };
-    auto item_end = [&](long long rb_, int band_) {
+    auto item_end = [&](long long rb_, int band_) __attribute__((always_inline)) {
 #pragma unroll
         for (int g = 0; g < RGW; ++g) {
             const long long row = rb_ + wave * (16 * RGW) + 16 * g + i16;
@@ -715,7 +719,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
         const long long m0 = (long long)t * 64;
         const float* qm_s = qms + buf * 64 + 4 * g4;
-        auto epilogue = [&](auto masked) {
+        auto epilogue = [&](auto masked) __attribute__((always_inline)) {
             constexpr bool MASKED = decltype(masked)::value;
             typedef float f32x2 __attribute__((ext_vector_type(2)));
 #pragma unroll
@@ -1083,11 +1087,14 @@ namespace nplda {
 // written back half filled and re-opened — 436 MB of L2 write-backs per cfg3 call for 94 MB of candidates.  An odd number of
 // 128-byte lines between rows: 264 - 268 MB for 160 / 224 / 288 / 544 / 1056 / 2080 floats (312 at 32, 343 at 64);
 // tools/exp_rowpad.sh, profiles/r05q_rowpad.txt.  (Times: fused kernel unchanged, select kernel 83 -> 80 us.)
-// The split form of the fused kernel (three bf16 pieces, six passes) serves the two shipped dimensions' block counts;
-// NPLDA_COHORT_SPLIT=0 keeps the fp32-input MFMA form (A/B runs).
-static bool split_enabled(int ksteps) {
-    static const bool on = !(getenv("NPLDA_COHORT_SPLIT") && getenv("NPLDA_COHORT_SPLIT")[0] == '0');
-    return on && (ksteps == 10 || ksteps == 11);
+// The split form of the fused kernel (three bf16 pieces, six passes) serves the two shipped dimensions' block counts.  The
+// cohort's split image is ALWAYS built for them (pre-pass / CohortState: ~5 us), so that the choice of kernel can be made per
+// call: NPLDA_COHORT_SPLIT=0 selects the fp32-input MFMA form (read at every call — bench.py times both forms in one
+// process, tests/test_cohort_fused_gpu.py compares them).
+static bool split_supported(int ksteps) { return ksteps == 10 || ksteps == 11; }
+static bool split_selected(int ksteps) {
+    const char* e = getenv("NPLDA_COHORT_SPLIT");
+    return split_supported(ksteps) && !(e && e[0] == '0');
 }
 
 static int fused_row_pad() {
@@ -1215,7 +1222,7 @@ static int fused_prepass(const FusedFixed& F, const float* z_coh, const float* q
     }
     const size_t nfrag = (size_t)(Mp / 16) * (Mp / 16) * 256;
     hipLaunchKernelGGL(cohort_prep_kernel, dim3((unsigned)((nfrag + 255) / 256)), dim3(256), 0, st, pa);
-    if (split_enabled(Mp / 16)) {  // the cohort in three bf16 pieces, fragment order (what the split fused kernel streams)
+    if (split_supported(Mp / 16)) {  // the cohort in three bf16 pieces, fragment order (what the split fused kernel streams)
         const SplitArgs sa = {z_coh, M, ldz, Mp, F.img};
         const long long nthr = (M + 63) / 64 * split_ksteps(Mp) * 256;
         hipLaunchKernelGGL(cohort_split_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, st, sa);
@@ -1345,7 +1352,7 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
         else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 1, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa);        \
     } else if (lowest) hipLaunchKernelGGL((cohort_fused2_kernel<true, NBV, 2, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa); \
     else hipLaunchKernelGGL((cohort_fused2_kernel<false, NBV, 2, 4, 8, true>), dim3((unsigned)grid), dim3(512), 0, st, fa)
-    if (split_enabled(ksteps)) {
+    if (split_selected(ksteps)) {
         if (ksteps == 10) { NPLDA_LAUNCH_SPLIT(10); } else { NPLDA_LAUNCH_SPLIT(11); }
     } else
     switch (ksteps) {

@@ -16,6 +16,7 @@ python bench.py --workload cfg5 --batch 2048 > $O/bench_cfg5_b2048.json 2>> $O/b
 python bench.py --workload secondary > $O/extra.json 2> $O/extra.err
 python tools/size_sweep.py 150 > $O/size_sweep.txt 2>&1
 python tools/size_sweep.py 170 >> $O/size_sweep.txt 2>&1
+export NPLDA_BENCH_NO_FORM_AB=1   # cfg3 passes below run ONE form of the fused cohort kernel (the default: split)
 cd /tmp; export TMPDIR=/tmp
 rocprofv3 --kernel-trace -d /tmp/tr1 -- python $R/bench.py --no-cpu-baseline --no-alt --no-clock-probe --steps 60 > /tmp/tr1.log 2>&1
 python $R/tools/rocpd_summary.py --series 12 /tmp/tr1/*/*.db > $O/bench_trace.txt
@@ -46,7 +47,7 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   score_pairs_D170_B1048576=$O/pmc_fwd170:nplda_fwd_v5_kernel \
   train_step_D150_B4096=$O/pmc_cfg2:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
   head_step_dx_D150_B4096=$O/pmc_cfg5:train_fb_small_kernel+wgrad_fm_kernel+train_update_kernel \
-  cohort_stats_D150_R22000_M10000=$O/pmc_cfg3:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R22000_M10000=$O/pmc_cfg3:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_split_kernel+cohort_fallback_kernel \
   "score_indexed_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel<false" \
   "score_indexed_D170_B1048576_N1200000=$O/pmc_regimeB170:score_indexed_kernel<false" \
   "score_indexed_self_D150_B1048576_N1200000=$O/pmc_regimeB150:score_indexed_kernel<true" \
@@ -54,9 +55,10 @@ python tools/traffic_from_pmc.py $O/traffic.json \
   gb_score_D170_B524288=$O/pmc_gb:nplda_fwd_kernel \
   score_pairs_D150_B524288=$O/pmc_cfg1_s2:nplda_fwd_v6_kernel score_pairs_D150_B262144=$O/pmc_cfg1_s4:nplda_fwd_v6_kernel \
   score_pairs_D150_B131072=$O/pmc_cfg1_s8:nplda_fwd_v6_kernel \
-  cohort_stats_D150_R11000_M10000=$O/pmc_cfg3_s2:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
-  cohort_stats_D150_R5500_M10000=$O/pmc_cfg3_s4:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
-  cohort_stats_D150_R2750_M10000=$O/pmc_cfg3_s8:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R11000_M10000=$O/pmc_cfg3_s2:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_split_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R5500_M10000=$O/pmc_cfg3_s4:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_split_kernel+cohort_fallback_kernel \
+  cohort_stats_D150_R2750_M10000=$O/pmc_cfg3_s8:cohort_fused2_kernel+cohort_finish_kernel+wgrad_kernel+cohort_rowthr_kernel+cohort_prep_kernel+cohort_split_kernel+cohort_fallback_kernel \
   > $O/traffic.log 2>&1
 tail -3 $O/traffic.log
+python tools/emulate_ranks.py > $O/emulated_ranks.txt 2>&1
 tail -c 400 $O/bench.json
