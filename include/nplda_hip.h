@@ -293,7 +293,10 @@ size_t nplda_cohort_workspace_bytes_ex(int64_t R, int64_t M, int topn, int D1, i
  * cohort scores S[r, m] = NeuralPlda score of (row r, cohort m); std is the population std (ddof = 0);
  * "top" = the topn SMALLEST scores when select_lowest != 0 (the reference's behaviour:
  * adaptive_score_normalization.py:32-36 sorts ascending and keeps [:N]) or the topn largest otherwise.
- * The reference does not compute cohort scores at all (it reads a TSV, :27): this is new functionality. */
+ * The reference does not compute cohort scores at all (it reads a TSV, :27): this is new functionality.
+ * Arithmetic of the fused path at D2 in 145 .. 176 (round 6): the GEMM takes each fp32 operand as three bf16 pieces and forms
+ * a product from six bf16 MFMA passes with fp32 accumulation — the same fp32 products to rounding (dropped terms < 2^-26 of a
+ * product); the environment variable NPLDA_COHORT_SPLIT=0, read at every call, selects fp32-input MFMAs instead. */
 int nplda_cohort_stats_f32(const float* z_rows, const float* q_rows, int64_t R, const float* z_coh,
                            const float* q_coh, int64_t M, int64_t ldz, const void* packed, int D0, int D1,
                            int D2, int topn, int select_lowest, double* stats, void* ws, size_t ws_bytes,
