@@ -645,7 +645,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         if constexpr (SPLIT) {
             // A step is one k32-block of CG column groups: 3 CG fragment reads feed 6 CG RGW MFMAs (four independent
             // accumulator chains: a 16x16x32 MFMA issues every 16 cycles, its result is ready ~2.5 issue slots later).  Small
-            // terms first: mm, hl, lh, hm, mh, hh.  The next step's fragments are read in the middle of this step's MFMAs.
+            // terms first: mm, hl, lh, hm, mh, hh.  The next step's fragments are read behind this step's first pass.
             constexpr int CG = 4 / RGW, SPK = 4 / CG, NSTEP = NK * SPK;
             const bf16x8* tb3 = reinterpret_cast<const bf16x8*>(tb);
             bf16x8 af3[2][CG][3];
@@ -661,8 +661,6 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     _Pragma("unroll") for (int cc = 0; cc < CG; ++cc) _Pragma("unroll") for (int g = 0; g < RGW; ++g)                 \
         acc[g][c0 + cc] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af3[s & 1][cc][PA], brow3[g][ks][PB], acc[g][c0 + cc], 0, 0, 0)
                 NPLDA_CF_PASS(1, 1);
-                NPLDA_CF_PASS(0, 2);
-                NPLDA_CF_PASS(2, 0);
                 __builtin_amdgcn_sched_barrier(0);
                 if (s + 1 < NSTEP) {
                     const int ks1 = (s + 1) / SPK, c1 = ((s + 1) % SPK) * CG;
@@ -672,9 +670,15 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
                         for (int p = 0; p < 3; ++p) af3[(s + 1) & 1][cc][p] = tb3[((ks1 * 4 + c1 + cc) * 3 + p) * 64];
                 }
                 __builtin_amdgcn_sched_barrier(0);
+                NPLDA_CF_PASS(0, 2);
+                NPLDA_CF_PASS(2, 0);
                 NPLDA_CF_PASS(0, 1);
                 NPLDA_CF_PASS(1, 0);
                 NPLDA_CF_PASS(0, 0);
+                // (the end of a step is a scheduling barrier too: without it hipcc hoists the next step's first MFMAs — the ones
+                // that wait for the fragments just asked for — to four MFMAs behind the reads, and every step exposes most of an
+                // LDS round trip: read in the assembly.  Reads after the first pass: twenty MFMAs between request and first use.)
+                __builtin_amdgcn_sched_barrier(0);
 #undef NPLDA_CF_PASS
             }
         } else {
