@@ -1124,6 +1124,9 @@ FusedPlan cohort_fused_plan(long long M, int topn, int Mp) {
     FusedPlan p = {};
     p.eligible = false;
     if (M < 4096 || topn < 1 || Mp < 16 || Mp > NPLDA_MAX_DIM) return p;
+    // (the fixed part of a workspace holds the cohort's split image, 12 ceil(Mp / 32) KiB per 64 cohort rows: kept under 1 GiB —
+    // the sizing functions budget 4 GiB per workspace — so a cohort of more than ~1.1 M utterances takes the spilling path)
+    if ((size_t)((M + 63) / 64) * split_tile_bytes(Mp) > ((size_t)1 << 30)) return p;
     // candidates proposed per row: about twice the wanted count, and relatively more when N is small — the proposal
     // sits far out in the tail there, where a row's distribution agrees least with the normal model
     // NPLDA_COHORT_WANT: the factor on N (default 2).  On the bench's Gaussian rows 1.4 is 22 us faster (select 104 -> 88 us,

@@ -38,3 +38,23 @@ def test_dynamic_symbol_table_is_the_declared_abi_only(hip_lib):
     hdr = open(os.path.join(ROOT, "include", "nplda_hip.h")).read()
     declared = set(re.findall(r"\b((?:nplda|gb)_[a-z0-9_]+)\s*\(", hdr))
     assert exported == declared, sorted(exported ^ declared)
+
+
+def test_cohort_sizes_include_the_split_image(hip_lib):
+    """Round 6: the fixed part of a cohort workspace / a CohortState holds the cohort's split image (three bf16 pieces in
+    fragment order: 12 * ceil(16 NB / 32) KiB per 64 cohort rows) — pure host arithmetic, no device needed; a cohort whose
+    image would pass 1 GiB is not eligible for the fused path (the sizing functions budget 4 GiB per workspace)."""
+    import ctypes
+    lib = hip_lib
+    for fn in (lib.nplda_cohort_state_bytes, lib.nplda_cohort_fused_min_workspace_bytes):
+        fn.restype = ctypes.c_size_t
+        fn.argtypes = [ctypes.c_int64, ctypes.c_int, ctypes.c_int, ctypes.c_int]
+    for D, kib in ((150, 60), (170, 72)):
+        M = 10000
+        image = (M + 63) // 64 * kib * 1024
+        state = lib.nplda_cohort_state_bytes(M, 500, D, D)
+        assert image < state < image + (4 << 20), (D, state, image)
+        assert lib.nplda_cohort_fused_min_workspace_bytes(M, 500, D, D) > state
+    assert lib.nplda_cohort_fused_min_workspace_bytes(1_000_000, 500, 150, 150) > 0
+    assert lib.nplda_cohort_state_bytes(1_200_000, 500, 150, 150) == 0       # 1.07 GiB of image: the spilling path
+    assert lib.nplda_cohort_fused_min_workspace_bytes(1_200_000, 500, 150, 150) == 0
