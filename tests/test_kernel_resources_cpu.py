@@ -67,8 +67,8 @@ def test_register_budget_of_the_fused_cohort_kernel():
     for calls with few rows): one 512-thread block per CU = two waves per SIMD = at most 256 registers, and NO scratch — a spill
     inside the tile loop is paid in matrix-pipe time.  The 16-wave forms (NPLDA_COHORT_NW=16, 128 registers) are opt-in and may
     spill a few bytes.  Round 6: the SPLIT forms (three bf16 pieces, six passes; the default at NB = 10 / 11) hold 3 x the
-    operand registers per k: NB = 10 fits; NB = 11 with two row groups sits at 256 and keeps eleven per-item values in scratch
-    (outside the MFMA loop: read in the assembly) — bounded here so that it does not grow unnoticed."""
+    operand registers per k: NB = 10 fits; NB = 11 with two row groups sits at 256 and keeps seventeen per-item values (68 bytes)
+    in scratch (outside the MFMA loop: read in the assembly) — bounded here so that it does not grow unnoticed."""
     res = _resources("nplda_cohort_fused.hip")
     fused = {k: v for k, v in res.items() if "cohort_fused2_kernel" in k and "ELi8ELb0EEEvNS_9FusedArgsE" in k}
     assert len(fused) >= 8, sorted(res)
@@ -78,7 +78,7 @@ def test_register_budget_of_the_fused_cohort_kernel():
     assert len(split) == 8, sorted(res)   # LOWEST x NB in {10, 11} x RGW in {1, 2}
     for k, v in split.items():
         tight = "ELi11ELi2E" in k
-        assert v["ScratchSize"] <= (64 if tight else 0) and v["VGPRs"] + v["AGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)
+        assert v["ScratchSize"] <= (96 if tight else 0) and v["VGPRs"] + v["AGPRs"] <= 256 and v["Occupancy"] >= 2, (k, v)
 
 
 def test_balanced_tile_kernels_keep_their_row_pointers_out_of_scratch():
