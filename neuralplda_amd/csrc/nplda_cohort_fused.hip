@@ -460,7 +460,8 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
     constexpr int abl = 0;
 #define NPLDA_CF_STAMP(i) do { } while (0)
 #endif
-    if (a.prio && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    if (a.prio == 1 && wave >= NW / 2) __builtin_amdgcn_s_setprio(1);
+    if (SPLIT && a.prio == 2) __builtin_amdgcn_s_setprio(3);
     long long rb = 0, nrb = 0;
     int band = 0, lbn = 0, t = 0, t1 = 0, nlb0 = 0, nlbn = 0;  // `band`: the list band being filled; the item ends at lbn
     if (tid == 0) nxt_s[0] = atomicAdd(a.ctr + xcd, 1u);
@@ -638,6 +639,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
 #pragma unroll
             for (int c = 0; c < 4; ++c) acc[g][c] = f32x4{0.f, 0.f, 0.f, 0.f};
         const f32x4* tb = tbuf + buf * NF * 64 + lane;
+        if (SPLIT && a.prio == 2) __builtin_amdgcn_s_setprio(0);   // (the MFMA loop at priority 0 ...)
         // The A fragments of the next k16-step are read in the MIDDLE of this step's MFMAs (two register sets, the reads
         // pinned by scheduling barriers: hipcc otherwise sinks them to just before their use, and it waits lgkmcnt(0)
         // there).  The two waves of a SIMD run this loop in step, so an LDS round trip that is not covered by 16 MFMAs
@@ -718,6 +720,7 @@ __global__ __launch_bounds__(64 * NW, 1) void cohort_fused2_kernel(const FusedAr
         // phases together with a barrier at this point gives the same tile time (24.6 k + 4.6 k) and a kernel 2 % slower.)
         // the operand rows of the NEXT item are fetched here, under the epilogue of this item's last tile
         NPLDA_CF_STAMP(2);
+        if (SPLIT && a.prio == 2) __builtin_amdgcn_s_setprio(3);   // (... everything else of the tile at 3: tools/exp_mfma_yield.hip)
         if (last_of_item && have_next && !(abl & 4096)) item_rows(nrb);  // (abl 4096: keeps the old rows — timing only)
 
         // ---- statistics epilogue: lane (i16, g4) of (g, c) holds row 16 g + i16 of the wave, columns 16 c + 4 g4 + r ----
@@ -1315,7 +1318,13 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + rpb - 1) / rpb); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
     fa.nsub = p.nsub; fa.q = p.q; fa.ksub = p.ksub; fa.lrow = lrow;
-    { static const int pr = getenv("NPLDA_COHORT_PRIO") ? atoi(getenv("NPLDA_COHORT_PRIO")) : 1; fa.prio = pr; }
+    // (the split form: 2 = the MFMA loop at priority 0, everything else of a tile at 3 — with a bf16 MFMA stream at priority 0 the
+    // partner's VALU instructions at priority 3 issue beside it at no cost to the stream, which the fp32-input MFMAs do not allow:
+    // tools/exp_mfma_yield.hip, profiles/r06fin5_mfma_yield_bf16.txt; in the kernel 375 - 380 us against 381 (no priorities)
+    // and 386 - 392 (the fp32 form's static 1) in two interleaved repetitions, profiles/r06j_split_prio_ab.txt — small, the
+    // kernel is at the power cap)
+    { static const int pr = getenv("NPLDA_COHORT_PRIO") ? atoi(getenv("NPLDA_COHORT_PRIO")) : -1;
+      fa.prio = pr >= 0 ? pr : (split_selected(ksteps) ? 2 : 1); }
 #ifdef NPLDA_COHORT_ABLATE
     {
         static unsigned long long* dstamps = nullptr;

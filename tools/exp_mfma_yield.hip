@@ -25,6 +25,7 @@ __global__ __launch_bounds__(512, 1) void k(unsigned long long* stamps, float* o
         for (int i = 0; i < 2; ++i)
 #pragma unroll
             for (int j = 0; j < 16; ++j) big[i][j] = 0.f;
+        const f32x4 a4 = {a, b, a + 1.f, b + 1.f}, b4 = {b, a, b - 1.f, a - 1.f};  // (eight bf16 each for the bf16 forms)
         t0 = __builtin_readcyclecounter();
         for (int it = 0; it < iters; ++it) {
 #pragma unroll
@@ -32,6 +33,15 @@ __global__ __launch_bounds__(512, 1) void k(unsigned long long* stamps, float* o
                 if (Y == 6) {  // 32x32x2 (16 passes, 64 cycles): half as many for the same FLOPs
                     if (m & 1) continue;
                     asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+v"(big[(m >> 1) & 1]) : "v"(a), "v"(b));
+                    continue;
+                }
+                if (Y == 10) {  // bf16 16x16x32 (16 cycles): the split form of the cohort GEMM (round 6, last session)
+                    asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+v"(acc[m & 7]) : "v"(a4), "v"(b4));
+                    continue;
+                }
+                if (Y == 11) {  // bf16 32x32x16 (32 cycles)
+                    if (m & 1) continue;
+                    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+v"(big[(m >> 1) & 1]) : "v"(a4), "v"(b4));
                     continue;
                 }
                 if (Y == 7) {  // every MFMA depends on the previous one (one accumulator)
@@ -102,5 +112,11 @@ int main() {
     run<8, 4, 0>("MFMA + s_sleep 0");
     run<6, 4, 0>("32x32x2 back-to-back (per 2 slots)");
     run<6, 8, 0>("32x32x2 back-to-back (per 2 slots)");
+    run<10, 1, 0>("bf16 16x16x32 back-to-back, 8 accumulators");
+    run<10, 2, 0>("bf16 16x16x32 back-to-back, 8 accumulators");
+    run<10, 4, 0>("bf16 16x16x32 back-to-back, 8 accumulators");
+    run<10, 2, 1>("bf16 16x16x32, MFMA wave prio 0 / partner prio 3");
+    run<11, 2, 0>("bf16 32x32x16 back-to-back (per 2 slots)");
+    run<11, 4, 0>("bf16 32x32x16 back-to-back (per 2 slots)");
     return 0;
 }
