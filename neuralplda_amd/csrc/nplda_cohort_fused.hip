@@ -1313,7 +1313,10 @@ int cohort_fused_run(const FusedPlan& p, const float* z_rows, const float* q_row
     // last round (fewer than three items per resident block: an 8-way row shard of cfg3 is 11 tiles x 32 list bands for
     // 256 CUs, 1.4 items each; as 22 x 32 half-size items the slowest CU carries 7.5 tile-units instead of 10).  Same
     // results, bit for bit (cohort_fused2_kernel).
-    const bool half_tiles = p.q > 1 && ((R + 255) / 256) * p.nbands * p.q < 3 * resident;
+    // (the split form's 128-row tile carries the full 60 - 72 KiB of tile DMA for half the MFMAs: it pays only below TWO items
+    // per resident block — 2 750 rows 0.108 against 0.117 ms, 5 500 rows 0.155 against 0.151: tools/cohort_half_ab.sh)
+    bool half_tiles = p.q > 1 && ((R + 255) / 256) * p.nbands * p.q < (split_selected(ksteps) ? 2 : 3) * resident;
+    if (const char* e = getenv("NPLDA_COHORT_HALF")) half_tiles = p.q > 1 && e[0] == '1';   // (A/B runs: force 128- / 256-row tiles)
     const int rpb = half_tiles ? 128 : 256;
     fa.R = R; fa.M = M; fa.ldz = ldz; fa.ksteps = ksteps; fa.nbands = p.nbands; fa.ny = (int)((R + rpb - 1) / rpb); fa.nx = p.nx;
     fa.ctr = ctl; fa.crow = crow; fa.trow = trow; fa.lists = lists; fa.counts = counts; fa.part = part;
